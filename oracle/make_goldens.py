@@ -100,7 +100,7 @@ def build_inputs(mol_ids, n_confs, seed, charge_model="am1BCC", with_param_refs=
     return mols
 
 
-def ref_graph(m, n_confs, with_param_refs, n_per_ref=(6, 3)):
+def ref_graph(m, n_confs, with_param_refs, n_per_ref=(6, 3), nan_refs=True):
     bonds = [tuple(int(x) for x in b) for b in m["bonds"]]
     mol = RefMolecule(atoms=list(range(len(m["z"]))), bonds=bonds, impropers=[tuple(int(x) for x in r) for r in m["impropers"]],
                       atomic_numbers=[int(x) for x in m["z"]], partial_charges=[float(x) for x in m["q"]],
@@ -122,7 +122,7 @@ def ref_graph(m, n_confs, with_param_refs, n_per_ref=(6, 3)):
                 v = np.abs(v)
             g.nodes[lvl].data[name + "_ref"] = torch.from_numpy(v)
         # a few NaN references (molecules without classical parameters are stored like this)
-        if m["seed"] % 2 == 1 and g.num_nodes("n3") > 2:
+        if nan_refs and m["seed"] % 2 == 1 and g.num_nodes("n3") > 2:
             g.nodes["n3"].data["k_ref"][:2] = float("nan")
     g = ref_dgl_utils.set_number_confs(g, n_confs)
     return g, mol
@@ -263,7 +263,7 @@ def main():
 
     # ---- Energy only, on "classical" parameters (suffix _ref), incl. the torsion offset option
     mols = build_inputs(pick_small(4, 8, 40, start=200), n_confs=6, seed=77)
-    graphs = [ref_graph(m, 6, True)[0] for m in mols]
+    graphs = [ref_graph(m, 6, True, nan_refs=False)[0] for m in mols]
     g = ref_dgl_utils.batch(graphs)
     with zero_dihedral_noise():
         g = RefEnergy(suffix="_ref", write_suffix="_classical", gradients=True)(g)

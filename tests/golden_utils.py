@@ -43,7 +43,7 @@ def molecules_of(fx):
     return mols
 
 
-def param_refs(m, g, n_per=(6, 3)):
+def param_refs(m, g, n_per=(6, 3), nan_refs=True):
     """the synthetic classical parameters make_goldens.py attached (same generator, same order)."""
     rng = np.random.default_rng(int(m["seed"]))
     for lvl, name, mean, std, shape1 in [("n2", "k", 700., 150., None), ("n2", "eq", 1.2, 0.15, None), ("n3", "k", 100., 25., None),
@@ -55,11 +55,11 @@ def param_refs(m, g, n_per=(6, 3)):
         if name == "k" and shape1 is None:
             v = np.abs(v)
         g.nodes[lvl].data[name + "_ref"] = torch.from_numpy(v)
-    if int(m["seed"]) % 2 == 1 and g.num_nodes("n3") > 2:
+    if nan_refs and int(m["seed"]) % 2 == 1 and g.num_nodes("n3") > 2:
         g.nodes["n3"].data["k_ref"][:2] = float("nan")
 
 
-def build_batch(mols, n_confs, with_param_refs=True, n_per=(6, 3)):
+def build_batch(mols, n_confs, with_param_refs=True, n_per=(6, 3), nan_refs=True):
     graphs = []
     for m in mols:
         mol = Molecule(atoms=list(range(len(m["z"]))), bonds=[tuple(int(x) for x in b) for b in m["bonds"]],
@@ -74,7 +74,7 @@ def build_batch(mols, n_confs, with_param_refs=True, n_per=(6, 3)):
         g.nodes["g"].data["energy_ref"] = torch.from_numpy(m["energy_ref"].copy())
         g.nodes["n1"].data["gradient_ref"] = torch.from_numpy(m["gradient_ref"].copy())
         if with_param_refs:
-            param_refs(m, g, n_per)
+            param_refs(m, g, n_per, nan_refs)
         g = set_number_confs(g, n_confs)
         graphs.append(g)
     return batch(graphs)
