@@ -1,0 +1,13 @@
+"""grappa_amd: MI355X-native engine for the Grappa hot path (GrappaModel forward / predict, Energy,
+MolwiseLoss train step) behind the reference's Python API.  See DESIGN.md."""
+from .batch import MolBatch, batch, unbatch, set_number_confs, delete_dummy_confs
+from .molecule import Molecule
+from .parameters import Parameters
+from .model import GrappaModel
+from .energy import Energy
+from .loss import MolwiseLoss
+from .deploy import get_default_model_config, model_from_config, model_from_dict
+from .grappa import Grappa
+
+__all__ = ["MolBatch", "batch", "unbatch", "set_number_confs", "delete_dummy_confs", "Molecule", "Parameters", "GrappaModel",
+           "Energy", "MolwiseLoss", "get_default_model_config", "model_from_config", "model_from_dict", "Grappa"]

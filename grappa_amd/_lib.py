@@ -1,0 +1,97 @@
+"""ctypes binding of libgrappa_hip.so (the C ABI of include/grappa_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C grappa_amd/csrc`.  There is
+no CPU fallback: if the shared object is missing or does not load, importing the product's compute
+path raises (tests on a CPU-only box use a test-only backend, see tests/).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrappa_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_kcontig", C.c_int), ("b_kcontig", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
+                ("C2", C.c_void_p), ("ldc2", C.c_int), ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int),
+                ("aux", C.c_void_p), ("ldaux", C.c_int), ("pre", C.c_void_p), ("ldpre", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+                ("accumulate", C.c_int)]
+
+
+class MMDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("C", C.c_int), ("B", C.c_int), ("xyz", C.c_void_p), ("T", C.c_int * 4),
+                ("idx", C.c_void_p * 4), ("k", C.c_void_p * 4), ("eq", C.c_void_p * 4), ("mol_ptr", C.c_void_p * 4),
+                ("n_per", C.c_int * 4), ("offset_torsion", C.c_int), ("inc_ptr", C.c_void_p), ("inc_code", C.c_void_p),
+                ("atom_molptr", C.c_void_p)]
+
+
+class PLossDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("mol_ptr", C.c_void_p * 6), ("p", C.c_void_p * 6), ("ref", C.c_void_p * 6),
+                ("width", C.c_int * 6), ("ref_width", C.c_int * 6), ("fac", C.c_float * 6), ("reg", C.c_float * 6),
+                ("pw", C.c_void_p), ("inv_B", C.c_float)]
+
+
+VP4 = C.c_void_p * 4
+VP6 = C.c_void_p * 6
+
+# every symbol include/grappa_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+SIGNATURES = {
+    "grappa_abi_version": (_i, []),
+    "grappa_build_arch": (C.c_char_p, []),
+    "grappa_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
+    "grappa_gemm_f32": (_i, [_vp, C.POINTER(GemmDesc), _vp, _sz]),
+    "grappa_colsum_workspace_bytes": (_sz, [_i, _i]),
+    "grappa_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz]),
+    "grappa_act_dropout_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i]),
+    "grappa_add_f32": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "grappa_layernorm_fwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "grappa_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "grappa_layernorm_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
+    "grappa_gat_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "grappa_gat_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "grappa_neighbor_mean_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i]),
+    "grappa_charge_encoding_f32": (_i, [_vp, _i, _vp, _i, _f, _f, _vp, _i, _i]),
+    "grappa_tuple_gather_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i]),
+    "grappa_tuple_gather_bwd_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i]),
+    "grappa_seqattn_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "grappa_seqattn_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "grappa_perm_concat_fwd_f32": (_i, [_vp, _i, _i, _i, _i, c_int_p, _vp, _vp]),
+    "grappa_perm_concat_bwd_f32": (_i, [_vp, _i, _i, _i, _i, c_int_p, _vp, _vp]),
+    "grappa_param_out_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),
+    "grappa_param_out_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp]),
+    "grappa_mm_energy_fwd_f32": (_i, [_vp, C.POINTER(MMDesc), _vp, _vp, C.POINTER(VP4), C.POINTER(VP4)]),
+    "grappa_mm_gradient_fwd_f32": (_i, [_vp, C.POINTER(MMDesc), _vp]),
+    "grappa_mm_bwd_f32": (_i, [_vp, C.POINTER(MMDesc), _vp, _vp, C.POINTER(VP4), C.POINTER(VP4)]),
+    "grappa_loss_ef_fwd_bwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp]),
+    "grappa_loss_param_fwd_bwd_f32": (_i, [_vp, C.POINTER(PLossDesc), _vp, C.POINTER(VP6)]),
+    "grappa_sumsq_workspace_bytes": (_sz, [_sz]),
+    "grappa_sumsq_f32": (_i, [_vp, _sz, _vp, _vp, _i, _vp, _sz]),
+    "grappa_adam_step_f32": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _f]),
+    "grappa_dropout_keep": (_i, [_u64, _u64, _f]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"or `make -C grappa_amd/csrc` (there is no CPU fallback for the Grappa HIP path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.grappa_abi_version() != 1:
+        raise RuntimeError("libgrappa_hip.so: ABI version mismatch")
+    _lib = lib
+    return lib

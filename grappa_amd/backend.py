@@ -1,0 +1,433 @@
+"""Tensor-level marshalling onto the C ABI (include/grappa_hip.h).
+
+`HipBackend` is the product's only compute backend: every method checks its tensor arguments on
+the host (device, dtype, contiguity, shapes the kernels assume) and enqueues HIP kernels of
+libgrappa_hip.so on torch's current stream.  There is deliberately NO CPU implementation here;
+`get_backend()` raises when the library or a GPU is missing.  Tests on CPU-only machines install
+a test-only backend through `set_backend()` (tests/conftest.py) to exercise the host logic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+_BACKEND = None
+
+
+def set_backend(b) -> None:
+    global _BACKEND
+    _BACKEND = b
+
+
+def get_backend():
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+class GrappaHipError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "GRAPPA_ERR_ARG (unsupported shape / null pointer)", -2: "GRAPPA_ERR_LAUNCH", -3: "GRAPPA_ERR_WORKSPACE"}
+
+
+def _chk(rc: int, what: str) -> None:
+    if rc != 0:
+        raise GrappaHipError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32_2d(t: torch.Tensor, name: str, dev) -> int:
+    """validate a (rows, cols) fp32 view with unit inner stride; return its leading dimension."""
+    if t.dtype != torch.float32 or t.device != dev or t.dim() != 2:
+        raise ValueError(f"{name}: expected a 2-d float32 tensor on {dev}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name}: inner stride must be 1")
+    if t.shape[0] > 1:
+        if t.stride(0) < t.shape[1]:
+            raise ValueError(f"{name}: overlapping rows (stride {t.stride(0)} < {t.shape[1]} columns)")
+        return t.stride(0)
+    return max(t.shape[1], 1)
+
+
+def _flat(t: torch.Tensor, name: str, dev, dtype=torch.float32) -> None:
+    if t.dtype != dtype or t.device != dev or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous {dtype} tensor on {dev}")
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError("grappa_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = _lib.load()
+        self._ws = {}
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _workspace(self, nbytes: int, dev) -> torch.Tensor:
+        key = (dev, torch.cuda.current_stream().cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ dense
+    def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
+             drop_p=0.0, drop_seed=0, accumulate=False, out2=None) -> None:
+        dev = out.device
+        d = _lib.GemmDesc()
+        d.M, d.N, d.K = M, N, K
+        d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
+        ar, ac = (M, K) if a_kcontig else (K, M)
+        br, bc = (N, K) if b_kcontig else (K, N)
+        if tuple(a.shape) != (ar, ac) or tuple(b.shape) != (br, bc) or tuple(out.shape) != (M, N):
+            raise ValueError(f"gemm: shapes A{tuple(a.shape)} B{tuple(b.shape)} C{tuple(out.shape)} do not match M={M} N={N} K={K}")
+        d.A, d.lda = a.data_ptr(), _f32_2d(a, "A", dev)
+        d.B, d.ldb = b.data_ptr(), _f32_2d(b, "B", dev)
+        d.C, d.ldc = out.data_ptr(), _f32_2d(out, "C", dev)
+        if out2 is not None:
+            if tuple(out2.shape) != (M, N):
+                raise ValueError("gemm: out2 shape")
+            d.C2, d.ldc2 = out2.data_ptr(), _f32_2d(out2, "C2", dev)
+        if bias is not None:
+            _flat(bias, "bias", dev)
+            if bias.numel() != N:
+                raise ValueError("gemm: bias length")
+            d.bias = bias.data_ptr()
+        if res is not None:
+            if tuple(res.shape) != (M, N):
+                raise ValueError("gemm: res shape")
+            d.res, d.ldres = res.data_ptr(), _f32_2d(res, "res", dev)
+        if aux is not None:
+            if tuple(aux.shape) != (M, N):
+                raise ValueError("gemm: aux shape")
+            d.aux, d.ldaux = aux.data_ptr(), _f32_2d(aux, "aux", dev)
+        if pre is not None:
+            if tuple(pre.shape) != (M, N):
+                raise ValueError("gemm: pre shape")
+            d.pre, d.ldpre = pre.data_ptr(), _f32_2d(pre, "pre", dev)
+        d.act, d.drop_p, d.drop_seed, d.accumulate = int(act), float(drop_p), int(drop_seed) & (2 ** 64 - 1), int(accumulate)
+        if M == 0 or N == 0:
+            return
+        if K == 0:
+            raise ValueError("gemm: K == 0")
+        need = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
+        ws = self._workspace(need, dev) if need else None
+        _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0), "grappa_gemm_f32")
+
+    def colsum(self, x, out, accumulate=False) -> None:
+        dev = out.device
+        M, N = x.shape
+        ldx = _f32_2d(x, "x", dev)
+        _flat(out, "out", dev)
+        if out.numel() != N:
+            raise ValueError("colsum: out length")
+        ws = self._workspace(self.lib.grappa_colsum_workspace_bytes(M, N), dev)
+        _chk(self.lib.grappa_colsum_f32(self._stream(), M, N, x.data_ptr(), ldx, out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()),
+             "grappa_colsum_f32")
+
+    def act_dropout_bwd(self, dy, y, drop_p, drop_seed, dz) -> None:
+        dev = dz.device
+        M, N = dy.shape
+        if tuple(dz.shape) != (M, N) or (y is not None and tuple(y.shape) != (M, N)):
+            raise ValueError("act_dropout_bwd: shapes")
+        _chk(self.lib.grappa_act_dropout_bwd_f32(self._stream(), M, N, dy.data_ptr(), _f32_2d(dy, "dy", dev), _ptr(y),
+                                                 _f32_2d(y, "y", dev) if y is not None else 0, float(drop_p),
+                                                 int(drop_seed) & (2 ** 64 - 1), dz.data_ptr(), _f32_2d(dz, "dz", dev)), "grappa_act_dropout_bwd_f32")
+
+    def add(self, x, z, y) -> None:
+        dev = y.device
+        for t, n in ((x, "x"), (z, "z"), (y, "y")):
+            _flat(t, n, dev)
+        if not (x.numel() == z.numel() == y.numel()):
+            raise ValueError("add: sizes")
+        _chk(self.lib.grappa_add_f32(self._stream(), x.numel(), x.data_ptr(), z.data_ptr(), y.data_ptr()), "grappa_add_f32")
+
+    # ------------------------------------------------------------------ layer norm
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd) -> None:
+        dev = y.device
+        M, W = x.shape
+        _flat(gamma, "gamma", dev), _flat(beta, "beta", dev)
+        if gamma.numel() != W or beta.numel() != W or tuple(y.shape) != (M, W):
+            raise ValueError("layernorm: shapes")
+        if mean is not None:
+            _flat(mean, "mean", dev), _flat(rstd, "rstd", dev)
+            if mean.numel() != M or rstd.numel() != M:
+                raise ValueError("layernorm: stats length")
+        _chk(self.lib.grappa_layernorm_fwd_f32(self._stream(), M, W, x.data_ptr(), _f32_2d(x, "x", dev), gamma.data_ptr(), beta.data_ptr(),
+                                               y.data_ptr(), _f32_2d(y, "y", dev), _ptr(mean), _ptr(rstd)), "grappa_layernorm_fwd_f32")
+
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True) -> None:
+        dev = dx.device
+        M, W = x.shape
+        for t, n, k in ((mean, "mean", M), (rstd, "rstd", M), (gamma, "gamma", W), (dgamma, "dgamma", W), (dbeta, "dbeta", W)):
+            _flat(t, n, dev)
+            if t.numel() != k:
+                raise ValueError(f"layernorm_bwd: {n} length")
+        if tuple(dy.shape) != (M, W) or tuple(dx.shape) != (M, W):
+            raise ValueError("layernorm_bwd: shapes")
+        ws = self._workspace(self.lib.grappa_layernorm_bwd_workspace_bytes(M, W), dev)
+        _chk(self.lib.grappa_layernorm_bwd_f32(self._stream(), M, W, dy.data_ptr(), _f32_2d(dy, "dy", dev), x.data_ptr(), _f32_2d(x, "x", dev),
+                                               mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _f32_2d(dx, "dx", dev),
+                                               dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()),
+             "grappa_layernorm_bwd_f32")
+
+    # ------------------------------------------------------------------ graph
+    def _csr_check(self, plan, N, dev):
+        if plan.N != N or plan.indptr.device != dev or plan.indptr.dtype != torch.int32 or plan.indptr.numel() != N + 1:
+            raise ValueError("graph plan does not match the feature tensor (atoms / device)")
+        if plan.indices.numel() != plan.E or plan.rev.numel() != plan.E:
+            raise ValueError("graph plan: edge arrays")
+
+    def gat_fwd(self, plan, ft, H, D, out, alpha) -> None:
+        dev = out.device
+        N = ft.shape[0]
+        self._csr_check(plan, N, dev)
+        _flat(ft, "ft", dev), _flat(out, "out", dev), _flat(alpha, "alpha", dev)
+        if ft.shape[1] != H * D or out.shape != ft.shape or alpha.numel() != plan.E * H:
+            raise ValueError("gat_fwd: shapes")
+        _chk(self.lib.grappa_gat_fwd_f32(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(), ft.data_ptr(),
+                                         out.data_ptr(), alpha.data_ptr()), "grappa_gat_fwd_f32")
+
+    def gat_bwd(self, plan, ft, out, alpha, dout, H, D, dft) -> None:
+        dev = dft.device
+        N = ft.shape[0]
+        self._csr_check(plan, N, dev)
+        for t, n in ((ft, "ft"), (out, "out"), (alpha, "alpha"), (dout, "dout"), (dft, "dft")):
+            _flat(t, n, dev)
+        if ft.shape[1] != H * D or out.shape != ft.shape or dout.shape != ft.shape or dft.shape != ft.shape or alpha.numel() != plan.E * H:
+            raise ValueError("gat_bwd: shapes")
+        delta = torch.empty((N, H), dtype=torch.float32, device=dev)
+        _chk(self.lib.grappa_gat_bwd_f32(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(), plan.rev.data_ptr(),
+                                         ft.data_ptr(), out.data_ptr(), alpha.data_ptr(), dout.data_ptr(), dft.data_ptr(), delta.data_ptr()),
+             "grappa_gat_bwd_f32")
+
+    def neighbor_mean(self, plan, x, out, scale_by_neighbor: bool) -> None:
+        dev = out.device
+        N, F = x.shape
+        self._csr_check(plan, N, dev)
+        _flat(x, "x", dev), _flat(out, "out", dev)
+        if out.shape != x.shape:
+            raise ValueError("neighbor_mean: shapes")
+        _chk(self.lib.grappa_neighbor_mean_f32(self._stream(), N, F, plan.indptr.data_ptr(), plan.indices.data_ptr(), x.data_ptr(), out.data_ptr(),
+                                               int(scale_by_neighbor)), "grappa_neighbor_mean_f32")
+
+    def charge_encoding(self, q, dim, lo, hi, out, col0) -> None:
+        dev = out.device
+        _flat(q, "q", dev)
+        N = q.numel()
+        if out.shape[0] != N or col0 + dim > out.shape[1]:
+            raise ValueError("charge_encoding: shapes")
+        _chk(self.lib.grappa_charge_encoding_f32(self._stream(), N, q.data_ptr(), dim, float(lo), float(hi), out.data_ptr(), _f32_2d(out, "out", dev),
+                                                 col0), "grappa_charge_encoding_f32")
+
+    # ------------------------------------------------------------------ tuples
+    def tuple_gather_fwd(self, a, idx, s, pe, x) -> None:
+        dev = x.device
+        T = idx.shape[0]
+        W = x.shape[1]
+        if idx.dtype != torch.int32 or idx.device != dev or not idx.is_contiguous() or (T and idx.shape[1] != s):
+            raise ValueError("tuple_gather_fwd: idx must be contiguous int32 (T,s)")
+        if x.shape[0] != s * T or a.shape[1] < W:
+            raise ValueError("tuple_gather_fwd: shapes")
+        if pe is not None:
+            _flat(pe, "pe", dev)
+            if pe.numel() != s:
+                raise ValueError("tuple_gather_fwd: pe length")
+        _chk(self.lib.grappa_tuple_gather_fwd_f32(self._stream(), T, s, W, a.data_ptr(), _f32_2d(a, "a", dev), idx.data_ptr(), _ptr(pe),
+                                                  x.data_ptr(), _f32_2d(x, "x", dev)), "grappa_tuple_gather_fwd_f32")
+
+    def tuple_gather_bwd(self, inv_ptr, inv_rows, dx, da, has_pe: bool, accumulate=False) -> None:
+        dev = da.device
+        N, W = da.shape[0], dx.shape[1]
+        if inv_ptr.dtype != torch.int32 or inv_ptr.numel() != N + 1 or inv_ptr.device != dev or inv_rows.dtype != torch.int32:
+            raise ValueError("tuple_gather_bwd: inverse incidence")
+        if da.shape[1] < W or inv_rows.numel() != dx.shape[0]:
+            raise ValueError("tuple_gather_bwd: shapes")
+        _chk(self.lib.grappa_tuple_gather_bwd_f32(self._stream(), N, W, inv_ptr.data_ptr(), inv_rows.data_ptr(), dx.data_ptr(),
+                                                  _f32_2d(dx, "dx", dev), da.data_ptr(), _f32_2d(da, "da", dev), int(has_pe), int(accumulate)),
+             "grappa_tuple_gather_bwd_f32")
+
+    def seqattn_fwd(self, qkv, s, T, nheads, out) -> None:
+        dev = out.device
+        _flat(qkv, "qkv", dev), _flat(out, "out", dev)
+        F = out.shape[1]
+        if qkv.shape != (s * T, 3 * F) or out.shape[0] != s * T or F % nheads:
+            raise ValueError("seqattn_fwd: shapes")
+        _chk(self.lib.grappa_seqattn_fwd_f32(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), out.data_ptr()), "grappa_seqattn_fwd_f32")
+
+    def seqattn_bwd(self, qkv, dout, s, T, nheads, dqkv) -> None:
+        dev = dqkv.device
+        _flat(qkv, "qkv", dev), _flat(dout, "dout", dev), _flat(dqkv, "dqkv", dev)
+        F = dout.shape[1]
+        if qkv.shape != (s * T, 3 * F) or dqkv.shape != qkv.shape or dout.shape[0] != s * T:
+            raise ValueError("seqattn_bwd: shapes")
+        _chk(self.lib.grappa_seqattn_bwd_f32(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr()),
+             "grappa_seqattn_bwd_f32")
+
+    def perm_concat_fwd(self, x, s, T, perms: Sequence[Sequence[int]], z) -> None:
+        dev = z.device
+        _flat(x, "x", dev), _flat(z, "z", dev)
+        F, P = x.shape[1], len(perms)
+        if x.shape[0] != s * T or z.shape != (P * T, s * F):
+            raise ValueError("perm_concat_fwd: shapes")
+        arr = (C.c_int * (P * s))(*[int(v) for p in perms for v in p])
+        _chk(self.lib.grappa_perm_concat_fwd_f32(self._stream(), s, T, F, P, arr, x.data_ptr(), z.data_ptr()), "grappa_perm_concat_fwd_f32")
+
+    def perm_concat_bwd(self, dz, s, T, perms, dx) -> None:
+        dev = dx.device
+        _flat(dz, "dz", dev), _flat(dx, "dx", dev)
+        F, P = dx.shape[1], len(perms)
+        if dx.shape[0] != s * T or dz.shape != (P * T, s * F):
+            raise ValueError("perm_concat_bwd: shapes")
+        arr = (C.c_int * (P * s))(*[int(v) for p in perms for v in p])
+        _chk(self.lib.grappa_perm_concat_bwd_f32(self._stream(), s, T, F, P, arr, dz.data_ptr(), dx.data_ptr()), "grappa_perm_concat_bwd_f32")
+
+    def param_out_fwd(self, kind, o, T, P, n_per, gated, cutoff, consts, k, eq) -> None:
+        dev = k.device
+        _flat(o, "o", dev), _flat(consts, "consts", dev), _flat(k, "k", dev)
+        if o.shape[0] != P * T:
+            raise ValueError("param_out_fwd: shapes")
+        if eq is not None:
+            _flat(eq, "eq", dev)
+        _chk(self.lib.grappa_param_out_fwd_f32(self._stream(), kind, T, P, n_per, int(gated), float(cutoff), o.data_ptr(), o.shape[1],
+                                               consts.data_ptr(), k.data_ptr(), _ptr(eq)), "grappa_param_out_fwd_f32")
+
+    def param_out_bwd(self, kind, o, T, P, n_per, gated, cutoff, consts, dk, deq, d_o) -> None:
+        dev = d_o.device
+        _flat(o, "o", dev), _flat(consts, "consts", dev), _flat(d_o, "d_o", dev)
+        for t, n in ((dk, "dk"), (deq, "deq")):
+            if t is not None:
+                _flat(t, n, dev)
+        if o.shape[0] != P * T or d_o.shape != o.shape:
+            raise ValueError("param_out_bwd: shapes")
+        _chk(self.lib.grappa_param_out_bwd_f32(self._stream(), kind, T, P, n_per, int(gated), float(cutoff), o.data_ptr(), o.shape[1],
+                                               consts.data_ptr(), _ptr(dk), _ptr(deq), d_o.data_ptr()), "grappa_param_out_bwd_f32")
+
+    # ------------------------------------------------------------------ MM energy
+    def _mm_desc(self, plan, xyz, ks, eqs, n_per, offset_torsion):
+        from .constants import TUPLE_LEVELS
+        dev = xyz.device
+        _flat(xyz, "xyz", dev)
+        N, Cc = xyz.shape[0], xyz.shape[1]
+        if N != plan.N or xyz.shape[2] != 3 or plan.indptr.device != dev:
+            raise ValueError("mm: xyz does not match the batch plan")
+        d = _lib.MMDesc()
+        d.N, d.C, d.B = N, Cc, plan.B
+        d.xyz = xyz.data_ptr()
+        for l, lvl in enumerate(TUPLE_LEVELS):
+            T = plan.T[lvl]
+            d.T[l] = T
+            d.idx[l] = plan.idx32[lvl].data_ptr()
+            d.mol_ptr[l] = plan.mol_ptr[lvl].data_ptr()
+            k = ks[l]
+            _flat(k, f"k[{lvl}]", dev)
+            if l < 2:
+                if k.numel() != T:
+                    raise ValueError(f"mm: k[{lvl}] length")
+                _flat(eqs[l], f"eq[{lvl}]", dev)
+                if eqs[l].numel() != T:
+                    raise ValueError(f"mm: eq[{lvl}] length")
+                d.eq[l] = eqs[l].data_ptr()
+                d.n_per[l] = 0
+            else:
+                if k.numel() != T * n_per[l]:
+                    raise ValueError(f"mm: k[{lvl}] must be (T,{n_per[l]})")
+                d.n_per[l] = n_per[l]
+            d.k[l] = k.data_ptr()
+        d.offset_torsion = int(offset_torsion)
+        d.inc_ptr, d.inc_code, d.atom_molptr = plan.inc_ptr.data_ptr(), plan.inc_code.data_ptr(), plan.atom_molptr.data_ptr()
+        return d
+
+    def mm_energy_fwd(self, plan, xyz, ks, eqs, n_per, offset_torsion, energy, term_energy, tuple_e=None, tuple_x=None) -> None:
+        d = self._mm_desc(plan, xyz, ks, eqs, n_per, offset_torsion)
+        te = _lib.VP4(*[_ptr(t) for t in (tuple_e or [None] * 4)])
+        tx = _lib.VP4(*[_ptr(t) for t in (tuple_x or [None] * 4)])
+        _chk(self.lib.grappa_mm_energy_fwd_f32(self._stream(), C.byref(d), energy.data_ptr(), _ptr(term_energy), C.byref(te), C.byref(tx)),
+             "grappa_mm_energy_fwd_f32")
+
+    def mm_gradient_fwd(self, plan, xyz, ks, eqs, n_per, grad) -> None:
+        d = self._mm_desc(plan, xyz, ks, eqs, n_per, False)
+        _flat(grad, "grad", xyz.device)
+        if grad.shape != xyz.shape:
+            raise ValueError("mm_gradient_fwd: grad shape")
+        _chk(self.lib.grappa_mm_gradient_fwd_f32(self._stream(), C.byref(d), grad.data_ptr()), "grappa_mm_gradient_fwd_f32")
+
+    def mm_bwd(self, plan, xyz, ks, eqs, n_per, offset_torsion, gE, gG, gks, geqs) -> None:
+        d = self._mm_desc(plan, xyz, ks, eqs, n_per, offset_torsion)
+        for t, n in ((gE, "gE"), (gG, "gG")):
+            if t is not None:
+                _flat(t, n, xyz.device)
+        a = _lib.VP4(*[_ptr(t) for t in gks])
+        b = _lib.VP4(*[_ptr(t) for t in geqs])
+        _chk(self.lib.grappa_mm_bwd_f32(self._stream(), C.byref(d), _ptr(gE), _ptr(gG), C.byref(a), C.byref(b)), "grappa_mm_bwd_f32")
+
+    # ------------------------------------------------------------------ loss
+    def loss_ef(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, wE, wG, inv_B, loss_mol, gE, gG) -> None:
+        dev = loss_mol.device
+        B = plan.B
+        Cc = energy.shape[1] if energy is not None else grad.shape[1]
+        for t, n in ((energy, "energy"), (energy_ref, "energy_ref"), (is_dummy, "is_dummy"), (grad, "grad"), (grad_ref, "grad_ref"),
+                     (gE, "gE"), (gG, "gG"), (loss_mol, "loss_mol")):
+            if t is not None:
+                _flat(t, n, dev)
+        _chk(self.lib.grappa_loss_ef_fwd_bwd_f32(self._stream(), B, Cc, plan.N, plan.atom_molptr.data_ptr(), _ptr(energy), _ptr(energy_ref),
+                                                 _ptr(is_dummy), _ptr(grad), _ptr(grad_ref), float(wE), float(wG), float(inv_B),
+                                                 loss_mol.data_ptr(), _ptr(gE), _ptr(gG)), "grappa_loss_ef_fwd_bwd_f32")
+
+    def loss_param(self, plan, params, refs, fac, reg, pw, inv_B, loss_mol, gps) -> None:
+        """params/refs/gps: lists of 6 tensors-or-None in the order n2_k, n2_eq, n3_k, n3_eq, n4_k, n4_improper_k."""
+        dev = loss_mol.device
+        lv = ["n2", "n2", "n3", "n3", "n4", "n4_improper"]
+        d = _lib.PLossDesc()
+        d.B = plan.B
+        for l in range(6):
+            p = params[l]
+            d.mol_ptr[l] = plan.mol_ptr[lv[l]].data_ptr()
+            if p is None:
+                continue
+            _flat(p, f"p[{l}]", dev)
+            T = plan.T[lv[l]]
+            w = p.numel() // T if T else (p.shape[1] if p.dim() == 2 else 1)
+            d.p[l], d.width[l] = p.data_ptr(), max(w, 1)
+            if refs[l] is not None:
+                _flat(refs[l], f"ref[{l}]", dev)
+                d.ref[l] = refs[l].data_ptr()
+                d.ref_width[l] = max(refs[l].numel() // T if T else 1, 1)
+            d.fac[l], d.reg[l] = float(fac[l]), float(reg[l])
+        if pw is not None:
+            _flat(pw, "pw", dev)
+            d.pw = pw.data_ptr()
+        d.inv_B = float(inv_B)
+        g = _lib.VP6(*[_ptr(t) for t in gps])
+        _chk(self.lib.grappa_loss_param_fwd_bwd_f32(self._stream(), C.byref(d), loss_mol.data_ptr(), C.byref(g)), "grappa_loss_param_fwd_bwd_f32")
+
+    # ------------------------------------------------------------------ optimiser
+    def sumsq(self, x, out, accumulate=False) -> None:
+        dev = out.device
+        _flat(x, "x", dev)
+        ws = self._workspace(self.lib.grappa_sumsq_workspace_bytes(x.numel()), dev)
+        _chk(self.lib.grappa_sumsq_f32(self._stream(), x.numel(), x.data_ptr(), out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()),
+             "grappa_sumsq_f32")
+
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale, sumsq, max_norm) -> None:
+        dev = p.device
+        for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+            _flat(t, n, dev)
+        _chk(self.lib.grappa_adam_step_f32(self._stream(), p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), float(lr),
+                                           float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
+                                           _ptr(sumsq), float(max_norm)), "grappa_adam_step_f32")

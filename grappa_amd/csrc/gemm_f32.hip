@@ -1,0 +1,323 @@
+// fp32 GEMM with fused epilogue on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32,
+// bitwise a k-ordered fmaf chain; peak 157.3 TFLOP/s on MI355X).
+//
+// Structure: 256-thread workgroup (4 wavefronts), BMxBNx32 tile, global -> registers -> LDS with two
+// LDS stages (one barrier per K-step of 32), each wavefront owns a (BM/WAVES_M)x(BN/WAVES_N) sub-tile as
+// 32x32 MFMA accumulators.  Operands are stored in LDS so that the 64 lanes of one MFMA operand read hit
+// 64 different banks:
+//   K-contiguous source  (X[M,K], W[N,K], dY[M,N']): S[row][32+1]  (pad 1 -> bank = (row+k) % 32)
+//   row-contiguous source (W[N',K'] for dgrad, dY/X for wgrad): S[k][BROW]
+// XCD-aware tile order: workgroups that land on the same XCD (blockIdx % 8 equal) walk consecutive column
+// tiles of the same row panel, so the big activation panel is fetched into one L2 only.
+// Split-K (wgrad: K = #tokens) writes fp32 slabs that a second kernel sums in a fixed order (bitwise
+// reproducible) before applying the epilogue.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+struct GemmParams {
+    grappa_gemm_desc d;
+    int vecA, vecB;        // 16-byte vector loads legal for A / B
+    int k_per_split;       // multiple of BK
+    int nsplit;
+    float* slab;           // [nsplit, M, N] when nsplit > 1
+    float drop_scale;
+    int tiles_m, tiles_n;
+};
+
+template <int BROW, bool KCONT>
+struct Tile {
+    static constexpr int SIZE = KCONT ? BROW * (BK + 1) : BK * BROW;
+    static constexpr int NV = BROW * BK / 4 / NTHREADS;   // float4 per thread
+};
+
+template <int BROW, bool KCONT>
+__device__ inline void load_tile(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend, int vec,
+                                 float4 (&v)[Tile<BROW, KCONT>::NV]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Tile<BROW, KCONT>::NV; ++i) {
+        const int f = tid + i * NTHREADS;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KCONT) {
+            const int row = f >> 3, kq = (f & 7) << 2;
+            const int gr = row0 + row, gk = k0 + kq;
+            if (gr < R && gk < Kend) {
+                const float* p = src + (size_t)gr * ld + gk;
+                if (vec && gk + 3 < Kend) {
+                    r = *reinterpret_cast<const float4*>(p);
+                } else {
+                    r.x = p[0];
+                    if (gk + 1 < Kend) r.y = p[1];
+                    if (gk + 2 < Kend) r.z = p[2];
+                    if (gk + 3 < Kend) r.w = p[3];
+                }
+            }
+        } else {
+            constexpr int QR = BROW / 4;
+            const int k = f / QR, rq = (f % QR) << 2;
+            const int gk = k0 + k, gr = row0 + rq;
+            if (gk < Kend && gr < R) {
+                const float* p = src + (size_t)gk * ld + gr;
+                if (vec && gr + 3 < R) {
+                    r = *reinterpret_cast<const float4*>(p);
+                } else {
+                    r.x = p[0];
+                    if (gr + 1 < R) r.y = p[1];
+                    if (gr + 2 < R) r.z = p[2];
+                    if (gr + 3 < R) r.w = p[3];
+                }
+            }
+        }
+        v[i] = r;
+    }
+}
+
+template <int BROW, bool KCONT>
+__device__ inline void store_tile(float* __restrict__ S, const float4 (&v)[Tile<BROW, KCONT>::NV]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Tile<BROW, KCONT>::NV; ++i) {
+        const int f = tid + i * NTHREADS;
+        if (KCONT) {
+            const int row = f >> 3, kq = (f & 7) << 2;
+            float* q = S + row * (BK + 1) + kq;
+            q[0] = v[i].x; q[1] = v[i].y; q[2] = v[i].z; q[3] = v[i].w;
+        } else {
+            constexpr int QR = BROW / 4;
+            const int k = f / QR, rq = (f % QR) << 2;
+            *reinterpret_cast<float4*>(S + k * BROW + rq) = v[i];
+        }
+    }
+}
+
+template <int BROW, bool KCONT>
+__device__ inline float read_operand(const float* __restrict__ S, int row, int k) {
+    return KCONT ? S[row * (BK + 1) + k] : S[k * BROW + row];
+}
+
+__device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v) {
+    const grappa_gemm_desc& d = p.d;
+    if (d.pre) v += d.pre[(size_t)m * d.ldpre + n];
+    if (d.bias) v += d.bias[n];
+    if (d.act == GRAPPA_ACT_ELU) v = grappa_elu(v);
+    if (d.aux) v *= grappa_elu_grad_from_out(d.aux[(size_t)m * d.ldaux + n]);
+    float* out = d.C;
+    int ldo = d.ldc;
+    if (d.C2) {
+        d.C[(size_t)m * d.ldc + n] = v;
+        out = d.C2;
+        ldo = d.ldc2;
+    }
+    if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
+    if (d.res) v += d.res[(size_t)m * d.ldres + n];
+    float* o = out + (size_t)m * ldo + n;
+    if (d.accumulate) v += *o;
+    *o = v;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int ASZ = Tile<BM, AK>::SIZE, BSZ = Tile<BN, BKC>::SIZE;
+    extern __shared__ float smem[];   // stage s: A at s*(ASZ+BSZ), B behind it
+
+    const grappa_gemm_desc& d = p.d;
+    // XCD-aware bijective remap of the linear workgroup id (blocks b and b+8 share an XCD)
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tile_m = wgid / p.tiles_n, tile_n = wgid % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(d.K, kbeg + p.k_per_split);
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    float4 ra[Tile<BM, AK>::NV], rb[Tile<BN, BKC>::NV];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile<BM, AK>(d.A, d.lda, m0, kbeg, d.M, kend, p.vecA, ra);
+        load_tile<BN, BKC>(d.B, d.ldb, n0, kbeg, d.N, kend, p.vecB, rb);
+        store_tile<BM, AK>(smem, ra);
+        store_tile<BN, BKC>(smem + ASZ, rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool has_next = kt + 1 < nk;
+        if (has_next) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            load_tile<BM, AK>(d.A, d.lda, m0, k0, d.M, kend, p.vecA, ra);
+            load_tile<BN, BKC>(d.B, d.ldb, n0, k0, d.N, kend, p.vecB, rb);
+        }
+        const float* a_s = smem + cur * (ASZ + BSZ);
+        const float* b_s = a_s + ASZ;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = read_operand<BM, AK>(a_s, wm0 + i * 32 + lr, kk + lh);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = read_operand<BN, BKC>(b_s, wn0 + j * 32 + lr, kk + lh);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (has_next) {
+            float* nxt = smem + (cur ^ 1) * (ASZ + BSZ);
+            store_tile<BM, AK>(nxt, ra);
+            store_tile<BN, BKC>(nxt + ASZ, rb);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 accumulator: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 32 + lr;
+            if (n >= d.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= d.M) continue;
+                if (p.nsplit > 1)
+                    p.slab[((size_t)split * d.M + m) * d.N + n] = acc[i][j][e];
+                else
+                    epilogue_store(p, m, n, acc[i][j][e]);
+            }
+        }
+}
+
+__global__ __launch_bounds__(NTHREADS) void gemm_splitk_reduce_kernel(GemmParams p) {
+    const size_t total = (size_t)p.d.M * p.d.N;
+    for (size_t i = (size_t)blockIdx.x * NTHREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * NTHREADS) {
+        float v = 0.0f;
+        for (int s = 0; s < p.nsplit; ++s) v += p.slab[(size_t)s * total + i];
+        epilogue_store(p, (int)(i / p.d.N), (int)(i % p.d.N), v);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC>
+int launch_cfg(hipStream_t st, GemmParams& p) {
+    constexpr int ASZ = Tile<BM, AK>::SIZE, BSZ = Tile<BN, BKC>::SIZE;
+    constexpr size_t smem = 2 * (size_t)(ASZ + BSZ) * sizeof(float);
+    auto kern = gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, AK, BKC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return GRAPPA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    p.tiles_m = (p.d.M + BM - 1) / BM;
+    p.tiles_n = (p.d.N + BN - 1) / BN;
+    dim3 grid(p.tiles_m * p.tiles_n, p.nsplit);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, st, p);
+    return grappa_launch_status();
+}
+
+struct Plan { int cfg; int nsplit; int k_per_split; };
+
+// cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128
+Plan make_plan(int M, int N, int K) {
+    Plan pl;
+    if (N <= 32) pl.cfg = 2;
+    else if (M <= 32) pl.cfg = 3;
+    else {
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        pl.cfg = (t128 >= 192) ? 0 : 1;
+    }
+    const int bm = pl.cfg == 0 ? 128 : pl.cfg == 1 ? 64 : pl.cfg == 2 ? 128 : 32;
+    const int bn = pl.cfg == 0 ? 128 : pl.cfg == 1 ? 64 : pl.cfg == 2 ? 32 : 128;
+    const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    int nsplit = 1;
+    if (tiles < 256 && K >= 16 * BK) {
+        nsplit = (int)((512 + tiles - 1) / tiles);
+        const int maxs = K / (8 * BK);
+        if (nsplit > maxs) nsplit = maxs;
+        if (nsplit > 64) nsplit = 64;
+        if (nsplit < 1) nsplit = 1;
+    }
+    int kps = (K + nsplit - 1) / nsplit;
+    kps = (kps + BK - 1) / BK * BK;
+    nsplit = (K + kps - 1) / kps;
+    pl.nsplit = nsplit;
+    pl.k_per_split = kps;
+    return pl;
+}
+
+template <bool AK, bool BKC>
+int dispatch(hipStream_t st, GemmParams& p, int cfg) {
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128, 2, 2, AK, BKC>(st, p);
+        case 1: return launch_cfg<64, 64, 2, 2, AK, BKC>(st, p);
+        case 2: return launch_cfg<128, 32, 4, 1, AK, BKC>(st, p);
+        default: return launch_cfg<32, 128, 1, 4, AK, BKC>(st, p);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    Plan pl = make_plan(M, N, K);
+    return pl.nsplit > 1 ? (size_t)pl.nsplit * M * N * sizeof(float) : 0;
+}
+
+extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes) {
+    if (!d || !d->A || !d->B || !d->C) return GRAPPA_ERR_ARG;
+    if (d->M < 0 || d->N < 0 || d->K < 0) return GRAPPA_ERR_ARG;
+    if (d->M == 0 || d->N == 0) return GRAPPA_OK;
+    if (d->K == 0) return GRAPPA_ERR_ARG;
+    if (d->a_kcontig == 0 && d->b_kcontig == 1) return GRAPPA_ERR_ARG;   // layout never needed by the path
+    if (d->drop_p < 0.0f || d->drop_p >= 1.0f) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GemmParams p;
+    p.d = *d;
+    p.vecA = ((reinterpret_cast<uintptr_t>(d->A) & 15) == 0 && (d->lda & 3) == 0) ? 1 : 0;
+    p.vecB = ((reinterpret_cast<uintptr_t>(d->B) & 15) == 0 && (d->ldb & 3) == 0) ? 1 : 0;
+    p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
+    Plan pl = make_plan(d->M, d->N, d->K);
+    p.nsplit = pl.nsplit;
+    p.k_per_split = pl.k_per_split;
+    p.slab = nullptr;
+    if (pl.nsplit > 1) {
+        const size_t need = (size_t)pl.nsplit * d->M * d->N * sizeof(float);
+        if (!ws || ws_bytes < need) return GRAPPA_ERR_WORKSPACE;
+        p.slab = reinterpret_cast<float*>(ws);
+    }
+    int rc;
+    if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg);
+    else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg);
+    else rc = dispatch<false, false>(st, p, pl.cfg);
+    if (rc != GRAPPA_OK) return rc;
+    if (pl.nsplit > 1) {
+        const size_t total = (size_t)d->M * d->N;
+        int blocks = (int)((total + NTHREADS - 1) / NTHREADS);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(NTHREADS), 0, st, p);
+        rc = grappa_launch_status();
+    }
+    return rc;
+}

@@ -1,0 +1,253 @@
+// Graph message passing on the bonded-neighbour CSR (destination-major).  HBM-bound gathers:
+// one wavefront owns one destination node; a feature row (F = H*D floats, 2 KB for the production
+// model) is read as coalesced 16-byte chunks, chunk c = lane + 64*i; a head spans D/4 adjacent lanes,
+// so per-head dot products are xor-shuffle reductions inside aligned lane groups.  Degree is 1..6 for
+// molecules: softmax runs online in registers, the next neighbour row is prefetched while the current
+// one is reduced.  The backward pass gathers through the reverse-edge index (symmetric graph): no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 8;   // float4 chunks per lane: F <= 2048
+
+struct Row {
+    float4 v[MAXC];
+};
+
+template <int NC>
+__device__ inline void load_row(const float* __restrict__ base, int node, int F, int lane, int nvec, float4 (&r)[NC]) {
+    const float4* p = reinterpret_cast<const float4*>(base + (size_t)node * F);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        r[i] = (c < nvec) ? p[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ inline float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+// ---------------------------------------------------------------------------------------------
+// forward: NC = chunks per lane (compile-time: 1, 2, 4, 8); lanes_per_head = D/4
+template <int NC>
+__global__ __launch_bounds__(256) void gat_fwd_kernel(int N, int H, int D, const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                      const float* __restrict__ ft, float* __restrict__ out, float* __restrict__ alpha) {
+    const int lane = threadIdx.x & 63;
+    const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (v >= N) return;
+    const int F = H * D, nvec = F >> 2, lph = D >> 2;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    float4 fv[NC], cur[NC], nxt[NC], acc[NC];
+    float mx[NC], den[NC];
+    load_row<NC>(ft, v, F, lane, nvec, fv);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        mx[i] = -INFINITY;
+        den[i] = 0.f;
+    }
+    const int e0 = indptr[v], e1 = indptr[v + 1];
+    if (e0 < e1) load_row<NC>(ft, indices[e0], F, lane, nvec, nxt);
+    for (int e = e0; e < e1; ++e) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) cur[i] = nxt[i];
+        if (e + 1 < e1) load_row<NC>(ft, indices[e + 1], F, lane, nvec, nxt);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const float s = group_sum(dot4(cur[i], fv[i]), lph) * inv_sqrt_d;
+            const int c = lane + 64 * i;
+            if (c < nvec && (lane % lph) == 0) alpha[(size_t)e * H + (c / lph)] = s;   // raw score, normalised below
+            const float m_new = fmaxf(mx[i], s);
+            const float corr = expf(mx[i] - m_new);     // exp(-inf) = 0 on the first edge
+            const float w = expf(s - m_new);
+            den[i] = den[i] * corr + w;
+            acc[i].x = acc[i].x * corr + w * cur[i].x;
+            acc[i].y = acc[i].y * corr + w * cur[i].y;
+            acc[i].z = acc[i].z * corr + w * cur[i].z;
+            acc[i].w = acc[i].w * corr + w * cur[i].w;
+            mx[i] = m_new;
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(out + (size_t)v * F);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            const float inv = den[i] > 0.f ? 1.0f / den[i] : 0.f;
+            o[c] = make_float4(acc[i].x * inv, acc[i].y * inv, acc[i].z * inv, acc[i].w * inv);
+            if ((lane % lph) == 0) {
+                const int h = c / lph;
+                for (int e = e0; e < e1; ++e) {
+                    const size_t a = (size_t)e * H + h;
+                    alpha[a] = expf(alpha[a] - mx[i]) * inv;
+                }
+            }
+        }
+    }
+}
+
+// delta[v,h] = <dout_v[h], out_v[h]>
+template <int NC>
+__global__ __launch_bounds__(256) void gat_delta_kernel(int N, int H, int D, const float* __restrict__ out, const float* __restrict__ dout,
+                                                        float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (v >= N) return;
+    const int F = H * D, nvec = F >> 2, lph = D >> 2;
+    float4 a[NC], b[NC];
+    load_row<NC>(out, v, F, lane, nvec, a);
+    load_row<NC>(dout, v, F, lane, nvec, b);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const float s = group_sum(dot4(a[i], b[i]), lph);
+        const int c = lane + 64 * i;
+        if (c < nvec && (lane % lph) == 0) delta[(size_t)v * H + c / lph] = s;
+    }
+}
+
+// dft_u = sum_{e in in(u), w = indices[e]}  alpha[rev e] * dout_w
+//                                          + ( ds(u->w) + ds(w->u) ) * ft_w / sqrt(D)
+//   ds(u->w)[h] = alpha[rev e][h] * (<dout_w[h], ft_u[h]> - delta[w,h])      (u is the source of edge u->w)
+//   ds(w->u)[h] = alpha[e][h]     * (<dout_u[h], ft_w[h]> - delta[u,h])      (u is the destination of edge w->u)
+template <int NC>
+__global__ __launch_bounds__(256) void gat_bwd_kernel(int N, int H, int D, const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                      const int* __restrict__ rev, const float* __restrict__ ft,
+                                                      const float* __restrict__ alpha, const float* __restrict__ dout,
+                                                      const float* __restrict__ delta, float* __restrict__ dft) {
+    const int lane = threadIdx.x & 63;
+    const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (u >= N) return;
+    const int F = H * D, nvec = F >> 2, lph = D >> 2;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    float4 fu[NC], du[NC], fw[NC], dw[NC], acc[NC];
+    float delta_u[NC];
+    load_row<NC>(ft, u, F, lane, nvec, fu);
+    load_row<NC>(dout, u, F, lane, nvec, du);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = lane + 64 * i;
+        delta_u[i] = (c < nvec) ? delta[(size_t)u * H + c / lph] : 0.f;
+    }
+    const int e0 = indptr[u], e1 = indptr[u + 1];
+    for (int e = e0; e < e1; ++e) {
+        const int w = indices[e];
+        const int er = rev[e];
+        load_row<NC>(ft, w, F, lane, nvec, fw);
+        load_row<NC>(dout, w, F, lane, nvec, dw);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            const int h = (c < nvec) ? c / lph : 0;
+            const float a_uw = (c < nvec) ? alpha[(size_t)er * H + h] : 0.f;   // weight of u in w's softmax
+            const float a_wu = (c < nvec) ? alpha[(size_t)e * H + h] : 0.f;    // weight of w in u's softmax
+            const float d_w = (c < nvec) ? delta[(size_t)w * H + h] : 0.f;
+            const float dot_src = group_sum(dot4(dw[i], fu[i]), lph);          // <dout_w, ft_u>
+            const float dot_dst = group_sum(dot4(du[i], fw[i]), lph);          // <dout_u, ft_w>
+            const float coef = (a_uw * (dot_src - d_w) + a_wu * (dot_dst - delta_u[i])) * inv_sqrt_d;
+            acc[i].x += a_uw * dw[i].x + coef * fw[i].x;
+            acc[i].y += a_uw * dw[i].y + coef * fw[i].y;
+            acc[i].z += a_uw * dw[i].z + coef * fw[i].z;
+            acc[i].w += a_uw * dw[i].w + coef * fw[i].w;
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(dft + (size_t)u * F);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) o[c] = acc[i];
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void neighbor_mean_kernel(int N, int F, const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                            const float* __restrict__ x, float* __restrict__ out, int scale_by_neighbor) {
+    const int lane = threadIdx.x & 63;
+    const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (v >= N) return;
+    const int nvec = F >> 2;
+    float4 acc[NC], r[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int e0 = indptr[v], e1 = indptr[v + 1];
+    const float self_scale = e1 > e0 ? 1.0f / (float)(e1 - e0) : 0.f;
+    for (int e = e0; e < e1; ++e) {
+        const int u = indices[e];
+        load_row<NC>(x, u, F, lane, nvec, r);
+        float sc = self_scale;
+        if (scale_by_neighbor) {
+            const int du = indptr[u + 1] - indptr[u];
+            sc = du > 0 ? 1.0f / (float)du : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            acc[i].x += sc * r[i].x; acc[i].y += sc * r[i].y; acc[i].z += sc * r[i].z; acc[i].w += sc * r[i].w;
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(out + (size_t)v * F);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) o[c] = acc[i];
+    }
+}
+
+inline int chunks_for(int F) {
+    const int nvec = F / 4;
+    const int nc = (nvec + 63) / 64;
+    return nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : 8;
+}
+inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+inline bool head_shape_ok(int H, int D) {
+    if (H <= 0 || D <= 0 || (D & 3)) return false;
+    const int lph = D / 4;
+    return pow2(lph) && lph <= 64 && H * D <= 2048;
+}
+
+#define DISPATCH_NC(nc, KERN, grid, st, ...)                                                    \
+    switch (nc) {                                                                               \
+        case 1: hipLaunchKernelGGL(KERN<1>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
+        case 2: hipLaunchKernelGGL(KERN<2>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
+        case 4: hipLaunchKernelGGL(KERN<4>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
+        default: hipLaunchKernelGGL(KERN<8>, grid, dim3(256), 0, st, __VA_ARGS__); break;       \
+    }
+
+}  // namespace
+
+extern "C" int grappa_gat_fwd_f32(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const float* ft,
+                                  float* out, float* alpha) {
+    if (N < 0 || E < 0 || !head_shape_ok(H, D)) return GRAPPA_ERR_ARG;
+    if (N == 0) return GRAPPA_OK;
+    if (!indptr || !ft || !out || !alpha || (E > 0 && !indices)) return GRAPPA_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(ft) | reinterpret_cast<uintptr_t>(out)) & 15) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((N + 3) / 4);
+    DISPATCH_NC(chunks_for(H * D), gat_fwd_kernel, grid, st, N, H, D, indptr, indices, ft, out, alpha);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_gat_bwd_f32(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const int* rev,
+                                  const float* ft, const float* out, const float* alpha, const float* dout, float* dft, float* delta) {
+    if (N < 0 || E < 0 || !head_shape_ok(H, D)) return GRAPPA_ERR_ARG;
+    if (N == 0) return GRAPPA_OK;
+    if (!indptr || !ft || !out || !alpha || !dout || !dft || !delta || (E > 0 && (!indices || !rev))) return GRAPPA_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(ft) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dft)) & 15)
+        return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((N + 3) / 4);
+    const int nc = chunks_for(H * D);
+    DISPATCH_NC(nc, gat_delta_kernel, grid, st, N, H, D, out, dout, delta);
+    DISPATCH_NC(nc, gat_bwd_kernel, grid, st, N, H, D, indptr, indices, rev, ft, alpha, dout, delta, dft);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_neighbor_mean_f32(void* stream, int N, int F, const int* indptr, const int* indices, const float* x, float* out,
+                                        int scale_by_neighbor) {
+    if (N < 0 || F <= 0 || (F & 3) || F > 2048) return GRAPPA_ERR_ARG;
+    if (N == 0) return GRAPPA_OK;
+    if (!indptr || !indices || !x || !out) return GRAPPA_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((N + 3) / 4);
+    DISPATCH_NC(chunks_for(F), neighbor_mean_kernel, grid, st, N, F, indptr, indices, x, out, scale_by_neighbor);
+    return grappa_launch_status();
+}

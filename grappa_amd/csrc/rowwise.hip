@@ -1,0 +1,363 @@
+// HBM-bound row-wise kernels: LayerNorm fwd/bwd (one wavefront per row, row held in registers as
+// float4 chunks), column sums (bias gradients), activation/dropout backward, sum of squares, fused
+// Adam with global-norm clipping, charge encoding.  All fp32; every global access is a 16-byte
+// coalesced access where the shape allows it.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 8;   // 8 float4 per lane * 64 lanes = 2048 floats
+
+template <bool STORE_STATS>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, int ldy, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nvec = W >> 2;
+    for (int row = wave_global; row < M; row += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+        float4 v[LN_MAX_CHUNKS];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                v[i] = xr[c];
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        }
+        const float mean = wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
+        float4* yr = reinterpret_cast<float4*>(y + (size_t)row * ldy);
+#pragma unroll
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+                const float4 b = reinterpret_cast<const float4*>(beta)[c];
+                float4 o;
+                o.x = (v[i].x - mean) * rstd * g.x + b.x;
+                o.y = (v[i].y - mean) * rstd * g.y + b.y;
+                o.z = (v[i].z - mean) * rstd * g.z + b.z;
+                o.w = (v[i].w - mean) * rstd * g.w + b.w;
+                yr[c] = o;
+            }
+        }
+        if (STORE_STATS && lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+    }
+}
+
+// dx per row; per-block partial dgamma/dbeta into part[block][2][W]
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const float* __restrict__ dy, int lddy,
+                                                            const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            float* __restrict__ dx, int lddx, float* __restrict__ part) {
+    extern __shared__ float red[];   // [4 waves][2][W]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_global = blockIdx.x * 4 + wave;
+    const int nwaves = gridDim.x * 4;
+    const int nvec = W >> 2;
+    float4 dg[LN_MAX_CHUNKS], db[LN_MAX_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = wave_global; row < M; row += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+        const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * lddy);
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[LN_MAX_CHUNKS], g[LN_MAX_CHUNKS];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float4 xv = xr[c], dv = dyr[c], gm = reinterpret_cast<const float4*>(gamma)[c];
+                xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+                g[i].x = dv.x * gm.x; g[i].y = dv.y * gm.y; g[i].z = dv.z * gm.z; g[i].w = dv.w * gm.w;
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                dg[i].x += dv.x * xh[i].x; dg[i].y += dv.y * xh[i].y; dg[i].z += dv.z * xh[i].z; dg[i].w += dv.w * xh[i].w;
+                db[i].x += dv.x; db[i].y += dv.y; db[i].z += dv.z; db[i].w += dv.w;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)W, m2 = wave_sum(s2) / (float)W;
+        float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * lddx);
+#pragma unroll
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float4 o;
+                o.x = rs * (g[i].x - m1 - xh[i].x * m2);
+                o.y = rs * (g[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (g[i].z - m1 - xh[i].z * m2);
+                o.w = rs * (g[i].w - m1 - xh[i].w * m2);
+                dxr[c] = o;
+            }
+        }
+    }
+    // block reduction of the per-wave partials (fixed order -> reproducible)
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 0) * W)[c] = dg[i];
+            reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 1) * W)[c] = db[i];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * W; j += 256) {
+        const int which = j / W, col = j % W;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(size_t)(w * 2 + which) * W + col];
+        part[((size_t)blockIdx.x * 2 + which) * W + col] = s;
+    }
+}
+
+// out[j] (+)= sum_b part[b*stride + j]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int nblocks, int stride, int n, const float* __restrict__ part,
+                                                              float* __restrict__ out, int accumulate) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * stride + j];
+    out[j] = accumulate ? out[j] + s : s;
+}
+
+// column sums: block = 256 threads = 64 columns x 4 row-lanes... simple: each block owns a row stripe,
+// threads stride over columns; partials[block][N]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const float* __restrict__ x, int ldx, int rows_per_block,
+                                                             float* __restrict__ part) {
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + n];
+        part[(size_t)blockIdx.x * N + n] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_dropout_bwd_kernel(int M, int N, const float* __restrict__ dy, int lddy,
+                                                              const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
+                                                              float* __restrict__ dz, int lddz) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float v = dy[(size_t)m * lddy + n];
+        if (p > 0.f) v = grappa_keep(seed, i, p) ? v * scale : 0.f;
+        if (y) v *= grappa_elu_grad_from_out(y[(size_t)m * ldy + n]);
+        dz[(size_t)m * lddz + n] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(size_t n, const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i] + z[i];
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(size_t n, const float* __restrict__ x, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void sumsq_final_kernel(int nblocks, const float* __restrict__ part, float* __restrict__ out, int accumulate) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) s += part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
+                                                   float bc1, float bc2, float grad_scale, const float* __restrict__ sumsq, float max_norm) {
+    float clip = 1.0f;
+    if (sumsq) {
+        const float norm = sqrtf(sumsq[0]) * grad_scale;
+        clip = fminf(1.0f, max_norm / (norm + 1e-6f));
+    }
+    const float gs = grad_scale * clip;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i] * gs;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+__global__ __launch_bounds__(256) void charge_encoding_kernel(int N, const float* __restrict__ q, int dim, float lo, float hi,
+                                                              float* __restrict__ out, int ldo, int col0) {
+    const int half = dim / 2;
+    const int total = N * half;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int n = i / half, j = i % half;
+        const float v = fminf(fmaxf(q[n], lo), hi);
+        const float s = (v + hi) / (hi - lo);
+        const float f = expf((float)j * -logf(10000.0f) / (float)half);
+        out[(size_t)n * ldo + col0 + 2 * j] = sinf(s * f);
+        out[(size_t)n * ldo + col0 + 2 * j + 1] = cosf(s * f);
+    }
+}
+
+inline int grid_for(size_t n, int cap = 2048) {
+    size_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > (size_t)cap) b = cap;
+    return (int)b;
+}
+inline int ln_blocks(int M) {
+    int b = (M + 3) / 4;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return b;
+}
+inline int colsum_blocks(int M) {
+    int b = (M + 63) / 64;
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
+                                        float* y, int ldy, float* mean, float* rstd) {
+    if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (ldy & 3)) return GRAPPA_ERR_ARG;
+    if (M == 0) return GRAPPA_OK;
+    if (!x || !gamma || !beta || !y) return GRAPPA_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
+        return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = ln_blocks(M) > 2048 ? 2048 : ln_blocks(M);
+    if (mean && rstd)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd);
+    return grappa_launch_status();
+}
+
+extern "C" size_t grappa_layernorm_bwd_workspace_bytes(int M, int W) {
+    return (size_t)ln_blocks(M) * 2 * W * sizeof(float);
+}
+
+extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
+                                        const float* mean, const float* rstd, const float* gamma, float* dx, int lddx,
+                                        float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
+    if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return GRAPPA_ERR_ARG;
+    if (M == 0) return GRAPPA_OK;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return GRAPPA_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(gamma)) & 15)
+        return GRAPPA_ERR_ARG;
+    const int blocks = ln_blocks(M);
+    const size_t need = (size_t)blocks * 2 * W * sizeof(float);
+    if (!ws || ws_bytes < need) return GRAPPA_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    const size_t smem = (size_t)4 * 2 * W * sizeof(float);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part);
+    int rc = grappa_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((W + 255) / 256), dim3(256), 0, st, blocks, 2 * W, W, part, dgamma, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((W + 255) / 256), dim3(256), 0, st, blocks, 2 * W, W, part + W, dbeta, accumulate);
+    return grappa_launch_status();
+}
+
+extern "C" size_t grappa_colsum_workspace_bytes(int M, int N) { return (size_t)colsum_blocks(M) * N * sizeof(float); }
+
+extern "C" int grappa_colsum_f32(void* stream, int M, int N, const float* x, int ldx, float* out, int accumulate, void* ws, size_t ws_bytes) {
+    if (M < 0 || N <= 0 || !out) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (M == 0) {
+        if (!accumulate) { if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st) != hipSuccess) return GRAPPA_ERR_LAUNCH; }
+        return GRAPPA_OK;
+    }
+    if (!x) return GRAPPA_ERR_ARG;
+    const int blocks = colsum_blocks(M);
+    if (!ws || ws_bytes < (size_t)blocks * N * sizeof(float)) return GRAPPA_ERR_WORKSPACE;
+    const int rpb = (M + blocks - 1) / blocks;
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, st, M, N, x, ldx, rpb, part);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, blocks, N, N, part, out, accumulate);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
+                                          float drop_p, uint64_t drop_seed, float* dz, int lddz) {
+    if (M < 0 || N < 0 || drop_p < 0.f || drop_p >= 1.f) return GRAPPA_ERR_ARG;
+    if (M == 0 || N == 0) return GRAPPA_OK;
+    if (!dy || !dz) return GRAPPA_ERR_ARG;
+    const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float* y) {
+    if (n == 0) return GRAPPA_OK;
+    if (!x || !z || !y) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, x, z, y);
+    return grappa_launch_status();
+}
+
+extern "C" size_t grappa_sumsq_workspace_bytes(size_t n) { return (size_t)grid_for(n, 1024) * sizeof(float); }
+
+extern "C" int grappa_sumsq_f32(void* stream, size_t n, const float* x, float* out, int accumulate, void* ws, size_t ws_bytes) {
+    if (!out) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = grid_for(n, 1024);
+    if (!ws || ws_bytes < (size_t)blocks * sizeof(float)) return GRAPPA_ERR_WORKSPACE;
+    if (n > 0 && !x) return GRAPPA_ERR_ARG;
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, n, x, part);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, blocks, part, out, accumulate);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_adam_step_f32(void* stream, size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, float grad_scale, const float* sumsq,
+                                    float max_norm) {
+    if (n == 0) return GRAPPA_OK;
+    if (!p || !g || !m || !v || step < 1) return GRAPPA_ERR_ARG;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, m, v, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2, grad_scale, sumsq, max_norm);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_charge_encoding_f32(void* stream, int N, const float* q, int dim, float lo, float hi, float* out, int ldo, int col0) {
+    if (N < 0 || dim <= 0 || (dim & 1) || hi <= lo) return GRAPPA_ERR_ARG;
+    if (N == 0) return GRAPPA_OK;
+    if (!q || !out) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(charge_encoding_kernel, dim3(grid_for((size_t)N * dim / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       N, q, dim, lo, hi, out, ldo, col0);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_dropout_keep(uint64_t seed, uint64_t index, float p) { return grappa_keep(seed, index, p) ? 1 : 0; }
+extern "C" int grappa_abi_version(void) { return GRAPPA_ABI_VERSION; }
+extern "C" const char* grappa_build_arch(void) { return "gfx950"; }

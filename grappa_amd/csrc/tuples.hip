@@ -1,0 +1,417 @@
+// n-body (tuple) stage kernels.  Token tables are (s*T, F) row-major with row = pos*T + t.
+//  * tuple_gather fwd/bwd : index gather of projected atom rows (+ positional-encoding column); the backward
+//    sums through the inverse incidence (atom -> token rows) -- deterministic, no atomics;
+//  * seqattn fwd/bwd      : multi-head self-attention over the s <= 4 tokens of a tuple, one wavefront per
+//    tuple, everything in registers (scores are s*s per head);
+//  * perm_concat fwd/bwd  : the symmetriser's permuted concatenation;
+//  * param_out fwd/bwd    : output maps ToPositive / ToRange / gated torsion / hard cutoff.
+#include "common.h"
+
+namespace {
+
+struct Perms {
+    int p[6][4];
+};
+
+// ------------------------------------------------------------------------------------------------ gather
+__global__ __launch_bounds__(256) void tuple_gather_fwd_kernel(int T, int s, int W, const float* __restrict__ a, int lda,
+                                                               const int* __restrict__ idx, const float* __restrict__ pe,
+                                                               float* __restrict__ x, int ldx) {
+    const int lane = threadIdx.x & 63;
+    const int nrows = s * T, nvec = W >> 2;
+    const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave0; r < nrows; r += nw) {
+        const int pos = r / T, t = r - pos * T;
+        const int atom = idx[(size_t)t * s + pos];
+        const float4* src = reinterpret_cast<const float4*>(a + (size_t)atom * lda);
+        float4* dst = reinterpret_cast<float4*>(x + (size_t)r * ldx);
+        const float pev = pe ? pe[pos] : 0.f;
+        for (int c = lane; c < nvec; c += 64) {
+            float4 v = src[c];
+            if (pe && c == nvec - 1) v.w = pev;
+            dst[c] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tuple_gather_bwd_kernel(int N, int W, const int* __restrict__ inv_ptr, const int* __restrict__ inv_rows,
+                                                               const float* __restrict__ dx, int lddx, float* __restrict__ da, int ldda,
+                                                               int has_pe, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = W >> 2;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    const int r0 = inv_ptr[n], r1 = inv_ptr[n + 1];
+    float4* dst = reinterpret_cast<float4*>(da + (size_t)n * ldda);
+    for (int c = lane; c < nvec; c += 64) {
+        float4 acc = accumulate ? dst[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = r0; j < r1; ++j) {
+            float4 v = reinterpret_cast<const float4*>(dx + (size_t)inv_rows[j] * lddx)[c];
+            if (has_pe && c == nvec - 1) v.w = 0.f;
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        dst[c] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+__device__ inline float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+template <int S>
+__global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, const float* __restrict__ qkv, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= T) return;
+    const int nvec = F >> 2, lph = dh >> 2;
+    const float scale = 1.0f / sqrtf((float)dh);
+    for (int c0 = 0; c0 < nvec; c0 += 64) {
+        const int c = c0 + lane;
+        const bool ok = c < nvec;
+        float4 q[S], k[S], v[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const float4* row = reinterpret_cast<const float4*>(qkv + ((size_t)i * T + t) * 3 * F);
+            q[i] = ok ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            k[i] = ok ? row[nvec + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i] = ok ? row[2 * nvec + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            float sc[S], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                sc[j] = group_sum(dot4(q[i], k[j]), lph) * scale;
+                mx = fmaxf(mx, sc[j]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                sc[j] = expf(sc[j] - mx);
+                den += sc[j];
+            }
+            const float inv = 1.0f / den;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const float p = sc[j] * inv;
+                o.x += p * v[j].x; o.y += p * v[j].y; o.z += p * v[j].z; o.w += p * v[j].w;
+            }
+            if (ok) reinterpret_cast<float4*>(out + ((size_t)i * T + t) * F)[c] = o;
+        }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                          float* __restrict__ dqkv) {
+    const int lane = threadIdx.x & 63;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= T) return;
+    const int nvec = F >> 2, lph = dh >> 2;
+    const float scale = 1.0f / sqrtf((float)dh);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = 0; c0 < nvec; c0 += 64) {
+        const int c = c0 + lane;
+        const bool ok = c < nvec;
+        float4 q[S], k[S], v[S], go[S], dq[S], dk[S], dv[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const float4* row = reinterpret_cast<const float4*>(qkv + ((size_t)i * T + t) * 3 * F);
+            q[i] = ok ? row[c] : zero;
+            k[i] = ok ? row[nvec + c] : zero;
+            v[i] = ok ? row[2 * nvec + c] : zero;
+            go[i] = ok ? reinterpret_cast<const float4*>(dout + ((size_t)i * T + t) * F)[c] : zero;
+            dq[i] = zero; dk[i] = zero; dv[i] = zero;
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            float p[S], dp[S], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                p[j] = group_sum(dot4(q[i], k[j]), lph) * scale;
+                mx = fmaxf(mx, p[j]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                p[j] = expf(p[j] - mx);
+                den += p[j];
+            }
+            const float inv = 1.0f / den;
+            float dsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                p[j] *= inv;
+                dp[j] = group_sum(dot4(go[i], v[j]), lph);
+                dsum += p[j] * dp[j];
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const float ds = p[j] * (dp[j] - dsum) * scale;
+                dq[i].x += ds * k[j].x; dq[i].y += ds * k[j].y; dq[i].z += ds * k[j].z; dq[i].w += ds * k[j].w;
+                dk[j].x += ds * q[i].x; dk[j].y += ds * q[i].y; dk[j].z += ds * q[i].z; dk[j].w += ds * q[i].w;
+                dv[j].x += p[j] * go[i].x; dv[j].y += p[j] * go[i].y; dv[j].z += p[j] * go[i].z; dv[j].w += p[j] * go[i].w;
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                float4* row = reinterpret_cast<float4*>(dqkv + ((size_t)i * T + t) * 3 * F);
+                row[c] = dq[i];
+                row[nvec + c] = dk[i];
+                row[2 * nvec + c] = dv[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ symmetriser input
+__global__ __launch_bounds__(256) void perm_concat_fwd_kernel(int s, int T, int F, int P, Perms perms, const float* __restrict__ x,
+                                                              float* __restrict__ z) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = F >> 2;
+    const long total = (long)P * T * s;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long w = wave0; w < total; w += nw) {
+        const int j = (int)(w % s);
+        const long pt = w / s;
+        const int t = (int)(pt % T), p = (int)(pt / T);
+        const int src_pos = perms.p[p][j];
+        const float4* src = reinterpret_cast<const float4*>(x + ((size_t)src_pos * T + t) * F);
+        float4* dst = reinterpret_cast<float4*>(z + ((size_t)p * T + t) * ((size_t)s * F) + (size_t)j * F);
+        for (int c = lane; c < nvec; c += 64) dst[c] = src[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void perm_concat_bwd_kernel(int s, int T, int F, int P, Perms inv, const float* __restrict__ dz,
+                                                              float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = F >> 2;
+    const long total = (long)s * T;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long w = wave0; w < total; w += nw) {
+        const int i = (int)(w / T), t = (int)(w % T);
+        float4* dst = reinterpret_cast<float4*>(dx + (size_t)w * F);
+        for (int c = lane; c < nvec; c += 64) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = 0; p < P; ++p) {
+                const int j = inv.p[p][i];
+                const float4 v = reinterpret_cast<const float4*>(dz + ((size_t)p * T + t) * ((size_t)s * F) + (size_t)j * F)[c];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            dst[c] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ output maps
+__device__ inline float to_positive(float c, float mos, float std, float mn) { return std * (grappa_elu(mos + c - 1.0f) + 1.0f) + mn; }
+__device__ inline float to_positive_grad(float c, float mos, float std) {
+    const float z = mos + c - 1.0f;
+    return std * (z > 0.f ? 1.0f : expf(z));
+}
+
+__global__ __launch_bounds__(256) void param_out_fwd_kernel(int kind, int T, int P, int n_per, int gated, float cutoff,
+                                                            const float* __restrict__ o, int ldo, const float* __restrict__ cst,
+                                                            float* __restrict__ k, float* __restrict__ eq) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    if (kind == GRAPPA_OUT_TORSION) {
+        for (int n = 0; n < n_per; ++n) {
+            float c = 0.f, g = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float* row = o + ((size_t)p * T + t) * ldo;
+                c += row[n];
+                if (gated) g += row[n_per + n];
+            }
+            float v = gated ? c * grappa_sigmoid(g) * cst[n] : c * cst[n] + cst[n_per + n];
+            if (cutoff > 0.f) v = fabsf(v) > cutoff ? v : 0.f;
+            k[(size_t)t * n_per + n] = v;
+        }
+        return;
+    }
+    float c0 = 0.f, c1 = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float* row = o + ((size_t)p * T + t) * ldo;
+        c0 += row[0];
+        c1 += row[1];
+    }
+    if (kind == GRAPPA_OUT_BOND) eq[t] = to_positive(c0, cst[0], cst[1], cst[2]);
+    else eq[t] = cst[1] * grappa_sigmoid(cst[0] * c0);
+    k[t] = to_positive(c1, cst[3], cst[4], cst[5]);
+}
+
+__global__ __launch_bounds__(256) void param_out_bwd_kernel(int kind, int T, int P, int n_per, int gated, float cutoff, int nout,
+                                                            const float* __restrict__ o, int ldo, const float* __restrict__ cst,
+                                                            const float* __restrict__ dk, const float* __restrict__ deq,
+                                                            float* __restrict__ d_o) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    if (kind == GRAPPA_OUT_TORSION) {
+        for (int n = 0; n < n_per; ++n) {
+            float c = 0.f, g = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float* row = o + ((size_t)p * T + t) * ldo;
+                c += row[n];
+                if (gated) g += row[n_per + n];
+            }
+            const float sg = gated ? grappa_sigmoid(g) : 0.f;
+            const float v = gated ? c * sg * cst[n] : c * cst[n] + cst[n_per + n];
+            float up = dk ? dk[(size_t)t * n_per + n] : 0.f;
+            if (cutoff > 0.f && !(fabsf(v) > cutoff)) up = 0.f;
+            const float dc = gated ? up * sg * cst[n] : up * cst[n];
+            const float dg = gated ? up * c * cst[n] * sg * (1.0f - sg) : 0.f;
+            for (int p = 0; p < P; ++p) {
+                float* row = d_o + ((size_t)p * T + t) * ldo;
+                row[n] = dc;
+                if (gated) row[n_per + n] = dg;
+            }
+        }
+        return;
+    }
+    float c0 = 0.f, c1 = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float* row = o + ((size_t)p * T + t) * ldo;
+        c0 += row[0];
+        c1 += row[1];
+    }
+    const float ueq = deq ? deq[t] : 0.f, uk = dk ? dk[t] : 0.f;
+    float d0;
+    if (kind == GRAPPA_OUT_BOND) d0 = ueq * to_positive_grad(c0, cst[0], cst[1]);
+    else {
+        const float sg = grappa_sigmoid(cst[0] * c0);
+        d0 = ueq * cst[1] * cst[0] * sg * (1.0f - sg);
+    }
+    const float d1 = uk * to_positive_grad(c1, cst[3], cst[4]);
+    for (int p = 0; p < P; ++p) {
+        float* row = d_o + ((size_t)p * T + t) * ldo;
+        row[0] = d0;
+        row[1] = d1;
+        for (int j = 2; j < nout; ++j) row[j] = 0.f;   // the harmonic gate column has no effect (reference quirk Q3)
+    }
+}
+
+inline int wave_grid(long nwaves, int cap = 8192) {
+    long b = (nwaves + 3) / 4;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int grappa_tuple_gather_fwd_f32(void* stream, int T, int s, int W, const float* a, int lda, const int* idx, const float* pe,
+                                           float* x, int ldx) {
+    if (T < 0 || s < 1 || s > 4 || W <= 0 || (W & 3) || (lda & 3) || (ldx & 3)) return GRAPPA_ERR_ARG;
+    if (T == 0) return GRAPPA_OK;
+    if (!a || !idx || !x || !aligned16(a) || !aligned16(x)) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(tuple_gather_fwd_kernel, dim3(wave_grid((long)s * T)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, s, W, a,
+                       lda, idx, pe, x, ldx);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_tuple_gather_bwd_f32(void* stream, int N, int W, const int* inv_ptr, const int* inv_rows, const float* dx, int lddx,
+                                           float* da, int ldda, int has_pe, int accumulate) {
+    if (N < 0 || W <= 0 || (W & 3) || (lddx & 3) || (ldda & 3)) return GRAPPA_ERR_ARG;
+    if (N == 0) return GRAPPA_OK;
+    if (!inv_ptr || !da || !aligned16(da) || (dx && !aligned16(dx))) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(tuple_gather_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), N, W, inv_ptr,
+                       inv_rows, dx, lddx, da, ldda, has_pe, accumulate);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_seqattn_fwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out) {
+    if (s < 1 || s > 4 || T < 0 || nheads <= 0 || dh <= 0 || (dh & 3) || !pow2(dh / 4) || dh / 4 > 64 || nheads * dh > 1024) return GRAPPA_ERR_ARG;
+    if (T == 0) return GRAPPA_OK;
+    if (!qkv || !out || !aligned16(qkv) || !aligned16(out)) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((T + 3) / 4);
+    const int F = nheads * dh;
+    switch (s) {
+        case 1: hipLaunchKernelGGL(seqattn_fwd_kernel<1>, grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+        case 2: hipLaunchKernelGGL(seqattn_fwd_kernel<2>, grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+        case 3: hipLaunchKernelGGL(seqattn_fwd_kernel<3>, grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+        default: hipLaunchKernelGGL(seqattn_fwd_kernel<4>, grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+    }
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_seqattn_bwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv) {
+    if (s < 1 || s > 4 || T < 0 || nheads <= 0 || dh <= 0 || (dh & 3) || !pow2(dh / 4) || dh / 4 > 64 || nheads * dh > 1024) return GRAPPA_ERR_ARG;
+    if (T == 0) return GRAPPA_OK;
+    if (!qkv || !dout || !dqkv || !aligned16(qkv) || !aligned16(dout) || !aligned16(dqkv)) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((T + 3) / 4);
+    const int F = nheads * dh;
+    switch (s) {
+        case 1: hipLaunchKernelGGL(seqattn_bwd_kernel<1>, grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+        case 2: hipLaunchKernelGGL(seqattn_bwd_kernel<2>, grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+        case 3: hipLaunchKernelGGL(seqattn_bwd_kernel<3>, grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+        default: hipLaunchKernelGGL(seqattn_bwd_kernel<4>, grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+    }
+    return grappa_launch_status();
+}
+
+static int fill_perms(int s, int P, const int* h_perm, Perms& fwd, Perms& inv) {
+    if (s < 1 || s > 4 || P < 1 || P > 6 || !h_perm) return GRAPPA_ERR_ARG;
+    for (int p = 0; p < P; ++p) {
+        int seen = 0;
+        for (int j = 0; j < s; ++j) {
+            const int v = h_perm[p * s + j];
+            if (v < 0 || v >= s) return GRAPPA_ERR_ARG;
+            fwd.p[p][j] = v;
+            inv.p[p][v] = j;
+            seen |= 1 << v;
+        }
+        if (seen != (1 << s) - 1) return GRAPPA_ERR_ARG;
+    }
+    return GRAPPA_OK;
+}
+
+extern "C" int grappa_perm_concat_fwd_f32(void* stream, int s, int T, int F, int P, const int* h_perm, const float* x, float* z) {
+    Perms fwd, inv;
+    if (int rc = fill_perms(s, P, h_perm, fwd, inv)) return rc;
+    if (T < 0 || F <= 0 || (F & 3)) return GRAPPA_ERR_ARG;
+    if (T == 0) return GRAPPA_OK;
+    if (!x || !z || !aligned16(x) || !aligned16(z)) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(perm_concat_fwd_kernel, dim3(wave_grid((long)P * T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P,
+                       fwd, x, z);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_perm_concat_bwd_f32(void* stream, int s, int T, int F, int P, const int* h_perm, const float* dz, float* dx) {
+    Perms fwd, inv;
+    if (int rc = fill_perms(s, P, h_perm, fwd, inv)) return rc;
+    if (T < 0 || F <= 0 || (F & 3)) return GRAPPA_ERR_ARG;
+    if (T == 0) return GRAPPA_OK;
+    if (!dz || !dx || !aligned16(dz) || !aligned16(dx)) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(perm_concat_bwd_kernel, dim3(wave_grid((long)T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P, inv,
+                       dz, dx);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_param_out_fwd_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff, const float* o, int ldo,
+                                        const float* consts, float* k, float* eq) {
+    if (T < 0 || P < 1 || kind < 0 || kind > 2) return GRAPPA_ERR_ARG;
+    if (kind == GRAPPA_OUT_TORSION && (n_per < 1 || ldo < (gated ? 2 : 1) * n_per)) return GRAPPA_ERR_ARG;
+    if (kind != GRAPPA_OUT_TORSION && ldo < 2) return GRAPPA_ERR_ARG;
+    if (T == 0) return GRAPPA_OK;
+    if (!o || !consts || !k || (kind != GRAPPA_OUT_TORSION && !eq)) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(param_out_fwd_kernel, dim3((T + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, T, P, n_per, gated,
+                       cutoff, o, ldo, consts, k, eq);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_param_out_bwd_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff, const float* o, int ldo,
+                                        const float* consts, const float* dk, const float* deq, float* d_o) {
+    if (T < 0 || P < 1 || kind < 0 || kind > 2) return GRAPPA_ERR_ARG;
+    if (kind == GRAPPA_OUT_TORSION && (n_per < 1 || ldo < (gated ? 2 : 1) * n_per)) return GRAPPA_ERR_ARG;
+    if (kind != GRAPPA_OUT_TORSION && ldo < 2) return GRAPPA_ERR_ARG;
+    if (T == 0) return GRAPPA_OK;
+    if (!o || !consts || !d_o) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(param_out_bwd_kernel, dim3((T + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, T, P, n_per, gated,
+                       cutoff, ldo, o, ldo, consts, dk, deq, d_o);
+    return grappa_launch_status();
+}

@@ -1,0 +1,466 @@
+"""`GrappaModel`: drop-in for the reference's `grappa.models.GrappaModel` (models/grappa.py:7-132) whose
+forward runs on the hand-written HIP kernels of libgrappa_hip.so.
+
+The module tree only HOLDS parameters, with the reference's attribute names so that state dicts are
+interchangeable key for key (`gnn.pre_dense.0.weight`, `gnn.att_blocks.{i}.graph_module.fc.weight`, the
+aliased `gnn.blocks.{i}.*`, `parameter_writer.bond_writer.bond_model.grappa_transformer.transformer.{l}.attn.in_proj_weight`,
+`...symmetriser.mlp.{j}.linear1.weight`, buffers `to_k.mean_over_std`, `k_std`, ... -- SURVEY.md section 8(b)).
+torch.nn.Linear / LayerNorm / MultiheadAttention instances are used as parameter containers (same
+initialisation as the reference); their forward() is never called.  All arithmetic goes through
+grappa_amd.ops (block-level autograd nodes -> C ABI).
+
+Restrictions (raise at construction): layer_norm=True, self_interaction=True,
+learnable_statistics=False -- the only values the reference's shipped configurations use.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backend import get_backend
+from .constants import CHARGE_ENCODING_DIM, DEFAULT_FEAT_DIMS, get_default_statistics
+
+
+# ------------------------------------------------------------------------------------------------ GNN
+class _GraphFC(nn.Module):
+    """holds DotGatConv's single bias-free projection as `fc.weight` (DGL naming)."""
+
+    def __init__(self, in_feats, out_feats, num_heads):
+        super().__init__()
+        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+
+
+class _SageParams(nn.Module):
+    """DGL SAGEConv('mean') parameter names: fc_self.weight, fc_neigh.weight, bias."""
+
+    def __init__(self, in_feats, out_feats):
+        super().__init__()
+        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=False)
+        self.fc_self = nn.Linear(in_feats, out_feats, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_feats))
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, in_feats, num_heads, dropout):
+        super().__init__()
+        assert in_feats % num_heads == 0
+        self.num_heads, self.p = num_heads, float(dropout)
+        self.graph_module = _GraphFC(in_feats, in_feats // num_heads, num_heads)
+        self.layer_norm = nn.LayerNorm(in_feats)
+        self.head_reducer = nn.Linear(in_feats, in_feats)
+        self.interaction_norm = nn.LayerNorm(in_feats)
+        self.self_interaction = nn.Sequential(nn.Linear(in_feats, 4 * in_feats), nn.ELU(), nn.Linear(4 * in_feats, in_feats), nn.ELU())
+
+    def forward(self, plan, h):
+        p = self.p if self.training else 0.0
+        s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+        si = self.self_interaction
+        return ops.AttBlockFn.apply(h, plan, self.num_heads, p, s1, s2, self.layer_norm.weight, self.layer_norm.bias,
+                                    self.graph_module.fc.weight, self.head_reducer.weight, self.head_reducer.bias,
+                                    self.interaction_norm.weight, self.interaction_norm.bias, si[0].weight, si[0].bias,
+                                    si[2].weight, si[2].bias)
+
+
+class ResidualConvBlock(nn.Module):
+    def __init__(self, in_feats, dropout):
+        super().__init__()
+        self.p = float(dropout)
+        self.graph_module = _SageParams(in_feats, in_feats)
+        self.layer_norm = nn.LayerNorm(in_feats)
+        self.self_interaction = nn.Sequential(nn.Linear(in_feats, in_feats), nn.ELU())
+        self.interaction_norm = nn.LayerNorm(in_feats)
+
+    def forward(self, plan, h):
+        p = self.p if self.training else 0.0
+        s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+        gm = self.graph_module
+        return ops.ConvBlockFn.apply(h, plan, p, s1, s2, self.layer_norm.weight, self.layer_norm.bias, gm.fc_self.weight,
+                                     gm.fc_neigh.weight, gm.bias, self.interaction_norm.weight, self.interaction_norm.bias,
+                                     self.self_interaction[0].weight, self.self_interaction[0].bias)
+
+
+class GrappaGNN(nn.Module):
+    """reference models/graph_attention.py:11-183"""
+
+    def __init__(self, out_feats=512, in_feats=None, node_feats=None, n_conv=3, n_att=3, n_heads=8,
+                 in_feat_name=("atomic_number", "ring_encoding", "partial_charge"), in_feat_dims={}, conv_dropout=0.,
+                 attention_dropout=0., final_dropout=0., initial_dropout=0., charge_encoding=True):
+        super().__init__()
+        if not isinstance(in_feat_name, (list, tuple)):
+            in_feat_name = [in_feat_name]
+        self.in_feat_name = list(in_feat_name)
+        dims = dict(DEFAULT_FEAT_DIMS)
+        dims.update(in_feat_dims)
+        if in_feats is None:
+            in_feats = sum(dims[f] for f in self.in_feat_name)
+        if node_feats is None:
+            node_feats = out_feats
+        self.charge_encoding = charge_encoding
+        self.in_feats = in_feats + (CHARGE_ENCODING_DIM if charge_encoding else 0)
+        self.p_initial, self.p_final = float(initial_dropout), float(final_dropout)
+        self.pre_dense = nn.Sequential(nn.Linear(self.in_feats, node_feats), nn.ELU())
+        self.no_convs = (n_conv + n_att) == 0
+        if not self.no_convs:
+            self.conv_blocks = nn.ModuleList([ResidualConvBlock(node_feats, conv_dropout) for _ in range(n_conv)])
+            self.att_blocks = nn.ModuleList([ResidualAttentionBlock(node_feats, n_heads, attention_dropout) for _ in range(n_att)])
+        self.post_dense = nn.Sequential(nn.Linear(node_feats, out_feats))
+        if not self.no_convs:
+            self.blocks = self.conv_blocks + self.att_blocks       # same aliasing as the reference (state-dict keys twice)
+
+    def input_features(self, g) -> torch.Tensor:
+        d = g.nodes["n1"].data
+        cols = [d[f].float() if d[f].dim() >= 2 else d[f].unsqueeze(-1).float() for f in self.in_feat_name]
+        n_plain = sum(c.shape[1] for c in cols)
+        N = cols[0].shape[0]
+        x = torch.zeros((N, self.in_feats), dtype=torch.float32, device=cols[0].device)
+        if n_plain + (CHARGE_ENCODING_DIM if self.charge_encoding else 0) != self.in_feats:
+            raise AssertionError(f"the input features must have {self.in_feats} columns in total, got {n_plain}")
+        torch.cat(cols, dim=-1, out=x[:, :n_plain])
+        if self.charge_encoding:
+            get_backend().charge_encoding(d["partial_charge"].float().contiguous(), CHARGE_ENCODING_DIM, -2.0, 2.0, x, n_plain)
+        return x
+
+    def forward(self, g):
+        plan = g.plan()
+        x = self.input_features(g)
+        p0 = self.p_initial if self.training else 0.0
+        h = ops.LinearFn.apply(x, self.pre_dense[0].weight, self.pre_dense[0].bias, ops.ELU, p0, ops.next_seed() if p0 > 0 else 0)
+        if not self.no_convs:
+            for blk in self.blocks:
+                h = blk(plan, h)
+        p1 = self.p_final if self.training else 0.0
+        h = ops.LinearFn.apply(h, self.post_dense[0].weight, self.post_dense[0].bias, 0, p1, ops.next_seed() if p1 > 0 else 0)
+        g.nodes["n1"].data["h"] = h
+        return g
+
+
+# ------------------------------------------------------------------------------------------------ writers
+class FeedForwardLayer(nn.Module):
+    """parameter holder: linear1, linear2, norm1 (reference models/network_utils.py:5-54)"""
+
+    def __init__(self, in_feats, hidden_feats, out_feats):
+        super().__init__()
+        self.linear1 = nn.Linear(in_feats, hidden_feats)
+        self.linear2 = nn.Linear(hidden_feats, out_feats)
+        self.norm1 = nn.LayerNorm(in_feats)
+
+    def params(self):
+        return (self.norm1.weight, self.norm1.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+
+
+class DottedAttWithMLP(nn.Module):
+    def __init__(self, n_feats, num_heads, hidden_feats, dropout):
+        super().__init__()
+        assert n_feats % num_heads == 0, f"Number of features ({n_feats}) must be divisible by the number of heads ({num_heads})."
+        self.num_heads, self.p = num_heads, float(dropout)
+        self.norm1 = nn.LayerNorm(n_feats)
+        self.attn = nn.MultiheadAttention(n_feats, num_heads, dropout=0)
+        self.ff = FeedForwardLayer(n_feats, hidden_feats, n_feats)
+
+    def forward(self, x, s, T):
+        p = self.p if self.training else 0.0
+        s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+        return ops.TransformerLayerFn.apply(x, s, T, self.num_heads, p, s1, s2, self.norm1.weight, self.norm1.bias,
+                                            self.attn.in_proj_weight, self.attn.in_proj_bias, self.attn.out_proj.weight,
+                                            self.attn.out_proj.bias, *self.ff.params())
+
+
+class GrappaTransformer(nn.Module):
+    def __init__(self, n_feats, n_heads, hidden_feats, n_layers, positional_encoding: Optional[torch.Tensor], dropout):
+        super().__init__()
+        if positional_encoding is not None:
+            self.register_buffer("positional_encoding", positional_encoding.float())
+            n_feats = n_feats + positional_encoding.shape[1]
+        else:
+            self.positional_encoding = None
+        if n_feats % n_heads:
+            raise ValueError(f"The number of input features cannot be divided by the number of heads: {n_feats} / {n_heads}")
+        self.n_feats = n_feats
+        self.transformer = nn.Sequential(*[DottedAttWithMLP(n_feats, n_heads, hidden_feats, dropout) for _ in range(n_layers)])
+
+
+class Symmetriser(nn.Module):
+    def __init__(self, in_feats, out_feats, permutations: torch.Tensor, hidden_feats, n_layers):
+        super().__init__()
+        assert n_layers >= 1, "n_layers must be >= 1"
+        P, s = permutations.shape
+        assert torch.all(permutations[0].int() == torch.arange(s).int()), "permutations must include the identity permutation at the zeroth entry."
+        self.register_buffer("permutation_prefactors", torch.ones(P, dtype=torch.float32).view(P, 1, 1))
+        self.register_buffer("permutations", permutations.int())
+        self.n_seq, self.out_feats = s, out_feats
+        layers = [FeedForwardLayer(in_feats * s, hidden_feats, hidden_feats if n_layers > 1 else out_feats)]
+        for i in range(1, n_layers):
+            layers.append(FeedForwardLayer(hidden_feats, hidden_feats, out_feats if i == n_layers - 1 else hidden_feats))
+        self.mlp = nn.Sequential(*layers)
+        self._perm_list = [tuple(int(v) for v in p) for p in permutations.tolist()]
+
+
+class SymmetrisedTransformer(nn.Module):
+    def __init__(self, n_feats, n_heads, hidden_feats, n_layers, out_feats, permutations, dropout, symmetriser_layers,
+                 symmetriser_hidden_feats, positional_encoding):
+        super().__init__()
+        if n_layers > 0:
+            self.grappa_transformer = GrappaTransformer(n_feats, n_heads, hidden_feats, n_layers, positional_encoding, dropout)
+            width = self.grappa_transformer.n_feats
+        else:
+            self.grappa_transformer = None
+            width = n_feats
+        self.symmetriser = Symmetriser(width, out_feats, permutations, symmetriser_hidden_feats, symmetriser_layers)
+
+    def forward(self, x, s, T):
+        """x: (s*T, F) token table (row = pos*T + t) -> (P*T, out_feats), one row per permuted copy."""
+        if self.grappa_transformer is not None:
+            for layer in self.grappa_transformer.transformer:
+                x = layer(x, s, T)
+        sym = self.symmetriser
+        flat = [t for ff in sym.mlp for t in ff.params()]
+        return ops.SymmetriserFn.apply(x, s, T, sym._perm_list, len(sym.mlp), *flat)
+
+
+class RepProjector(nn.Module):
+    def __init__(self, dim_tupel, in_feats, out_feats, improper=False):
+        super().__init__()
+        self.dim_tupel, self.improper = dim_tupel, improper
+        self.mlp = nn.Sequential(nn.Linear(in_feats, out_feats), nn.ELU())
+
+
+class ToPositive(nn.Module):
+    def __init__(self, mean, std, min_=0.):
+        super().__init__()
+        self.register_buffer("mean_over_std", torch.tensor(float(mean / std)))
+        self.register_buffer("std", torch.tensor(float(std)))
+        self.register_buffer("min_", torch.tensor(float(min_)))
+
+
+class ToRange(nn.Module):
+    def __init__(self, max_, std):
+        super().__init__()
+        self.register_buffer("std_over_max", torch.tensor(float(std / max_)).float())
+        self.register_buffer("max", torch.tensor(float(max_)).float())
+
+
+def _pos_enc(s, positional_encoding, wrong_symmetry=False):
+    if not positional_encoding or s == 2:
+        return None
+    if s == 3:
+        return torch.tensor([[0.], [1.], [0.]])
+    if wrong_symmetry:
+        return torch.tensor([[0.], [0.], [1.], [0.]])
+    return torch.tensor([[0.], [1.], [1.], [0.]])
+
+
+class _WriterBase(nn.Module):
+    level = "n2"
+    s = 2
+    kind = 0
+
+    def _model(self) -> SymmetrisedTransformer:
+        raise NotImplementedError
+
+    def _consts(self) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _tokens(self, g):
+        plan = g.plan()
+        lvl = self.level
+        h = g.nodes["n1"].data["h"]
+        model = self._model()
+        pe = None
+        if model.grappa_transformer is not None and model.grappa_transformer.positional_encoding is not None:
+            pe = model.grappa_transformer.positional_encoding.reshape(-1).contiguous()
+        lin = self.rep_projector.mlp[0]
+        x = ops.ProjGatherFn.apply(h, lin.weight, lin.bias, plan.idx32[lvl], plan.inv_ptr[lvl], plan.inv_rows[lvl], self.s, pe)
+        return x, plan.T[lvl]
+
+
+class WriteBondParameters(_WriterBase):
+    level, s, kind = "n2", 2, 0
+
+    def __init__(self, rep_feats, between_feats, suffix, stats, n_att, n_heads, dense_layers, dropout, symmetriser_feats, gate):
+        super().__init__()
+        eps = 1e-6
+        self.suffix, self.gate = suffix, gate
+        self.rep_projector = RepProjector(2, rep_feats, between_feats)
+        self.bond_model = SymmetrisedTransformer(between_feats, n_heads, between_feats, n_att, 2 + int(gate),
+                                                 torch.tensor([[0, 1], [1, 0]], dtype=torch.int32), dropout, dense_layers,
+                                                 symmetriser_feats, None)
+        self.to_k = ToPositive(stats["mean"]["n2_k"].item(), stats["std"]["n2_k"].item() + eps)
+        self.to_eq = ToPositive(stats["mean"]["n2_eq"].item(), stats["std"]["n2_eq"].item() + eps)
+
+    def _model(self):
+        return self.bond_model
+
+    def _consts(self):
+        return torch.stack([self.to_eq.mean_over_std, self.to_eq.std, self.to_eq.min_, self.to_k.mean_over_std, self.to_k.std,
+                            self.to_k.min_]).float().contiguous()
+
+    def forward(self, g):
+        x, T = self._tokens(g)
+        o = self.bond_model(x, 2, T)
+        k, eq = ops.ParamOutFn.apply(o, 0, T, 2, 0, False, 0.0, self._consts())
+        g.nodes["n2"].data["eq" + self.suffix] = eq
+        g.nodes["n2"].data["k" + self.suffix] = k           # harmonic_gate has no effect on the outputs (reference quirk Q3)
+        return g
+
+
+class WriteAngleParameters(_WriterBase):
+    level, s, kind = "n3", 3, 1
+
+    def __init__(self, rep_feats, between_feats, suffix, stats, n_att, n_heads, dense_layers, dropout, symmetriser_feats,
+                 positional_encoding, gate):
+        super().__init__()
+        eps = 1e-6
+        self.suffix, self.gate = suffix, gate
+        proj = between_feats - 1 if positional_encoding else between_feats
+        self.rep_projector = RepProjector(3, rep_feats, proj)
+        self.angle_model = SymmetrisedTransformer(proj, n_heads, between_feats, n_att, 2 + int(gate),
+                                                  torch.tensor([[0, 1, 2], [2, 1, 0]], dtype=torch.int32), dropout, dense_layers,
+                                                  symmetriser_feats, _pos_enc(3, positional_encoding))
+        self.to_k = ToPositive(stats["mean"]["n3_k"].item(), stats["std"]["n3_k"].item() + eps)
+        self.to_eq = ToRange(math.pi, stats["std"]["n3_eq"].item() + eps)
+
+    def _model(self):
+        return self.angle_model
+
+    def _consts(self):
+        z = torch.zeros((), dtype=torch.float32, device=self.to_k.std.device)
+        return torch.stack([self.to_eq.std_over_max, self.to_eq.max, z, self.to_k.mean_over_std, self.to_k.std, self.to_k.min_]).float().contiguous()
+
+    def forward(self, g):
+        if "n3" not in g.ntypes:
+            return g
+        x, T = self._tokens(g)
+        o = self.angle_model(x, 3, T)
+        k, eq = ops.ParamOutFn.apply(o, 1, T, 2, 0, False, 0.0, self._consts())
+        g.nodes["n3"].data["eq" + self.suffix] = eq
+        g.nodes["n3"].data["k" + self.suffix] = k
+        return g
+
+
+class WriteTorsionParameters(_WriterBase):
+    s, kind = 4, 2
+
+    def __init__(self, rep_feats, between_feats, suffix, n_periodicity, improper, n_att, n_heads, dense_layers, dropout,
+                 symmetriser_feats, stats, positional_encoding, gated, wrong_symmetry, cutoff):
+        super().__init__()
+        eps = 1e-1 if gated else 1e-2
+        self.gated, self.improper, self.suffix, self.cutoff_value = gated, improper, suffix, float(cutoff)
+        self.level = "n4_improper" if improper else "n4"
+        self.register_buffer("n_periodicity", torch.tensor(n_periodicity).long())
+        self._n_per = int(n_periodicity)
+        if not improper:
+            km, ks = stats["mean"]["n4_k"], stats["std"]["n4_k"] + eps
+        elif "n4_improper_k" not in stats["mean"]:
+            km, ks = torch.zeros(n_periodicity), torch.ones(n_periodicity)
+        else:
+            km, ks = stats["mean"]["n4_improper_k"], stats["std"]["n4_improper_k"] + eps
+            if len(km) < n_periodicity or len(ks) < n_periodicity:
+                raise ValueError(f"n_periodicity is {n_periodicity} but the param_statistics contains {len(km)} values for the improper torsion parameters.")
+        self.register_buffer("k_mean", km[:n_periodicity].clone().float().unsqueeze(0))
+        self.register_buffer("k_std", ks[:n_periodicity].clone().float().unsqueeze(0))
+        proj = between_feats - 1 if positional_encoding else between_feats
+        self.rep_projector = RepProjector(4, rep_feats, proj, improper=improper)
+        pe = _pos_enc(4, positional_encoding)
+        if not improper:
+            perms = [[0, 1, 2, 3], [3, 2, 1, 0]]
+        elif wrong_symmetry:
+            perms = [[0, 1, 2, 3], [3, 1, 2, 0], [1, 3, 2, 0], [0, 3, 2, 1], [3, 0, 2, 1], [1, 0, 2, 3]]
+            pe = _pos_enc(4, True, True)
+        else:
+            perms = [[0, 1, 2, 3], [3, 1, 2, 0]]
+        self._P = len(perms)
+        n_out = 2 * n_periodicity if gated else n_periodicity
+        self.torsion_model = SymmetrisedTransformer(proj, n_heads, between_feats, n_att, n_out, torch.tensor(perms, dtype=torch.int32),
+                                                    dropout, dense_layers, symmetriser_feats, pe)
+
+    def _model(self):
+        return self.torsion_model
+
+    def _consts(self):
+        return torch.cat([self.k_std.reshape(-1), self.k_mean.reshape(-1)]).float().contiguous()
+
+    def forward(self, g):
+        lvl = self.level
+        if lvl not in g.ntypes:
+            return g
+        x, T = self._tokens(g)
+        o = self.torsion_model(x, 4, T)
+        k = ops.ParamOutFn.apply(o, 2, T, self._P, self._n_per, self.gated, self.cutoff_value, self._consts())
+        g.nodes[lvl].data["k" + self.suffix] = k
+        return g
+
+
+class WriteParameters(nn.Module):
+    """reference models/interaction_parameters.py:10-135"""
+
+    def __init__(self, cfg: Dict, stats: Dict, suffix=""):
+        super().__init__()
+        rep, drop, pos = cfg["graph_node_features"], cfg["parameter_dropout"], cfg["positional_encoding"]
+        gate = cfg["harmonic_gate"]
+        self.bond_writer = WriteBondParameters(rep, cfg["bond_transformer_width"], suffix, stats, cfg["bond_transformer_depth"],
+                                               cfg["bond_n_heads"], cfg["bond_symmetriser_depth"], drop, cfg["bond_symmetriser_width"], gate)
+        self.angle_writer = WriteAngleParameters(rep, cfg["angle_transformer_width"], suffix, stats, cfg["angle_transformer_depth"],
+                                                 cfg["angle_n_heads"], cfg["angle_symmetriser_depth"], drop,
+                                                 cfg["angle_symmetriser_width"], pos, gate)
+        self.proper_writer = WriteTorsionParameters(rep, cfg["proper_transformer_width"], suffix, cfg["n_periodicity_proper"], False,
+                                                    cfg["proper_transformer_depth"], cfg["proper_n_heads"], cfg["proper_symmetriser_depth"],
+                                                    drop, cfg["proper_symmetriser_width"], stats, pos, cfg["gated_torsion"], False,
+                                                    cfg["torsion_cutoff"])
+        self.improper_writer = WriteTorsionParameters(rep, cfg["improper_transformer_width"], suffix, cfg["n_periodicity_improper"], True,
+                                                      cfg["improper_transformer_depth"], cfg["improper_n_heads"],
+                                                      cfg["improper_symmetriser_depth"], drop, cfg["improper_symmetriser_width"], stats, pos,
+                                                      cfg["gated_torsion"], cfg["wrong_symmetry"], cfg["torsion_cutoff"])
+
+    def forward(self, g):
+        g = self.bond_writer(g)
+        g = self.angle_writer(g)
+        g = self.proper_writer(g)
+        g = self.improper_writer(g)
+        return g
+
+
+class GrappaModel(nn.Module):
+    """Same constructor keywords, defaults and `forward(g) -> g` contract as the reference (models/grappa.py:51, :111-132)."""
+
+    def __init__(self, graph_node_features: int = 512, in_feats: int = None,
+                 in_feat_name: Union[str, List[str]] = ["atomic_number", "ring_encoding", "partial_charge"],
+                 in_feat_dims: Dict[str, int] = {}, gnn_width: int = None, gnn_attentional_layers: int = 3, gnn_convolutions: int = 3,
+                 gnn_attention_heads: int = 8, gnn_dropout_attention: float = 0., gnn_dropout_initial: float = 0.,
+                 gnn_dropout_conv: float = 0., gnn_dropout_final: float = 0., parameter_dropout: float = 0.,
+                 bond_transformer_depth=2, bond_n_heads=8, bond_transformer_width=512, bond_symmetriser_depth=2, bond_symmetriser_width=256,
+                 angle_transformer_depth=2, angle_n_heads=8, angle_transformer_width=512, angle_symmetriser_depth=2, angle_symmetriser_width=256,
+                 proper_transformer_depth=2, proper_n_heads=8, proper_transformer_width=512, proper_symmetriser_depth=2, proper_symmetriser_width=256,
+                 improper_transformer_depth=2, improper_n_heads=8, improper_transformer_width=512, improper_symmetriser_depth=2,
+                 improper_symmetriser_width=256, n_periodicity_proper=6, n_periodicity_improper=3, gated_torsion: bool = False,
+                 wrong_symmetry=False, positional_encoding=True, layer_norm=True, self_interaction=True, learnable_statistics: bool = False,
+                 param_statistics: dict = None, torsion_cutoff=1.e-4, harmonic_gate: bool = False):
+        super().__init__()
+        if not (layer_norm and self_interaction) or learnable_statistics:
+            raise NotImplementedError("grappa_amd implements layer_norm=True, self_interaction=True, learnable_statistics=False "
+                                      "(the values of every configuration the reference ships)")
+        if param_statistics is None:
+            param_statistics = get_default_statistics()
+        cfg = dict(locals())
+        for k in ("self", "__class__", "param_statistics"):
+            cfg.pop(k, None)
+        self.model_config = cfg
+        self.gnn = GrappaGNN(out_feats=graph_node_features, in_feats=in_feats, node_feats=gnn_width, n_conv=gnn_convolutions,
+                             n_att=gnn_attentional_layers, n_heads=gnn_attention_heads, in_feat_name=in_feat_name,
+                             in_feat_dims=in_feat_dims, conv_dropout=gnn_dropout_conv, attention_dropout=gnn_dropout_attention,
+                             final_dropout=gnn_dropout_final, initial_dropout=gnn_dropout_initial)
+        self.parameter_writer = WriteParameters(cfg, param_statistics)
+        self.field_of_view = gnn_attentional_layers + gnn_convolutions + 3
+
+    def forward(self, g):
+        # tuple-index consistency (reference grappa.py:122-128) is validated once per batch, on the host, when the plan is built
+        g.plan()
+        g = self.gnn(g)
+        g = self.parameter_writer(g)
+        return g

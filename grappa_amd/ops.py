@@ -1,0 +1,508 @@
+"""Block-level autograd nodes of the Grappa hot path.
+
+Each `torch.autograd.Function` below is one block of the reference's model with a hand-sequenced
+forward AND backward made of C-ABI kernel calls (grappa_amd.backend): nothing inside a block is
+differentiated by torch.  Gradient fan-in inside a block (residual branches) is folded into GEMM
+epilogues (`res=`), parameter gradients are accumulated by the kernels straight into `param.grad`
+(flat-buffer friendly: one RCCL all-reduce / one fused Adam over all of them), and dropout masks are
+regenerated from a counter-based hash instead of being stored.
+
+Reference blocks restated (file:line under /root/reference/src/grappa/):
+  LinearFn            models/graph_attention.py:98-101, :125-127 (pre_dense / post_dense)
+  AttBlockFn          models/graph_attention.py:276-310  (ResidualAttentionBlock + DGL DotGatConv)
+  ConvBlockFn         models/graph_attention.py:383-415  (ResidualConvBlock + DGL SAGEConv 'mean')
+  ProjGatherFn        models/interaction_parameters.py:155-180 (RepProjector) + perm_equiv_transformer.py:134-141
+  TransformerLayerFn  models/network_utils.py:112-133 (DottedAttWithMLP) incl. :44-54 (FeedForwardLayer)
+  SymmetriserFn       models/perm_equiv_transformer.py:239-276
+  ParamOutFn          models/interaction_parameters.py:252-266, :347-362, :536-560
+  MMEnergyFn          models/energy.py:99-145 + models/internal_coordinates.py:15-125
+  MolwiseLossFn       training/loss.py:45-167
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from .backend import get_backend
+from .constants import TUPLE_LEVELS
+
+ELU = 1
+_SEED = {"base": 0x5DEECE66D, "counter": 0}
+
+
+def manual_seed(seed: int) -> None:
+    """seed of the counter-based dropout masks (independent of torch's generators)."""
+    _SEED["base"] = int(seed) & (2 ** 63 - 1)
+    _SEED["counter"] = 0
+
+
+def next_seed() -> int:
+    _SEED["counter"] += 1
+    return (_SEED["base"] * 6364136223846793005 + _SEED["counter"] * 1442695040888963407) & (2 ** 63 - 1)
+
+
+def _new(shape, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _zeros(shape, like: torch.Tensor) -> torch.Tensor:
+    return torch.zeros(shape, dtype=torch.float32, device=like.device)
+
+
+def _pgrad(p: torch.Tensor) -> torch.Tensor:
+    """gradient buffer of a parameter (kernels accumulate into it)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# shared sub-sequences (plain functions on the backend; used inside the Functions)
+def _linear_bwd_params(be, dz, x, w, b):
+    """dW += dz^T x ; db += colsum(dz)."""
+    M, N = dz.shape
+    K = x.shape[1]
+    if M == 0:
+        return
+    if w.requires_grad:
+        be.gemm(dz, x, _pgrad(w), M=N, N=K, K=M, a_kcontig=False, b_kcontig=False, accumulate=True)
+    if b is not None and b.requires_grad:
+        be.colsum(dz, _pgrad(b), accumulate=True)
+
+
+def _ln_fwd(be, x, w, b):
+    M = x.shape[0]
+    y = _new(x.shape, x)
+    mean, rstd = _new((M,), x), _new((M,), x)
+    be.layernorm_fwd(x, w, b, y, mean, rstd)
+    return y, mean, rstd
+
+
+def _ln_bwd(be, dy, x, mean, rstd, w, b):
+    dx = _new(x.shape, x)
+    if x.shape[0] == 0:
+        return dx
+    be.layernorm_bwd(dy, x, mean, rstd, w, dx, _pgrad(w), _pgrad(b), accumulate=True)
+    return dx
+
+
+def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip):
+    """FeedForward: xn = LN(x); u = ELU(xn W1^T + b1); y = act2(u W2^T + b2); out = drop(y) (+ xn)."""
+    M = x.shape[0]
+    xn, mean, rstd = _ln_fwd(be, x, norm_w, norm_b)
+    Hd, Nout = w1.shape[0], w2.shape[0]
+    u = _new((M, Hd), x)
+    be.gemm(xn, w1, u, M=M, N=Hd, K=x.shape[1], bias=b1, act=ELU)
+    out = _new((M, Nout), x)
+    res = xn if skip else None
+    pre = None
+    if act2:
+        pre = _new((M, Nout), x)
+        be.gemm(u, w2, pre, M=M, N=Nout, K=Hd, bias=b2, act=ELU, drop_p=drop_p, drop_seed=seed, res=res, out2=out)
+    else:
+        be.gemm(u, w2, out, M=M, N=Nout, K=Hd, bias=b2, drop_p=drop_p, drop_seed=seed, res=res)
+    return out, (x, mean, rstd, xn, u, pre)
+
+
+def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip):
+    x, mean, rstd, xn, u, pre = saved
+    M = x.shape[0]
+    dout = _c(dout)
+    if act2 or drop_p > 0:
+        dz2 = _new(dout.shape, dout)
+        be.act_dropout_bwd(dout, pre if act2 else None, drop_p, seed, dz2)
+    else:
+        dz2 = dout
+    _linear_bwd_params(be, dz2, u, w2, b2)
+    dz1 = _new(u.shape, u)
+    be.gemm(dz2, w2, dz1, M=M, N=u.shape[1], K=dz2.shape[1], b_kcontig=False, aux=u)          # fused ELU'(u)
+    _linear_bwd_params(be, dz1, xn, w1, b1)
+    dxn = _new(xn.shape, xn)
+    be.gemm(dz1, w1, dxn, M=M, N=xn.shape[1], K=u.shape[1], b_kcontig=False, res=dout if skip else None)
+    return _ln_bwd(be, dxn, x, mean, rstd, norm_w, norm_b)
+
+
+# ------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = drop(act(x W^T + b))   (pre_dense / post_dense)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, drop_p, seed):
+        be = get_backend()
+        x = _c(x)
+        M, K = x.shape
+        N = w.shape[0]
+        y = _new((M, N), x)
+        pre = None
+        if act and drop_p > 0:
+            pre = _new((M, N), x)
+            be.gemm(x, w, pre, M=M, N=N, K=K, bias=b, act=act, drop_p=drop_p, drop_seed=seed, out2=y)
+        else:
+            be.gemm(x, w, y, M=M, N=N, K=K, bias=b, act=act, drop_p=drop_p, drop_seed=seed)
+        ctx.save_for_backward(x, w, b, pre if pre is not None else (y if act else None))
+        ctx.cfg = (act, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = get_backend()
+        x, w, b, ysaved = ctx.saved_tensors
+        act, drop_p, seed = ctx.cfg
+        dy = _c(dy)
+        if act or drop_p > 0:
+            dz = _new(dy.shape, dy)
+            be.act_dropout_bwd(dy, ysaved if act else None, drop_p, seed, dz)
+        else:
+            dz = dy
+        _linear_bwd_params(be, dz, x, w, b)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _new(x.shape, x)
+            be.gemm(dz, w, dx, M=x.shape[0], N=x.shape[1], K=w.shape[0], b_kcontig=False)
+        return dx, None, None, None, None, None
+
+
+class AttBlockFn(Function):
+    @staticmethod
+    def forward(ctx, h, plan, heads, drop_p, seed1, seed2, ln_w, ln_b, w_fc, w_r, b_r, ln2_w, ln2_b, w1, b1, w2, b2):
+        be = get_backend()
+        h = _c(h)
+        N, Fd = h.shape
+        h1, mean1, rstd1 = _ln_fwd(be, h, ln_w, ln_b)
+        ft = _new((N, w_fc.shape[0]), h)
+        be.gemm(h1, w_fc, ft, M=N, N=w_fc.shape[0], K=Fd)
+        m = _new(ft.shape, h)
+        alpha = _new((plan.E, heads), h)
+        be.gat_fwd(plan, ft, heads, ft.shape[1] // heads, m, alpha)
+        h3 = _new((N, Fd), h)
+        be.gemm(m, w_r, h3, M=N, N=Fd, K=m.shape[1], bias=b_r, drop_p=drop_p, drop_seed=seed1, res=h1)
+        out, ff_saved = _ff_fwd(be, h3, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
+        ctx.plan, ctx.cfg = plan, (heads, drop_p, seed1, seed2)
+        ctx.ff_saved = ff_saved
+        ctx.save_for_backward(h, mean1, rstd1, h1, ft, m, alpha, ln_w, ln_b, w_fc, w_r, b_r, ln2_w, ln2_b, w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        be = get_backend()
+        h, mean1, rstd1, h1, ft, m, alpha, ln_w, ln_b, w_fc, w_r, b_r, ln2_w, ln2_b, w1, b1, w2, b2 = ctx.saved_tensors
+        heads, drop_p, seed1, seed2 = ctx.cfg
+        plan = ctx.plan
+        N, Fd = h.shape
+        dh3 = _ff_bwd(be, ctx.ff_saved, dout, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
+        ctx.ff_saved = None
+        if drop_p > 0:
+            dzr = _new(dh3.shape, dh3)
+            be.act_dropout_bwd(dh3, None, drop_p, seed1, dzr)
+        else:
+            dzr = dh3
+        _linear_bwd_params(be, dzr, m, w_r, b_r)
+        dm = _new(m.shape, m)
+        be.gemm(dzr, w_r, dm, M=N, N=m.shape[1], K=Fd, b_kcontig=False)
+        dft = _new(ft.shape, ft)
+        be.gat_bwd(plan, ft, m, alpha, dm, heads, ft.shape[1] // heads, dft)
+        _linear_bwd_params(be, dft, h1, w_fc, None)
+        dh1 = _new(h1.shape, h1)
+        be.gemm(dft, w_fc, dh1, M=N, N=Fd, K=ft.shape[1], b_kcontig=False, res=dh3)        # + residual branch
+        dh = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
+        return (dh,) + (None,) * 16
+
+
+class ConvBlockFn(Function):
+    """LN -> SAGE(mean): ELU(W_self h + W_neigh mean_N(h) + b) -> drop -> +skip -> LN -> ELU(W h + b) -> drop -> +skip."""
+
+    @staticmethod
+    def forward(ctx, h, plan, drop_p, seed1, seed2, ln_w, ln_b, w_self, w_neigh, bias, ln2_w, ln2_b, w, b):
+        be = get_backend()
+        h = _c(h)
+        N, Fd = h.shape
+        h1, mean1, rstd1 = _ln_fwd(be, h, ln_w, ln_b)
+        mn = _new((N, Fd), h)
+        be.neighbor_mean(plan, h1, mn, False)
+        t = _new((N, Fd), h)
+        be.gemm(mn, w_neigh, t, M=N, N=Fd, K=Fd)
+        y1 = _new((N, Fd), h)          # ELU output before dropout
+        h3 = _new((N, Fd), h)
+        be.gemm(h1, w_self, y1, M=N, N=Fd, K=Fd, bias=bias, pre=t, act=ELU, drop_p=drop_p, drop_seed=seed1, res=h1, out2=h3)
+        h4, mean2, rstd2 = _ln_fwd(be, h3, ln2_w, ln2_b)
+        y2 = _new((N, Fd), h)
+        out = _new((N, Fd), h)
+        be.gemm(h4, w, y2, M=N, N=Fd, K=Fd, bias=b, act=ELU, drop_p=drop_p, drop_seed=seed2, res=h4, out2=out)
+        ctx.plan, ctx.cfg = plan, (drop_p, seed1, seed2)
+        ctx.save_for_backward(h, mean1, rstd1, h1, mn, y1, h3, mean2, rstd2, h4, y2, ln_w, ln_b, w_self, w_neigh, bias, ln2_w, ln2_b, w, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        be = get_backend()
+        (h, mean1, rstd1, h1, mn, y1, h3, mean2, rstd2, h4, y2, ln_w, ln_b, w_self, w_neigh, bias, ln2_w, ln2_b, w, b) = ctx.saved_tensors
+        drop_p, seed1, seed2 = ctx.cfg
+        plan = ctx.plan
+        N, Fd = h.shape
+        dout = _c(dout)
+        dz2 = _new(dout.shape, dout)
+        be.act_dropout_bwd(dout, y2, drop_p, seed2, dz2)
+        _linear_bwd_params(be, dz2, h4, w, b)
+        dh4 = _new(h4.shape, h4)
+        be.gemm(dz2, w, dh4, M=N, N=Fd, K=Fd, b_kcontig=False, res=dout)
+        dh3 = _ln_bwd(be, dh4, h3, mean2, rstd2, ln2_w, ln2_b)
+        dz1 = _new(dh3.shape, dh3)
+        be.act_dropout_bwd(dh3, y1, drop_p, seed1, dz1)
+        _linear_bwd_params(be, dz1, h1, w_self, bias)
+        _linear_bwd_params(be, dz1, mn, w_neigh, None)
+        dmn = _new(mn.shape, mn)
+        be.gemm(dz1, w_neigh, dmn, M=N, N=Fd, K=Fd, b_kcontig=False)
+        dh1 = _new(h1.shape, h1)
+        be.neighbor_mean(plan, dmn, dh1, True)                         # transpose of the mean aggregation
+        be.gemm(dz1, w_self, dh1, M=N, N=Fd, K=Fd, b_kcontig=False, res=dh3, accumulate=True)
+        dh = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
+        return (dh,) + (None,) * 13
+
+
+class ProjGatherFn(Function):
+    """a = ELU(h W^T + b) (N, Wp); x[pos*T+t] = [a[idx[t,pos]], pe[pos]] (s*T, Wp + has_pe)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, idx32, inv_ptr, inv_rows, s, pe):
+        be = get_backend()
+        h = _c(h)
+        N, R = h.shape
+        Wp = w.shape[0]
+        Fd = Wp + (1 if pe is not None else 0)
+        T = idx32.shape[0]
+        a = _zeros((N, Fd), h)
+        be.gemm(h, w, a[:, :Wp], M=N, N=Wp, K=R, bias=b, act=ELU)
+        x = _new((s * T, Fd), h)
+        if T:
+            be.tuple_gather_fwd(a, idx32, s, pe, x)
+        ctx.save_for_backward(h, w, b, a, inv_ptr, inv_rows)
+        ctx.cfg = (s, T, Wp, pe is not None)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        be = get_backend()
+        h, w, b, a, inv_ptr, inv_rows = ctx.saved_tensors
+        s, T, Wp, has_pe = ctx.cfg
+        N, R = h.shape
+        if T == 0:
+            return (torch.zeros_like(h),) + (None,) * 7
+        dx = _c(dx)
+        da = _new(a.shape, a)
+        be.tuple_gather_bwd(inv_ptr, inv_rows, dx, da, has_pe, False)
+        dz = _new((N, Wp), a)
+        be.act_dropout_bwd(da[:, :Wp], a[:, :Wp], 0.0, 0, dz)
+        _linear_bwd_params(be, dz, h, w, b)
+        dh = _new(h.shape, h)
+        be.gemm(dz, w, dh, M=N, N=R, K=Wp, b_kcontig=False)
+        return (dh,) + (None,) * 7
+
+
+class TransformerLayerFn(Function):
+    """x1 = LN(x); a = MHA(x1); x2 = drop(a Wo^T + bo) + x1; out = FF(x2) (skip on the normed input)."""
+
+    @staticmethod
+    def forward(ctx, x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2):
+        be = get_backend()
+        x = _c(x)
+        M, Fd = x.shape
+        x1, mean1, rstd1 = _ln_fwd(be, x, n1_w, n1_b)
+        qkv = _new((M, 3 * Fd), x)
+        be.gemm(x1, w_in, qkv, M=M, N=3 * Fd, K=Fd, bias=b_in)
+        att = _new((M, Fd), x)
+        if T:
+            be.seqattn_fwd(qkv, s, T, nheads, att)
+        x2 = _new((M, Fd), x)
+        be.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x1)
+        out, ff_saved = _ff_fwd(be, x2, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        ctx.cfg = (s, T, nheads, drop_p, seed1, seed2)
+        ctx.ff_saved = ff_saved
+        ctx.save_for_backward(x, mean1, rstd1, x1, qkv, att, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        be = get_backend()
+        x, mean1, rstd1, x1, qkv, att, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2 = ctx.saved_tensors
+        s, T, nheads, drop_p, seed1, seed2 = ctx.cfg
+        M, Fd = x.shape
+        if M == 0:
+            return (torch.zeros_like(x),) + (None,) * 18
+        dx2 = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        ctx.ff_saved = None
+        if drop_p > 0:
+            dzo = _new(dx2.shape, dx2)
+            be.act_dropout_bwd(dx2, None, drop_p, seed1, dzo)
+        else:
+            dzo = dx2
+        _linear_bwd_params(be, dzo, att, w_o, b_o)
+        datt = _new(att.shape, att)
+        be.gemm(dzo, w_o, datt, M=M, N=Fd, K=Fd, b_kcontig=False)
+        dqkv = _new(qkv.shape, qkv)
+        be.seqattn_bwd(qkv, datt, s, T, nheads, dqkv)
+        _linear_bwd_params(be, dqkv, x1, w_in, b_in)
+        dx1 = _new(x1.shape, x1)
+        be.gemm(dqkv, w_in, dx1, M=M, N=Fd, K=3 * Fd, b_kcontig=False, res=dx2)
+        dx = _ln_bwd(be, dx1, x, mean1, rstd1, n1_w, n1_b)
+        return (dx,) + (None,) * 18
+
+
+class SymmetriserFn(Function):
+    """o[p*T+t] = mlp(concat_j x[perm_p[j]*T + t]) for every permutation p (the sum over p is taken by ParamOutFn).
+    layers: list of (norm_w, norm_b, w1, b1, w2, b2, skip)."""
+
+    @staticmethod
+    def forward(ctx, x, s, T, perms, n_layers, *params):
+        be = get_backend()
+        x = _c(x)
+        Fd = x.shape[1]
+        P = len(perms)
+        layers = [params[6 * i:6 * i + 6] for i in range(n_layers)]
+        z = _new((P * T, s * Fd), x)
+        if T:
+            be.perm_concat_fwd(x, s, T, perms, z)
+        saved = []
+        cur = z
+        for i, (nw, nb, w1, b1, w2, b2) in enumerate(layers):
+            skip = (i != 0) and (i != n_layers - 1)
+            cur, sv = _ff_fwd(be, cur, nw, nb, w1, b1, w2, b2, False, 0.0, 0, skip)
+            saved.append(sv)
+        ctx.cfg = (s, T, perms, n_layers, tuple(x.shape))
+        ctx.saved_layers = saved
+        ctx.layers = layers
+        return cur
+
+    @staticmethod
+    def backward(ctx, dout):
+        be = get_backend()
+        s, T, perms, n_layers, xshape = ctx.cfg
+        nret = 5 + 6 * n_layers
+        if T == 0:
+            return (torch.zeros(xshape, dtype=torch.float32, device=dout.device),) + (None,) * (nret - 1)
+        g = _c(dout)
+        for i in reversed(range(n_layers)):
+            nw, nb, w1, b1, w2, b2 = ctx.layers[i]
+            skip = (i != 0) and (i != n_layers - 1)
+            g = _ff_bwd(be, ctx.saved_layers[i], g, nw, nb, w1, b1, w2, b2, False, 0.0, 0, skip)
+        ctx.saved_layers = None
+        dx = torch.empty(xshape, dtype=torch.float32, device=dout.device)
+        be.perm_concat_bwd(g, s, T, perms, dx)
+        return (dx,) + (None,) * (nret - 1)
+
+
+class ParamOutFn(Function):
+    """(k, eq) = output map of sum_p o[p*T+t]; kind 0 bond, 1 angle, 2 torsion (eq is None)."""
+
+    @staticmethod
+    def forward(ctx, o, kind, T, P, n_per, gated, cutoff, consts):
+        be = get_backend()
+        o = _c(o)
+        if kind == 2:
+            k = _new((T, n_per), o)
+            eq = None
+        else:
+            k, eq = _new((T,), o), _new((T,), o)
+        if T:
+            be.param_out_fwd(kind, o, T, P, n_per, gated, cutoff, consts, k, eq)
+        ctx.save_for_backward(o, consts)
+        ctx.cfg = (kind, T, P, n_per, gated, cutoff)
+        if kind == 2:
+            return k
+        return k, eq
+
+    @staticmethod
+    def backward(ctx, dk, deq=None):
+        be = get_backend()
+        o, consts = ctx.saved_tensors
+        kind, T, P, n_per, gated, cutoff = ctx.cfg
+        d_o = _new(o.shape, o)
+        if T:
+            be.param_out_bwd(kind, o, T, P, n_per, gated, cutoff, consts, _c(dk) if dk is not None else None,
+                             _c(deq) if deq is not None else None, d_o)
+        return (d_o,) + (None,) * 7
+
+
+class MMEnergyFn(Function):
+    """(E (B,C), E_terms (4,B,C), G (N,C,3)) from xyz and the force-field parameters; backward -> dL/dk, dL/deq."""
+
+    @staticmethod
+    def forward(ctx, xyz, plan, n_per, offset_torsion, want_gradient, tuple_out, k2, eq2, k3, eq3, k4, k4i):
+        be = get_backend()
+        xyz = _c(xyz)
+        ks = [_c(k2), _c(k3), _c(k4), _c(k4i)]
+        eqs = [_c(eq2), _c(eq3), None, None]
+        B, Cc = plan.B, xyz.shape[1]
+        energy = _new((B, Cc), xyz)
+        terms = _new((4, B, Cc), xyz)
+        te = tx = None
+        if tuple_out is not None:
+            te, tx = tuple_out
+        be.mm_energy_fwd(plan, xyz, ks, eqs, n_per, offset_torsion, energy, terms, te, tx)
+        grad = _new(xyz.shape, xyz)
+        if want_gradient:
+            be.mm_gradient_fwd(plan, xyz, ks, eqs, n_per, grad)
+        else:
+            grad.zero_()
+        ctx.plan, ctx.cfg = plan, (n_per, offset_torsion, want_gradient)
+        ctx.save_for_backward(xyz, *ks, eqs[0], eqs[1])
+        ctx.mark_non_differentiable(terms)
+        return energy, terms, grad
+
+    @staticmethod
+    def backward(ctx, gE, gterms, gG):
+        be = get_backend()
+        xyz, k2, k3, k4, k4i, eq2, eq3 = ctx.saved_tensors
+        n_per, offset_torsion, want_gradient = ctx.cfg
+        plan = ctx.plan
+        ks, eqs = [k2, k3, k4, k4i], [eq2, eq3, None, None]
+        gks = [torch.zeros_like(k) for k in ks]
+        geqs = [torch.zeros_like(eq2), torch.zeros_like(eq3), None, None]
+        be.mm_bwd(plan, xyz, ks, eqs, n_per, offset_torsion, _c(gE) if gE is not None else None,
+                  _c(gG) if (gG is not None and want_gradient) else None, gks, geqs)
+        return None, None, None, None, None, None, gks[0], geqs[0], gks[1], geqs[1], gks[2], gks[3]
+
+
+class MolwiseLossFn(Function):
+    """scalar loss = sum_m l_m * inv_B; the gradients are produced by the same kernels in the forward pass."""
+
+    @staticmethod
+    def forward(ctx, plan, cfg, energy, gradient, k2, eq2, k3, eq3, k4, k4i):
+        be = get_backend()
+        dev = plan.device
+        B = plan.B
+        inv_B = cfg["inv_B"]
+        loss_mol = torch.zeros((B,), dtype=torch.float32, device=dev)
+        wE, wG = cfg["energy_weight"], cfg["gradient_weight"]
+        gE = torch.zeros_like(energy) if (energy is not None and wE != 0) else None
+        gG = torch.zeros_like(gradient) if (gradient is not None and wG != 0) else None
+        if wE != 0 or wG != 0:
+            be.loss_ef(plan, _c(energy) if wE != 0 else None, cfg["energy_ref"] if wE != 0 else None, cfg["is_dummy"],
+                       _c(gradient) if wG != 0 else None, cfg["gradient_ref"] if wG != 0 else None, wE, wG, inv_B, loss_mol, gE, gG)
+        params = [k2, eq2, k3, eq3, k4, k4i]
+        gps = [None] * 6
+        if cfg["param_active"]:
+            params_c = [(_c(p) if (p is not None and cfg["param_used"][i]) else None) for i, p in enumerate(params)]
+            gps = [torch.zeros_like(p) if p is not None else None for p in params_c]
+            be.loss_param(plan, params_c, cfg["refs"], cfg["fac"], cfg["reg"], cfg["pw"], inv_B, loss_mol, gps)
+        ctx.grads = (gE, gG, gps)
+        ctx.loss_mol = loss_mol
+        ctx.mark_non_differentiable(loss_mol)
+        return loss_mol.sum() * inv_B, loss_mol
+
+    @staticmethod
+    def backward(ctx, gl, _gmol):
+        gE, gG, gps = ctx.grads
+        one = (gl.numel() == 1 and float(gl) == 1.0) if gl.device.type == "cpu" else False
+
+        def sc(t):
+            if t is None:
+                return None
+            return t if one else t * gl
+
+        return (None, None, sc(gE), sc(gG)) + tuple(sc(g) for g in gps)

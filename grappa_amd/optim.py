@@ -1,0 +1,76 @@
+"""Flat parameter/gradient buffers + fused Adam with global-norm clipping.
+
+The reference trains with torch.optim.Adam(lr, weight_decay) under Lightning's gradient_clip_val=10
+(training/lightning_model.py:297-299, lightning_trainer.py:92).  Here all parameters (40.8 M for the
+production model) live in ONE fp32 buffer and all gradients in another: the HIP kernels accumulate
+into views of the gradient buffer, data parallelism is one all-reduce of it, and the optimiser step is
+two kernels (sum of squares, Adam with the clip factor computed on the device -- no host sync).
+"""
+from typing import Iterable, List, Optional
+
+import torch
+
+from .backend import get_backend
+
+
+class FlatParams:
+    """Re-points every distinct parameter of a module into one contiguous buffer (and its .grad likewise)."""
+
+    def __init__(self, module: torch.nn.Module):
+        params, seen = [], set()
+        for p in module.parameters():
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                params.append(p)
+        if not params:
+            raise ValueError("module has no trainable parameters")
+        dev = params[0].device
+        sizes = [((p.numel() + 3) // 4) * 4 for p in params]        # keep every view 16-byte aligned
+        total = sum(sizes)
+        self.data = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p, sz in zip(params, sizes):
+            n = p.numel()
+            self.data[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.data[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            off += sz
+        self.params: List[torch.nn.Parameter] = params
+        self.numel = total
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class FusedAdam:
+    def __init__(self, flat: FlatParams, lr: float = 1.5e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 max_grad_norm: Optional[float] = 10.0):
+        self.flat = flat
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.m = torch.zeros_like(flat.data)
+        self.v = torch.zeros_like(flat.data)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=flat.data.device)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale: float = 1.0):
+        be = get_backend()
+        self.step_count += 1
+        sumsq = None
+        if self.max_grad_norm is not None:
+            be.sumsq(self.flat.grad, self.sumsq, accumulate=False)
+            sumsq = self.sumsq
+        be.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                     self.step_count, grad_scale, sumsq, self.max_grad_norm if self.max_grad_norm is not None else 0.0)
+
+    def grad_norm(self) -> torch.Tensor:
+        return torch.sqrt(self.sumsq[0])
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count = int(sd["step"]); self.lr = float(sd.get("lr", self.lr))

@@ -1,0 +1,243 @@
+/* grappa_hip.h -- C ABI of libgrappa_hip.so: the MI355X (gfx950) kernels of the Grappa hot path.
+ *
+ * The reference (hits-mbm-dev/grappa) has no native layer: every function below replaces a piece of
+ * Python that today expands into torch/DGL device kernels.  Each entry point cites the reference
+ * lines (relative to /root/reference/src/grappa/) whose arithmetic it computes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed / torch.cuda tensor storage) unless named h_*;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - no allocation, no global state, re-entrant per stream; scratch comes from the caller
+ *     (`ws`, `ws_bytes`; sizes from the *_workspace_bytes() queries);
+ *   - return 0 on success, a negative GRAPPA_ERR_* otherwise (never throws / aborts);
+ *   - fp32 activations, int32 indices, row-major, leading dimensions in ELEMENTS.
+ */
+#ifndef GRAPPA_HIP_H
+#define GRAPPA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAPPA_OK 0
+#define GRAPPA_ERR_ARG (-1)        /* unsupported shape / null pointer / bad enum */
+#define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
+#define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
+
+#define GRAPPA_ABI_VERSION 1
+int grappa_abi_version(void);
+/* name of the offload arch the library was compiled for ("gfx950") */
+const char* grappa_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense blocks (fp32 MFMA v_mfma_f32_32x32x2_f32).  C = epilogue(opA(A) * opB(B)).
+ *   A(m,k) = a_kcontig ? A[m*lda + k] : A[k*lda + m]
+ *   B(n,k) = b_kcontig ? B[n*ldb + k] : B[k*ldb + n]
+ *   forward  Y = X W^T      : a_kcontig=1 (X[M,K]),  b_kcontig=1 (W[N,K])   nn.Linear
+ *   dgrad    dX = dY W      : a_kcontig=1 (dY[M,N']), b_kcontig=0 (W[N',K'])
+ *   wgrad    dW = dY^T X    : a_kcontig=0 (dY[tok,N']), b_kcontig=0 (X[tok,K'])
+ * epilogue, in this order, per element v = acc(m,n):
+ *   v += pre[m,n]                          (pre != NULL: pre-activation addend, e.g. a second GEMM's result)
+ *   v += bias[n]                           (bias != NULL)
+ *   v  = elu(v)                            (act == GRAPPA_ACT_ELU)
+ *   v *= (aux[m,n] > 0 ? 1 : aux[m,n]+1)   (aux != NULL: ELU'(z) from the saved ELU output)
+ *   if (C2) { C[m,n] = v; }                (pre-dropout copy kept for the backward pass)
+ *   v  = keep(seed, m*N+n) ? v/(1-p) : 0   (drop_p > 0; counter based, see grappa_dropout_keep)
+ *   v += res[m,n]                          (res != NULL)
+ *   v += OUT[m,n]                          (accumulate != 0)
+ *   OUT[m,n] = v                           OUT = C2 ? C2 : C
+ * Replaces: torch.nn.Linear / ELU / Dropout / residual adds in models/graph_attention.py:98-101,
+ * :125-127, :261-272, :286-308; models/network_utils.py:44-54, :112-126 (in_proj/out_proj of
+ * nn.MultiheadAttention); models/interaction_parameters.py:148-161; perm_equiv_transformer.py:231-264.
+ */
+#define GRAPPA_ACT_NONE 0
+#define GRAPPA_ACT_ELU 1
+
+typedef struct grappa_gemm_desc {
+    int M, N, K;
+    int a_kcontig, b_kcontig;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    float* C2; int ldc2;          /* optional second output (see above) */
+    const float* bias;            /* [N] or NULL */
+    const float* res; int ldres;  /* [M,N] or NULL */
+    const float* aux; int ldaux;  /* [M,N] or NULL */
+    const float* pre; int ldpre;  /* [M,N] or NULL */
+    int act;
+    float drop_p;
+    uint64_t drop_seed;
+    int accumulate;
+} grappa_gemm_desc;
+
+size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);
+int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes);
+
+/* out[n] (+)= sum_m x[m*ldx + n]   (bias gradients) */
+size_t grappa_colsum_workspace_bytes(int M, int N);
+int grappa_colsum_f32(void* stream, int M, int N, const float* x, int ldx, float* out, int accumulate,
+                      void* ws, size_t ws_bytes);
+
+/* dz = dy * keep(seed,idx)/(1-p) * (y ? elu'(y) : 1)   elementwise over an [M,N] view (backward of the
+ * act+dropout epilogue).  y == NULL: no activation.  dz may alias dy. */
+int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
+                               float drop_p, uint64_t drop_seed, float* dz, int lddz);
+
+/* y = x + z elementwise (used to merge gradient branches); y may alias x */
+int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float* y);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (eps = 1e-5, biased variance), one wavefront per row.
+ * W % 4 == 0 and W <= 2048.  Replaces torch.nn.LayerNorm in graph_attention.py:258,:265;
+ * network_utils.py:38,:98. */
+int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
+                             float* y, int ldy, float* mean, float* rstd);
+size_t grappa_layernorm_bwd_workspace_bytes(int M, int W);
+/* dx may alias dy.  dgamma/dbeta: accumulate != 0 adds to the existing values. */
+int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
+                             const float* mean, const float* rstd, const float* gamma,
+                             float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                             void* ws, size_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph attention message passing (DGL DotGatConv, graph_attention.py:249/:283 -> DGL u_dot_v +
+ * edge_softmax + u_mul_e/sum): for every destination v and head h
+ *     alpha_uv = softmax_{u in N(v)} <ft_u,ft_v>/sqrt(D),  out_v = sum_u alpha_uv ft_u.
+ * CSR by destination: indptr[N+1], indices[E] (source ids).  F = H*D floats per row, D % 4 == 0,
+ * D/4 a power of two <= 64, F <= 2048.  alpha[E,H] is written for the backward pass.
+ * Backward (dft = dL/dft) uses rev[E] (slot of the reverse edge; the bond graph is symmetric) and
+ * delta[N,H] scratch; it gathers -- no atomics, bitwise reproducible. */
+int grappa_gat_fwd_f32(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices,
+                       const float* ft, float* out, float* alpha);
+int grappa_gat_bwd_f32(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const int* rev,
+                       const float* ft, const float* out, const float* alpha, const float* dout,
+                       float* dft, float* delta /* [N,H] scratch */);
+/* DGL SAGEConv 'mean' aggregation (graph_attention.py:360-363,:391):
+ * out_v = sum_{u in N(v)} x_u * (scale_by_neighbor ? 1/deg(u) : 1/deg(v)).
+ * forward: scale_by_neighbor = 0; backward (symmetric graph): scale_by_neighbor = 1 on d(out). */
+int grappa_neighbor_mean_f32(void* stream, int N, int F, const int* indptr, const int* indices,
+                             const float* x, float* out, int scale_by_neighbor);
+
+/* ------------------------------------------------------------------------------------------------
+ * Input featurisation: sinusoidal encoding of the partial charge, graph_attention.py:428-444.
+ * enc[n, 2j] = sin(s f_j), enc[n, 2j+1] = cos(s f_j), s = (clamp(q,lo,hi)+hi)/(hi-lo), f_j = 1e4^(-j/(dim/2)).
+ * Written into out[n*ldo + col0 ...]. */
+int grappa_charge_encoding_f32(void* stream, int N, const float* q, int dim, float lo, float hi, float* out, int ldo, int col0);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tuple (n-body) stage.  Token table layout everywhere: row = pos*T + t  (the reference's
+ * (n_seq, n_batch, n_feats) tensors, interaction_parameters.py:173-178).
+ * gather : x[pos*T+t, 0:W] = a[idx[t*s+pos], 0:W]; if pe: x[.., W-1] = pe[pos]  (RepProjector gather
+ *          + positional-encoding concat, perm_equiv_transformer.py:134-141).
+ * gather_bwd: da[n, 0:W] = sum over rows r in inv_rows[inv_ptr[n] : inv_ptr[n+1]] of dx[r, 0:W]
+ *          (column W-1 zeroed when has_pe). */
+int grappa_tuple_gather_fwd_f32(void* stream, int T, int s, int W, const float* a, int lda, const int* idx,
+                                const float* pe, float* x, int ldx);
+int grappa_tuple_gather_bwd_f32(void* stream, int N, int W, const int* inv_ptr, const int* inv_rows,
+                                const float* dx, int lddx, float* da, int ldda, int has_pe, int accumulate);
+
+/* nn.MultiheadAttention over the s <= 4 tokens of each tuple (network_utils.py:105,:122):
+ * qkv[pos*T+t, 3F] = [q|k|v], head h = columns h*dh.. of each third; out[pos*T+t, F].
+ * dh % 4 == 0, dh/4 a power of two, F = nheads*dh <= 1024. */
+int grappa_seqattn_fwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out);
+int grappa_seqattn_bwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv);
+
+/* Symmetriser input (perm_equiv_transformer.py:248-261): z[p*T+t, j*F+f] = x[perm[p*s+j]*T+t, f].
+ * bwd: dx[i*T+t, f] = sum_p dz[p*T+t, inv_p(i)*F+f].  h_perm is a HOST array (P*s ints). */
+int grappa_perm_concat_fwd_f32(void* stream, int s, int T, int F, int P, const int* h_perm, const float* x, float* z);
+int grappa_perm_concat_bwd_f32(void* stream, int s, int T, int F, int P, const int* h_perm, const float* dz, float* dx);
+
+/* Output maps (interaction_parameters.py:252-266, :347-362, :536-560; final_layer.py:52,:91-97;
+ * network_utils.py:144-145).  o[P*T, ldo] is the symmetriser MLP output for all P permuted copies;
+ * c = sum_p o[p*T+t, :].
+ *   kind BOND : eq = std_e*(elu(mos_e + c0 - 1)+1)+min_e ; k = std_k*(elu(mos_k + c1 - 1)+1)+min_k
+ *   kind ANGLE: eq = max*sigmoid(som*c0)                 ; k as above
+ *   kind TORSION: gated ? k_n = c_n*sigmoid(c_{np+n})*k_std[n] : k_n = c_n*k_std[n]+k_mean[n];
+ *                 k_n = |k_n| > cutoff ? k_n : 0
+ * consts (device, float): BOND  [mos_e,std_e,min_e,mos_k,std_k,min_k];
+ *                         ANGLE [som,max,0,mos_k,std_k,min_k];  TORSION [k_std[np] | k_mean[np]]. */
+#define GRAPPA_OUT_BOND 0
+#define GRAPPA_OUT_ANGLE 1
+#define GRAPPA_OUT_TORSION 2
+int grappa_param_out_fwd_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff,
+                             const float* o, int ldo, const float* consts, float* k, float* eq);
+int grappa_param_out_bwd_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff,
+                             const float* o, int ldo, const float* consts, const float* dk, const float* deq,
+                             float* d_o);
+
+/* ------------------------------------------------------------------------------------------------
+ * Molecular-mechanics energy / force and its backward (models/internal_coordinates.py:15-125,:150-210;
+ * models/energy.py:8-71,:99-145).  xyz[N,C,3].  Per level: idx[T,s], k (T or T*n_per), eq (T), mol_ptr[B+1].
+ *   energy  : E[b,c] = sum of 1/2 k (x-eq)^2 (bonds, angles) + sum_n k_n cos(n phi) (+|k_n| if offset)
+ *             per-term totals term_energy[4,B,C]; optional per-tuple energies tuple_e[l] (T_l,C).
+ *   gradient: G[a,c,:] = dE/dxyz via the atom->tuple incidence (inc_ptr[N+1], inc_code = t<<4|level<<2|pos).
+ *   backward: given gE[B,C] and gG[N,C,3] (either may be NULL): gk, geq per tuple (closed form of the
+ *             double backward through autograd.grad(create_graph=True), energy.py:139).
+ * conf_mask[B,C] (NULL = all ones) is NOT applied here; dummy conformations are handled by the loss. */
+typedef struct grappa_mm_desc {
+    int N, C, B;
+    const float* xyz;
+    int T[4];                 /* n2, n3, n4, n4_improper */
+    const int* idx[4];
+    const float* k[4];
+    const float* eq[4];       /* [2],[3] unused */
+    const int* mol_ptr[4];
+    int n_per[4];             /* [0],[1] unused */
+    int offset_torsion;
+    const int* inc_ptr;
+    const int* inc_code;
+    const int* atom_molptr;   /* [B+1] */
+} grappa_mm_desc;
+
+int grappa_mm_energy_fwd_f32(void* stream, const grappa_mm_desc* d, float* energy, float* term_energy,
+                             float* const tuple_e[4], float* const tuple_x[4]);
+int grappa_mm_gradient_fwd_f32(void* stream, const grappa_mm_desc* d, float* grad);
+int grappa_mm_bwd_f32(void* stream, const grappa_mm_desc* d, const float* gE, const float* gG,
+                      float* const gk[4], float* const geq[4]);
+
+/* ------------------------------------------------------------------------------------------------
+ * MolwiseLoss (training/loss.py:45-167 with utils/graph_utils.py:35-86), one workgroup per molecule:
+ *  l_m = wE*mean_c((E-<E>)-(Eref-<Eref>))^2 + wG*mean_{a,c,xyz}(G-Gref)^2   over real conformations
+ *  loss_mol[b] = l_m ; gE = d(sum_m l_m * inv_B)/dE ; gG likewise.  is_dummy may be NULL. */
+int grappa_loss_ef_fwd_bwd_f32(void* stream, int B, int C, int N, const int* atom_molptr,
+                               const float* energy, const float* energy_ref, const float* is_dummy,
+                               const float* grad, const float* grad_ref, float wE, float wG, float inv_B,
+                               float* loss_mol, float* gE, float* gG);
+/* parameter MSE vs classical parameters (NaN references masked) + L2 on torsion k, per molecule:
+ *  loss_mol[b] += pw[b] * sum_levels fac_l^2 sum (p-pref)^2 / (#entries) + reg terms; d/dp written to gp[l]
+ *  (every entry of gp[l] is overwritten).  levels: 0 n2_k, 1 n2_eq, 2 n3_k, 3 n3_eq, 4 n4_k, 5 n4_improper_k.
+ *  ref[l] may be NULL (level skipped in the MSE); width[l] = columns; ref_width[l] = columns of ref. */
+typedef struct grappa_ploss_desc {
+    int B;
+    const int* mol_ptr[6];
+    const float* p[6];
+    const float* ref[6];
+    int width[6];
+    int ref_width[6];
+    float fac[6];
+    float reg[6];             /* L2 prefactor per level (only [4],[5] non-zero in the reference) */
+    const float* pw;          /* [B] parameter weight per molecule, or NULL = no MSE term */
+    float inv_B;
+} grappa_ploss_desc;
+int grappa_loss_param_fwd_bwd_f32(void* stream, const grappa_ploss_desc* d, float* loss_mol, float* const gp[6]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser (training/lightning_model.py:297-299 Adam; lightning_trainer.py:92 gradient_clip_val=10):
+ * sumsq: out[0] (+)= sum x^2.  adam: p -= lr * mhat/(sqrt(vhat)+eps) with g scaled by
+ * clip = min(1, max_norm/(sqrt(*sumsq)+1e-6)) when sumsq != NULL; grad_scale multiplies g first. */
+size_t grappa_sumsq_workspace_bytes(size_t n);
+int grappa_sumsq_f32(void* stream, size_t n, const float* x, float* out, int accumulate, void* ws, size_t ws_bytes);
+int grappa_adam_step_f32(void* stream, size_t n, float* p, const float* g, float* m, float* v,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float grad_scale, const float* sumsq, float max_norm);
+
+/* the dropout decision used by every kernel above, exposed for tests: 1 = keep */
+int grappa_dropout_keep(uint64_t seed, uint64_t index, float p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPPA_HIP_H */

@@ -86,3 +86,13 @@ def rel_err(a, b, floor):
     if a.size == 0:
         return 0.0
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def rel_err_scaled(a, b, floor_frac=1e-3, floor_abs=0.0):
+    """max |a-b| / max(|b|, floor) with floor = max(floor_abs, floor_frac * max|b|): element-wise relative error whose
+    floor follows the scale of the tensor (forces/energies are sums of O(20) large terms that cancel; an element that
+    cancels to ~0 keeps the absolute rounding error of its summands)."""
+    b64 = np.asarray(b, dtype=np.float64)
+    if b64.size == 0:
+        return 0.0
+    return rel_err(a, b, max(floor_abs, floor_frac * float(np.abs(b64).max())))

@@ -1,0 +1,66 @@
+"""CPU: the product's model / energy / loss host logic (block-level forward+backward sequencing in
+grappa_amd.ops, batch plan, state-dict layout) driven through the test-only RefBackend, against the
+golden fixtures produced by the reference."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+import grappa_amd
+from grappa_amd import Energy, GrappaModel, MolwiseLoss
+
+# parity: |a-b| <= 1e-4 * max(|b|, floor); floors = the scale below which a quantity is physically zero
+# (bond/angle k ~ 1e2..1e3, torsion k: statistics std 0.1..1.2 kcal/mol and a hard cutoff at 1e-4)
+FLOORS = {"k": 1e-3, "kt": 1e-2, "eq": 1e-4, "energy": 1e-3, "gradient": 1e-2}
+
+
+def _run(fx_name, n_confs, refs):
+    fx = gu.load(fx_name)
+    cfg = gu.config_of(fx)
+    g = gu.build_batch(gu.molecules_of(fx), n_confs, refs, (cfg["n_periodicity_proper"], cfg["n_periodicity_improper"]))
+    model = GrappaModel(**cfg)
+    missing = model.load_state_dict(gu.state_dict_of(fx))
+    model.eval()
+    g = Energy()(model(g))
+    loss = MolwiseLoss(**gu.loss_kwargs_of(fx))(g)
+    loss.backward()
+    return fx, g, loss, model
+
+
+@pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False)])
+def test_product_host_path_matches_reference(ref_backend, name, n_confs, refs):
+    fx, g, loss, model = _run(name, n_confs, refs)
+    out = gu.outputs_of(fx)
+    for lvl in ["n2", "n3", "n4", "n4_improper"]:
+        assert np.array_equal(out[f"{lvl}_idxs"], g.nodes[lvl].data["idxs"].numpy())
+        assert gu.rel_err(g.nodes[lvl].data["k"].detach(), out[f"{lvl}_k"], FLOORS["kt" if lvl.startswith("n4") else "k"]) < 1e-4, lvl
+        if lvl in ("n2", "n3"):
+            assert gu.rel_err(g.nodes[lvl].data["eq"].detach(), out[f"{lvl}_eq"], FLOORS["eq"]) < 1e-4, lvl
+        assert gu.rel_err(g.nodes[lvl].data["x"], out[f"{lvl}_x"], 1e-3) < 1e-4, lvl
+        assert gu.rel_err(g.nodes["g"].data[f"energy_{lvl}"], out[f"energy_{lvl}"], 1e-3) < 1e-4, lvl
+    assert gu.rel_err(g.nodes["n1"].data["h"].detach(), out["h"], 1e-1) < 1e-4   # h = O(1) embedding
+    assert gu.rel_err_scaled(g.nodes["g"].data["energy"].detach(), out["energy"], 1e-3, FLOORS["energy"]) < 1e-4
+    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach(), out["gradient"], 1e-3, FLOORS["gradient"]) < 1e-4
+    assert gu.rel_err(loss.detach(), out["loss"], 1e-6) < 1e-4
+    n = 0
+    for k, p in model.named_parameters():
+        ref = out.get("grad::" + k)
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = max(float(np.abs(ref).max()), 1e-8)
+        assert float(np.abs(p.grad.numpy() - ref).max()) / scale < 2e-3, k
+        n += 1
+    assert n > 50
+
+
+def test_state_dict_keys_match_reference():
+    fx = gu.load("ref_small_att.npz")
+    sd_ref = gu.state_dict_of(fx)
+    sd = GrappaModel(**gu.config_of(fx)).state_dict()
+    assert list(sd.keys()) == list(sd_ref.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(sd_ref[k].shape) and sd[k].dtype == sd_ref[k].dtype, k
+    prod = grappa_amd.model_from_config(grappa_amd.get_default_model_config())
+    assert sum(p.numel() for p in prod.parameters()) == 40803347
+    assert len(prod.state_dict()) == 410
