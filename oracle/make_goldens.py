@@ -11,7 +11,6 @@ loss.backward().  The dihedral noise (models/internal_coordinates.py:194-196, SU
 to zero while the goldens are produced; a noise-on run is recorded beside it to bound its effect.
 Batches avoid exactly-3 angles / exactly-3 conformations (torch.cross axis quirk).
 """
-import hashlib
 import os
 import sys
 import warnings
@@ -34,6 +33,8 @@ from grappa.utils import dgl_utils as ref_dgl_utils  # noqa: E402
 from grappa.utils.graph_utils import get_default_statistics  # noqa: E402
 
 from grappa_amd import featurize, tuple_indices  # noqa: E402  (graph featuriser only: rdkit is absent)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_utils import keyed_state_dict  # noqa: E402  (weights derived from state-dict keys; shared with the tests)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 POOL = np.load(os.path.join(ROOT, "grappa_amd", "data", "espaloma_pool.npz"))
@@ -43,39 +44,6 @@ def pool_molecule(i):
     a0, a1 = POOL["atom_ptr"][i], POOL["atom_ptr"][i + 1]
     b0, b1 = POOL["bond_ptr"][i], POOL["bond_ptr"][i + 1]
     return POOL["z"][a0:a1].astype(np.int64), POOL["bonds"][b0:b1].astype(np.int64), POOL["xyz"][a0:a1].astype(np.float32)
-
-
-def keyed_tensor(key: str, shape, scale: float) -> torch.Tensor:
-    seed = int.from_bytes(hashlib.sha256(key.encode()).digest()[:4], "little")
-    gen = torch.Generator().manual_seed(seed)
-    return (torch.rand(tuple(shape), generator=gen) * 2 - 1) * scale
-
-
-def keyed_state_dict(model) -> dict:
-    """Deterministic weights from the state-dict key (so that both sides can regenerate the
-    production-size weights without shipping them): U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for matrices,
-    small biases, LayerNorm gamma near 1."""
-    sd = model.state_dict()
-    new = {}
-    for k, v in sd.items():
-        if not v.dtype.is_floating_point or k.endswith(("positional_encoding", "permutation_prefactors", "k_mean", "k_std",
-                                                           "mean_over_std", ".std", "min_", "std_over_max", ".max")):
-            new[k] = v.clone()
-        elif v.dim() == 2:
-            new[k] = keyed_tensor(k, v.shape, 1.0 / np.sqrt(v.shape[1]))
-        elif "norm" in k and k.endswith("weight"):
-            new[k] = 1.0 + keyed_tensor(k, v.shape, 0.1)
-        else:
-            new[k] = keyed_tensor(k, v.shape, 0.05)
-    # gnn.blocks.* aliases gnn.att_blocks.* / gnn.conv_blocks.* (SURVEY Q5): keep them identical
-    for k in list(new.keys()):
-        if k.startswith("gnn.blocks."):
-            parts = k.split(".")
-            i = int(parts[2])
-            n_conv = len(model.gnn.conv_blocks)
-            alias = (f"gnn.conv_blocks.{i}." if i < n_conv else f"gnn.att_blocks.{i - n_conv}.") + ".".join(parts[3:])
-            new[k] = new[alias]
-    return new
 
 
 def build_inputs(mol_ids, n_confs, seed, charge_model="am1BCC", with_param_refs=True, pad_confs_of=None):
@@ -219,11 +187,18 @@ def save(name, cfg, mols, out, sd=None, extra=None):
     print("wrote", path, os.path.getsize(path))
 
 
-def pick_small(n, lo, hi, start=0, need_no_improper=False):
+def n_improper_centres(i):
+    z, bonds, _ = pool_molecule(i)
+    nd = tuple_indices.get_neighbor_dict([tuple(b) for b in bonds.tolist()], sort=True)
+    return len(tuple_indices.improper_centres_from_bonds(bonds.tolist(), nd, z))
+
+
+def pick_small(n, lo, hi, start=0, impropers=True):
+    """n pool molecules with lo..hi atoms; impropers=True: only molecules WITH improper centres, False: only without."""
     ids = []
     for i in range(start, len(POOL["atom_ptr"]) - 1):
         na = POOL["atom_ptr"][i + 1] - POOL["atom_ptr"][i]
-        if lo <= na <= hi:
+        if lo <= na <= hi and (n_improper_centres(i) > 0) == impropers:
             ids.append(i)
         if len(ids) == n:
             break
@@ -240,7 +215,11 @@ def main():
     cfg = small_config()
     out, sd, _ = run_reference(cfg, mols, 4, loss_kwargs=loss_kwargs)
     out_noise, _, _ = run_reference(cfg, mols, 4, state_dict=sd, loss_kwargs=loss_kwargs, noise=True, grads="none")
-    extra = {"noise::energy_maxabs": np.array([np.abs(out_noise["energy"] - out["energy"]).max()]),
+    # with improper_regularisation > 0 the reference's loss is NaN as soon as one molecule has no impropers
+    mols_q4 = mols[:2] + build_inputs(pick_small(1, 5, 30, impropers=False), n_confs=4, seed=3)
+    out_q4, _, _ = run_reference(cfg, mols_q4, 4, state_dict=sd, loss_kwargs=loss_kwargs, grads="none")
+    extra = {"q4::reference_loss_with_improper_free_molecule": out_q4["loss"],
+             "noise::energy_maxabs": np.array([np.abs(out_noise["energy"] - out["energy"]).max()]),
              "noise::gradient_maxabs": np.array([np.abs(out_noise["gradient"] - out["gradient"]).max()]),
              "loss_kwargs_keys": np.array(list(loss_kwargs.keys())), "loss_kwargs_vals": np.array(list(loss_kwargs.values()))}
     save("ref_small_att.npz", cfg, mols, out, sd, extra)

@@ -1,0 +1,226 @@
+"""GPU (-m gpu): the whole hot path on the HIP kernels -- GrappaModel -> Energy -> MolwiseLoss -> backward ->
+fused Adam -- against (1) the golden fixtures produced by the reference's own modules and (2) the oracle
+(oracle/cpu_ref.py) on larger seeded batches; plus size-independent properties at BASELINE.json's C2 size.
+Tolerance (north star): 1e-4 relative, |a-b| <= 1e-4*max(|b|, floor), floors written below."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+
+pytestmark = pytest.mark.gpu
+
+FLOORS = {"k": 1e-3, "kt": 5e-2, "eq": 1e-4}   # see tests/test_host_model.py for the reasoning behind the floors
+TOL = 1e-4
+
+
+def _assert_loaded():
+    import ctypes
+    from grappa_amd import _lib
+    assert isinstance(_lib.load(), ctypes.CDLL)
+
+
+def _check_graph(g, out, loss):
+    for lvl in ["n2", "n3", "n4", "n4_improper"]:
+        assert np.array_equal(out[f"{lvl}_idxs"], g.nodes[lvl].data["idxs"].cpu().numpy())
+        assert gu.rel_err(g.nodes[lvl].data["k"].detach().cpu(), out[f"{lvl}_k"], FLOORS["kt" if lvl.startswith("n4") else "k"]) < TOL, lvl
+        if lvl in ("n2", "n3"):
+            assert gu.rel_err(g.nodes[lvl].data["eq"].detach().cpu(), out[f"{lvl}_eq"], FLOORS["eq"]) < TOL, lvl
+        assert gu.rel_err_scaled(g.nodes["g"].data[f"energy_{lvl}"].cpu(), out[f"energy_{lvl}"], 1e-3, 1e-3) < TOL, lvl
+    assert gu.rel_err(g.nodes["n1"].data["h"].detach().cpu(), out["h"], 1e-1) < TOL
+    assert gu.rel_err_scaled(g.nodes["g"].data["energy"].detach().cpu(), out["energy"], 1e-3, 1e-3) < TOL
+    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach().cpu(), out["gradient"], 1e-3, 1e-2) < TOL
+    assert gu.rel_err(loss.detach().cpu(), out["loss"], 1e-6) < TOL
+
+
+@pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False)])
+def test_small_configs_against_reference_goldens(name, n_confs, refs):
+    from grappa_amd import Energy, GrappaModel, MolwiseLoss
+    _assert_loaded()
+    fx = gu.load(name)
+    cfg = gu.config_of(fx)
+    g = gu.build_batch(gu.molecules_of(fx), n_confs, refs, (cfg["n_periodicity_proper"], cfg["n_periodicity_improper"])).to("cuda")
+    model = GrappaModel(**cfg)
+    model.load_state_dict(gu.state_dict_of(fx))
+    model = model.to("cuda").eval()
+    g = Energy()(model(g))
+    loss = MolwiseLoss(**gu.loss_kwargs_of(fx))(g)
+    loss.backward()
+    out = gu.outputs_of(fx)
+    _check_graph(g, out, loss)
+    n = 0
+    for k, p in model.named_parameters():
+        ref = out.get("grad::" + k)
+        if ref is None:
+            continue
+        scale = max(float(np.abs(ref).max()), 1e-8)
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / scale < 2e-3, k
+        n += 1
+    assert n > 50
+
+
+def test_production_config_against_reference_golden():
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config
+    fx = gu.load("ref_prod.npz")
+    cfg = gu.config_of(fx)
+    assert cfg == get_default_model_config()
+    model = model_from_config(cfg)
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").eval()
+    g = gu.build_batch(gu.molecules_of(fx), 4, True).to("cuda")
+    g = Energy()(model(g))
+    loss = MolwiseLoss(**gu.loss_kwargs_of(fx))(g)
+    loss.backward()
+    out = gu.outputs_of(fx)
+    _check_graph(g, out, loss)
+    norms = dict(zip(out["grad_norm_keys"].tolist(), out["grad_norm_vals"].tolist()))
+    checked = 0
+    for k, p in model.named_parameters():
+        if k in norms and norms[k] > 1e-6:
+            assert abs(float(p.grad.norm()) - norms[k]) / norms[k] < 5e-3, k
+            checked += 1
+    assert checked > 150
+
+
+def _oracle_step(cfg, sd, g_cpu, loss_kwargs):
+    from oracle import cpu_ref
+    model = cpu_ref.RefGrappaModel(**cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    g = cpu_ref.RefEnergy()(model(g_cpu))
+    loss = cpu_ref.RefMolwiseLoss(**loss_kwargs)(g)
+    loss.backward()
+    return model, g, loss
+
+
+def test_production_config_against_oracle_on_a_larger_batch():
+    """32 molecules x 8 conformations, production widths: HIP vs the oracle on the same seeded inputs, incl. every parameter gradient."""
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config
+    from grappa_amd.datasets import build_batch_from_pool
+    cfg = get_default_model_config()
+    ids = list(range(500, 532))
+    lk = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
+    model = model_from_config(cfg)
+    sd = gu.keyed_state_dict(model)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    g = build_batch_from_pool(ids, n_confs=8, seed=3).to("cuda")
+    g = Energy()(model(g))
+    loss = MolwiseLoss(**lk)(g)
+    loss.backward()
+    ref_model, rg, rloss = _oracle_step(cfg, sd, build_batch_from_pool(ids, n_confs=8, seed=3), lk)
+    out = {"h": rg.nodes["n1"].data["h"].detach().numpy(), "loss": rloss.detach().numpy().reshape(1),
+           "energy": rg.nodes["g"].data["energy"].detach().numpy(), "gradient": rg.nodes["n1"].data["gradient"].detach().numpy()}
+    for lvl in ["n2", "n3", "n4", "n4_improper"]:
+        out[f"{lvl}_idxs"] = rg.nodes[lvl].data["idxs"].numpy()
+        out[f"{lvl}_k"] = rg.nodes[lvl].data["k"].detach().numpy()
+        out[f"energy_{lvl}"] = rg.nodes["g"].data[f"energy_{lvl}"].numpy()
+        if lvl in ("n2", "n3"):
+            out[f"{lvl}_eq"] = rg.nodes[lvl].data["eq"].detach().numpy()
+    _check_graph(g, out, loss)
+    ref_grads = dict(ref_model.named_parameters())
+    worst = 0.0
+    for k, p in model.named_parameters():
+        r = ref_grads[k].grad
+        if r is None:
+            continue
+        scale = max(float(r.abs().max()), 1e-8)
+        worst = max(worst, float((p.grad.cpu() - r).abs().max()) / scale)
+        assert float((p.grad.cpu() - r).abs().max()) / scale < 5e-3, k
+    print("worst relative parameter-gradient error vs oracle:", worst)
+
+
+def test_train_step_decreases_loss_and_matches_oracle_adam():
+    """two fused-Adam steps (flat buffers, device-side clip) track torch.optim.Adam + clip_grad_norm_ on the oracle."""
+    from grappa_amd import Energy, GrappaModel, MolwiseLoss
+    from grappa_amd.optim import FlatParams, FusedAdam
+    from oracle import cpu_ref
+    fx = gu.load("ref_small_att.npz")
+    cfg = gu.config_of(fx)
+    lk = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0)
+    mols = gu.molecules_of(fx)
+    model = GrappaModel(**cfg)
+    model.load_state_dict(gu.state_dict_of(fx))
+    model = model.to("cuda").eval()
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=1e-3, max_grad_norm=10.0)
+    ref = cpu_ref.RefGrappaModel(**cfg)
+    ref.load_state_dict(gu.state_dict_of(fx))
+    ref.eval()
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    losses, rlosses = [], []
+    for step in range(3):
+        g = gu.build_batch(mols, 4, False).to("cuda")
+        opt.zero_grad()
+        loss = MolwiseLoss(**lk)(Energy()(model(g)))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        rg = gu.build_batch(mols, 4, False)
+        ropt.zero_grad()
+        rl = cpu_ref.RefMolwiseLoss(**lk)(cpu_ref.RefEnergy()(ref(rg)))
+        rl.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0)
+        ropt.step()
+        rlosses.append(float(rl))
+    assert losses[-1] < losses[0]
+    for a, b in zip(losses, rlosses):
+        assert abs(a - b) / abs(b) < 1e-3, (losses, rlosses)
+
+
+def test_properties_at_c2_size():
+    """BASELINE.json configs[1] (256 molecules of 20-40 atoms, 32 conformations, production model, train-mode dropout):
+    size-independent properties instead of a CPU recomputation."""
+    from grappa_amd import Energy, get_default_model_config, model_from_config, ops
+    from grappa_amd.datasets import build_batch_from_pool, build_workload, workload_molecule_ids
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda")
+    ids = workload_molecule_ids("C2-pubchem-b256", seed=0)
+    g = build_workload("C2-pubchem-b256", seed=0).to("cuda")
+    model.eval()
+    with torch.no_grad():
+        g = Energy()(model(g))
+    E, G = g.nodes["g"].data["energy"], g.nodes["n1"].data["gradient"]
+    assert torch.isfinite(E).all() and torch.isfinite(G).all()
+    plan = g.plan()
+    # (1) zero net force per molecule and conformation (translation invariance of the MM energy)
+    ptr = plan.atom_molptr.long()
+    seg = torch.repeat_interleave(torch.arange(plan.B, device="cuda"), ptr[1:] - ptr[:-1])
+    net = torch.zeros(plan.B, E.shape[1], 3, device="cuda").index_add(0, seg, G)
+    assert float(net.abs().max()) < 1e-4 * float(G.abs().max()) * 40
+    # (2) batching invariance (reference tests/unbatch.py): molecule 17 alone == inside the batch
+    with torch.no_grad():
+        g1 = Energy()(model(build_batch_from_pool([ids[17]], n_confs=32, seed=0).to("cuda")))
+    e1 = g1.nodes["g"].data["energy"][0]
+    assert gu.rel_err_scaled(E[17].cpu(), e1.cpu().numpy(), 1e-3, 1e-3) < 1e-4
+    a0, a1 = int(ptr[17]), int(ptr[18])
+    assert gu.rel_err_scaled(G[a0:a1].cpu(), g1.nodes["n1"].data["gradient"].cpu().numpy(), 1e-3, 1e-2) < 1e-4
+    # (3) permutation symmetry of the heads: reversing every proper torsion leaves k unchanged
+    k4 = g.nodes["n4"].data["k"].clone()
+    g2 = build_workload("C2-pubchem-b256", seed=0)
+    g2.nodes["n4"].data["idxs"] = g2.nodes["n4"].data["idxs"].flip(1).contiguous()
+    g2 = g2.to("cuda")
+    with torch.no_grad():
+        g2 = model(g2)
+    assert gu.rel_err(g2.nodes["n4"].data["k"].cpu(), k4.cpu().numpy(), 1e-2) < 1e-4
+    # (4) train mode: dropout is active, finite, and reproducible for a fixed seed
+    model.train()
+    ops.manual_seed(123)
+    with torch.no_grad():
+        ka = model(build_workload("C2-pubchem-b256", seed=0).to("cuda")).nodes["n2"].data["k"].clone()
+    ops.manual_seed(123)
+    with torch.no_grad():
+        kb = model(build_workload("C2-pubchem-b256", seed=0).to("cuda")).nodes["n2"].data["k"].clone()
+    assert torch.equal(ka, kb) and torch.isfinite(ka).all()
+    assert not torch.allclose(ka, g.nodes["n2"].data["k"])
+
+
+def test_predict_drop_in():
+    from grappa_amd import Grappa, Molecule, get_default_model_config, model_from_config
+    from grappa_amd.datasets import molecule_from_pool
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    params = Grappa(model, device="cuda").predict(molecule_from_pool(42))
+    assert params.bond_k.shape[0] == params.bonds.shape[0] and params.proper_ks.shape[1] == 6 and params.improper_ks.shape[1] == 3
+    assert (params.proper_ks >= 0).all() and np.isin(params.proper_phases, [0.0, np.float32(np.pi)]).all()
