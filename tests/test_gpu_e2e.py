@@ -29,7 +29,7 @@ def _check_graph(g, out, loss):
         assert gu.rel_err_scaled(g.nodes["g"].data[f"energy_{lvl}"].cpu(), out[f"energy_{lvl}"], 1e-3, 1e-3) < TOL, lvl
     assert gu.rel_err(g.nodes["n1"].data["h"].detach().cpu(), out["h"], 1e-1) < TOL
     assert gu.rel_err_scaled(g.nodes["g"].data["energy"].detach().cpu(), out["energy"], 1e-3, 1e-3) < TOL
-    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach().cpu(), out["gradient"], 1e-3, 1e-2) < TOL
+    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach().cpu(), out["gradient"], 1e-2, 1e-2) < TOL
     assert gu.rel_err(loss.detach().cpu(), out["loss"], 1e-6) < TOL
 
 
@@ -195,7 +195,7 @@ def test_properties_at_c2_size():
     e1 = g1.nodes["g"].data["energy"][0]
     assert gu.rel_err_scaled(E[17].cpu(), e1.cpu().numpy(), 1e-3, 1e-3) < 1e-4
     a0, a1 = int(ptr[17]), int(ptr[18])
-    assert gu.rel_err_scaled(G[a0:a1].cpu(), g1.nodes["n1"].data["gradient"].cpu().numpy(), 1e-3, 1e-2) < 1e-4
+    assert gu.rel_err_scaled(G[a0:a1].cpu(), g1.nodes["n1"].data["gradient"].cpu().numpy(), 1e-2, 1e-2) < 1e-4
     # (3) permutation symmetry of the heads: reversing every proper torsion leaves k unchanged
     k4 = g.nodes["n4"].data["k"].clone()
     g2 = build_workload("C2-pubchem-b256", seed=0)

@@ -41,7 +41,7 @@ def test_product_host_path_matches_reference(ref_backend, name, n_confs, refs):
         assert gu.rel_err(g.nodes["g"].data[f"energy_{lvl}"], out[f"energy_{lvl}"], 1e-3) < 1e-4, lvl
     assert gu.rel_err(g.nodes["n1"].data["h"].detach(), out["h"], 1e-1) < 1e-4   # h = O(1) embedding
     assert gu.rel_err_scaled(g.nodes["g"].data["energy"].detach(), out["energy"], 1e-3, FLOORS["energy"]) < 1e-4
-    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach(), out["gradient"], 1e-3, FLOORS["gradient"]) < 1e-4
+    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach(), out["gradient"], 1e-2, FLOORS["gradient"]) < 1e-4   # floor: 1 % of max|G| (k_bond*ulp(r) ~ 1e-4 abs per term)
     assert gu.rel_err(loss.detach(), out["loss"], 1e-6) < 1e-4
     n = 0
     for k, p in model.named_parameters():

@@ -21,7 +21,7 @@ def test_production_golden_matches_oracle():
         floor = 5e-2 if lvl.startswith("n4") else 1e-3
         assert gu.rel_err(g.nodes[lvl].data["k"].detach(), out[f"{lvl}_k"], floor) < 1e-4, lvl
     assert gu.rel_err_scaled(g.nodes["g"].data["energy"].detach(), out["energy"], 1e-3, 1e-3) < 1e-4
-    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach(), out["gradient"], 1e-3, 1e-2) < 1e-4
+    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach(), out["gradient"], 1e-2, 1e-2) < 1e-4
     assert gu.rel_err(loss.detach(), out["loss"], 1e-6) < 1e-4
     norms = dict(zip(out["grad_norm_keys"].tolist(), out["grad_norm_vals"].tolist()))
     for k, p in model.named_parameters():
