@@ -1,0 +1,183 @@
+"""bench.py -- molecules/sec of one full Grappa train step (GrappaModel -> Energy with forces -> MolwiseLoss ->
+backward -> all-reduce -> fused Adam with grad clipping) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): 256 molecules of 20-40 atoms PER GPU drawn from the Espaloma
+molecule pool, 32 conformations, production model (40.8 M parameters, random init), fp32, train mode (dropout on),
+synthetic charges / coordinates / reference energies+forces.  Weak scaling: every rank gets its own 256 molecules,
+gradients are summed with one RCCL all-reduce of the flat gradient buffer.
+The JSON line also carries `roofline` (fp32 MFMA GEMM family: algorithmic 2MNK FLOPs / HIP-event kernel time, measured
+in an instrumented repetition of the same steps right after the timed region; plus the GAT kernels vs HBM) and
+`cpu_baseline` (the oracle's CPU restatement of the same train step on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec
+
+
+def keyed_init(model):
+    """deterministic non-trivial weights (same scheme as the parity tests)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_utils as gu
+    model.load_state_dict(gu.keyed_state_dict(model))
+
+
+def cpu_baseline(workload: str, n_mols: int, steps: int):
+    """the oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same workload"""
+    from grappa_amd import get_default_model_config
+    from grappa_amd.datasets import build_batch_from_pool, workload_molecule_ids
+    from oracle import cpu_ref
+    import golden_utils as gu
+    torch.set_num_threads(os.cpu_count())
+    ids = workload_molecule_ids(workload, seed=0)[:n_mols]
+    model = cpu_ref.RefGrappaModel(**get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1.5e-5)
+    loss_fn = cpu_ref.RefMolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
+    energy = cpu_ref.RefEnergy()
+    times = []
+    for it in range(steps + 1):
+        g = build_batch_from_pool(ids, n_confs=32, seed=0)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = loss_fn(energy(model(g)))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": n_mols / t, "unit": "molecules/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n_mols} molecules of {workload} x 32 conformations, production model fp32, median of {steps} train steps "
+                      f"(oracle/cpu_ref.py, torch {torch.__version__} CPU)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C2-pubchem-b256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import WORKLOADS, build_workload
+    from grappa_amd.dist import all_reduce_gradients
+    from grappa_amd.optim import FlatParams, FusedAdam
+
+    be = get_backend()
+    model = model_from_config(get_default_model_config())
+    keyed_init(model)
+    model = model.to(dev).train()
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=1.5e-5, max_grad_norm=10.0)
+    energy = Energy()
+    loss_fn = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
+    per_gpu = WORKLOADS[args.workload][0]
+    loss_fn.global_batch_size = per_gpu * world
+    ops.manual_seed(1234 + rank)
+    g = build_workload(args.workload, seed=rank).to(dev)
+    plan = g.plan()
+
+    def step():
+        opt.zero_grad()
+        for lvl in ("n2", "n3", "n4", "n4_improper"):         # drop last step's outputs
+            for k in ("k", "eq"):
+                g.nodes[lvl].data.pop(k, None)
+        loss = loss_fn(energy(model(g)))
+        loss.backward()
+        all_reduce_gradients(flat.grad)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+
+    # instrumented repetition of the same steps: HIP events around every GEMM / GAT launch on the launch stream
+    be.start_profile()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    prof = be.stop_profile()
+    dt_prof = time.perf_counter() - t1
+
+    if rank == 0:
+        n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
+        achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<*> (v_mfma_f32_32x32x2_f32)", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "launches_per_step": n / args.steps, "avg_launch_us": 1e3 * ms / max(n, 1), "gflop_per_launch": fl / max(n, 1) / 1e9,
+                "kernel_ms_per_step": ms / args.steps}
+        gat = {}
+        for fam in ("gat_fwd", "gat_bwd"):
+            n_, ms_, fl_, by_ = prof.get(fam, (0, 0.0, 0.0, 0.0))
+            a = (by_ / (ms_ * 1e-3)) / 1e9 if ms_ > 0 else 0.0
+            gat[fam] = {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
+                        "avg_launch_us": 1e3 * ms_ / max(n_, 1), "mb_per_launch": by_ / max(n_, 1) / 1e6}
+        out = {
+            "metric": "molecules/sec (train step, energy+force loss)", "value": per_gpu * world * args.steps / dt, "unit": "molecules/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {per_gpu} molecules/GPU (20-40 atoms, Espaloma pool), 32 conformations, "
+                                   f"production GrappaModel 40.8M params random-init, train mode (dropout on), Adam + clip 10",
+                       "molecules_per_gpu": per_gpu, "global_batch": per_gpu * world, "conformations": 32, "atoms_rank0": plan.N,
+                       "tuples_rank0": {k: int(v) for k, v in plan.T.items()}, "parallelism": f"dp{world}"},
+            "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": 1e3 * dt_prof / args.steps, "final_loss": final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, 2)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,32 @@ class HipBackend:
             raise RuntimeError("grappa_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self._ws = {}
+        self._prof = None      # list of (kernel family, algorithmic flops, algorithmic bytes, start event, end event) when profiling
+
+    # ------------------------------------------------------------------ in-process kernel timing (bench.py roofline)
+    def start_profile(self) -> None:
+        self._prof = []
+
+    def stop_profile(self):
+        """-> {family: (launches, total_ms, algorithmic_flops, algorithmic_bytes)}; events are recorded on the stream
+        the kernels run on (torch's current stream)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, fl, by, e0, e1 in self._prof or []:
+            n, ms, f, b = out.get(name, (0, 0.0, 0.0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
+        self._prof = None
+        return out
+
+    def _timed(self, name, flops, nbytes, launch) -> None:
+        if self._prof is None:
+            launch()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        self._prof.append((name, float(flops), float(nbytes), e0, e1))
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -127,7 +153,9 @@ class HipBackend:
             raise ValueError("gemm: K == 0")
         need = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
         ws = self._workspace(need, dev) if need else None
-        _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0), "grappa_gemm_f32")
+        self._timed("gemm_f32", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
+                    lambda: _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0),
+                                 "grappa_gemm_f32"))
 
     def colsum(self, x, out, accumulate=False) -> None:
         dev = out.device
@@ -200,8 +228,11 @@ class HipBackend:
         _flat(ft, "ft", dev), _flat(out, "out", dev), _flat(alpha, "alpha", dev)
         if ft.shape[1] != H * D or out.shape != ft.shape or alpha.numel() != plan.E * H:
             raise ValueError("gat_fwd: shapes")
-        _chk(self.lib.grappa_gat_fwd_f32(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(), ft.data_ptr(),
-                                         out.data_ptr(), alpha.data_ptr()), "grappa_gat_fwd_f32")
+        # algorithmic bytes: one source row per edge + col index, one dst row read + one output row write + indptr per node
+        nbytes = plan.E * (H * D * 4 + 4) + N * (2 * H * D * 4 + 4)
+        self._timed("gat_fwd", 2.0 * plan.E * H * D * 2, nbytes,
+                    lambda: _chk(self.lib.grappa_gat_fwd_f32(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(),
+                                                             ft.data_ptr(), out.data_ptr(), alpha.data_ptr()), "grappa_gat_fwd_f32"))
 
     def gat_bwd(self, plan, ft, out, alpha, dout, H, D, dft) -> None:
         dev = dft.device
@@ -212,9 +243,11 @@ class HipBackend:
         if ft.shape[1] != H * D or out.shape != ft.shape or dout.shape != ft.shape or dft.shape != ft.shape or alpha.numel() != plan.E * H:
             raise ValueError("gat_bwd: shapes")
         delta = torch.empty((N, H), dtype=torch.float32, device=dev)
-        _chk(self.lib.grappa_gat_bwd_f32(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(), plan.rev.data_ptr(),
-                                         ft.data_ptr(), out.data_ptr(), alpha.data_ptr(), dout.data_ptr(), dft.data_ptr(), delta.data_ptr()),
-             "grappa_gat_bwd_f32")
+        nbytes = plan.E * (2 * H * D * 4 + 4) + N * (4 * H * D * 4 + 4)
+        self._timed("gat_bwd", 2.0 * plan.E * H * D * 5, nbytes,
+                    lambda: _chk(self.lib.grappa_gat_bwd_f32(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(),
+                                                             plan.rev.data_ptr(), ft.data_ptr(), out.data_ptr(), alpha.data_ptr(), dout.data_ptr(),
+                                                             dft.data_ptr(), delta.data_ptr()), "grappa_gat_bwd_f32"))
 
     def neighbor_mean(self, plan, x, out, scale_by_neighbor: bool) -> None:
         dev = out.device

@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads and exports every symbol include/grappa_hip.h declares (no compute calls: no GPU here),
+and the ctypes binding table covers exactly that set."""
+import ctypes
+import os
+import re
+
+from grappa_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "grappa_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(grappa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/grappa_hip.h but not exported by libgrappa_hip.so"
+    assert sorted(_lib.SIGNATURES.keys()) == names
+
+
+def test_host_only_entry_points():
+    lib = _lib.load()
+    assert lib.grappa_abi_version() == 1
+    assert lib.grappa_build_arch() == b"gfx950"
+    # pure host helpers: workspace queries and the dropout hash
+    assert lib.grappa_gemm_f32_workspace_bytes(512, 512, 100000) > 0
+    assert lib.grappa_gemm_f32_workspace_bytes(100000, 2048, 512) == 0
+    assert lib.grappa_layernorm_bwd_workspace_bytes(1000, 512) == 250 * 2 * 512 * 4
+    from oracle.ops_ref import dropout_keep
+    import torch
+    idx = torch.arange(0, 2000, dtype=torch.int64)
+    for seed in (0, 12345, 2 ** 63 - 1):
+        want = dropout_keep(seed, idx, 0.3)
+        got = torch.tensor([lib.grappa_dropout_keep(seed, int(i), 0.3) for i in idx], dtype=torch.bool)
+        assert torch.equal(got, want)
+
+
+def test_product_has_no_cpu_fallback():
+    """without a GPU the product backend must refuse to start (no silent eager/PyTorch path)."""
+    import pytest
+    import torch
+    from grappa_amd import backend
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    old = backend._BACKEND
+    backend.set_backend(None)
+    try:
+        with pytest.raises(RuntimeError):
+            backend.get_backend()
+    finally:
+        backend.set_backend(old)
+    # and the product package never imports the oracle
+    import subprocess, sys
+    code = "import sys, grappa_amd, grappa_amd.ops, grappa_amd.datasets, grappa_amd.optim, grappa_amd.dist; assert not any(m.startswith('oracle') for m in sys.modules)"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
