@@ -66,6 +66,10 @@ def cpu_baseline(workload: str, n_mols: int, steps: int):
                       f"(oracle/cpu_ref.py, torch {torch.__version__} CPU)"}
 
 
+def log(*a):
+    print(f"[bench {time.strftime('%H:%M:%S')}]", *a, file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +98,7 @@ def main():
     from grappa_amd.dist import all_reduce_gradients
     from grappa_amd.optim import FlatParams, FusedAdam
 
+    log("imports done; building model")
     be = get_backend()
     model = model_from_config(get_default_model_config())
     keyed_init(model)
@@ -105,8 +110,10 @@ def main():
     per_gpu = WORKLOADS[args.workload][0]
     loss_fn.global_batch_size = per_gpu * world
     ops.manual_seed(1234 + rank)
+    log("model ready; building workload")
     g = build_workload(args.workload, seed=rank).to(dev)
     plan = g.plan()
+    log(f"workload ready: atoms {plan.N} tuples {plan.T}; warmup")
 
     def step():
         opt.zero_grad()
@@ -137,7 +144,8 @@ def main():
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
+    log(f"timed region done: {1e3 * dt / args.steps:.1f} ms/step; instrumented pass")
 
     # instrumented repetition of the same steps: HIP events around every GEMM / GAT launch on the launch stream
     be.start_profile()
@@ -147,6 +155,7 @@ def main():
     prof = be.stop_profile()
     dt_prof = time.perf_counter() - t1
 
+    log("instrumented pass done")
     if rank == 0:
         n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
         achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
@@ -171,6 +180,7 @@ def main():
             "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": 1e3 * dt_prof / args.steps, "final_loss": final_loss,
         }
         if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle) ...")
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, 2)
         else:
             out["cpu_baseline"] = None
