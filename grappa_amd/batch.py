@@ -171,6 +171,12 @@ class MolBatch:
             g._plan = self._plan
         return g
 
+    def cuda(self, device=None) -> "MolBatch":
+        return self.to("cuda" if device is None else device)
+
+    def cpu(self) -> "MolBatch":
+        return self.to("cpu")
+
     def plan(self) -> BatchPlan:
         """Index structures on the graph's device (cached)."""
         if self._plan is None or self._plan.device != self.device:

@@ -239,30 +239,38 @@ int launch_cfg(hipStream_t st, GemmParams& p) {
 
 struct Plan { int cfg; int nsplit; int k_per_split; };
 
-// cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128
+// cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
+constexpr int CFG_BM[5] = {128, 64, 128, 32, 128};
+constexpr int CFG_BN[5] = {128, 64, 32, 128, 64};
+
+// Tile choice: the largest tile that still gives the 256 CUs >= ~1.5 workgroups each; when the output is small and K is
+// long (weight gradients: K = #tokens) fill the chip with split-K slabs instead of shrinking the tile.
 Plan make_plan(int M, int N, int K) {
     Plan pl;
+    pl.nsplit = 1;
+    auto tiles_of = [&](int c) { return (long)((M + CFG_BM[c] - 1) / CFG_BM[c]) * ((N + CFG_BN[c] - 1) / CFG_BN[c]); };
+    int max_split = K >= 16 * BK ? K / (8 * BK) : 1;
+    if (max_split > 64) max_split = 64;
     if (N <= 32) pl.cfg = 2;
     else if (M <= 32) pl.cfg = 3;
     else {
-        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-        pl.cfg = (t128 >= 192) ? 0 : 1;
+        const int order[3] = {0, 4, 1};
+        pl.cfg = -1;
+        for (int i = 0; i < 3 && pl.cfg < 0; ++i)
+            if (tiles_of(order[i]) >= 400) pl.cfg = order[i];                 // enough tiles without splitting K
+        for (int i = 0; i < 3 && pl.cfg < 0; ++i)
+            if (tiles_of(order[i]) * max_split >= 400) pl.cfg = order[i];     // big tile + split-K
+        if (pl.cfg < 0) pl.cfg = 1;
     }
-    const int bm = pl.cfg == 0 ? 128 : pl.cfg == 1 ? 64 : pl.cfg == 2 ? 128 : 32;
-    const int bn = pl.cfg == 0 ? 128 : pl.cfg == 1 ? 64 : pl.cfg == 2 ? 32 : 128;
-    const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const long tiles = tiles_of(pl.cfg);
     int nsplit = 1;
-    if (tiles < 256 && K >= 16 * BK) {
+    if (tiles < 400 && max_split > 1) {
         nsplit = (int)((512 + tiles - 1) / tiles);
-        const int maxs = K / (8 * BK);
-        if (nsplit > maxs) nsplit = maxs;
-        if (nsplit > 64) nsplit = 64;
-        if (nsplit < 1) nsplit = 1;
+        if (nsplit > max_split) nsplit = max_split;
     }
     int kps = (K + nsplit - 1) / nsplit;
     kps = (kps + BK - 1) / BK * BK;
-    nsplit = (K + kps - 1) / kps;
-    pl.nsplit = nsplit;
+    pl.nsplit = (K + kps - 1) / kps;
     pl.k_per_split = kps;
     return pl;
 }
@@ -273,7 +281,8 @@ int dispatch(hipStream_t st, GemmParams& p, int cfg) {
         case 0: return launch_cfg<128, 128, 2, 2, AK, BKC>(st, p);
         case 1: return launch_cfg<64, 64, 2, 2, AK, BKC>(st, p);
         case 2: return launch_cfg<128, 32, 4, 1, AK, BKC>(st, p);
-        default: return launch_cfg<32, 128, 1, 4, AK, BKC>(st, p);
+        case 3: return launch_cfg<32, 128, 1, 4, AK, BKC>(st, p);
+        default: return launch_cfg<128, 64, 2, 2, AK, BKC>(st, p);
     }
 }
 

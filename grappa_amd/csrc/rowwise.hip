@@ -131,14 +131,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
     }
 }
 
-// out[j] (+)= sum_b part[b*stride + j]
-__global__ __launch_bounds__(256) void reduce_partials_kernel(int nblocks, int stride, int n, const float* __restrict__ part,
-                                                              float* __restrict__ out, int accumulate) {
+// out[g*out_stride + j] (+)= sum over rows b in group g of part[b*stride + j]   (grid.y = number of groups)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(int nrows, int stride, int n, const float* __restrict__ part,
+                                                          float* __restrict__ out, int out_stride, int accumulate, int rows_per_group) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * stride + j];
-    out[j] = accumulate ? out[j] + s : s;
+    const int b0 = blockIdx.y * rows_per_group;
+    const int b1 = min(nrows, b0 + rows_per_group);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {       // four independent loads in flight
+        s0 += part[(size_t)b * stride + j];
+        s1 += part[(size_t)(b + 1) * stride + j];
+        s2 += part[(size_t)(b + 2) * stride + j];
+        s3 += part[(size_t)(b + 3) * stride + j];
+    }
+    for (; b < b1; ++b) s0 += part[(size_t)b * stride + j];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* o = out + (size_t)blockIdx.y * out_stride + j;
+    *o = accumulate ? *o + s : s;
+}
+
+constexpr int REDUCE_GROUPS = 32;
+
+// fixed-order two-stage reduction of per-block partials; scratch holds REDUCE_GROUPS * n floats
+inline void reduce_rows(hipStream_t st, int nrows, int stride, int n, const float* part, float* out, int accumulate, float* scratch) {
+    const dim3 gx((n + 255) / 256);
+    if (nrows <= 2 * REDUCE_GROUPS) {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, nrows, stride, n, part, out, 0, accumulate, nrows);
+        return;
+    }
+    const int rpg = (nrows + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
+    const int groups = (nrows + rpg - 1) / rpg;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, groups), dim3(256), 0, st, nrows, stride, n, part, scratch, n, 0, rpg);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, groups, n, n, scratch, out, 0, accumulate, groups);
 }
 
 // column sums: block = 256 threads = 64 columns x 4 row-lanes... simple: each block owns a row stripe,
@@ -262,7 +288,7 @@ extern "C" int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float*
 }
 
 extern "C" size_t grappa_layernorm_bwd_workspace_bytes(int M, int W) {
-    return (size_t)ln_blocks(M) * 2 * W * sizeof(float);
+    return ((size_t)ln_blocks(M) * 2 * W + (size_t)REDUCE_GROUPS * W) * sizeof(float);
 }
 
 extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
@@ -274,20 +300,23 @@ extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float*
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(gamma)) & 15)
         return GRAPPA_ERR_ARG;
     const int blocks = ln_blocks(M);
-    const size_t need = (size_t)blocks * 2 * W * sizeof(float);
+    const size_t need = ((size_t)blocks * 2 * W + (size_t)REDUCE_GROUPS * W) * sizeof(float);
     if (!ws || ws_bytes < need) return GRAPPA_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* part = reinterpret_cast<float*>(ws);
+    float* scratch = part + (size_t)blocks * 2 * W;
     const size_t smem = (size_t)4 * 2 * W * sizeof(float);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part);
     int rc = grappa_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((W + 255) / 256), dim3(256), 0, st, blocks, 2 * W, W, part, dgamma, accumulate);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((W + 255) / 256), dim3(256), 0, st, blocks, 2 * W, W, part + W, dbeta, accumulate);
+    reduce_rows(st, blocks, 2 * W, W, part, dgamma, accumulate, scratch);
+    reduce_rows(st, blocks, 2 * W, W, part + W, dbeta, accumulate, scratch);     // stream order makes the scratch reuse safe
     return grappa_launch_status();
 }
 
-extern "C" size_t grappa_colsum_workspace_bytes(int M, int N) { return (size_t)colsum_blocks(M) * N * sizeof(float); }
+extern "C" size_t grappa_colsum_workspace_bytes(int M, int N) {
+    return ((size_t)colsum_blocks(M) * N + (size_t)REDUCE_GROUPS * N) * sizeof(float);
+}
 
 extern "C" int grappa_colsum_f32(void* stream, int M, int N, const float* x, int ldx, float* out, int accumulate, void* ws, size_t ws_bytes) {
     if (M < 0 || N <= 0 || !out) return GRAPPA_ERR_ARG;
@@ -298,11 +327,12 @@ extern "C" int grappa_colsum_f32(void* stream, int M, int N, const float* x, int
     }
     if (!x) return GRAPPA_ERR_ARG;
     const int blocks = colsum_blocks(M);
-    if (!ws || ws_bytes < (size_t)blocks * N * sizeof(float)) return GRAPPA_ERR_WORKSPACE;
+    if (!ws || ws_bytes < ((size_t)blocks * N + (size_t)REDUCE_GROUPS * N) * sizeof(float)) return GRAPPA_ERR_WORKSPACE;
     const int rpb = (M + blocks - 1) / blocks;
+    const int used = (M + rpb - 1) / rpb;
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, st, M, N, x, ldx, rpb, part);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, blocks, N, N, part, out, accumulate);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(used), dim3(256), 0, st, M, N, x, ldx, rpb, part);
+    reduce_rows(st, used, N, N, part, out, accumulate, part + (size_t)blocks * N);
     return grappa_launch_status();
 }
 

@@ -1,0 +1,87 @@
+"""Per-shape timing of the fp32 MFMA GEMM on the GPU box: every distinct (M,N,K,layout) the production model issues in one
+train step of the C2 workload, timed with HIP events (10 repetitions after 2 warm-ups).  Prints TFLOP/s per shape and the
+step-weighted total.  Usage: python tools/gemm_shapes_bench.py [--record]"""
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+DEV = "cuda"
+
+
+def record_shapes():
+    """run one train step with a recording wrapper around the backend's gemm"""
+    import golden_utils as gu
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_workload
+    be = get_backend()
+    shapes = collections.Counter()
+    orig = be.gemm
+
+    def rec(a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, **kw):
+        shapes[(M, N, K, int(a_kcontig), int(b_kcontig), a.stride(0) if a.dim() == 2 and a.shape[0] > 1 else 0,
+                b.stride(0) if b.shape[0] > 1 else 0, out.stride(0) if out.shape[0] > 1 else 0)] += 1
+        return orig(a, b, out, M=M, N=N, K=K, a_kcontig=a_kcontig, b_kcontig=b_kcontig, **kw)
+
+    be.gemm = rec
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to(DEV).train()
+    g = build_workload(WORKLOAD, seed=0).to(DEV)
+    loss = MolwiseLoss(param_weight=0.0)(Energy()(model(g)))
+    loss.backward()
+    if DEV == "cuda":
+        torch.cuda.synchronize()
+    be.gemm = orig
+    return shapes
+
+
+WORKLOAD = "C2-pubchem-b256"
+
+
+def main():
+    global DEV, WORKLOAD
+    from grappa_amd.backend import get_backend
+    if "--cpu-dry-run" in sys.argv:        # host-logic check with the test-only backend (no timing)
+        from grappa_amd import backend
+        from oracle.ops_ref import RefBackend
+        backend.set_backend(RefBackend())
+        DEV, WORKLOAD = "cpu", "C1-dipeptide-b8"
+        for k, v in sorted(record_shapes().items()):
+            print(k, v)
+        return
+    shapes = record_shapes()
+    be = get_backend()
+    rows = []
+    for (M, N, K, ak, bk, lda, ldb, ldc), cnt in sorted(shapes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1]):
+        A = torch.randn((M, K) if ak else (K, M), device="cuda")
+        B = torch.randn((N, K) if bk else (K, N), device="cuda")
+        C = torch.empty((M, N), device="cuda")
+        for _ in range(2):
+            be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        fl = 2.0 * M * N * K
+        rows.append((M, N, K, ak, bk, cnt, ms, fl / ms / 1e9, cnt * ms, cnt * fl))
+    tot_ms = sum(r[8] for r in rows)
+    tot_fl = sum(r[9] for r in rows)
+    print(f"{'M':>7} {'N':>5} {'K':>7} ak bk  cnt   ms/call  TFLOP/s  ms/step  share")
+    for M, N, K, ak, bk, cnt, ms, tf, sms, sfl in sorted(rows, key=lambda r: -r[8]):
+        print(f"{M:7d} {N:5d} {K:7d}  {ak}  {bk} {cnt:4d} {ms:9.3f} {tf:8.1f} {sms:8.2f} {100 * sms / tot_ms:6.1f}%")
+    print(f"total: {tot_ms:.1f} ms/step, {tot_fl / 1e12:.2f} TFLOP/step, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
