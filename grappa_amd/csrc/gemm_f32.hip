@@ -36,45 +36,50 @@ struct Tile {
     static constexpr int NV = BROW * BK / 4 / NTHREADS;   // float4 per thread
 };
 
+// Interior tiles (whole tile in range, 16-byte loads legal): unconditional float4 loads -- no per-load branches, so all
+// loads of a K-step are in flight together.  Edge tiles: branch-free scalar loads from clamped addresses + select.
 template <int BROW, bool KCONT>
-__device__ inline void load_tile(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend, int vec,
-                                 float4 (&v)[Tile<BROW, KCONT>::NV]) {
+__device__ inline void load_tile_fast(const float* __restrict__ src, int ld, int row0, int k0, float4 (&v)[Tile<BROW, KCONT>::NV]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < Tile<BROW, KCONT>::NV; ++i) {
         const int f = tid + i * NTHREADS;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KCONT) {
             const int row = f >> 3, kq = (f & 7) << 2;
-            const int gr = row0 + row, gk = k0 + kq;
-            if (gr < R && gk < Kend) {
-                const float* p = src + (size_t)gr * ld + gk;
-                if (vec && gk + 3 < Kend) {
-                    r = *reinterpret_cast<const float4*>(p);
-                } else {
-                    r.x = p[0];
-                    if (gk + 1 < Kend) r.y = p[1];
-                    if (gk + 2 < Kend) r.z = p[2];
-                    if (gk + 3 < Kend) r.w = p[3];
-                }
-            }
+            v[i] = *reinterpret_cast<const float4*>(src + (size_t)(row0 + row) * ld + (k0 + kq));
         } else {
             constexpr int QR = BROW / 4;
             const int k = f / QR, rq = (f % QR) << 2;
-            const int gk = k0 + k, gr = row0 + rq;
-            if (gk < Kend && gr < R) {
-                const float* p = src + (size_t)gk * ld + gr;
-                if (vec && gr + 3 < R) {
-                    r = *reinterpret_cast<const float4*>(p);
-                } else {
-                    r.x = p[0];
-                    if (gr + 1 < R) r.y = p[1];
-                    if (gr + 2 < R) r.z = p[2];
-                    if (gr + 3 < R) r.w = p[3];
-                }
-            }
+            v[i] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + k) * ld + (row0 + rq));
         }
-        v[i] = r;
+    }
+}
+
+template <int BROW, bool KCONT>
+__device__ inline void load_tile_edge(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend,
+                                      float4 (&v)[Tile<BROW, KCONT>::NV]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Tile<BROW, KCONT>::NV; ++i) {
+        const int f = tid + i * NTHREADS;
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int gr, gk;
+            if (KCONT) {
+                gr = row0 + (f >> 3);
+                gk = k0 + ((f & 7) << 2) + j;
+            } else {
+                constexpr int QR = BROW / 4;
+                gk = k0 + f / QR;
+                gr = row0 + ((f % QR) << 2) + j;
+            }
+            const bool ok = gr < R && gk < Kend;
+            const int cr = ok ? gr : 0, ck = ok ? gk : 0;           // element (0,0) always exists
+            const float x = KCONT ? src[(size_t)cr * ld + ck] : src[(size_t)ck * ld + cr];
+            e[j] = ok ? x : 0.0f;
+        }
+        v[i] = make_float4(e[0], e[1], e[2], e[3]);
     }
 }
 
@@ -121,6 +126,63 @@ __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v
     *o = v;
 }
 
+template <int BM, int BN, int TM, int TN, bool AK, bool BKC>
+__device__ inline void compute_tile(const float* __restrict__ a_s, const float* __restrict__ b_s, f32x16 (&acc)[TM][TN], int wm0, int wn0,
+                                    int lr, int lh) {
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = read_operand<BM, AK>(a_s, wm0 + i * 32 + lr, kk + lh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = read_operand<BN, BKC>(b_s, wn0 + j * 32 + lr, kk + lh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int BM, int BN, int TM, int TN, bool AK, bool BKC, bool FAST>
+__device__ inline void mainloop(const grappa_gemm_desc& d, float* __restrict__ smem, f32x16 (&acc)[TM][TN], int m0, int n0, int kbeg,
+                                int kend, int nk, int wm0, int wn0, int lr, int lh) {
+    constexpr int ASZ = Tile<BM, AK>::SIZE, BSZ = Tile<BN, BKC>::SIZE;
+    float4 ra[Tile<BM, AK>::NV], rb[Tile<BN, BKC>::NV];
+    auto load = [&](int k0) {
+        if (FAST) {
+            load_tile_fast<BM, AK>(d.A, d.lda, m0, k0, ra);
+            load_tile_fast<BN, BKC>(d.B, d.ldb, n0, k0, rb);
+        } else {
+            load_tile_edge<BM, AK>(d.A, d.lda, m0, k0, d.M, kend, ra);
+            load_tile_edge<BN, BKC>(d.B, d.ldb, n0, k0, d.N, kend, rb);
+        }
+    };
+    if (nk > 0) {
+        load(kbeg);
+        store_tile<BM, AK>(smem, ra);
+        store_tile<BN, BKC>(smem + ASZ, rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt + 1 < nk; ++kt) {          // steady state: prefetch tile kt+1 while computing tile kt
+        const int cur = kt & 1;
+        load(kbeg + (kt + 1) * BK);
+        // keep the prefetch at the TOP of the K-step: without the scheduling barriers hipcc sinks the global loads below
+        // the MFMA block (shorter live ranges) and the whole memory latency is exposed in front of the LDS stores
+        __builtin_amdgcn_sched_barrier(0);
+        const float* a_s = smem + cur * (ASZ + BSZ);
+        compute_tile<BM, BN, TM, TN, AK, BKC>(a_s, a_s + ASZ, acc, wm0, wn0, lr, lh);
+        __builtin_amdgcn_sched_barrier(0);
+        float* nxt = smem + (cur ^ 1) * (ASZ + BSZ);
+        store_tile<BM, AK>(nxt, ra);
+        store_tile<BN, BKC>(nxt + ASZ, rb);
+        __syncthreads();
+    }
+    if (nk > 0) {                                   // last tile: compute only
+        const float* a_s = smem + ((nk - 1) & 1) * (ASZ + BSZ);
+        compute_tile<BM, BN, TM, TN, AK, BKC>(a_s, a_s + ASZ, acc, wm0, wn0, lr, lh);
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -151,45 +213,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    float4 ra[Tile<BM, AK>::NV], rb[Tile<BN, BKC>::NV];
+    // One decision per workgroup (not per load, not per K-step): interior workgroups run a loop whose global loads are
+    // unconditional 16-byte loads, all in flight together behind the MFMAs; edge workgroups take the guarded loop.
     const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        load_tile<BM, AK>(d.A, d.lda, m0, kbeg, d.M, kend, p.vecA, ra);
-        load_tile<BN, BKC>(d.B, d.ldb, n0, kbeg, d.N, kend, p.vecB, rb);
-        store_tile<BM, AK>(smem, ra);
-        store_tile<BN, BKC>(smem + ASZ, rb);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool has_next = kt + 1 < nk;
-        if (has_next) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            load_tile<BM, AK>(d.A, d.lda, m0, k0, d.M, kend, p.vecA, ra);
-            load_tile<BN, BKC>(d.B, d.ldb, n0, k0, d.N, kend, p.vecB, rb);
-        }
-        const float* a_s = smem + cur * (ASZ + BSZ);
-        const float* b_s = a_s + ASZ;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = read_operand<BM, AK>(a_s, wm0 + i * 32 + lr, kk + lh);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = read_operand<BN, BKC>(b_s, wn0 + j * 32 + lr, kk + lh);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (has_next) {
-            float* nxt = smem + (cur ^ 1) * (ASZ + BSZ);
-            store_tile<BM, AK>(nxt, ra);
-            store_tile<BN, BKC>(nxt + ASZ, rb);
-        }
-        __syncthreads();
-    }
+    const bool fast = p.vecA && p.vecB && (m0 + BM <= d.M) && (n0 + BN <= d.N) && ((kend - kbeg) % BK == 0);
+    if (fast)
+        mainloop<BM, BN, TM, TN, AK, BKC, true>(d, smem, acc, m0, n0, kbeg, kend, nk, wm0, wn0, lr, lh);
+    else
+        mainloop<BM, BN, TM, TN, AK, BKC, false>(d, smem, acc, m0, n0, kbeg, kend, nk, wm0, wn0, lr, lh);
 
     // C/D layout of the 32x32 accumulator: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
 #pragma unroll
