@@ -1,16 +1,19 @@
 // fp32 GEMM with fused epilogue on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32,
 // bitwise a k-ordered fmaf chain; peak 157.3 TFLOP/s on MI355X).
 //
-// Structure: 256-thread workgroup (4 wavefronts), BMxBNx32 tile, global -> registers -> LDS with two
-// LDS stages (one barrier per K-step of 32), each wavefront owns a (BM/WAVES_M)x(BN/WAVES_N) sub-tile as
-// 32x32 MFMA accumulators.  Operands are stored in LDS so that the 64 lanes of one MFMA operand read hit
-// 64 different banks:
+// Structure: 256-thread workgroup (4 wavefronts), BMxBNx32 tile, each wavefront owns a (BM/WAVES_M)x(BN/WAVES_N)
+// sub-tile as 32x32 MFMA accumulators.  Software pipeline per K-step of 32 (register prefetch distance 2, two LDS stages):
+//   [issue the 16-byte global loads of tile kt+2] [MFMAs on the first half of tile kt] [LDS stores of tile kt+1, loaded one
+//   step earlier -> no exposed wait] [MFMAs on the second half] [one barrier]
+// pinned with scheduling barriers (hipcc otherwise sinks the loads below the MFMA block and exposes the memory latency).
+// Operands sit in LDS so that the 64 lanes of one MFMA operand read hit 64 different banks:
 //   K-contiguous source  (X[M,K], W[N,K], dY[M,N']): S[row][32+1]  (pad 1 -> bank = (row+k) % 32)
 //   row-contiguous source (W[N',K'] for dgrad, dY/X for wgrad): S[k][BROW]
-// XCD-aware tile order: workgroups that land on the same XCD (blockIdx % 8 equal) walk consecutive column
-// tiles of the same row panel, so the big activation panel is fetched into one L2 only.
-// Split-K (wgrad: K = #tokens) writes fp32 slabs that a second kernel sums in a fixed order (bitwise
-// reproducible) before applying the epilogue.
+// Ragged M/N edges cost nothing in the main loop: out-of-range rows are CLAMPED to a valid row (their results are never
+// stored), out-of-range K is zero-selected; only shapes whose leading dimension forbids 16-byte loads (K = 85, ld = 511)
+// take the scalar-load kernel.  Workgroup order is XCD-aware: consecutive logical ids (= one XCD's L2) are the column tiles
+// of one row panel and, for split-K, the tiles of one K-slice.  Split-K (weight gradients: K = #tokens) writes fp32 slabs
+// that a second kernel sums in a fixed order (bitwise reproducible) before applying the epilogue.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,7 +25,6 @@ constexpr int NTHREADS = 256;
 
 struct GemmParams {
     grappa_gemm_desc d;
-    int vecA, vecB;        // 16-byte vector loads legal for A / B
     int k_per_split;       // multiple of BK
     int nsplit;
     float* slab;           // [nsplit, M, N] when nsplit > 1
@@ -36,28 +38,35 @@ struct Tile {
     static constexpr int NV = BROW * BK / 4 / NTHREADS;   // float4 per thread
 };
 
-// Interior tiles (whole tile in range, 16-byte loads legal): unconditional float4 loads -- no per-load branches, so all
-// loads of a K-step are in flight together.  Edge tiles: branch-free scalar loads from clamped addresses + select.
+// 16-byte loads, branch free.  R = number of valid rows, Kend = end of this workgroup's K range.
 template <int BROW, bool KCONT>
-__device__ inline void load_tile_fast(const float* __restrict__ src, int ld, int row0, int k0, float4 (&v)[Tile<BROW, KCONT>::NV]) {
+__device__ inline void load_tile_vec(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend,
+                                     float4 (&v)[Tile<BROW, KCONT>::NV]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < Tile<BROW, KCONT>::NV; ++i) {
         const int f = tid + i * NTHREADS;
         if (KCONT) {
-            const int row = f >> 3, kq = (f & 7) << 2;
-            v[i] = *reinterpret_cast<const float4*>(src + (size_t)(row0 + row) * ld + (k0 + kq));
+            const int row = min(row0 + (f >> 3), R - 1);
+            const int gk = k0 + ((f & 7) << 2);
+            const bool ok = gk < Kend;                                // K % 4 == 0 on this path: a float4 is all in or all out
+            const float4 x = *reinterpret_cast<const float4*>(src + (size_t)row * ld + (ok ? gk : 0));
+            v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
             constexpr int QR = BROW / 4;
-            const int k = f / QR, rq = (f % QR) << 2;
-            v[i] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + k) * ld + (row0 + rq));
+            const int gk = k0 + f / QR;
+            const bool ok = gk < Kend;
+            const int row = min(row0 + ((f % QR) << 2), ((R + 3) & ~3) - 4);   // stays inside the (16-byte padded) row
+            const float4 x = *reinterpret_cast<const float4*>(src + (size_t)(ok ? gk : 0) * ld + row);
+            v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }
 
+// scalar loads from clamped addresses + select (shapes whose leading dimension / K forbid 16-byte loads)
 template <int BROW, bool KCONT>
-__device__ inline void load_tile_edge(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend,
-                                      float4 (&v)[Tile<BROW, KCONT>::NV]) {
+__device__ inline void load_tile_scalar(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend,
+                                        float4 (&v)[Tile<BROW, KCONT>::NV]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < Tile<BROW, KCONT>::NV; ++i) {
@@ -126,11 +135,11 @@ __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v
     *o = v;
 }
 
-template <int BM, int BN, int TM, int TN, bool AK, bool BKC>
-__device__ inline void compute_tile(const float* __restrict__ a_s, const float* __restrict__ b_s, f32x16 (&acc)[TM][TN], int wm0, int wn0,
+template <int BM, int BN, int TM, int TN, bool AK, bool BKC, int K0, int K1>
+__device__ inline void compute_part(const float* __restrict__ a_s, const float* __restrict__ b_s, f32x16 (&acc)[TM][TN], int wm0, int wn0,
                                     int lr, int lh) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = K0; kk < K1; kk += 2) {
         float a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = read_operand<BM, AK>(a_s, wm0 + i * 32 + lr, kk + lh);
@@ -143,61 +152,57 @@ __device__ inline void compute_tile(const float* __restrict__ a_s, const float* 
     }
 }
 
-template <int BM, int BN, int TM, int TN, bool AK, bool BKC, bool FAST>
-__device__ inline void mainloop(const grappa_gemm_desc& d, float* __restrict__ smem, f32x16 (&acc)[TM][TN], int m0, int n0, int kbeg,
-                                int kend, int nk, int wm0, int wn0, int lr, int lh) {
-    constexpr int ASZ = Tile<BM, AK>::SIZE, BSZ = Tile<BN, BKC>::SIZE;
-    float4 ra[Tile<BM, AK>::NV], rb[Tile<BN, BKC>::NV];
-    auto load = [&](int k0) {
-        if (FAST) {
-            load_tile_fast<BM, AK>(d.A, d.lda, m0, k0, ra);
-            load_tile_fast<BN, BKC>(d.B, d.ldb, n0, k0, rb);
-        } else {
-            load_tile_edge<BM, AK>(d.A, d.lda, m0, k0, d.M, kend, ra);
-            load_tile_edge<BN, BKC>(d.B, d.ldb, n0, k0, d.N, kend, rb);
-        }
-    };
-    if (nk > 0) {
-        load(kbeg);
-        store_tile<BM, AK>(smem, ra);
-        store_tile<BN, BKC>(smem + ASZ, rb);
-    }
-    __syncthreads();
-    for (int kt = 0; kt + 1 < nk; ++kt) {          // steady state: prefetch tile kt+1 while computing tile kt
-        const int cur = kt & 1;
-        load(kbeg + (kt + 1) * BK);
-        // keep the prefetch at the TOP of the K-step: without the scheduling barriers hipcc sinks the global loads below
-        // the MFMA block (shorter live ranges) and the whole memory latency is exposed in front of the LDS stores
-        __builtin_amdgcn_sched_barrier(0);
-        const float* a_s = smem + cur * (ASZ + BSZ);
-        compute_tile<BM, BN, TM, TN, AK, BKC>(a_s, a_s + ASZ, acc, wm0, wn0, lr, lh);
-        __builtin_amdgcn_sched_barrier(0);
-        float* nxt = smem + (cur ^ 1) * (ASZ + BSZ);
-        store_tile<BM, AK>(nxt, ra);
-        store_tile<BN, BKC>(nxt + ASZ, rb);
-        __syncthreads();
-    }
-    if (nk > 0) {                                   // last tile: compute only
-        const float* a_s = smem + ((nk - 1) & 1) * (ASZ + BSZ);
-        compute_tile<BM, BN, TM, TN, AK, BKC>(a_s, a_s + ASZ, acc, wm0, wn0, lr, lh);
+template <int BM, int BN, bool AK, bool BKC, bool VEC>
+__device__ inline void load_pair(const grappa_gemm_desc& d, int m0, int n0, int k0, int kend, float4 (&ra)[Tile<BM, AK>::NV],
+                                 float4 (&rb)[Tile<BN, BKC>::NV]) {
+    if (VEC) {
+        load_tile_vec<BM, AK>(d.A, d.lda, m0, k0, d.M, kend, ra);
+        load_tile_vec<BN, BKC>(d.B, d.ldb, n0, k0, d.N, kend, rb);
+    } else {
+        load_tile_scalar<BM, AK>(d.A, d.lda, m0, k0, d.M, kend, ra);
+        load_tile_scalar<BN, BKC>(d.B, d.ldb, n0, k0, d.N, kend, rb);
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
+// one K-step of the pipeline; LA/LB: register set receiving tile kt+2, SA/SB: register set holding tile kt+1
+template <int BM, int BN, int TM, int TN, bool AK, bool BKC, bool VEC, bool DO_LOAD, bool DO_STORE>
+__device__ inline void pipeline_step(const grappa_gemm_desc& d, float* __restrict__ smem, f32x16 (&acc)[TM][TN], int m0, int n0, int kend,
+                                     int k_load, int cur, int wm0, int wn0, int lr, int lh, float4 (&la)[Tile<BM, AK>::NV],
+                                     float4 (&lb)[Tile<BN, BKC>::NV], const float4 (&sa)[Tile<BM, AK>::NV],
+                                     const float4 (&sb)[Tile<BN, BKC>::NV]) {
+    constexpr int ASZ = Tile<BM, AK>::SIZE, BSZ = Tile<BN, BKC>::SIZE;
+    if (DO_LOAD) load_pair<BM, BN, AK, BKC, VEC>(d, m0, n0, k_load, kend, la, lb);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* a_s = smem + cur * (ASZ + BSZ);
+    compute_part<BM, BN, TM, TN, AK, BKC, 0, BK / 2>(a_s, a_s + ASZ, acc, wm0, wn0, lr, lh);
+    __builtin_amdgcn_sched_barrier(0);
+    if (DO_STORE) {
+        float* nxt = smem + (cur ^ 1) * (ASZ + BSZ);
+        store_tile<BM, AK>(nxt, sa);
+        store_tile<BN, BKC>(nxt + ASZ, sb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    compute_part<BM, BN, TM, TN, AK, BKC, BK / 2, BK>(a_s, a_s + ASZ, acc, wm0, wn0, lr, lh);
+    __syncthreads();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC, bool VEC>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int ASZ = Tile<BM, AK>::SIZE, BSZ = Tile<BN, BKC>::SIZE;
+    constexpr int ASZ = Tile<BM, AK>::SIZE;
     extern __shared__ float smem[];   // stage s: A at s*(ASZ+BSZ), B behind it
 
     const grappa_gemm_desc& d = p.d;
-    // XCD-aware bijective remap of the linear workgroup id (blocks b and b+8 share an XCD)
+    // XCD-aware bijective remap of the linear workgroup id (blocks b and b+8 share an XCD): consecutive LOGICAL ids run on one
+    // XCD.  Logical order = (split, tile_m, tile_n) with tile_n fastest.
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int tile_m = wgid / p.tiles_n, tile_n = wgid % p.tiles_n;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int split = wgid / ntiles, tile = wgid - split * ntiles;
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y;
     const int kbeg = split * p.k_per_split;
     const int kend = min(d.K, kbeg + p.k_per_split);
 
@@ -213,14 +218,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // One decision per workgroup (not per load, not per K-step): interior workgroups run a loop whose global loads are
-    // unconditional 16-byte loads, all in flight together behind the MFMAs; edge workgroups take the guarded loop.
     const int nk = (kend - kbeg + BK - 1) / BK;
-    const bool fast = p.vecA && p.vecB && (m0 + BM <= d.M) && (n0 + BN <= d.N) && ((kend - kbeg) % BK == 0);
-    if (fast)
-        mainloop<BM, BN, TM, TN, AK, BKC, true>(d, smem, acc, m0, n0, kbeg, kend, nk, wm0, wn0, lr, lh);
-    else
-        mainloop<BM, BN, TM, TN, AK, BKC, false>(d, smem, acc, m0, n0, kbeg, kend, nk, wm0, wn0, lr, lh);
+    if (nk > 0) {
+        float4 a0[Tile<BM, AK>::NV], b0[Tile<BN, BKC>::NV], a1[Tile<BM, AK>::NV], b1[Tile<BN, BKC>::NV];
+        load_pair<BM, BN, AK, BKC, VEC>(d, m0, n0, kbeg, kend, a0, b0);                   // tile 0 -> set 0 -> LDS stage 0
+        load_pair<BM, BN, AK, BKC, VEC>(d, m0, n0, kbeg + BK, kend, a1, b1);              // tile 1 -> set 1 (zeros past the end)
+        store_tile<BM, AK>(smem, a0);
+        store_tile<BN, BKC>(smem + ASZ, b0);
+        __syncthreads();
+        int kt = 0;
+#define GRAPPA_STEP(DL, DS, LA, LB, SA, SB) \
+    pipeline_step<BM, BN, TM, TN, AK, BKC, VEC, DL, DS>(d, smem, acc, m0, n0, kend, kbeg + (kt + 2) * BK, kt & 1, wm0, wn0, lr, lh, LA, LB, SA, SB)
+        // two K-steps per trip so that the register sets are compile-time names:
+        //   even kt: load tile kt+2 into set 0 (tile kt already lives in LDS), store tile kt+1 from set 1; odd kt: the other way round.
+        // Loads past the end of the K range are clamped + zero-selected, so every step but the last can prefetch unconditionally.
+        for (; kt + 2 < nk; kt += 2) {
+            GRAPPA_STEP(true, true, a0, b0, a1, b1);
+            ++kt;
+            GRAPPA_STEP(true, true, a1, b1, a0, b0);
+            --kt;
+        }
+        if (kt + 1 < nk) {                                    // two steps left (kt even)
+            GRAPPA_STEP(false, true, a0, b0, a1, b1);
+            ++kt;
+            GRAPPA_STEP(false, false, a1, b1, a0, b0);
+        } else if (kt < nk) {                                 // one step left
+            GRAPPA_STEP(false, false, a0, b0, a1, b1);
+        }
+#undef GRAPPA_STEP
+    }
 
     // C/D layout of the 32x32 accumulator: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
 #pragma unroll
@@ -250,11 +276,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_splitk_reduce_kernel(GemmParams
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC, bool VEC>
 int launch_cfg(hipStream_t st, GemmParams& p) {
-    constexpr int ASZ = Tile<BM, AK>::SIZE, BSZ = Tile<BN, BKC>::SIZE;
-    constexpr size_t smem = 2 * (size_t)(ASZ + BSZ) * sizeof(float);
-    auto kern = gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, AK, BKC>;
+    constexpr size_t smem = 2 * (size_t)(Tile<BM, AK>::SIZE + Tile<BN, BKC>::SIZE) * sizeof(float);
+    auto kern = gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, AK, BKC, VEC>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -263,7 +288,7 @@ int launch_cfg(hipStream_t st, GemmParams& p) {
     }
     p.tiles_m = (p.d.M + BM - 1) / BM;
     p.tiles_n = (p.d.N + BN - 1) / BN;
-    dim3 grid(p.tiles_m * p.tiles_n, p.nsplit);
+    dim3 grid(p.tiles_m * p.tiles_n * p.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, st, p);
     return grappa_launch_status();
 }
@@ -306,15 +331,22 @@ Plan make_plan(int M, int N, int K) {
     return pl;
 }
 
-template <bool AK, bool BKC>
-int dispatch(hipStream_t st, GemmParams& p, int cfg) {
+template <bool AK, bool BKC, bool VEC>
+int dispatch_cfg(hipStream_t st, GemmParams& p, int cfg) {
     switch (cfg) {
-        case 0: return launch_cfg<128, 128, 2, 2, AK, BKC>(st, p);
-        case 1: return launch_cfg<64, 64, 2, 2, AK, BKC>(st, p);
-        case 2: return launch_cfg<128, 32, 4, 1, AK, BKC>(st, p);
-        case 3: return launch_cfg<32, 128, 1, 4, AK, BKC>(st, p);
-        default: return launch_cfg<128, 64, 2, 2, AK, BKC>(st, p);
+        case 0: return launch_cfg<128, 128, 2, 2, AK, BKC, VEC>(st, p);
+        case 1: return launch_cfg<64, 64, 2, 2, AK, BKC, VEC>(st, p);
+        case 2: return launch_cfg<128, 32, 4, 1, AK, BKC, VEC>(st, p);
+        case 3: return launch_cfg<32, 128, 1, 4, AK, BKC, VEC>(st, p);
+        default: return launch_cfg<128, 64, 2, 2, AK, BKC, VEC>(st, p);
     }
+}
+
+template <bool AK, bool BKC>
+int dispatch(hipStream_t st, GemmParams& p, int cfg, bool vec) {
+    if (vec) return dispatch_cfg<AK, BKC, true>(st, p, cfg);
+    // scalar-load kernel: odd shapes only (K = 85, ld = 511, ...); the big tiles are not instantiated for it
+    return dispatch_cfg<AK, BKC, false>(st, p, (cfg == 0 || cfg == 4) ? 1 : cfg);
 }
 
 }  // namespace
@@ -335,8 +367,13 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GemmParams p;
     p.d = *d;
-    p.vecA = ((reinterpret_cast<uintptr_t>(d->A) & 15) == 0 && (d->lda & 3) == 0) ? 1 : 0;
-    p.vecB = ((reinterpret_cast<uintptr_t>(d->B) & 15) == 0 && (d->ldb & 3) == 0) ? 1 : 0;
+    // 16-byte loads: aligned base, leading dimension % 4 == 0, and for K-contiguous operands K % 4 == 0
+    const bool vecA = (reinterpret_cast<uintptr_t>(d->A) & 15) == 0 && (d->lda & 3) == 0 && (!d->a_kcontig || (d->K & 3) == 0);
+    const bool vecB = (reinterpret_cast<uintptr_t>(d->B) & 15) == 0 && (d->ldb & 3) == 0 && (!d->b_kcontig || (d->K & 3) == 0);
+    // row-contiguous operands read float4 along rows: the padded row (ld) must cover round_up(rows, 4)
+    const bool padA = d->a_kcontig || ((d->M + 3) & ~3) <= d->lda;
+    const bool padB = d->b_kcontig || ((d->N + 3) & ~3) <= d->ldb;
+    const bool vec = vecA && vecB && padA && padB;
     p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
     Plan pl = make_plan(d->M, d->N, d->K);
     p.nsplit = pl.nsplit;
@@ -348,9 +385,9 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
         p.slab = reinterpret_cast<float*>(ws);
     }
     int rc;
-    if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg);
-    else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg);
-    else rc = dispatch<false, false>(st, p, pl.cfg);
+    if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
+    else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
+    else rc = dispatch<false, false>(st, p, pl.cfg, vec);
     if (rc != GRAPPA_OK) return rc;
     if (pl.nsplit > 1) {
         const size_t total = (size_t)d->M * d->N;
