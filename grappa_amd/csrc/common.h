@@ -10,13 +10,21 @@ static inline int grappa_launch_status() {
     return hipGetLastError() == hipSuccess ? GRAPPA_OK : GRAPPA_ERR_LAUNCH;
 }
 
-// counter-based dropout decision: splitmix64 of (seed + index*golden); keep iff u >= p, u in [0,1) with 24 bits
+// counter-based dropout decision: a 32-bit finaliser (murmur3 fmix32) of the element index, keyed by the 64-bit seed;
+// keep iff u >= p with u = 24 random bits / 2^24.  ~10 integer ops per element (it runs in GEMM epilogues).
 __host__ __device__ inline uint32_t grappa_hash32(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 40);   // 24 random bits
+    uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+    h ^= (uint32_t)(idx >> 32) * 0x85EBCA77u;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    h += (uint32_t)(seed >> 32);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    return h >> 8;   // 24 random bits
 }
 __host__ __device__ inline bool grappa_keep(uint64_t seed, uint64_t idx, float p) {
     return (float)grappa_hash32(seed, idx) * (1.0f / 16777216.0f) >= p;

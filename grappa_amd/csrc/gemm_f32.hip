@@ -299,36 +299,45 @@ struct Plan { int cfg; int nsplit; int k_per_split; };
 constexpr int CFG_BM[5] = {128, 64, 128, 32, 128};
 constexpr int CFG_BN[5] = {128, 64, 32, 128, 64};
 
-// Tile choice: the largest tile that still gives the 256 CUs >= ~1.5 workgroups each; when the output is small and K is
-// long (weight gradients: K = #tokens) fill the chip with split-K slabs instead of shrinking the tile.
+// Tile choice by a small cost model: the busiest of the 256 CUs gets ceil(workgroups / 256) of them, each costing
+// BM*BN*k_per_split MFMA work divided by the tile's efficiency (smaller tiles re-read LDS more per MFMA); split-K (only when
+// K is long) adds the slab round trip.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
 Plan make_plan(int M, int N, int K) {
-    Plan pl;
-    pl.nsplit = 1;
-    auto tiles_of = [&](int c) { return (long)((M + CFG_BM[c] - 1) / CFG_BM[c]) * ((N + CFG_BN[c] - 1) / CFG_BN[c]); };
+    Plan best;
+    best.cfg = 1;
+    best.nsplit = 1;
+    best.k_per_split = (K + BK - 1) / BK * BK;
+    double best_cost = 1e300;
+    const int cands[5] = {0, 4, 1, 2, 3};
+    const double eff[5] = {1.00, 0.70, 0.55, 0.55, 0.93};          // indexed by cfg
     int max_split = K >= 16 * BK ? K / (8 * BK) : 1;
     if (max_split > 64) max_split = 64;
-    if (N <= 32) pl.cfg = 2;
-    else if (M <= 32) pl.cfg = 3;
-    else {
-        const int order[3] = {0, 4, 1};
-        pl.cfg = -1;
-        for (int i = 0; i < 3 && pl.cfg < 0; ++i)
-            if (tiles_of(order[i]) >= 400) pl.cfg = order[i];                 // enough tiles without splitting K
-        for (int i = 0; i < 3 && pl.cfg < 0; ++i)
-            if (tiles_of(order[i]) * max_split >= 400) pl.cfg = order[i];     // big tile + split-K
-        if (pl.cfg < 0) pl.cfg = 1;
+    for (int ci = 0; ci < 5; ++ci) {
+        const int c = cands[ci];
+        if (c == 2 && N > 32) continue;
+        if (c == 3 && M > 32) continue;
+        if ((c == 0 || c == 4 || c == 1) && (N <= 32 || M <= 32)) continue;
+        const long tiles = (long)((M + CFG_BM[c] - 1) / CFG_BM[c]) * ((N + CFG_BN[c] - 1) / CFG_BN[c]);
+        for (int ns = 1; ns <= max_split; ns = ns < 4 ? ns + 1 : ns + (ns + 3) / 4) {
+            int kps = (K + ns - 1) / ns;
+            kps = (kps + BK - 1) / BK * BK;
+            const int nsplit = (K + kps - 1) / kps;
+            const long wgs = tiles * nsplit;
+            const double rounds = (double)((wgs + 255) / 256);
+            // unit = one MAC on one CU (128 MAC/cycle/CU); + pipeline fill/epilogue per workgroup
+            double cost = rounds * (double)CFG_BM[c] * CFG_BN[c] * (kps + 2.0 * BK) / eff[c];
+            if (wgs <= 256) cost *= 1.3;            // a lone workgroup per CU cannot hide its barrier / LDS-store bubbles
+            // slab write + read (~2000 B/cycle chip-wide -> x128 MAC/cycle/CU) + the extra launch
+            if (nsplit > 1) cost += 1.5e6 + (double)nsplit * M * N * 0.5;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best.cfg = c;
+                best.nsplit = nsplit;
+                best.k_per_split = kps;
+            }
+        }
     }
-    const long tiles = tiles_of(pl.cfg);
-    int nsplit = 1;
-    if (tiles < 400 && max_split > 1) {
-        nsplit = (int)((512 + tiles - 1) / tiles);
-        if (nsplit > max_split) nsplit = max_split;
-    }
-    int kps = (K + nsplit - 1) / nsplit;
-    kps = (kps + BK - 1) / BK * BK;
-    pl.nsplit = (K + kps - 1) / kps;
-    pl.k_per_split = kps;
-    return pl;
+    return best;
 }
 
 template <bool AK, bool BKC, bool VEC>
@@ -355,6 +364,15 @@ extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     Plan pl = make_plan(M, N, K);
     return pl.nsplit > 1 ? (size_t)pl.nsplit * M * N * sizeof(float) : 0;
+}
+
+extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit) {
+    if (M <= 0 || N <= 0 || K <= 0 || !tile_m || !tile_n || !nsplit) return GRAPPA_ERR_ARG;
+    Plan pl = make_plan(M, N, K);
+    *tile_m = CFG_BM[pl.cfg];
+    *tile_n = CFG_BN[pl.cfg];
+    *nsplit = pl.nsplit;
+    return GRAPPA_OK;
 }
 
 extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes) {

@@ -16,28 +16,27 @@ import math
 import torch
 import torch.nn.functional as F
 
-MASK64 = (1 << 64) - 1
-
-
-def _u64_mul(a: torch.Tensor, c: int) -> torch.Tensor:
-    """(a * c) mod 2^64 with a as int64 bit patterns (two's complement multiplication wraps)."""
-    c_signed = c - (1 << 64) if c >= (1 << 63) else c
-    return a * c_signed
-
-
-def _lsr(a: torch.Tensor, n: int) -> torch.Tensor:
-    return (a >> n) & ((1 << (64 - n)) - 1)
+M32 = 0xFFFFFFFF
 
 
 def dropout_keep(seed: int, idx: torch.Tensor, p: float) -> torch.Tensor:
-    """splitmix64(seed + idx*golden) >> 40 as a 24-bit uniform; keep iff u >= p (csrc/common.h)."""
-    s = seed & MASK64
-    s_signed = s - (1 << 64) if s >= (1 << 63) else s
-    z = _u64_mul(idx.to(torch.int64), 0x9E3779B97F4A7C15) + s_signed
-    z = _u64_mul(z ^ _lsr(z, 30), 0xBF58476D1CE4E5B9)
-    z = _u64_mul(z ^ _lsr(z, 27), 0x94D049BB133111EB)
-    z = z ^ _lsr(z, 31)
-    u = _lsr(z, 40).to(torch.float32) * (1.0 / 16777216.0)
+    """csrc/common.h grappa_keep: murmur3-fmix32 style hash of the element index keyed by the 64-bit seed; 24-bit uniform;
+    keep iff u >= p.  int64 arithmetic masked to 32 bits."""
+    seed &= (1 << 64) - 1
+    lo, hi = seed & M32, (seed >> 32) & M32
+    i = idx.to(torch.int64)
+    h = ((i & M32) * 0x9E3779B1 + lo) & M32
+    h = h ^ ((((i >> 32) & M32) * 0x85EBCA77) & M32)
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & M32
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & M32
+    h = h ^ (h >> 16)
+    h = (h + hi) & M32
+    h = h ^ (h >> 15)
+    h = (h * 0x2C1B3C6D) & M32
+    h = h ^ (h >> 12)
+    u = (h >> 8).to(torch.float32) * (1.0 / 16777216.0)
     return u >= p
 
 
