@@ -18,7 +18,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_kcontig", C.c_int), ("b_kcontig", C.c_int),
                 ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
                 ("C2", C.c_void_p), ("ldc2", C.c_int), ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int),
-                ("aux", C.c_void_p), ("ldaux", C.c_int), ("pre", C.c_void_p), ("ldpre", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+                ("aux", C.c_void_p), ("ldaux", C.c_int), ("pre", C.c_void_p), ("ldpre", C.c_int), ("a_colsum", C.c_void_p), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
                 ("accumulate", C.c_int)]
 
 

@@ -113,7 +113,7 @@ class HipBackend:
 
     # ------------------------------------------------------------------ dense
     def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
-             drop_p=0.0, drop_seed=0, accumulate=False, out2=None) -> None:
+             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None) -> None:
         dev = out.device
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
@@ -146,6 +146,11 @@ class HipBackend:
             if tuple(pre.shape) != (M, N):
                 raise ValueError("gemm: pre shape")
             d.pre, d.ldpre = pre.data_ptr(), _f32_2d(pre, "pre", dev)
+        if a_colsum is not None:
+            _flat(a_colsum, "a_colsum", dev)
+            if a_kcontig or a_colsum.numel() != M:
+                raise ValueError("gemm: a_colsum needs the row-contiguous A layout and length M")
+            d.a_colsum = a_colsum.data_ptr()
         d.act, d.drop_p, d.drop_seed, d.accumulate = int(act), float(drop_p), int(drop_seed) & (2 ** 64 - 1), int(accumulate)
         if M == 0 or N == 0:
             return

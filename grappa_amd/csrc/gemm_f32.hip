@@ -28,6 +28,7 @@ struct GemmParams {
     int k_per_split;       // multiple of BK
     int nsplit;
     float* slab;           // [nsplit, M, N] when nsplit > 1
+    float* cs_slab;        // [nsplit, M] column-sum partials when nsplit > 1 and d.a_colsum
     float drop_scale;
     int tiles_m, tiles_n;
 };
@@ -165,11 +166,19 @@ __device__ inline void load_pair(const grappa_gemm_desc& d, int m0, int n0, int 
 }
 
 // one K-step of the pipeline; LA/LB: register set receiving tile kt+2, SA/SB: register set holding tile kt+1
+template <int NV>
+__device__ inline void colsum_accumulate(float4 (&cs)[NV], const float4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        cs[i].x += v[i].x; cs[i].y += v[i].y; cs[i].z += v[i].z; cs[i].w += v[i].w;
+    }
+}
+
 template <int BM, int BN, int TM, int TN, bool AK, bool BKC, bool VEC, bool DO_LOAD, bool DO_STORE>
 __device__ inline void pipeline_step(const grappa_gemm_desc& d, float* __restrict__ smem, f32x16 (&acc)[TM][TN], int m0, int n0, int kend,
                                      int k_load, int cur, int wm0, int wn0, int lr, int lh, float4 (&la)[Tile<BM, AK>::NV],
                                      float4 (&lb)[Tile<BN, BKC>::NV], const float4 (&sa)[Tile<BM, AK>::NV],
-                                     const float4 (&sb)[Tile<BN, BKC>::NV]) {
+                                     const float4 (&sb)[Tile<BN, BKC>::NV], float4 (&cs)[Tile<BM, AK>::NV], bool do_cs) {
     constexpr int ASZ = Tile<BM, AK>::SIZE, BSZ = Tile<BN, BKC>::SIZE;
     if (DO_LOAD) load_pair<BM, BN, AK, BKC, VEC>(d, m0, n0, k_load, kend, la, lb);
     __builtin_amdgcn_sched_barrier(0);
@@ -180,6 +189,7 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, float* __restric
         float* nxt = smem + (cur ^ 1) * (ASZ + BSZ);
         store_tile<BM, AK>(nxt, sa);
         store_tile<BN, BKC>(nxt + ASZ, sb);
+        if (!AK && do_cs) colsum_accumulate<Tile<BM, AK>::NV>(cs, sa);     // bias gradient rides on the wgrad's A tiles
     }
     __builtin_amdgcn_sched_barrier(0);
     compute_part<BM, BN, TM, TN, AK, BKC, BK / 2, BK>(a_s, a_s + ASZ, acc, wm0, wn0, lr, lh);
@@ -219,16 +229,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
+    // column sums of the row-contiguous A operand (sum over K of A(m,k)): computed by the tile_n == 0 workgroups from the
+    // A tiles they stage anyway (the bias gradient db = colsum(dz) of a weight-gradient GEMM)
+    const bool do_cs = !AK && d.a_colsum != nullptr && tile_n == 0;
+    float4 cs[Tile<BM, AK>::NV];
+#pragma unroll
+    for (int i = 0; i < Tile<BM, AK>::NV; ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (nk > 0) {
         float4 a0[Tile<BM, AK>::NV], b0[Tile<BN, BKC>::NV], a1[Tile<BM, AK>::NV], b1[Tile<BN, BKC>::NV];
         load_pair<BM, BN, AK, BKC, VEC>(d, m0, n0, kbeg, kend, a0, b0);                   // tile 0 -> set 0 -> LDS stage 0
         load_pair<BM, BN, AK, BKC, VEC>(d, m0, n0, kbeg + BK, kend, a1, b1);              // tile 1 -> set 1 (zeros past the end)
         store_tile<BM, AK>(smem, a0);
         store_tile<BN, BKC>(smem + ASZ, b0);
+        if (!AK && do_cs) colsum_accumulate<Tile<BM, AK>::NV>(cs, a0);
         __syncthreads();
         int kt = 0;
 #define GRAPPA_STEP(DL, DS, LA, LB, SA, SB) \
-    pipeline_step<BM, BN, TM, TN, AK, BKC, VEC, DL, DS>(d, smem, acc, m0, n0, kend, kbeg + (kt + 2) * BK, kt & 1, wm0, wn0, lr, lh, LA, LB, SA, SB)
+    pipeline_step<BM, BN, TM, TN, AK, BKC, VEC, DL, DS>(d, smem, acc, m0, n0, kend, kbeg + (kt + 2) * BK, kt & 1, wm0, wn0, lr, lh, LA, LB, SA, SB, cs, do_cs)
         // two K-steps per trip so that the register sets are compile-time names:
         //   even kt: load tile kt+2 into set 0 (tile kt already lives in LDS), store tile kt+1 from set 1; odd kt: the other way round.
         // Loads past the end of the K range are clamped + zero-selected, so every step but the last can prefetch unconditionally.
@@ -246,6 +263,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
             GRAPPA_STEP(false, false, a0, b0, a1, b1);
         }
 #undef GRAPPA_STEP
+    }
+
+    if (!AK && do_cs) {
+        // every thread holds partial sums for the 4 rows m = 4*(tid % QR) + {0..3}; threads tid, tid+QR, ... share them
+        constexpr int QR = BM / 4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < Tile<BM, AK>::NV; ++i) { t.x += cs[i].x; t.y += cs[i].y; t.z += cs[i].z; t.w += cs[i].w; }
+        float4* red = reinterpret_cast<float4*>(smem);          // the pipeline's last barrier has retired all LDS reads
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (threadIdx.x < QR) {
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < NTHREADS / QR; ++g) {
+                const float4 v = red[threadIdx.x + g * QR];
+                s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+            }
+            const float vals[4] = {s4.x, s4.y, s4.z, s4.w};
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + 4 * threadIdx.x + j;
+                if (m < d.M) {
+                    if (p.nsplit > 1) p.cs_slab[(size_t)split * d.M + m] = vals[j];
+                    else d.a_colsum[m] += vals[j];
+                }
+            }
+        }
     }
 
     // C/D layout of the 32x32 accumulator: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
@@ -269,6 +312,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
 
 __global__ __launch_bounds__(NTHREADS) void gemm_splitk_reduce_kernel(GemmParams p) {
     const size_t total = (size_t)p.d.M * p.d.N;
+    if (p.d.a_colsum && blockIdx.x == 0) {
+        for (int m = threadIdx.x; m < p.d.M; m += NTHREADS) {
+            float v = 0.0f;
+            for (int s = 0; s < p.nsplit; ++s) v += p.cs_slab[(size_t)s * p.d.M + m];
+            p.d.a_colsum[m] += v;
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * NTHREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * NTHREADS) {
         float v = 0.0f;
         for (int s = 0; s < p.nsplit; ++s) v += p.slab[(size_t)s * total + i];
@@ -363,7 +413,7 @@ int dispatch(hipStream_t st, GemmParams& p, int cfg, bool vec) {
 extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     Plan pl = make_plan(M, N, K);
-    return pl.nsplit > 1 ? (size_t)pl.nsplit * M * N * sizeof(float) : 0;
+    return pl.nsplit > 1 ? ((size_t)pl.nsplit * M * N + (size_t)pl.nsplit * M) * sizeof(float) : 0;
 }
 
 extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit) {
@@ -397,10 +447,13 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     p.nsplit = pl.nsplit;
     p.k_per_split = pl.k_per_split;
     p.slab = nullptr;
+    p.cs_slab = nullptr;
+    if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     if (pl.nsplit > 1) {
-        const size_t need = (size_t)pl.nsplit * d->M * d->N * sizeof(float);
+        const size_t need = ((size_t)pl.nsplit * d->M * d->N + (size_t)pl.nsplit * d->M) * sizeof(float);
         if (!ws || ws_bytes < need) return GRAPPA_ERR_WORKSPACE;
         p.slab = reinterpret_cast<float*>(ws);
+        p.cs_slab = p.slab + (size_t)pl.nsplit * d->M * d->N;
     }
     int rc;
     if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);

@@ -70,9 +70,12 @@ def _linear_bwd_params(be, dz, x, w, b):
     K = x.shape[1]
     if M == 0:
         return
+    want_b = b is not None and b.requires_grad
     if w.requires_grad:
-        be.gemm(dz, x, _pgrad(w), M=N, N=K, K=M, a_kcontig=False, b_kcontig=False, accumulate=True)
-    if b is not None and b.requires_grad:
+        # the bias gradient colsum(dz) is produced by the same kernel from the dz tiles it stages anyway
+        be.gemm(dz, x, _pgrad(w), M=N, N=K, K=M, a_kcontig=False, b_kcontig=False, accumulate=True,
+                a_colsum=_pgrad(b) if want_b else None)
+    elif want_b:
         be.colsum(dz, _pgrad(b), accumulate=True)
 
 

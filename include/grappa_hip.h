@@ -67,6 +67,7 @@ typedef struct grappa_gemm_desc {
     const float* res; int ldres;  /* [M,N] or NULL */
     const float* aux; int ldaux;  /* [M,N] or NULL */
     const float* pre; int ldpre;  /* [M,N] or NULL */
+    float* a_colsum;              /* [M] or NULL; a_kcontig == 0 only: a_colsum[m] += sum_k A(m,k)  (bias gradient of a wgrad GEMM) */
     int act;
     float drop_p;
     uint64_t drop_seed;

@@ -100,6 +100,22 @@ def test_gemm_epilogues(hip, ref):
             assert torch.equal((o2_h.cpu() - res) == 0, (o2_r - res) == 0) or kw.get("drop_p", 0) == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 5000), (1536, 512, 3001), (511, 256, 700), (12, 256, 4097), (2048, 512, 300)])
+def test_gemm_wgrad_with_fused_bias_gradient(hip, ref, M, N, K):
+    """dW += dz^T x and db += colsum(dz) from one launch (with and without split-K)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    ldz = (M + 3) // 4 * 4
+    dz_full, x = torch.randn(K, ldz, generator=g), torch.randn(K, N, generator=g)
+    dz = dz_full[:, :M]
+    w_r, b_r = torch.ones(M, N), torch.ones(M)
+    ref.gemm(dz, x, w_r, M=M, N=N, K=K, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=b_r)
+    w_h, b_h = torch.ones(M, N, device="cuda"), torch.ones(M, device="cuda")
+    hip.gemm(dz_full.cuda()[:, :M], x.cuda(), w_h, M=M, N=N, K=K, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=b_h)
+    torch.cuda.synchronize()
+    _cmp(w_h, w_r, 2e-5, f"wgrad {M}x{N}x{K}")
+    _cmp(b_h, b_r, 2e-5, f"fused bias gradient {M}x{N}x{K}")
+
+
 def test_gemm_strided_views(hip, ref):
     g = torch.Generator().manual_seed(2)
     N_, R, Wp = 200, 256, 511
