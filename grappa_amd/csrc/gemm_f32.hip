@@ -348,6 +348,7 @@ struct Plan { int cfg; int nsplit; int k_per_split; };
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
 constexpr int CFG_BM[5] = {128, 64, 128, 32, 128};
 constexpr int CFG_BN[5] = {128, 64, 32, 128, 64};
+constexpr int CFG_CONC[5] = {2, 4, 4, 4, 3};      // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 KB, VGPR budget)
 
 // Tile choice by a small cost model: the busiest of the 256 CUs gets ceil(workgroups / 256) of them, each costing
 // BM*BN*k_per_split MFMA work divided by the tile's efficiency (smaller tiles re-read LDS more per MFMA); split-K (only when
@@ -373,11 +374,17 @@ Plan make_plan(int M, int N, int K) {
             kps = (kps + BK - 1) / BK * BK;
             const int nsplit = (K + kps - 1) / kps;
             const long wgs = tiles * nsplit;
-            const double rounds = (double)((wgs + 255) / 256);
-            // unit = one MAC on one CU (128 MAC/cycle/CU); + pipeline fill/epilogue per workgroup
-            double cost = rounds * (double)CFG_BM[c] * CFG_BN[c] * (kps + 2.0 * BK) / eff[c];
-            if (wgs <= 256) cost *= 1.3;            // a lone workgroup per CU cannot hide its barrier / LDS-store bubbles
-            // slab write + read (~2000 B/cycle chip-wide -> x128 MAC/cycle/CU) + the extra launch
+            // unit = one MAC on one CU (128 MAC/cycle/CU).  A CU runs `conc` workgroups of this tile at once (LDS/VGPR limit),
+            // each then `conc` times slower; the chip drains the grid in ceil(wgs / (256*conc)) such rounds.
+            const int conc = CFG_CONC[c];
+            const double tile_cost = (double)CFG_BM[c] * CFG_BN[c] * (kps + 3.0 * BK) / eff[c];   // + pipeline fill / epilogue
+            double cost;
+            if (wgs <= 256L * conc) {
+                const double per_cu = (double)((wgs + 255) / 256);
+                cost = per_cu * tile_cost * (per_cu < 2 ? 1.3 : 1.0);     // a lone workgroup cannot hide its barrier / LDS-store bubbles
+            } else {
+                cost = (double)((wgs + 256L * conc - 1) / (256L * conc)) * conc * tile_cost;
+            }
             if (nsplit > 1) cost += 1.5e6 + (double)nsplit * M * N * 0.5;
             if (cost < best_cost) {
                 best_cost = cost;

@@ -1,0 +1,45 @@
+"""Small PMC probe workloads for rocprofv3 --pmc passes (one process, a few launches each):
+   python tools/pmc_probe.py gemm   -> 10 launches of the 83328x512x512 forward GEMM (+ dgrad + wgrad variants)
+   python tools/pmc_probe.py gat    -> 10 launches of gat_fwd / gat_bwd on the C3-size graph (1024 molecules)
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def gemm():
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    for (M, N, K, ak, bk) in [(83328, 512, 512, 1, 1), (83328, 512, 512, 1, 0), (512, 512, 83328, 0, 0)]:
+        A = torch.randn((M, K) if ak else (K, M), device="cuda")
+        B = torch.randn((N, K) if bk else (K, N), device="cuda")
+        C = torch.empty((M, N), device="cuda")
+        for _ in range(10):
+            be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk))
+    torch.cuda.synchronize()
+
+
+def gat():
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_workload
+    be = get_backend()
+    g = build_workload("C3-espaloma-b1024", seed=0).to("cuda")
+    plan = g.plan()
+    H, D = 16, 32
+    ft = torch.randn(plan.N, H * D, device="cuda")
+    dout = torch.randn(plan.N, H * D, device="cuda")
+    out, alpha, dft = torch.empty_like(ft), torch.empty(plan.E, H, device="cuda"), torch.empty_like(ft)
+    for _ in range(10):
+        be.gat_fwd(plan, ft, H, D, out, alpha)
+        be.gat_bwd(plan, ft, out, alpha, dout, H, D, dft)
+    torch.cuda.synchronize()
+    print("atoms", plan.N, "edges", plan.E, "fwd algorithmic MB", (plan.E * (H * D * 4 + 4) + plan.N * (2 * H * D * 4 + 4)) / 1e6,
+          "bwd algorithmic MB", (plan.E * (2 * H * D * 4 + 4) + plan.N * (4 * H * D * 4 + 4)) / 1e6)
+
+
+if __name__ == "__main__":
+    {"gemm": gemm, "gat": gat}[sys.argv[1]]()
