@@ -159,8 +159,19 @@ def main():
     if rank == 0:
         n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
         achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process; the committed
+        # rocprofv3 --pmc summary of this same command (tools/pmc_traffic.py -> profiles/pmc_traffic_c2.json) is reported
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
+        if args.workload == "C2-pubchem-b256" and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))["families"]["gemm_f32"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)"
+            except Exception:
+                traffic = None
         roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<*> (v_mfma_f32_32x32x2_f32)", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": by / max(n, 1),
                 "launches_per_step": n / args.steps, "avg_launch_us": 1e3 * ms / max(n, 1), "gflop_per_launch": fl / max(n, 1) / 1e9,
                 "kernel_ms_per_step": ms / args.steps}
         gat = {}

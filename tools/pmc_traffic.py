@@ -1,0 +1,51 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` into per-kernel-family HBM traffic per launch.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc/bench_FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc/bench_WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmc/bench_FETCH_SIZE gpurun_out/pmc/bench_WRITE_SIZE > gpurun_out/pmc_traffic_c2.json
+
+Units and corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
+bytes of wide coalesced (16 B/lane) streaming reads, so it is doubled; WRITE_SIZE is exact for 16 B/lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+FAMILIES = {"gemm_f32": r"gemm_f32_kernel", "gemm_splitk_reduce": r"gemm_splitk_reduce_kernel", "gat_fwd": r"gat_fwd_kernel",
+            "gat_bwd": r"gat_bwd_kernel|gat_delta_kernel", "layernorm": r"layernorm_", "seqattn": r"seqattn_"}
+
+
+def collect(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    tot, cnt = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        for fam, pat in FAMILIES.items():
+            if re.search(pat, r["Kernel_Name"]):
+                tot[fam] += float(r["Counter_Value"])
+                cnt[fam] += 1
+    return tot, cnt
+
+
+def main():
+    fdir, wdir = sys.argv[1], sys.argv[2]
+    ft, fc = collect(fdir, "FETCH_SIZE")
+    wt, wc = collect(wdir, "WRITE_SIZE")
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1",
+           "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "families": {}}
+    for fam in FAMILIES:
+        if fc[fam] == 0:
+            continue
+        n = fc[fam]
+        fetch_b, write_b = 2.0 * ft[fam] * 1024.0, wt[fam] * 1024.0 * (n / max(wc[fam], 1))
+        out["families"][fam] = {"launches": n, "fetch_bytes_per_launch": fetch_b / n, "write_bytes_per_launch": write_b / n,
+                                "hbm_bytes_per_launch": (fetch_b + write_b) / n}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
