@@ -240,6 +240,21 @@ def main():
     extra = {"loss_kwargs_keys": np.array(list(loss_kwargs.keys())), "loss_kwargs_vals": np.array(list(loss_kwargs.values()))}
     save("ref_prod.npz", cfg, mols, out, None, extra)
 
+    # ---- collate (N1): the reference's collate_fn on molecules with different conformation counts, seeded sub-sampling
+    from grappa.data.GraphDataLoader import get_collate_fn as ref_get_collate_fn
+    mols = build_inputs(pick_small(4, 8, 20, start=300), n_confs=6, seed=91, pad_confs_of={0: 9, 2: 3, 3: 7})
+    col = {}
+    for strategy in (4, "min", "max", "mean"):
+        graphs = [ref_graph(m, m["xyz"].shape[1], False)[0] for m in mols]
+        torch.manual_seed(1234)
+        gb, names = ref_get_collate_fn(conf_strategy=strategy)([(g, f"ds{i % 2}") for i, g in enumerate(graphs)])
+        col[f"{strategy}::xyz"] = to_np(gb.nodes["n1"].data["xyz"])
+        col[f"{strategy}::is_dummy"] = to_np(gb.nodes["g"].data["is_dummy"])
+        col[f"{strategy}::energy_ref"] = to_np(gb.nodes["g"].data["energy_ref"])
+        col[f"{strategy}::gradient_ref"] = to_np(gb.nodes["n1"].data["gradient_ref"])
+        col[f"{strategy}::n4_idxs"] = to_np(gb.nodes["n4"].data["idxs"])
+    save("ref_collate.npz", {}, mols, col)
+
     # ---- Energy only, on "classical" parameters (suffix _ref), incl. the torsion offset option
     mols = build_inputs(pick_small(4, 8, 40, start=200), n_confs=6, seed=77)
     graphs = [ref_graph(m, 6, True, nan_refs=False)[0] for m in mols]
