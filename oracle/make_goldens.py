@@ -255,6 +255,43 @@ def main():
         col[f"{strategy}::n4_idxs"] = to_np(gb.nodes["n4"].data["idxs"])
     save("ref_collate.npz", {}, mols, col)
 
+    # ---- MolData .npz schema (N2): the reference's MolData.from_dict(...).to_dgl() on a synthetic record
+    from grappa.data import MolData as RefMolData
+    m = build_inputs(pick_small(1, 10, 18, start=400), n_confs=5, seed=17)[0]
+    gref, mol = ref_graph(m, 5, False)
+    rng = np.random.default_rng(4)
+    n, C = len(m["z"]), 5
+    nb, na, npr, ni = [gref.num_nodes(l) for l in ("n2", "n3", "n4", "n4_improper")]
+    record = dict(mol.to_dict())
+    record.update(xyz=rng.normal(size=(C, n, 3)).astype(np.float32), energy=rng.normal(size=C).astype(np.float32),
+                  gradient=rng.normal(size=(C, n, 3)).astype(np.float32), energy_ref=rng.normal(size=C).astype(np.float32),
+                  gradient_ref=rng.normal(size=(C, n, 3)).astype(np.float32), mol_id=np.array("mol-0"), smiles=np.array("C"),
+                  bond_k=rng.uniform(300, 900, nb).astype(np.float32), bond_eq=rng.uniform(1, 1.5, nb).astype(np.float32),
+                  angle_k=rng.uniform(50, 150, na).astype(np.float32), angle_eq=rng.uniform(1.7, 2.2, na).astype(np.float32),
+                  proper_ks=rng.uniform(0, 2, (npr, 4)).astype(np.float32), proper_phases=(rng.integers(0, 2, (npr, 4)) * np.pi).astype(np.float32),
+                  improper_ks=rng.uniform(0, 5, (ni, 6)).astype(np.float32), improper_phases=(rng.integers(0, 2, (ni, 6)) * np.pi).astype(np.float32),
+                  energy_reference_ff=rng.normal(size=C).astype(np.float32), gradient_reference_ff=rng.normal(size=(C, n, 3)).astype(np.float32))
+    # the reference's Molecule.from_dict re-derives ring_encoding / degree through RDKit (absent offline); the record already
+    # carries both features, so the RDKit call is skipped for features that are present (the only runtime patch besides the noise)
+    _orig_add = RefMolecule.add_features
+
+    def _add_features_without_rdkit(self, feat_names=("ring_encoding", "degree", "mass"), **kw):
+        names = [feat_names] if isinstance(feat_names, str) else list(feat_names)
+        names = [f for f in names if not (f in ("ring_encoding", "degree") and f in self.additional_features)]
+        return _orig_add(self, names, **kw) if names else None
+
+    RefMolecule.add_features = _add_features_without_rdkit
+    try:
+        gd = RefMolData.from_dict(record).to_dgl()
+    finally:
+        RefMolecule.add_features = _orig_add
+    rec_out = {"record::" + k: np.asarray(v) for k, v in record.items()}
+    for nt in ("g", "n1", "n2", "n3", "n4", "n4_improper"):
+        for k, v in gd.nodes[nt].data.items():
+            rec_out[f"graph::{nt}::{k}"] = to_np(v)
+    np.savez_compressed(os.path.join(OUT, "ref_moldata.npz"), **rec_out)
+    print("wrote ref_moldata.npz")
+
     # ---- Energy only, on "classical" parameters (suffix _ref), incl. the torsion offset option
     mols = build_inputs(pick_small(4, 8, 40, start=200), n_confs=6, seed=77)
     graphs = [ref_graph(m, 6, True, nan_refs=False)[0] for m in mols]
