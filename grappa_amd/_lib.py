@@ -44,7 +44,7 @@ SIGNATURES = {
     "grappa_abi_version": (_i, []),
     "grappa_build_arch": (C.c_char_p, []),
     "grappa_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
-    "grappa_gemm_f32_plan": (_i, [_i, _i, _i, c_int_p, c_int_p, c_int_p]),
+    "grappa_gemm_f32_plan": (_i, [_i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "grappa_gemm_f32": (_i, [_vp, C.POINTER(GemmDesc), _vp, _sz]),
     "grappa_colsum_workspace_bytes": (_sz, [_i, _i]),
     "grappa_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz]),

@@ -27,10 +27,13 @@ struct GemmParams {
     grappa_gemm_desc d;
     int k_per_split;       // multiple of BK
     int nsplit;
-    float* slab;           // [nsplit, M, N] when nsplit > 1
+    float* slab;           // [nsplit, ntiles_launch, BM*BN] tile-local partial sums when nsplit > 1
     float* cs_slab;        // [nsplit, M] column-sum partials when nsplit > 1 and d.a_colsum
     float drop_scale;
     int tiles_m, tiles_n;
+    int tile_begin;        // this launch handles tiles [tile_begin, tile_begin + ntiles_launch) of the tiles_m x tiles_n grid
+    int ntiles_launch;
+    int bm, bn;            // tile shape (for the reduce kernel)
 };
 
 template <int BROW, bool KCONT>
@@ -209,8 +212,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int split = wgid / ntiles, tile = wgid - split * ntiles;
+    const int split = wgid / p.ntiles_launch, tile_local = wgid - split * p.ntiles_launch;
+    const int tile = p.tile_begin + tile_local;
     const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = split * p.k_per_split;
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
                 const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m >= d.M) continue;
                 if (p.nsplit > 1)
-                    p.slab[((size_t)split * d.M + m) * d.N + n] = acc[i][j][e];
+                    p.slab[((size_t)split * p.ntiles_launch + tile_local) * (BM * BN) + (size_t)(m - m0) * BN + (n - n0)] = acc[i][j][e];
                 else
                     epilogue_store(p, m, n, acc[i][j][e]);
             }
@@ -311,18 +314,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
 }
 
 __global__ __launch_bounds__(NTHREADS) void gemm_splitk_reduce_kernel(GemmParams p) {
-    const size_t total = (size_t)p.d.M * p.d.N;
+    const int tile_elems = p.bm * p.bn;
+    const size_t total = (size_t)p.ntiles_launch * tile_elems;
+    const size_t split_stride = total;
     if (p.d.a_colsum && blockIdx.x == 0) {
-        for (int m = threadIdx.x; m < p.d.M; m += NTHREADS) {
-            float v = 0.0f;
-            for (int s = 0; s < p.nsplit; ++s) v += p.cs_slab[(size_t)s * p.d.M + m];
-            p.d.a_colsum[m] += v;
+        // column-sum partials were written by the tile_n == 0 workgroups of this launch
+        for (int tl = 0; tl < p.ntiles_launch; ++tl) {
+            const int tile = p.tile_begin + tl;
+            if (tile % p.tiles_n != 0) continue;
+            const int m0 = (tile / p.tiles_n) * p.bm;
+            for (int mi = threadIdx.x; mi < p.bm; mi += NTHREADS) {
+                const int m = m0 + mi;
+                if (m >= p.d.M) continue;
+                float v = 0.0f;
+                for (int s = 0; s < p.nsplit; ++s) v += p.cs_slab[(size_t)s * p.d.M + m];
+                p.d.a_colsum[m] += v;
+            }
         }
     }
     for (size_t i = (size_t)blockIdx.x * NTHREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * NTHREADS) {
+        const int tl = (int)(i / tile_elems), rem = (int)(i - (size_t)tl * tile_elems);
+        const int tile = p.tile_begin + tl;
+        const int m = (tile / p.tiles_n) * p.bm + rem / p.bn, n = (tile % p.tiles_n) * p.bn + rem % p.bn;
+        if (m >= p.d.M || n >= p.d.N) continue;
         float v = 0.0f;
-        for (int s = 0; s < p.nsplit; ++s) v += p.slab[(size_t)s * total + i];
-        epilogue_store(p, (int)(i / p.d.N), (int)(i % p.d.N), v);
+        for (int s = 0; s < p.nsplit; ++s) v += p.slab[(size_t)s * split_stride + i];
+        epilogue_store(p, m, n, v);
     }
 }
 
@@ -336,14 +353,17 @@ int launch_cfg(hipStream_t st, GemmParams& p) {
             return GRAPPA_ERR_LAUNCH;
         attr_set = true;
     }
-    p.tiles_m = (p.d.M + BM - 1) / BM;
-    p.tiles_n = (p.d.N + BN - 1) / BN;
-    dim3 grid(p.tiles_m * p.tiles_n * p.nsplit);
+    dim3 grid(p.ntiles_launch * p.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, st, p);
     return grappa_launch_status();
 }
 
-struct Plan { int cfg; int nsplit; int k_per_split; };
+struct Plan {
+    int cfg;
+    int nsplit, k_per_split;            // main launch (all tiles, or tiles [0, main_tiles) when a tail exists)
+    int main_tiles;                     // == total tiles when there is no tail
+    int tail_nsplit, tail_k_per_split;  // tail launch: tiles [main_tiles, tiles) with their K range split (0 = no tail)
+};
 
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
 constexpr int CFG_BM[5] = {128, 64, 128, 32, 128};
@@ -353,11 +373,14 @@ constexpr int CFG_CONC[5] = {2, 4, 4, 4, 3};      // co-resident workgroups per 
 // Tile choice by a small cost model: the busiest of the 256 CUs gets ceil(workgroups / 256) of them, each costing
 // BM*BN*k_per_split MFMA work divided by the tile's efficiency (smaller tiles re-read LDS more per MFMA); split-K (only when
 // K is long) adds the slab round trip.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
-Plan make_plan(int M, int N, int K) {
+Plan make_plan(int M, int N, int K, bool vec = true) {
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
     best.k_per_split = (K + BK - 1) / BK * BK;
+    best.main_tiles = 0;
+    best.tail_nsplit = 0;
+    best.tail_k_per_split = 0;
     double best_cost = 1e300;
     const int cands[5] = {0, 4, 1, 2, 3};
     const double eff[5] = {1.00, 0.70, 0.55, 0.55, 0.93};          // indexed by cfg
@@ -365,6 +388,7 @@ Plan make_plan(int M, int N, int K) {
     if (max_split > 64) max_split = 64;
     for (int ci = 0; ci < 5; ++ci) {
         const int c = cands[ci];
+        if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
         if ((c == 0 || c == 4 || c == 1) && (N <= 32 || M <= 32)) continue;
@@ -394,7 +418,38 @@ Plan make_plan(int M, int N, int K) {
             }
         }
     }
+    // Tail: with an unsplit K the grid is tiles = 256*q + rem workgroups; the rem tiles would cost the chip a whole extra
+    // round.  Run them as a second, split-K launch instead (rem * tail_nsplit ~ one workgroup per CU, each 1/tail_nsplit long).
+    const long tiles = (long)((M + CFG_BM[best.cfg] - 1) / CFG_BM[best.cfg]) * ((N + CFG_BN[best.cfg] - 1) / CFG_BN[best.cfg]);
+    best.main_tiles = (int)tiles;
+    if (best.nsplit == 1 && tiles > 256) {
+        const long rem = tiles % 256;
+        int ts = rem > 0 ? (int)(256 / rem) : 0;
+        const int max_tail_split = K >= 8 * BK ? K / (4 * BK) : 1;     // the tail may be cut finer than a full split-K GEMM
+        if (ts > max_tail_split) ts = max_tail_split;
+        if (ts > 64) ts = 64;
+        if (rem > 0 && rem <= 160 && ts >= 2) {
+            int kps = (K + ts - 1) / ts;
+            kps = (kps + BK - 1) / BK * BK;
+            best.tail_nsplit = (K + kps - 1) / kps;
+            best.tail_k_per_split = kps;
+            best.main_tiles = (int)(tiles - rem);
+            if (best.tail_nsplit < 2) { best.tail_nsplit = 0; best.main_tiles = (int)tiles; }
+        }
+    }
     return best;
+}
+
+size_t plan_workspace_floats(const Plan& pl, int M, int N) {
+    const long tiles = (long)((M + CFG_BM[pl.cfg] - 1) / CFG_BM[pl.cfg]) * ((N + CFG_BN[pl.cfg] - 1) / CFG_BN[pl.cfg]);
+    const size_t te = (size_t)CFG_BM[pl.cfg] * CFG_BN[pl.cfg];
+    size_t need = 0;
+    if (pl.nsplit > 1) need = (size_t)pl.nsplit * tiles * te + (size_t)pl.nsplit * M;
+    if (pl.tail_nsplit > 1) {
+        const size_t t = (size_t)pl.tail_nsplit * (tiles - pl.main_tiles) * te + (size_t)pl.tail_nsplit * M;
+        if (t > need) need = t;
+    }
+    return need;
 }
 
 template <bool AK, bool BKC, bool VEC>
@@ -412,23 +467,26 @@ template <bool AK, bool BKC>
 int dispatch(hipStream_t st, GemmParams& p, int cfg, bool vec) {
     if (vec) return dispatch_cfg<AK, BKC, true>(st, p, cfg);
     // scalar-load kernel: odd shapes only (K = 85, ld = 511, ...); the big tiles are not instantiated for it
-    return dispatch_cfg<AK, BKC, false>(st, p, (cfg == 0 || cfg == 4) ? 1 : cfg);
+    return dispatch_cfg<AK, BKC, false>(st, p, cfg);
 }
 
 }  // namespace
 
 extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    Plan pl = make_plan(M, N, K);
-    return pl.nsplit > 1 ? ((size_t)pl.nsplit * M * N + (size_t)pl.nsplit * M) * sizeof(float) : 0;
+    const size_t a = plan_workspace_floats(make_plan(M, N, K, true), M, N), b = plan_workspace_floats(make_plan(M, N, K, false), M, N);
+    return (a > b ? a : b) * sizeof(float);
 }
 
-extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit) {
-    if (M <= 0 || N <= 0 || K <= 0 || !tile_m || !tile_n || !nsplit) return GRAPPA_ERR_ARG;
+extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
+    if (M <= 0 || N <= 0 || K <= 0 || !tile_m || !tile_n || !nsplit || !tail_tiles || !tail_nsplit) return GRAPPA_ERR_ARG;
     Plan pl = make_plan(M, N, K);
     *tile_m = CFG_BM[pl.cfg];
     *tile_n = CFG_BN[pl.cfg];
     *nsplit = pl.nsplit;
+    const long tiles = (long)((M + CFG_BM[pl.cfg] - 1) / CFG_BM[pl.cfg]) * ((N + CFG_BN[pl.cfg] - 1) / CFG_BN[pl.cfg]);
+    *tail_tiles = pl.tail_nsplit > 1 ? (int)(tiles - pl.main_tiles) : 0;
+    *tail_nsplit = pl.tail_nsplit;
     return GRAPPA_OK;
 }
 
@@ -450,29 +508,45 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool padB = d->b_kcontig || ((d->N + 3) & ~3) <= d->ldb;
     const bool vec = vecA && vecB && padA && padB;
     p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
-    Plan pl = make_plan(d->M, d->N, d->K);
-    p.nsplit = pl.nsplit;
-    p.k_per_split = pl.k_per_split;
-    p.slab = nullptr;
-    p.cs_slab = nullptr;
+    Plan pl = make_plan(d->M, d->N, d->K, vec);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
-    if (pl.nsplit > 1) {
-        const size_t need = ((size_t)pl.nsplit * d->M * d->N + (size_t)pl.nsplit * d->M) * sizeof(float);
-        if (!ws || ws_bytes < need) return GRAPPA_ERR_WORKSPACE;
-        p.slab = reinterpret_cast<float*>(ws);
-        p.cs_slab = p.slab + (size_t)pl.nsplit * d->M * d->N;
-    }
-    int rc;
-    if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
-    else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
-    else rc = dispatch<false, false>(st, p, pl.cfg, vec);
-    if (rc != GRAPPA_OK) return rc;
-    if (pl.nsplit > 1) {
-        const size_t total = (size_t)d->M * d->N;
-        int blocks = (int)((total + NTHREADS - 1) / NTHREADS);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(NTHREADS), 0, st, p);
-        rc = grappa_launch_status();
-    }
+    const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
+    if (need > 0 && (!ws || ws_bytes < need)) return GRAPPA_ERR_WORKSPACE;
+    p.bm = CFG_BM[pl.cfg];
+    p.bn = CFG_BN[pl.cfg];
+    p.tiles_m = (d->M + p.bm - 1) / p.bm;
+    p.tiles_n = (d->N + p.bn - 1) / p.bn;
+    const int tiles = p.tiles_m * p.tiles_n;
+    const size_t te = (size_t)p.bm * p.bn;
+
+    auto launch = [&](int tile_begin, int ntiles, int nsplit, int kps) -> int {
+        p.tile_begin = tile_begin;
+        p.ntiles_launch = ntiles;
+        p.nsplit = nsplit;
+        p.k_per_split = kps;
+        p.slab = nullptr;
+        p.cs_slab = nullptr;
+        if (nsplit > 1) {
+            p.slab = reinterpret_cast<float*>(ws);
+            p.cs_slab = p.slab + (size_t)nsplit * ntiles * te;
+        }
+        int rc;
+        if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
+        else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
+        else rc = dispatch<false, false>(st, p, pl.cfg, vec);
+        if (rc != GRAPPA_OK) return rc;
+        if (nsplit > 1) {
+            const size_t total = (size_t)ntiles * te;
+            int blocks = (int)((total + NTHREADS - 1) / NTHREADS);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(NTHREADS), 0, st, p);
+            rc = grappa_launch_status();
+        }
+        return rc;
+    };
+    int rc = GRAPPA_OK;
+    if (pl.main_tiles > 0) rc = launch(0, pl.main_tiles, pl.nsplit, pl.k_per_split);
+    if (rc == GRAPPA_OK && pl.tail_nsplit > 1 && pl.main_tiles < tiles)
+        rc = launch(pl.main_tiles, tiles - pl.main_tiles, pl.tail_nsplit, pl.tail_k_per_split);
     return rc;
 }

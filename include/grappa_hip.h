@@ -75,8 +75,9 @@ typedef struct grappa_gemm_desc {
 } grappa_gemm_desc;
 
 size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);
-/* host-only: the tile (tile_m x tile_n x 32) and split-K factor the launcher will use for this shape */
-int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit);
+/* host-only: the tile (tile_m x tile_n x 32) and split-K factor the launcher will use for this shape, and the "tail": when the
+ * tile grid is 256*q + rem workgroups, the rem tiles run as a second launch with their K range split tail_nsplit ways */
+int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit);
 int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes);
 
 /* out[n] (+)= sum_m x[m*ldx + n]   (bias gradients) */
