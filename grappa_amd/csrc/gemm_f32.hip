@@ -294,21 +294,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
         }
     }
 
-    // C/D layout of the 32x32 accumulator: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
+    // C/D layout of the 32x32 accumulator: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
+    // Row-major walk: the 64-bit row offsets of every epilogue tensor are formed once per row, the per-column terms once per column.
+    int ncol[TN];
+    float bcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        ncol[j] = n0 + wn0 + j * 32 + lr;
+        bcol[j] = (d.bias && ncol[j] < d.N) ? d.bias[ncol[j]] : 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * 32 + lr;
-            if (n >= d.N) continue;
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (m >= d.M) continue;
+            if (p.nsplit > 1) {
+                float* srow = p.slab + ((size_t)split * p.ntiles_launch + tile_local) * (BM * BN) + (size_t)(m - m0) * BN - n0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m >= d.M) continue;
-                if (p.nsplit > 1)
-                    p.slab[((size_t)split * p.ntiles_launch + tile_local) * (BM * BN) + (size_t)(m - m0) * BN + (n - n0)] = acc[i][j][e];
-                else
-                    epilogue_store(p, m, n, acc[i][j][e]);
+                for (int j = 0; j < TN; ++j)
+                    if (ncol[j] < d.N) srow[ncol[j]] = acc[i][j][e];
+                continue;
+            }
+            const float* pre_r = d.pre ? d.pre + (size_t)m * d.ldpre : nullptr;
+            const float* aux_r = d.aux ? d.aux + (size_t)m * d.ldaux : nullptr;
+            const float* res_r = d.res ? d.res + (size_t)m * d.ldres : nullptr;
+            float* c_r = d.C + (size_t)m * d.ldc;
+            float* c2_r = d.C2 ? d.C2 + (size_t)m * d.ldc2 : nullptr;
+            const uint64_t drow = (uint64_t)m * (uint64_t)d.N;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = ncol[j];
+                if (n >= d.N) continue;
+                float v = acc[i][j][e];
+                if (pre_r) v += pre_r[n];
+                v += bcol[j];
+                if (d.act == GRAPPA_ACT_ELU) v = grappa_elu(v);
+                if (aux_r) v *= grappa_elu_grad_from_out(aux_r[n]);
+                float* o = c_r + n;
+                if (c2_r) {
+                    *o = v;
+                    o = c2_r + n;
+                }
+                if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, drow + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
+                if (res_r) v += res_r[n];
+                if (d.accumulate) v += *o;
+                *o = v;
             }
         }
 }
