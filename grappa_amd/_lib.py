@@ -10,6 +10,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrappa_hip.so")
 
+ABI_VERSION = 2
+# grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
+GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4}
+
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
 
@@ -19,7 +23,7 @@ class GemmDesc(C.Structure):
                 ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
                 ("C2", C.c_void_p), ("ldc2", C.c_int), ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int),
                 ("aux", C.c_void_p), ("ldaux", C.c_int), ("pre", C.c_void_p), ("ldpre", C.c_int), ("a_colsum", C.c_void_p), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
-                ("accumulate", C.c_int)]
+                ("accumulate", C.c_int), ("precision", C.c_int)]
 
 
 class MMDesc(C.Structure):
@@ -92,7 +96,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.grappa_abi_version() != 1:
+    if lib.grappa_abi_version() != ABI_VERSION:
         raise RuntimeError("libgrappa_hip.so: ABI version mismatch")
     _lib = lib
     return lib

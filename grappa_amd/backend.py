@@ -9,6 +9,7 @@ a test-only backend through `set_backend()` (tests/conftest.py) to exercise the 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -72,6 +73,7 @@ class HipBackend:
             raise RuntimeError("grappa_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self._ws = {}
+        self.gemm_precision = _lib.GEMM_PRECISIONS[os.environ.get("GRAPPA_GEMM_PRECISION", "f32")]
         self._prof = None      # list of (kernel family, algorithmic flops, algorithmic bytes, start event, end event) when profiling
 
     # ------------------------------------------------------------------ in-process kernel timing (bench.py roofline)
@@ -113,7 +115,7 @@ class HipBackend:
 
     # ------------------------------------------------------------------ dense
     def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
-             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None) -> None:
+             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None) -> None:
         dev = out.device
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
@@ -152,6 +154,7 @@ class HipBackend:
                 raise ValueError("gemm: a_colsum needs the row-contiguous A layout and length M")
             d.a_colsum = a_colsum.data_ptr()
         d.act, d.drop_p, d.drop_seed, d.accumulate = int(act), float(drop_p), int(drop_seed) & (2 ** 64 - 1), int(accumulate)
+        d.precision = self.gemm_precision if precision is None else _lib.GEMM_PRECISIONS[precision]
         if M == 0 or N == 0:
             return
         if K == 0:

@@ -14,27 +14,17 @@
 // take the scalar-load kernel.  Workgroup order is XCD-aware: consecutive logical ids (= one XCD's L2) are the column tiles
 // of one row panel and, for split-K, the tiles of one K-slice.  Split-K (weight gradients: K = #tokens) writes fp32 slabs
 // that a second kernel sums in a fixed order (bitwise reproducible) before applying the epilogue.
-#include "common.h"
+#include "gemm_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace grappa_gemm;
+
+int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool vec_kcontig);   // gemm_bf16x.hip
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK = GEMM_BK;
 constexpr int NTHREADS = 256;
 
-struct GemmParams {
-    grappa_gemm_desc d;
-    int k_per_split;       // multiple of BK
-    int nsplit;
-    float* slab;           // [nsplit, ntiles_launch, BM*BN] tile-local partial sums when nsplit > 1
-    float* cs_slab;        // [nsplit, M] column-sum partials when nsplit > 1 and d.a_colsum
-    float drop_scale;
-    int tiles_m, tiles_n;
-    int tile_begin;        // this launch handles tiles [tile_begin, tile_begin + ntiles_launch) of the tiles_m x tiles_n grid
-    int ntiles_launch;
-    int bm, bn;            // tile shape (for the reduce kernel)
-};
 
 template <int BROW, bool KCONT>
 struct Tile {
@@ -119,26 +109,6 @@ __device__ inline float read_operand(const float* __restrict__ S, int row, int k
     return KCONT ? S[row * (BK + 1) + k] : S[k * BROW + row];
 }
 
-__device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v) {
-    const grappa_gemm_desc& d = p.d;
-    if (d.pre) v += d.pre[(size_t)m * d.ldpre + n];
-    if (d.bias) v += d.bias[n];
-    if (d.act == GRAPPA_ACT_ELU) v = grappa_elu(v);
-    if (d.aux) v *= grappa_elu_grad_from_out(d.aux[(size_t)m * d.ldaux + n]);
-    float* out = d.C;
-    int ldo = d.ldc;
-    if (d.C2) {
-        d.C[(size_t)m * d.ldc + n] = v;
-        out = d.C2;
-        ldo = d.ldc2;
-    }
-    if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
-    if (d.res) v += d.res[(size_t)m * d.ldres + n];
-    float* o = out + (size_t)m * ldo + n;
-    if (d.accumulate) v += *o;
-    *o = v;
-}
-
 template <int BM, int BN, int TM, int TN, bool AK, bool BKC, int K0, int K1>
 __device__ inline void compute_part(const float* __restrict__ a_s, const float* __restrict__ b_s, f32x16 (&acc)[TM][TN], int wm0, int wn0,
                                     int lr, int lh) {
@@ -207,14 +177,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ float smem[];   // stage s: A at s*(ASZ+BSZ), B behind it
 
     const grappa_gemm_desc& d = p.d;
-    // XCD-aware bijective remap of the linear workgroup id (blocks b and b+8 share an XCD): consecutive LOGICAL ids run on one
-    // XCD.  Logical order = (split, tile_m, tile_n) with tile_n fastest.
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int split = wgid / p.ntiles_launch, tile_local = wgid - split * p.ntiles_launch;
-    const int tile = p.tile_begin + tile_local;
-    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    const TileCoord tc = map_workgroup(p);
+    const int split = tc.split, tile_local = tc.tile_local, tile_m = tc.tile_m, tile_n = tc.tile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = split * p.k_per_split;
     const int kend = min(d.K, kbeg + p.k_per_split);
@@ -294,84 +258,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
         }
     }
 
-    // C/D layout of the 32x32 accumulator: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
-    // Row-major walk: the 64-bit row offsets of every epilogue tensor are formed once per row, the per-column terms once per column.
-    int ncol[TN];
-    float bcol[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        ncol[j] = n0 + wn0 + j * 32 + lr;
-        bcol[j] = (d.bias && ncol[j] < d.N) ? d.bias[ncol[j]] : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (m >= d.M) continue;
-            if (p.nsplit > 1) {
-                float* srow = p.slab + ((size_t)split * p.ntiles_launch + tile_local) * (BM * BN) + (size_t)(m - m0) * BN - n0;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (ncol[j] < d.N) srow[ncol[j]] = acc[i][j][e];
-                continue;
-            }
-            const float* pre_r = d.pre ? d.pre + (size_t)m * d.ldpre : nullptr;
-            const float* aux_r = d.aux ? d.aux + (size_t)m * d.ldaux : nullptr;
-            const float* res_r = d.res ? d.res + (size_t)m * d.ldres : nullptr;
-            float* c_r = d.C + (size_t)m * d.ldc;
-            float* c2_r = d.C2 ? d.C2 + (size_t)m * d.ldc2 : nullptr;
-            const uint64_t drow = (uint64_t)m * (uint64_t)d.N;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = ncol[j];
-                if (n >= d.N) continue;
-                float v = acc[i][j][e];
-                if (pre_r) v += pre_r[n];
-                v += bcol[j];
-                if (d.act == GRAPPA_ACT_ELU) v = grappa_elu(v);
-                if (aux_r) v *= grappa_elu_grad_from_out(aux_r[n]);
-                float* o = c_r + n;
-                if (c2_r) {
-                    *o = v;
-                    o = c2_r + n;
-                }
-                if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, drow + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
-                if (res_r) v += res_r[n];
-                if (d.accumulate) v += *o;
-                *o = v;
-            }
-        }
-}
-
-__global__ __launch_bounds__(NTHREADS) void gemm_splitk_reduce_kernel(GemmParams p) {
-    const int tile_elems = p.bm * p.bn;
-    const size_t total = (size_t)p.ntiles_launch * tile_elems;
-    const size_t split_stride = total;
-    if (p.d.a_colsum && blockIdx.x == 0) {
-        // column-sum partials were written by the tile_n == 0 workgroups of this launch
-        for (int tl = 0; tl < p.ntiles_launch; ++tl) {
-            const int tile = p.tile_begin + tl;
-            if (tile % p.tiles_n != 0) continue;
-            const int m0 = (tile / p.tiles_n) * p.bm;
-            for (int mi = threadIdx.x; mi < p.bm; mi += NTHREADS) {
-                const int m = m0 + mi;
-                if (m >= p.d.M) continue;
-                float v = 0.0f;
-                for (int s = 0; s < p.nsplit; ++s) v += p.cs_slab[(size_t)s * p.d.M + m];
-                p.d.a_colsum[m] += v;
-            }
-        }
-    }
-    for (size_t i = (size_t)blockIdx.x * NTHREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * NTHREADS) {
-        const int tl = (int)(i / tile_elems), rem = (int)(i - (size_t)tl * tile_elems);
-        const int tile = p.tile_begin + tl;
-        const int m = (tile / p.tiles_n) * p.bm + rem / p.bn, n = (tile % p.tiles_n) * p.bn + rem % p.bn;
-        if (m >= p.d.M || n >= p.d.N) continue;
-        float v = 0.0f;
-        for (int s = 0; s < p.nsplit; ++s) v += p.slab[(size_t)s * split_stride + i];
-        epilogue_store(p, m, n, v);
-    }
+    tile_epilogue<BM, BN, TM, TN>(p, acc, m0, n0, wm0, wn0, lr, lh, split, tile_local);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool AK, bool BKC, bool VEC>
@@ -397,14 +284,17 @@ struct Plan {
 };
 
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
-constexpr int CFG_BM[5] = {128, 64, 128, 32, 128};
-constexpr int CFG_BN[5] = {128, 64, 32, 128, 64};
-constexpr int CFG_CONC[5] = {2, 4, 4, 4, 3};      // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 KB, VGPR budget)
+// cfg 5: the 128x128 tile of the bf16-split kernel (gemm_bf16x.hip), one 512-thread workgroup per CU
+constexpr int CFG_BM[6] = {128, 64, 128, 32, 128, 128};
+constexpr int CFG_BN[6] = {128, 64, 32, 128, 64, 128};
+constexpr int CFG_CONC[6] = {2, 4, 4, 4, 3, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 120 KB, VGPR budget)
 
 // Tile choice by a small cost model: the busiest of the 256 CUs gets ceil(workgroups / 256) of them, each costing
 // BM*BN*k_per_split MFMA work divided by the tile's efficiency (smaller tiles re-read LDS more per MFMA); split-K (only when
 // K is long) adds the slab round trip.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
-Plan make_plan(int M, int N, int K, bool vec = true) {
+bool use_bf16x(int M, int N, int precision) { return precision != GRAPPA_GEMM_F32_MFMA && M > 32 && N > 32; }
+
+Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false) {
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
@@ -413,12 +303,13 @@ Plan make_plan(int M, int N, int K, bool vec = true) {
     best.tail_nsplit = 0;
     best.tail_k_per_split = 0;
     double best_cost = 1e300;
-    const int cands[5] = {0, 4, 1, 2, 3};
-    const double eff[5] = {1.00, 0.70, 0.55, 0.55, 0.93};          // indexed by cfg
+    const int cands[6] = {0, 4, 1, 2, 3, 5};
+    const double eff[6] = {1.00, 0.70, 0.55, 0.55, 0.93, 1.00};    // indexed by cfg
     int max_split = K >= 16 * BK ? K / (8 * BK) : 1;
     if (max_split > 64) max_split = 64;
-    for (int ci = 0; ci < 5; ++ci) {
+    for (int ci = 0; ci < 6; ++ci) {
         const int c = cands[ci];
+        if (bf16x != (c == 5)) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
@@ -505,8 +396,14 @@ int dispatch(hipStream_t st, GemmParams& p, int cfg, bool vec) {
 
 extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const size_t a = plan_workspace_floats(make_plan(M, N, K, true), M, N), b = plan_workspace_floats(make_plan(M, N, K, false), M, N);
-    return (a > b ? a : b) * sizeof(float);
+    size_t a = plan_workspace_floats(make_plan(M, N, K, true), M, N);
+    const size_t b = plan_workspace_floats(make_plan(M, N, K, false), M, N);
+    if (b > a) a = b;
+    if (use_bf16x(M, N, GRAPPA_GEMM_F32_BF16X9)) {
+        const size_t c = plan_workspace_floats(make_plan(M, N, K, true, true), M, N);
+        if (c > a) a = c;
+    }
+    return a * sizeof(float);
 }
 
 extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
@@ -539,7 +436,9 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool padB = d->b_kcontig || ((d->N + 3) & ~3) <= d->ldb;
     const bool vec = vecA && vecB && padA && padB;
     p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
-    Plan pl = make_plan(d->M, d->N, d->K, vec);
+    if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
+    const bool bf16x = use_bf16x(d->M, d->N, d->precision);
+    Plan pl = make_plan(d->M, d->N, d->K, vec, bf16x);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
     if (need > 0 && (!ws || ws_bytes < need)) return GRAPPA_ERR_WORKSPACE;
@@ -562,17 +461,12 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             p.cs_slab = p.slab + (size_t)nsplit * ntiles * te;
         }
         int rc;
-        if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
+        if (bf16x) rc = grappa_launch_gemm_bf16x(st, p, d->precision, vec);
+        else if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
         else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
         else rc = dispatch<false, false>(st, p, pl.cfg, vec);
         if (rc != GRAPPA_OK) return rc;
-        if (nsplit > 1) {
-            const size_t total = (size_t)ntiles * te;
-            int blocks = (int)((total + NTHREADS - 1) / NTHREADS);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(NTHREADS), 0, st, p);
-            rc = grappa_launch_status();
-        }
+        if (nsplit > 1) rc = launch_splitk_reduce(st, p);
         return rc;
     };
     int rc = GRAPPA_OK;

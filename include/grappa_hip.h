@@ -27,7 +27,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 1
+#define GRAPPA_ABI_VERSION 2
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -56,6 +56,20 @@ const char* grappa_build_arch(void);
 #define GRAPPA_ACT_NONE 0
 #define GRAPPA_ACT_ELU 1
 
+/* Arithmetic of the product (grappa_gemm_desc.precision).  Inputs, outputs, epilogue and accumulation are fp32 in every mode.
+ *   F32_MFMA    native fp32 matrix instruction (default; 157 TFLOP/s peak)
+ *   F32_BF16X9  each fp32 operand split exactly into 3 bf16 pieces, all 9 partial products on the bf16 matrix cores: every
+ *               partial product is exact, the result differs from an fp32 FMA chain only by accumulation order
+ *   F32_BF16X6  the 6 largest partial products (drops terms <= 2^-24 |a||b|): fp32-grade, ~2 ulp per product
+ *   BF16X3      2 pieces / 3 products (~2^-16 relative);  BF16: operands rounded to bf16 (the "bf16" trainer precision of
+ *               the reference's configs, experiment/trainrun.py / Lightning `precision`)
+ * Shapes with M <= 32 or N <= 32 always take the native fp32 path. */
+#define GRAPPA_GEMM_F32_MFMA 0
+#define GRAPPA_GEMM_F32_BF16X9 1
+#define GRAPPA_GEMM_F32_BF16X6 2
+#define GRAPPA_GEMM_BF16X3 3
+#define GRAPPA_GEMM_BF16 4
+
 typedef struct grappa_gemm_desc {
     int M, N, K;
     int a_kcontig, b_kcontig;
@@ -72,6 +86,7 @@ typedef struct grappa_gemm_desc {
     float drop_p;
     uint64_t drop_seed;
     int accumulate;
+    int precision;                /* GRAPPA_GEMM_* */
 } grappa_gemm_desc;
 
 size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);

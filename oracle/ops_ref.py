@@ -49,7 +49,7 @@ class RefBackend:
 
     # ------------------------------------------------------------------ dense
     def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
-             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None):
+             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None):
         A = a if a_kcontig else a.t()
         Bm = b if b_kcontig else b.t()
         assert tuple(A.shape) == (M, K) and tuple(Bm.shape) == (N, K) and tuple(out.shape) == (M, N)

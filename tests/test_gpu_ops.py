@@ -76,7 +76,8 @@ def test_gemm_layouts(hip, ref, M, N, K, ak, bk):
     _cmp(out_h, out_r, 2e-5, f"gemm {M}x{N}x{K} ak={ak} bk={bk}")
 
 
-def test_gemm_epilogues(hip, ref):
+@pytest.mark.parametrize("precision", ["f32", "f32_bf16x9", "f32_bf16x6"])
+def test_gemm_epilogues(hip, ref, precision):
     g = torch.Generator().manual_seed(1)
     M, N, K = 333, 192, 160
     A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -91,17 +92,45 @@ def test_gemm_epilogues(hip, ref):
         o2_r, o2_h = (torch.zeros(M, N), torch.zeros(M, N, device="cuda")) if two else (None, None)
         ref.gemm(A, B, o_r, M=M, N=N, K=K, out2=o2_r, **kw)
         kw_h = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
-        hip.gemm(A.cuda(), B.cuda(), o_h, M=M, N=N, K=K, out2=o2_h, **kw_h)
+        hip.gemm(A.cuda(), B.cuda(), o_h, M=M, N=N, K=K, out2=o2_h, precision=precision, **kw_h)
         torch.cuda.synchronize()
-        _cmp(o_h, o_r, 2e-5, f"gemm epilogue {sorted(kw)}")
+        _cmp(o_h, o_r, 2e-5, f"gemm[{precision}] epilogue {sorted(kw)}")
         if two:
             _cmp(o2_h, o2_r, 2e-5, f"gemm epilogue out2 {sorted(kw)}")
             # the dropout mask itself must be the documented counter hash: identical zero pattern
             assert torch.equal((o2_h.cpu() - res) == 0, (o2_r - res) == 0) or kw.get("drop_p", 0) == 0
 
 
+# tolerance of each arithmetic mode of the GEMM (include/grappa_hip.h GRAPPA_GEMM_*) against a float64 product, relative to max|C|
+GEMM_MODE_TOL = {"f32": 1e-5, "f32_bf16x9": 2e-6, "f32_bf16x6": 2e-6, "bf16x3": 1e-4, "bf16": 2e-2}
+
+
+@pytest.mark.parametrize("precision", list(GEMM_MODE_TOL))
+@pytest.mark.parametrize("M,N,K,ak,bk", GEMM_CASES + [(8300, 1536, 512, 1, 1), (8300, 512, 2048, 1, 0), (33, 33, 31, 1, 1), (640, 640, 64, 0, 0)])
+def test_gemm_precision_modes(hip, M, N, K, ak, bk, precision):
+    """bf16-split emulation of the fp32 product: the x9 / x6 modes must be as close to the exact (float64) product as the native
+    fp32 matrix instruction is; operands with a wide dynamic range (1e-3 .. 1e3 scales per row) exercise the low-order pieces."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + 1)
+    A = torch.randn((M, K) if ak else (K, M), generator=g)
+    B = torch.randn((N, K) if bk else (K, N), generator=g)
+    A = A * torch.exp(torch.randn(A.shape, generator=g) * 2.0)        # log-normal magnitudes: exponents differ inside one dot product
+    exact = ((A if ak else A.t()).double() @ (B if bk else B.t()).double().t())
+    out_h = torch.empty(M, N, device="cuda")
+    hip.gemm(A.cuda(), B.cuda(), out_h, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), precision=precision)
+    torch.cuda.synchronize()
+    # row-wise scale: every row of C is compared with that row's own magnitude
+    err = ((out_h.cpu().double() - exact).abs().amax(dim=1) / exact.abs().amax(dim=1).clamp_min(1e-30)).max().item()
+    try:
+        with open(REPORT, "a") as f:
+            f.write(f"gemm[{precision}] {M}x{N}x{K} ak={ak} bk={bk}: max row-relative error vs float64 {err:.3e} tol {GEMM_MODE_TOL[precision]}\n")
+    except OSError:
+        pass
+    assert math.isfinite(err) and err < GEMM_MODE_TOL[precision], f"{precision} {M}x{N}x{K}: {err:.3e}"
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32_bf16x9", "f32_bf16x6"])
 @pytest.mark.parametrize("M,N,K", [(512, 512, 5000), (1536, 512, 3001), (511, 256, 700), (12, 256, 4097), (2048, 512, 300)])
-def test_gemm_wgrad_with_fused_bias_gradient(hip, ref, M, N, K):
+def test_gemm_wgrad_with_fused_bias_gradient(hip, ref, M, N, K, precision):
     """dW += dz^T x and db += colsum(dz) from one launch (with and without split-K)"""
     g = torch.Generator().manual_seed(M + N + K)
     ldz = (M + 3) // 4 * 4
@@ -110,10 +139,11 @@ def test_gemm_wgrad_with_fused_bias_gradient(hip, ref, M, N, K):
     w_r, b_r = torch.ones(M, N), torch.ones(M)
     ref.gemm(dz, x, w_r, M=M, N=N, K=K, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=b_r)
     w_h, b_h = torch.ones(M, N, device="cuda"), torch.ones(M, device="cuda")
-    hip.gemm(dz_full.cuda()[:, :M], x.cuda(), w_h, M=M, N=N, K=K, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=b_h)
+    hip.gemm(dz_full.cuda()[:, :M], x.cuda(), w_h, M=M, N=N, K=K, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=b_h,
+             precision=precision)
     torch.cuda.synchronize()
-    _cmp(w_h, w_r, 2e-5, f"wgrad {M}x{N}x{K}")
-    _cmp(b_h, b_r, 2e-5, f"fused bias gradient {M}x{N}x{K}")
+    _cmp(w_h, w_r, 2e-5, f"wgrad[{precision}] {M}x{N}x{K}")
+    _cmp(b_h, b_r, 2e-5, f"fused bias gradient[{precision}] {M}x{N}x{K}")
 
 
 def test_gemm_strided_views(hip, ref):

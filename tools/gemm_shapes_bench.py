@@ -59,28 +59,35 @@ def main():
         return
     shapes = record_shapes()
     be = get_backend()
+    # --precisions f32,f32_bf16x6,...: A/B the arithmetic modes in ONE process (same clocks, same buffers)
+    modes = ["f32"]
+    for a in sys.argv:
+        if a.startswith("--precisions="):
+            modes = a.split("=", 1)[1].split(",")
     rows = []
     for (M, N, K, ak, bk, lda, ldb, ldc), cnt in sorted(shapes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1]):
         A = torch.randn((M, K) if ak else (K, M), device="cuda")
         B = torch.randn((N, K) if bk else (K, N), device="cuda")
         C = torch.empty((M, N), device="cuda")
-        for _ in range(2):
-            be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk))
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        fl = 2.0 * M * N * K
-        rows.append((M, N, K, ak, bk, cnt, ms, fl / ms / 1e9, cnt * ms, cnt * fl))
-    tot_ms = sum(r[8] for r in rows)
-    tot_fl = sum(r[9] for r in rows)
-    print(f"{'M':>7} {'N':>5} {'K':>7} ak bk  cnt   ms/call  TFLOP/s  ms/step  share")
-    for M, N, K, ak, bk, cnt, ms, tf, sms, sfl in sorted(rows, key=lambda r: -r[8]):
-        print(f"{M:7d} {N:5d} {K:7d}  {ak}  {bk} {cnt:4d} {ms:9.3f} {tf:8.1f} {sms:8.2f} {100 * sms / tot_ms:6.1f}%")
-    print(f"total: {tot_ms:.1f} ms/step, {tot_fl / 1e12:.2f} TFLOP/step, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+        ms = []
+        for mode in modes:
+            for _ in range(2):
+                be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), precision=mode)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), precision=mode)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1) / 10)
+        rows.append((M, N, K, ak, bk, cnt, ms, 2.0 * M * N * K))
+    print(f"{'M':>7} {'N':>5} {'K':>7} ak bk  cnt " + " ".join(f"{m + ' ms':>14} {'TF':>6}" for m in modes))
+    for M, N, K, ak, bk, cnt, ms, fl in sorted(rows, key=lambda r: -r[5] * r[6][0]):
+        print(f"{M:7d} {N:5d} {K:7d}  {ak}  {bk} {cnt:4d} " + " ".join(f"{t:14.3f} {fl / t / 1e9:6.1f}" for t in ms))
+    tot_fl = sum(r[5] * r[7] for r in rows)
+    for i, m in enumerate(modes):
+        tot_ms = sum(r[5] * r[6][i] for r in rows)
+        print(f"total[{m}]: {tot_ms:.1f} ms/step, {tot_fl / 1e12:.2f} TFLOP/step, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":

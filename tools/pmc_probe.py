@@ -1,5 +1,5 @@
 """Small PMC probe workloads for rocprofv3 --pmc passes (one process, a few launches each):
-   python tools/pmc_probe.py gemm   -> 10 launches of the 83328x512x512 forward GEMM (+ dgrad + wgrad variants)
+   python tools/pmc_probe.py gemm [precision]  -> 10 launches of the 83328x512x512 forward GEMM (+ dgrad + wgrad variants)
    python tools/pmc_probe.py gat    -> 10 launches of gat_fwd / gat_bwd on the C3-size graph (1024 molecules)
 """
 import os
@@ -14,12 +14,13 @@ sys.path.insert(0, ROOT)
 def gemm():
     from grappa_amd.backend import get_backend
     be = get_backend()
+    precision = sys.argv[2] if len(sys.argv) > 2 else "f32"
     for (M, N, K, ak, bk) in [(83328, 512, 512, 1, 1), (83328, 512, 512, 1, 0), (512, 512, 83328, 0, 0)]:
         A = torch.randn((M, K) if ak else (K, M), device="cuda")
         B = torch.randn((N, K) if bk else (K, N), device="cuda")
         C = torch.empty((M, N), device="cuda")
         for _ in range(10):
-            be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk))
+            be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), precision=precision)
     torch.cuda.synchronize()
 
 
