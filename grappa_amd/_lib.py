@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgrappa_hip.so")
 
 ABI_VERSION = 2
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
-GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4}
+GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4, "dbg_x6": 0x102, "dbg_bf16": 0x104, "dbg2_x6": 0x202, "dbg3_x6": 0x302, "dbg4_x6": 0x402}
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)

@@ -5,91 +5,100 @@
 //   X9 : all 9 a_p*b_q -- every partial product is exact in fp32, so only the accumulation order differs from an fp32 FMA chain
 //   X6 : drops a1*b2, a2*b1, a2*b2 (each <= 2^-24 |a||b|): ~2 ulp of fp32 per product
 //   X3 : two pieces, a0*b0 + a0*b1 + a1*b0 (~2^-16 relative);  X1: plain bf16 operands (bf16 compute configs)
-// Structure: 512-thread workgroup (8 wavefronts as 2 x 4, 64x32 accumulators each), 128x128x32 tile, one workgroup per CU.
-// Global fp32 -> registers (prefetch distance 2) -> split to bf16 pieces -> LDS [piece][row][32 bf16 + 16 B pad] (two stages,
-// 120 KB), MFMA operand fragments are single ds_read_b128 (8 consecutive k of one row).  Row-contiguous ("k-major") sources are
-// transposed on the way in: a thread owns one row and reads its 4 k values with 4 row-coalesced dword loads.
+//
+// What bounds this kernel is the LDS, not the matrix pipe: three pieces triple every fragment read and every store, so the
+// tile is shaped to minimise LDS bytes per MFMA.  256x128 macro tile, 8 wavefronts as 4 x 2, each a 64x64 block of four 32x32
+// accumulators: 12 ds_read_b128 feed 24 MFMAs per 16-deep k-slab (a 64x32 wavefront tile needs 9 reads per 12 MFMAs and
+// saturates the LDS array at two wavefronts per SIMD).  K advances in slabs of 16: global fp32 -> registers (four slabs ahead)
+// -> split to bf16 pieces -> LDS [piece][row][16 bf16 + 16 B pad] in two stages of 54 KB; MFMA operand fragments are single
+// ds_read_b128 (8 consecutive k of one row).  Row-contiguous ("k-major") sources are transposed on the way in: a thread owns
+// one row and reads its 4 k values with 4 row-coalesced dword loads.  Per slab and wavefront: the first half of the MFMAs runs
+// interleaved with the split + LDS stores of the next slab, then one barrier, then the next slab's fragment reads are issued
+// and covered by the second half of the MFMAs.
 // Epilogue, split-K slabs, XCD-aware order and the tail launch are shared with the native kernel (gemm_common.h).
 #include "gemm_common.h"
 
 using namespace grappa_gemm;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int BK = GEMM_BK;
+constexpr int SK = 16;                  // k-slab per pipeline step (one 32x32x16 MFMA deep)
 constexpr int NT = 512;
-constexpr int BM = 128, BN = 128;
-constexpr int WAVES_N = 4;              // 2 x 4 wavefronts
-constexpr int TM = 2, TN = 1;           // 32x32 accumulators per wavefront: 64 x 32
-constexpr int ROWB = 80;                // LDS row: 32 bf16 (64 B) + 16 B pad -> conflict-free ds_read_b128 over 16 consecutive rows
-constexpr int PIECE_B = BM * ROWB;      // one bf16 piece of one operand tile
-constexpr int NQ = BM * BK / 4 / NT;    // quads (4 consecutive k of one row) per thread and operand = 2
+constexpr int ROWB = 48;                // LDS row: 16 bf16 (32 B) + 16 B pad -> conflict-free ds_read_b128 per 16-lane group
+constexpr int AHEAD = 4;                // register sets: slab s+4 is loaded while slab s is multiplied
 
 enum Mode { X1 = 1, X3 = 3, X6 = 6, X9 = 9 };
-template <int MODE> struct Pieces { static constexpr int NP = MODE == X1 ? 1 : (MODE == X3 ? 2 : 3); };
+template <int MODE> struct Pieces {
+    static constexpr int NP = MODE == X1 ? 1 : (MODE == X3 ? 2 : 3);
+    static constexpr int NPROD = MODE;
+};
 
 struct Quad { float x[4]; };
 
-// element (row, kq..kq+3) owned by this thread for quad slot i
-template <bool KCONT>
-__device__ inline void quad_coords(int i, int& row, int& kq) {
-    const int f = threadIdx.x + i * NT;
-    if (KCONT) { row = f >> 3; kq = (f & 7) << 2; }
-    else { row = f & (BM - 1); kq = (f >> 7) << 2; }
+// slab element (row, kq..kq+3) owned by this thread for quad slot j of an operand with ROWS rows.
+// K-contiguous source: 4 lanes cover the 64 bytes of one row; k-major source: 64 lanes cover 64 consecutive rows of one k.
+template <int ROWS, bool KCONT>
+__device__ inline void quad_coords(int j, int& row, int& kq) {
+    if (KCONT) {
+        row = (threadIdx.x >> 2) + 128 * j;
+        kq = (threadIdx.x & 3) << 2;
+    } else {
+        const int f = threadIdx.x + j * NT;
+        row = f & (ROWS - 1);
+        kq = (f / ROWS) << 2;
+    }
 }
 
 // Loads never wait for their data: out-of-range rows and k are only CLAMPED here (the addresses stay inside the operand);
-// the k tail is zeroed when the tile is split and stored (store_quads<MASK>), one pipeline step later.
-template <bool KCONT, bool VEC>
-__device__ inline void load_quads(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend, Quad (&q)[NQ]) {
+// the k tail is zeroed when the slab is split and stored (store_quads<MASK>), AHEAD - 1 steps later.
+template <int ROWS, bool KCONT, bool VEC>
+__device__ inline void load_quads(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend, Quad (&q)[ROWS / 128]) {
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
+    for (int j = 0; j < ROWS / 128; ++j) {
         int row, kq;
-        quad_coords<KCONT>(i, row, kq);
+        quad_coords<ROWS, KCONT>(j, row, kq);
         const int gr = min(row0 + row, R - 1);          // out-of-range rows are clamped: their results are never stored
         const int gk = k0 + kq;
         if (KCONT && VEC) {
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)gr * ld + (gk < Kend ? gk : 0));   // K % 4 == 0 here
-            q[i].x[0] = v.x; q[i].x[1] = v.y; q[i].x[2] = v.z; q[i].x[3] = v.w;
+            q[j].x[0] = v.x; q[j].x[1] = v.y; q[j].x[2] = v.z; q[j].x[3] = v.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ck = gk + j < Kend ? gk + j : 0;
-                q[i].x[j] = KCONT ? src[(size_t)gr * ld + ck] : src[(size_t)ck * ld + gr];
+            for (int e = 0; e < 4; ++e) {
+                const int ck = gk + e < Kend ? gk + e : 0;
+                q[j].x[e] = KCONT ? src[(size_t)gr * ld + ck] : src[(size_t)ck * ld + gr];
             }
         }
     }
 }
 
-__device__ inline unsigned f2u(float x) { return __float_as_uint(x); }
 __device__ inline float u2f(unsigned x) { return __uint_as_float(x); }
 
 // split 4 consecutive-k fp32 values into NP bf16 pieces (round to nearest even; the residual r - float(piece) is exact in
-// fp32) and store each piece's 4 values as one 8-byte LDS write.  krem = valid k of this tile counted from its first column
-// (MASK: the last tile of a K range, whose tail is zero-filled here).
-template <int NP, bool KCONT, bool MASK>
-__device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[NQ], int krem) {
+// fp32) and store each piece's 4 values as one 8-byte LDS write.  krem = valid k of this slab counted from its first column
+// (MASK: a slab at the end of a K range, whose tail is zero-filled here).
+template <int NP, int ROWS, bool KCONT, bool MASK>
+__device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[ROWS / 128], int krem) {
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
+    for (int j = 0; j < ROWS / 128; ++j) {
         int row, kq;
-        quad_coords<KCONT>(i, row, kq);
-        float r[4] = {q[i].x[0], q[i].x[1], q[i].x[2], q[i].x[3]};
+        quad_coords<ROWS, KCONT>(j, row, kq);
+        float r[4] = {q[j].x[0], q[j].x[1], q[j].x[2], q[j].x[3]};
         if (MASK) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = kq + j < krem ? r[j] : 0.f;
+            for (int e = 0; e < 4; ++e) r[e] = kq + e < krem ? r[e] : 0.f;
         }
         char* dst = opbase + row * ROWB + kq * 2;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             bf16x2 h01, h23;
             h01[0] = (__bf16)r[0]; h01[1] = (__bf16)r[1];
             h23[0] = (__bf16)r[2]; h23[1] = (__bf16)r[3];
             const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
-            *reinterpret_cast<uint2*>(dst + p * PIECE_B) = make_uint2(u01, u23);
+            *reinterpret_cast<uint2*>(dst + p * (ROWS * ROWB)) = make_uint2(u01, u23);
             if (p + 1 < NP) {                       // float(bf16) is the 16 bits moved to the top half of the word
                 r[0] -= u2f(u01 << 16); r[1] -= u2f(u01 & 0xffff0000u);
                 r[2] -= u2f(u23 << 16); r[3] -= u2f(u23 & 0xffff0000u);
@@ -98,32 +107,51 @@ __device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[NQ
     }
 }
 
-template <int NP>
-__device__ inline bf16x8 read_frag(const char* __restrict__ opbase, int piece, int row, int ks, int lh) {
-    return *reinterpret_cast<const bf16x8*>(opbase + piece * PIECE_B + row * ROWB + (ks * 16 + 8 * lh) * 2);
+template <int NQ>
+__device__ inline float quad_sum(const Quad (&q)[NQ]) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) s += (q[j].x[0] + q[j].x[1]) + (q[j].x[2] + q[j].x[3]);
+    return s;
 }
 
-template <int NP> struct Frags { bf16x8 a[TM][NP], b[TN][NP]; };
+template <int ROWS, bool KCONT>
+__device__ inline float quad_sum_masked(const Quad (&q)[ROWS / 128], int krem) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < ROWS / 128; ++j) {
+        int row, kq;
+        quad_coords<ROWS, KCONT>(j, row, kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += kq + e < krem ? q[j].x[e] : 0.f;
+    }
+    return s;
+}
 
-// MFMA operand fragments of one 16-deep k-step of a staged tile (18 ds_read_b128 for three pieces)
-template <int NP>
-__device__ inline void read_frags(const char* __restrict__ a_s, const char* __restrict__ b_s, int wm0, int wn0, int lr, int lh, int ks,
-                                  Frags<NP>& f) {
+template <int NP, int TM, int TN> struct Frags { bf16x8 a[TM][NP], b[TN][NP]; };
+
+// MFMA operand fragments of one staged slab ((TM + TN) * NP ds_read_b128)
+template <int NP, int BM, int BN, int TM, int TN>
+__device__ inline void read_frags(const char* __restrict__ stage, int wm0, int wn0, int lr, int lh, Frags<NP, TM, TN>& f) {
+    const char* a_s = stage + lh * 16;
+    const char* b_s = a_s + NP * BM * ROWB;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) f.a[i][p] = read_frag<NP>(a_s, p, wm0 + i * 32 + lr, ks, lh);
+        for (int i = 0; i < TM; ++i) f.a[i][p] = *reinterpret_cast<const bf16x8*>(a_s + p * (BM * ROWB) + (wm0 + i * 32 + lr) * ROWB);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) f.b[j][p] = read_frag<NP>(b_s, p, wn0 + j * 32 + lr, ks, lh);
+        for (int j = 0; j < TN; ++j) f.b[j][p] = *reinterpret_cast<const bf16x8*>(b_s + p * (BN * ROWB) + (wn0 + j * 32 + lr) * ROWB);
     }
 }
 
-// all partial products of the mode for one k-step, smallest terms first; consecutive MFMAs go to different accumulators
-template <int MODE>
-__device__ inline void mfma_kstep(const Frags<Pieces<MODE>::NP>& f, f32x16 (&acc)[TM][TN]) {
+// MFMAs [LO, HI) of one slab: products smallest first (pa + pb descending), the TM x TN accumulators innermost so that
+// consecutive MFMAs never depend on each other
+template <int MODE, int TM, int TN, int LO, int HI>
+__device__ inline void mfma_range(const Frags<Pieces<MODE>::NP, TM, TN>& f, f32x16 (&acc)[TM][TN]) {
     constexpr int NP = Pieces<MODE>::NP;
+    int idx = 0;
 #pragma unroll
-    for (int s = 2 * (NP - 1); s >= 0; --s) {                  // s = pa + pb, descending: smallest partial products first
+    for (int s = 2 * (NP - 1); s >= 0; --s) {
 #pragma unroll
         for (int pa = 0; pa < NP; ++pa) {
             const int pb = s - pa;
@@ -133,96 +161,99 @@ __device__ inline void mfma_kstep(const Frags<Pieces<MODE>::NP>& f, f32x16 (&acc
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[j][pb], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    // B fragment first: the accumulator holds the transposed tile (4 consecutive n per lane, tile_epilogue_rows)
+                    if (idx >= LO && idx < HI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j][pb], f.a[i][pa], acc[i][j], 0, 0, 0);
+                    ++idx;
+                }
         }
     }
 }
 
-template <int MODE, bool AK, bool BKC, bool VEC>
-__device__ inline void load_pair(const grappa_gemm_desc& d, int m0, int n0, int k0, int kend, Quad (&qa)[NQ], Quad (&qb)[NQ]) {
-    load_quads<AK, VEC>(d.A, d.lda, m0, k0, d.M, kend, qa);
-    load_quads<BKC, VEC>(d.B, d.ldb, n0, k0, d.N, kend, qb);
-}
-
-__device__ inline float quad_sum(const Quad (&q)[NQ]) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) s += (q[i].x[0] + q[i].x[1]) + (q[i].x[2] + q[i].x[3]);
-    return s;
-}
-
-template <bool KCONT>
-__device__ inline float quad_sum_masked(const Quad (&q)[NQ], int krem) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        int row, kq;
-        quad_coords<KCONT>(i, row, kq);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += kq + j < krem ? q[i].x[j] : 0.f;
-    }
-    return s;
-}
-
-// One K-step of 32.  On entry f0 holds the fragments of the first 16 k of stage `cur`; on exit those of stage cur^1.
-//   global loads of tile kt+2 -> L | fragment reads of the second 16 k | MFMAs on f0, interleaved with the bf16 split + LDS store
-//   of tile kt+1 (registers S) | barrier | fragment reads of the next stage | MFMAs on f1 (cover that read latency)
-// so the matrix pipe has work queued on both sides of the barrier.  TAIL = one of the last steps of the K range: loads / stores
-// happen only while tiles remain and the stored tile is masked to the valid k; main-loop steps do both unconditionally.
-struct KRange {
-    int kbeg, kend, nk, rot;
-    // first k of the tile processed at step t.  The K loop of a workgroup starts `rot` tiles into its range and wraps: workgroups
-    // that run side by side then read different 128-byte columns of the operands at any moment, instead of all hitting the L2
-    // channels that one column's addresses (rows 2^n bytes apart) map to.  rot == 0 when the range has a partial last tile.
-    __device__ inline int k_of(int t) const {
-        int x = t + rot;
-        x = x >= nk ? x - nk : x;
-        return kbeg + x * BK;
+// sched_group_barrier sequence for NMFMA x { 1 MFMA, a share of NVALU vector ops, a share of NWRITE LDS stores }
+template <int G, int NMFMA, int NWRITE, int NVALU>
+struct PhaseOrder {
+    static __device__ inline void emit() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (NVALU + NMFMA - 1) / NMFMA, 0);
+        constexpr int W = (G + 1) * NWRITE / NMFMA - G * NWRITE / NMFMA;
+        if (W > 0) __builtin_amdgcn_sched_group_barrier(0x200, W > 0 ? W : 1, 0);
+        PhaseOrder<G + 1, NMFMA, NWRITE, NVALU>::emit();
     }
 };
+template <int NMFMA, int NWRITE, int NVALU>
+struct PhaseOrder<NMFMA, NMFMA, NWRITE, NVALU> {
+    static __device__ inline void emit() {}
+};
 
-template <int MODE, bool AK, bool BKC, bool VEC, bool TAIL>
-__device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict__ smem, f32x16 (&acc)[TM][TN], int m0, int n0, const KRange& kr,
-                                     int kt, int wm0, int wn0, int lr, int lh, Quad (&la)[NQ], Quad (&lb)[NQ],
-                                     const Quad (&sa)[NQ], const Quad (&sb)[NQ], Frags<Pieces<MODE>::NP>& f0, float& cs, bool do_cs) {
-    constexpr int NP = Pieces<MODE>::NP;
-    constexpr int OPB = NP * PIECE_B, STAGE = 2 * OPB;
-    const int cur = kt & 1;
-    const bool do_store = !TAIL || kt + 1 < kr.nk;                // tile kt+1 exists
-    const bool do_load = !TAIL || kt + 2 < kr.nk;                 // tile kt+2 exists
-    if (do_load) load_pair<MODE, AK, BKC, VEC>(d, m0, n0, kr.k_of(kt + 2), kr.kend, la, lb);
-    __builtin_amdgcn_sched_barrier(0);
-    const char* a_s = smem + cur * STAGE;
-    char* nxt = smem + (cur ^ 1) * STAGE;
-    Frags<NP> f1;
-    read_frags<NP>(a_s, a_s + OPB, wm0, wn0, lr, lh, 1, f1);
-    mfma_kstep<MODE>(f0, acc);
-    if (do_store) {
-        const int krem = TAIL ? kr.kend - kr.k_of(kt + 1) : BK;
-        store_quads<NP, AK, TAIL>(nxt, sa, krem);
-        store_quads<NP, BKC, TAIL>(nxt + OPB, sb, krem);
-        if (!AK && do_cs) cs += TAIL ? quad_sum_masked<AK>(sa, krem) : quad_sum(sa);
+struct KRange {
+    int kbeg, kend, nsteps, kstride;
+    __device__ inline int k_of(int s) const { return kbeg + s * kstride; }
+};
+
+// One slab.  On entry fc holds the fragments of slab s (LDS stage s & 1); on exit fn holds those of slab s + 1.
+//   global loads of slab s+AHEAD -> L | first half of the MFMAs on fc, interleaved with the bf16 split + LDS store of slab s+1
+//   (registers S) into the other stage | barrier | fragment reads of slab s+1 -> fn | second half of the MFMAs on fc
+// TAIL = one of the last steps of the K range: loads / stores happen only while slabs remain and the stored slab is masked to
+// the valid k; main-loop steps do both unconditionally.
+template <int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool TAIL>
+__device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict__ smem, f32x16 (&acc)[2][BN / WN / 32], int m0, int n0,
+                                     const KRange& kr, int s, int wm0, int wn0, int lr, int lh, Quad (&la)[BM / 128], Quad (&lb)[BN / 128],
+                                     const Quad (&sa)[BM / 128], const Quad (&sb)[BN / 128],
+                                     const Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fc, Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fn,
+                                     float& cs, bool do_cs) {
+    constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
+    constexpr int STAGE = NP * (BM + BN) * ROWB;
+    constexpr int NM = Pieces<MODE>::NPROD * TM * TN;
+    const bool do_store = !TAIL || s + 1 < kr.nsteps;
+    const bool do_load = !TAIL || s + AHEAD < kr.nsteps;
+    if (do_load) {
+        load_quads<BM, AK, VEC>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
+        load_quads<BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    char* nxt = smem + ((s + 1) & 1) * STAGE;
+    mfma_range<MODE, TM, TN, 0, NM / 2>(fc, acc);
+    if (do_store) {
+        const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
+        store_quads<NP, BM, AK, TAIL>(nxt, sa, krem);
+        store_quads<NP, BN, BKC, TAIL>(nxt + NP * BM * ROWB, sb, krem);
+        if (!AK && do_cs) cs += TAIL ? quad_sum_masked<BM, AK>(sa, krem) : quad_sum(sa);
+    }
+    if (!TAIL) {
+        // issue order of this phase: one MFMA, then a slice of the split arithmetic and of the LDS stores, so that the matrix
+        // pipe runs under the vector work instead of before it (left alone the compiler bunches all MFMAs after the barrier)
+        constexpr int NQ = BM / 128 + BN / 128;
+        PhaseOrder<0, NM / 2, NQ * NP, NQ * (NP == 3 ? 30 : NP == 2 ? 18 : 6)>::emit();
+    }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    if (do_store) read_frags<NP>(nxt, nxt + OPB, wm0, wn0, lr, lh, 0, f0);
-    mfma_kstep<MODE>(f1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_store) read_frags<NP, BM, BN, TM, TN>(nxt, wm0, wn0, lr, lh, fn);
+    __builtin_amdgcn_sched_barrier(0);                 // the next slab's fragment reads are in flight before these MFMAs issue
+    mfma_range<MODE, TM, TN, NM / 2, NM>(fc, acc);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MODE, bool AK, bool BKC, bool VEC>
+template <int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_bf16x_kernel(GemmParams p) {
-    constexpr int NP = Pieces<MODE>::NP;
-    constexpr int OPB = NP * PIECE_B;
+    constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
+    constexpr int NQA = BM / 128, NQB = BN / 128;
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
     const TileCoord tc = map_workgroup(p);
     const int split = tc.split, tile_local = tc.tile_local, tile_n = tc.tile_n;
     const int m0 = tc.tile_m * BM, n0 = tile_n * BN;
-    const int kbeg = split * p.k_per_split;
-    const int kend = min(d.K, kbeg + p.k_per_split);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wm0 = (wave / WAVES_N) * 64, wn0 = (wave % WAVES_N) * 32;
+    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * (BN / WN);
     const int lr = lane & 31, lh = lane >> 5;
+    KRange kr;
+    kr.kbeg = split * p.k_per_split;
+    kr.kend = min(d.K, kr.kbeg + p.k_per_split);
+    kr.nsteps = (kr.kend - kr.kbeg + SK - 1) / SK;
+    kr.kstride = (d.precision & 0x100) ? 0 : SK;     // DEBUG
+    if (d.precision & 0x400) kr.nsteps = 0;          // DEBUG: epilogue only
+    const int nsteps = kr.nsteps;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -232,40 +263,56 @@ __global__ __launch_bounds__(NT) void gemm_bf16x_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    KRange kr;
-    kr.kbeg = kbeg;
-    kr.kend = kend;
-    kr.nk = (kend - kbeg + BK - 1) / BK;
-    kr.rot = 0;     // measured: a per-workgroup rotation gains 10-15 % on K-contiguous bf16 operands but loses 25 % on the wgrad layout
-    const int nk = kr.nk;
     const bool do_cs = !AK && d.a_colsum != nullptr && tile_n == 0;
-    float cs = 0.f;                    // sum over k of A(row, k) for the row this thread stages (row = tid & 127 for both quads)
-    if (nk > 0) {
-        Quad a0[NQ], b0[NQ], a1[NQ], b1[NQ];
-        Frags<NP> f0;
-        load_pair<MODE, AK, BKC, VEC>(d, m0, n0, kr.k_of(0), kend, a0, b0);
-        load_pair<MODE, AK, BKC, VEC>(d, m0, n0, nk > 1 ? kr.k_of(1) : kbeg, kend, a1, b1);
-        store_quads<NP, AK, true>(smem, a0, kend - kr.k_of(0));
-        store_quads<NP, BKC, true>(smem + OPB, b0, kend - kr.k_of(0));
-        if (!AK && do_cs) cs += quad_sum_masked<AK>(a0, kend - kr.k_of(0));
+    float cs = 0.f;                    // sum over k of A(row, k) for the row this thread stages (the same row for all its quads)
+    if (nsteps > 0) {
+        Quad a0[NQA], b0[NQB], a1[NQA], b1[NQB], a2[NQA], b2[NQB], a3[NQA], b3[NQB];
+        Frags<NP, TM, TN> fe, fo;      // fragments of even / odd slabs
+#define GRAPPA_LOAD(S, QA, QB)                                                                      \
+    load_quads<BM, AK, VEC>(d.A, d.lda, m0, kr.k_of((S) < nsteps ? (S) : 0), d.M, kr.kend, QA); \
+    load_quads<BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of((S) < nsteps ? (S) : 0), d.N, kr.kend, QB)
+        GRAPPA_LOAD(0, a0, b0);
+        GRAPPA_LOAD(1, a1, b1);
+        GRAPPA_LOAD(2, a2, b2);
+        GRAPPA_LOAD(3, a3, b3);
+#undef GRAPPA_LOAD
+        store_quads<NP, BM, AK, true>(smem, a0, kr.kend - kr.kbeg);
+        store_quads<NP, BN, BKC, true>(smem + NP * BM * ROWB, b0, kr.kend - kr.kbeg);
+        if (!AK && do_cs) cs += quad_sum_masked<BM, AK>(a0, kr.kend - kr.kbeg);
         __syncthreads();
-        read_frags<NP>(smem, smem + OPB, wm0, wn0, lr, lh, 0, f0);
-        int kt = 0;
-#define GRAPPA_STEP(TAIL, LA, LB, SA, SB) \
-    pipeline_step<MODE, AK, BKC, VEC, TAIL>(d, smem, acc, m0, n0, kr, kt, wm0, wn0, lr, lh, LA, LB, SA, SB, f0, cs, do_cs)
-        // main loop: two steps per trip (the register sets swap roles), never touching the last tile of the range
-        for (; kt + 3 < nk; kt += 2) {
-            GRAPPA_STEP(false, a0, b0, a1, b1);
-            ++kt;
-            GRAPPA_STEP(false, a1, b1, a0, b0);
-            --kt;
+        read_frags<NP, BM, BN, TM, TN>(smem, wm0, wn0, lr, lh, fe);
+        int s = 0;
+        // step s stores slab s+1 (register set (s+1) % 4) and loads slab s+4 into the set slab s occupied
+#define GRAPPA_STEP(TAIL, LA, LB, SA, SB, FC, FN) \
+    pipeline_step<MODE, BM, BN, WN, AK, BKC, VEC, TAIL>(d, smem, acc, m0, n0, kr, s, wm0, wn0, lr, lh, LA, LB, SA, SB, FC, FN, cs, do_cs)
+        // main loop: four steps per trip (the register sets rotate); never stores the last slab of the range and every load
+        // it issues is for an existing slab
+        for (; s + 7 < nsteps; s += 4) {
+            GRAPPA_STEP(false, a0, b0, a1, b1, fe, fo);
+            ++s;
+            GRAPPA_STEP(false, a1, b1, a2, b2, fo, fe);
+            ++s;
+            GRAPPA_STEP(false, a2, b2, a3, b3, fe, fo);
+            ++s;
+            GRAPPA_STEP(false, a3, b3, a0, b0, fo, fe);
+            s -= 3;
         }
-        for (; kt < nk; kt += 2) {                    // the last (up to 3) steps
-            GRAPPA_STEP(true, a0, b0, a1, b1);
-            if (kt + 1 < nk) {
-                ++kt;
-                GRAPPA_STEP(true, a1, b1, a0, b0);
-                --kt;
+        for (; s < nsteps; s += 4) {                  // the last (up to 7) steps
+            GRAPPA_STEP(true, a0, b0, a1, b1, fe, fo);
+            if (s + 1 < nsteps) {
+                ++s;
+                GRAPPA_STEP(true, a1, b1, a2, b2, fo, fe);
+                --s;
+            }
+            if (s + 2 < nsteps) {
+                s += 2;
+                GRAPPA_STEP(true, a2, b2, a3, b3, fe, fo);
+                s -= 2;
+            }
+            if (s + 3 < nsteps) {
+                s += 3;
+                GRAPPA_STEP(true, a3, b3, a0, b0, fo, fe);
+                s -= 3;
             }
         }
 #undef GRAPPA_STEP
@@ -276,22 +323,28 @@ __global__ __launch_bounds__(NT) void gemm_bf16x_kernel(GemmParams p) {
         float* red = reinterpret_cast<float*>(smem);
         red[threadIdx.x] = cs;
         __syncthreads();
-        if (threadIdx.x < BM) {
-            const float s = (red[threadIdx.x] + red[threadIdx.x + BM]) + (red[threadIdx.x + 2 * BM] + red[threadIdx.x + 3 * BM]);
+        if (threadIdx.x < BM) {                              // threads t, t + BM, ... staged row t
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT / BM; ++t) sum += red[threadIdx.x + t * BM];
             const int m = m0 + threadIdx.x;
             if (m < d.M) {
-                if (p.nsplit > 1) p.cs_slab[(size_t)split * d.M + m] = s;
-                else d.a_colsum[m] += s;
+                if (p.nsplit > 1) p.cs_slab[(size_t)split * d.M + m] = sum;
+                else d.a_colsum[m] += sum;
             }
         }
     }
-    tile_epilogue<BM, BN, TM, TN>(p, acc, m0, n0, wm0, wn0, lr, lh, split, tile_local);
+    if ((d.precision & 0x200) && acc[0][0][0] != 12345.f) return;     // DEBUG: no epilogue
+    __syncthreads();                                         // the stages (and the column-sum scratch) are dead: reuse as staging
+    tile_epilogue_rows<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES), m0, n0, wm0, wn0, lane, split, tile_local,
+                                       p.vec_io != 0);
 }
 
-template <int MODE, bool AK, bool BKC, bool VEC>
+template <int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
 int launch_mode(hipStream_t st, GemmParams& p) {
-    constexpr size_t smem = 2 * 2 * (size_t)Pieces<MODE>::NP * PIECE_B;
-    auto kern = gemm_bf16x_kernel<MODE, AK, BKC, VEC>;
+    constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (BM + BN) * ROWB, staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
+    constexpr size_t smem = stages > staging ? stages : staging;
+    auto kern = gemm_bf16x_kernel<MODE, BM, BN, WN, AK, BKC, VEC>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -302,23 +355,30 @@ int launch_mode(hipStream_t st, GemmParams& p) {
     return grappa_launch_status();
 }
 
-template <int MODE>
+template <int MODE, int BM, int BN, int WN>
 int launch_layout(hipStream_t st, GemmParams& p, bool vec) {
     const grappa_gemm_desc& d = p.d;
-    if (d.a_kcontig && d.b_kcontig) return vec ? launch_mode<MODE, true, true, true>(st, p) : launch_mode<MODE, true, true, false>(st, p);
-    if (d.a_kcontig) return vec ? launch_mode<MODE, true, false, true>(st, p) : launch_mode<MODE, true, false, false>(st, p);
-    return launch_mode<MODE, false, false, false>(st, p);     // row-contiguous operands never use the float4 path
+    if (d.a_kcontig && d.b_kcontig) return vec ? launch_mode<MODE, BM, BN, WN, true, true, true>(st, p) : launch_mode<MODE, BM, BN, WN, true, true, false>(st, p);
+    if (d.a_kcontig) return vec ? launch_mode<MODE, BM, BN, WN, true, false, true>(st, p) : launch_mode<MODE, BM, BN, WN, true, false, false>(st, p);
+    return launch_mode<MODE, BM, BN, WN, false, false, false>(st, p);     // row-contiguous operands never use the float4 path
+}
+
+template <int MODE>
+int launch_tile(hipStream_t st, GemmParams& p, bool vec) {
+    if (p.bm == 256 && p.bn == 128) return launch_layout<MODE, 256, 128, 2>(st, p, vec);     // 4 x 2 wavefronts of 64 x 64
+    if (p.bm == 128 && p.bn == 128) return launch_layout<MODE, 128, 128, 4>(st, p, vec);     // 2 x 4 wavefronts of 64 x 32
+    return GRAPPA_ERR_ARG;
 }
 
 }  // namespace
 
-// called by grappa_gemm_f32 (gemm_f32.hip) for precision != GRAPPA_GEMM_F32_MFMA; p.bm == p.bn == 128
+// called by grappa_gemm_f32 (gemm_f32.hip) for precision != GRAPPA_GEMM_F32_MFMA; (p.bm, p.bn) is 256x128 or 128x128
 int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool vec_kcontig) {
     switch (precision) {
-        case GRAPPA_GEMM_F32_BF16X9: return launch_layout<X9>(st, p, vec_kcontig);
-        case GRAPPA_GEMM_F32_BF16X6: return launch_layout<X6>(st, p, vec_kcontig);
-        case GRAPPA_GEMM_BF16X3: return launch_layout<X3>(st, p, vec_kcontig);
-        case GRAPPA_GEMM_BF16: return launch_layout<X1>(st, p, vec_kcontig);
+        case GRAPPA_GEMM_F32_BF16X9: return launch_tile<X9>(st, p, vec_kcontig);
+        case GRAPPA_GEMM_F32_BF16X6: return launch_tile<X6>(st, p, vec_kcontig);
+        case GRAPPA_GEMM_BF16X3: return launch_tile<X3>(st, p, vec_kcontig);
+        case GRAPPA_GEMM_BF16: return launch_tile<X1>(st, p, vec_kcontig);
         default: return GRAPPA_ERR_ARG;
     }
 }

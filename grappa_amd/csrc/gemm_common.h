@@ -20,6 +20,7 @@ struct GemmParams {
     int tile_begin;        // this launch handles tiles [tile_begin, tile_begin + ntiles_launch) of the tiles_m x tiles_n grid
     int ntiles_launch;
     int bm, bn;            // tile shape (for the reduce kernel)
+    int vec_io;            // every epilogue tensor is 16-byte aligned with a leading dimension % 4 == 0 (float4 epilogue)
 };
 
 __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v) {
@@ -115,6 +116,101 @@ __device__ inline void tile_epilogue(const GemmParams& p, const f32x16 (&acc)[TM
                 *o = v;
             }
         }
+}
+
+// Row-contiguous epilogue for kernels that compute the TRANSPOSED accumulator (MFMA called as B-fragment x A-fragment, so that
+// element e of lane (lr, lh) is C(m = lr, n = (e & 3) + 8*(e >> 2) + 4*lh): four consecutive n per register quad).
+// Per 32-row band the wavefront stages its 32 x (32*TN) block in a private LDS region with 16-byte writes, reads it back one
+// full row segment per 16 lanes and walks C / pre / aux / res / C2 with float4 accesses: 4x fewer memory instructions than the
+// element-wise walk and every store instruction covers whole 128-byte lines.  `vec_io` (host-checked: all epilogue tensors
+// 16-byte aligned with leading dimensions % 4 == 0) selects the float4 path; otherwise elements go through epilogue_store.
+constexpr int EPI_LD = 68;                          // floats per staged row (64 + 4 pad: conflict-free 16-byte writes)
+constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;     // private staging region per wavefront
+
+// one 32-row band (accumulator row i of the wavefront's TM x TN grid)
+template <int BM, int BN, int TN>
+__device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[TN], float* __restrict__ wave_buf, int m0, int n0, int mband,
+                                     int n, int lane, const float4& b4, int split, int tile_local, bool vec_io) {
+    const grappa_gemm_desc& d = p.d;
+    const int lr = lane & 31, lh = lane >> 5;
+    constexpr int ROWS_PER_IT = TN == 2 ? 4 : 8;                // 16 (TN == 2) or 8 lanes read one staged row
+    constexpr int NIT = 32 / ROWS_PER_IT;
+    const int rrow = TN == 2 ? (lane >> 4) : (lane >> 3), rc4 = TN == 2 ? ((lane & 15) << 2) : ((lane & 7) << 2);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(wave_buf + lr * EPI_LD + j * 32 + 8 * g + 4 * lh) =
+                make_float4(acc_i[j][4 * g], acc_i[j][4 * g + 1], acc_i[j][4 * g + 2], acc_i[j][4 * g + 3]);
+    for (int it = 0; it < NIT; ++it) {
+        const int row = it * ROWS_PER_IT + rrow;
+        const float4 v4 = *reinterpret_cast<const float4*>(wave_buf + row * EPI_LD + rc4);
+        const int m = mband + row;
+        if (m >= d.M || n >= d.N) continue;
+        if (p.nsplit > 1) {                                  // raw partial sums, tile-local [BM][BN] slab (always aligned)
+            float* srow = p.slab + ((size_t)split * p.ntiles_launch + tile_local) * (BM * BN) + (size_t)(m - m0) * BN + (n - n0);
+            *reinterpret_cast<float4*>(srow) = v4;
+            continue;
+        }
+        if (!vec_io || n + 3 >= d.N) {
+            const float ve[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n + q < d.N) epilogue_store(p, m, n + q, ve[q]);
+            continue;
+        }
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (d.pre) {
+            const float4 t = *reinterpret_cast<const float4*>(d.pre + (size_t)m * d.ldpre + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        if (d.act == GRAPPA_ACT_ELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = grappa_elu(v[q]);
+        }
+        if (d.aux) {
+            const float4 t = *reinterpret_cast<const float4*>(d.aux + (size_t)m * d.ldaux + n);
+            v[0] *= grappa_elu_grad_from_out(t.x); v[1] *= grappa_elu_grad_from_out(t.y);
+            v[2] *= grappa_elu_grad_from_out(t.z); v[3] *= grappa_elu_grad_from_out(t.w);
+        }
+        float* o = d.C + (size_t)m * d.ldc + n;
+        if (d.C2) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            o = d.C2 + (size_t)m * d.ldc2 + n;
+        }
+        if (d.drop_p > 0.0f) {
+            const uint64_t idx = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = grappa_keep(d.drop_seed, idx + q, d.drop_p) ? v[q] * p.drop_scale : 0.0f;
+        }
+        if (d.res) {
+            const float4 t = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (d.accumulate) {
+            const float4 t = *reinterpret_cast<const float4*>(o);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int BM, int BN, int TM, int TN>
+__device__ inline void tile_epilogue_rows(const GemmParams& p, const f32x16 (&acc)[TM][TN], float* __restrict__ wave_buf, int m0, int n0,
+                                          int wm0, int wn0, int lane, int split, int tile_local, bool vec_io) {
+    static_assert(TN * 32 <= 64 && TM == 2, "staging row holds 64 floats; two bands per wavefront");
+    const grappa_gemm_desc& d = p.d;
+    const int n = n0 + wn0 + (TN == 2 ? ((lane & 15) << 2) : ((lane & 7) << 2));
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && p.nsplit == 1) {
+        b4.x = n < d.N ? d.bias[n] : 0.f;
+        b4.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
+        b4.z = n + 2 < d.N ? d.bias[n + 2] : 0.f;
+        b4.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
+    }
+    epilogue_band<BM, BN, TN>(p, acc[0], wave_buf, m0, n0, m0 + wm0, n, lane, b4, split, tile_local, vec_io);
+    epilogue_band<BM, BN, TN>(p, acc[1], wave_buf, m0, n0, m0 + wm0 + 32, n, lane, b4, split, tile_local, vec_io);
 }
 
 constexpr int REDUCE_THREADS = 256;

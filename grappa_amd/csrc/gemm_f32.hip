@@ -284,10 +284,11 @@ struct Plan {
 };
 
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
-// cfg 5: the 128x128 tile of the bf16-split kernel (gemm_bf16x.hip), one 512-thread workgroup per CU
-constexpr int CFG_BM[6] = {128, 64, 128, 32, 128, 128};
-constexpr int CFG_BN[6] = {128, 64, 32, 128, 64, 128};
-constexpr int CFG_CONC[6] = {2, 4, 4, 4, 3, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 120 KB, VGPR budget)
+// cfg 5, 6: the 128x128 and 256x128 tiles of the bf16-split kernel (gemm_bf16x.hip), one 512-thread workgroup per CU
+constexpr int NCFG = 7;
+constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256};
+constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128};
+constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
 
 // Tile choice by a small cost model: the busiest of the 256 CUs gets ceil(workgroups / 256) of them, each costing
 // BM*BN*k_per_split MFMA work divided by the tile's efficiency (smaller tiles re-read LDS more per MFMA); split-K (only when
@@ -303,13 +304,15 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false) {
     best.tail_nsplit = 0;
     best.tail_k_per_split = 0;
     double best_cost = 1e300;
-    const int cands[6] = {0, 4, 1, 2, 3, 5};
-    const double eff[6] = {1.00, 0.70, 0.55, 0.55, 0.93, 1.00};    // indexed by cfg
+    const int cands[NCFG] = {0, 4, 1, 2, 3, 6, 5};
+    // indexed by cfg; the bf16-split tiles run ~2-3x the MAC rate of the native ones (same cost unit, so that the split-K
+    // slab terms below weigh correctly against them)
+    const double eff[NCFG] = {1.00, 0.70, 0.55, 0.55, 0.93, 1.60, 2.40};
     int max_split = K >= 16 * BK ? K / (8 * BK) : 1;
     if (max_split > 64) max_split = 64;
-    for (int ci = 0; ci < 6; ++ci) {
+    for (int ci = 0; ci < NCFG; ++ci) {
         const int c = cands[ci];
-        if (bf16x != (c == 5)) continue;
+        if (bf16x != (c >= 5)) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
@@ -436,8 +439,11 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool padB = d->b_kcontig || ((d->N + 3) & ~3) <= d->ldb;
     const bool vec = vecA && vecB && padA && padB;
     p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
-    if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
-    const bool bf16x = use_bf16x(d->M, d->N, d->precision);
+    auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
+    p.vec_io = al16(d->C, d->ldc) && al16(d->C2, d->ldc2) && al16(d->pre, d->ldpre) && al16(d->res, d->ldres) && al16(d->aux, d->ldaux);
+    const int prec = d->precision & 0xff;   // DEBUG
+    if (prec < GRAPPA_GEMM_F32_MFMA || prec > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
+    const bool bf16x = use_bf16x(d->M, d->N, prec);
     Plan pl = make_plan(d->M, d->N, d->K, vec, bf16x);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
@@ -461,7 +467,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             p.cs_slab = p.slab + (size_t)nsplit * ntiles * te;
         }
         int rc;
-        if (bf16x) rc = grappa_launch_gemm_bf16x(st, p, d->precision, vec);
+        if (bf16x) rc = grappa_launch_gemm_bf16x(st, p, prec, vec);
         else if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
         else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
         else rc = dispatch<false, false>(st, p, pl.cfg, vec);
