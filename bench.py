@@ -25,6 +25,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 16 * 157.3   # same table: the bf16 MFMA runs 16x the fp32 one (~2.5 PFLOP/s dense)
+# dominant kernel per GEMM arithmetic: (kernel, bf16 MFMAs issued per fp32 multiply-add column, i.e. partial products)
+GEMM_KERNELS = {"f32": ("gemm_f32_kernel<*> (v_mfma_f32_32x32x2_f32)", 0),
+                "f32_bf16x9": ("gemm_bf16x_kernel<9,*> (fp32 operands as 3 bf16 pieces, 9 partial products, v_mfma_f32_32x32x16_bf16)", 9),
+                "f32_bf16x6": ("gemm_bf16x_kernel<6,*> (fp32 operands as 3 bf16 pieces, 6 partial products, v_mfma_f32_32x32x16_bf16)", 6),
+                "bf16x3": ("gemm_bf16x_kernel<3,*>", 3), "bf16": ("gemm_bf16x_kernel<1,*>", 1)}
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
 
 
@@ -35,13 +41,15 @@ def keyed_init(model):
     model.load_state_dict(gu.keyed_state_dict(model))
 
 
-def cpu_baseline(workload: str, n_mols: int, steps: int):
-    """the oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same workload"""
+def cpu_baseline_child(workload: str, n_mols: int, steps: int, threads: int):
+    """the oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same workload; runs in
+    a child process of its own (`bench.py --cpu-baseline-child ...`) that never touches the GPU"""
     from grappa_amd import get_default_model_config
     from grappa_amd.datasets import build_batch_from_pool, workload_molecule_ids
     from oracle import cpu_ref
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_utils as gu
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(threads)
     ids = workload_molecule_ids(workload, seed=0)[:n_mols]
     model = cpu_ref.RefGrappaModel(**get_default_model_config())
     model.load_state_dict(gu.keyed_state_dict(model))
@@ -61,9 +69,26 @@ def cpu_baseline(workload: str, n_mols: int, steps: int):
         if it > 0:
             times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
-    return {"value": n_mols / t, "unit": "molecules/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{n_mols} molecules of {workload} x 32 conformations, production model fp32, median of {steps} train steps "
-                      f"(oracle/cpu_ref.py, torch {torch.__version__} CPU)"}
+    print(json.dumps({"value": n_mols / t, "unit": "molecules/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                      "sample": f"{n_mols} molecules of {workload} x 32 conformations, production model fp32, median of {steps} train "
+                                f"step(s) after one warm-up (oracle/cpu_ref.py, torch {torch.__version__} CPU, {threads} threads)"}), flush=True)
+
+
+def cpu_baseline(workload: str, n_mols: int, steps: int, limit_s: float):
+    """run the bounded CPU sample in a child process (started before this process touches the GPU) under a wall-clock limit"""
+    import subprocess
+    threads = max(1, min(16, os.cpu_count() or 1))       # more threads than this only oversubscribe the oracle's small per-op work
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", workload, str(n_mols), str(steps), str(threads)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=env)
+        for line in reversed(out.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "molecules/s", "cores": threads, "kind": "port", "sample": f"child failed: {out.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "molecules/s", "cores": threads, "kind": "port",
+                "sample": f"{n_mols} molecules x {steps + 1} train steps did not finish within {limit_s:.0f} s on {threads} threads"}
 
 
 def log(*a):
@@ -71,19 +96,31 @@ def log(*a):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
+        cpu_baseline_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C2-pubchem-b256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_bf16x6)")
+    ap.add_argument("--alt-precision", default="f32", help="also time K steps with this GEMM arithmetic (reported beside the default); '' to skip")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="molecules in the CPU baseline sample")
+    ap.add_argument("--cpu-limit", type=float, default=150.0, help="wall-clock limit of the CPU baseline child, seconds")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (functional test of the N>1 path on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # CPU baseline first, in a child process, before this process initialises the GPU (rank 0 at N = 1 only)
+    cpu_base = None
+    if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        log(f"cpu baseline (oracle, {args.cpu_sample} molecules, limit {args.cpu_limit:.0f} s) ...")
+        cpu_base = cpu_baseline(args.workload, args.cpu_sample, 1, args.cpu_limit)
+        log(f"cpu baseline: {cpu_base}")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
@@ -103,6 +140,8 @@ def main():
 
     log("imports done; building model")
     be = get_backend()
+    if args.gemm_precision:
+        be.set_gemm_precision(args.gemm_precision)
     model = model_from_config(get_default_model_config())
     keyed_init(model)
     model = model.to(dev).train()
@@ -159,6 +198,29 @@ def main():
     dt_prof = time.perf_counter() - t1
 
     log("instrumented pass done")
+    # the same K steps with the dense products on the native fp32 matrix instruction, for reference next to the default
+    alt = None
+    if args.alt_precision and args.alt_precision != be.gemm_precision_name:
+        default_precision = be.gemm_precision_name
+        be.set_gemm_precision(args.alt_precision)
+        step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_alt = time.perf_counter() - t2
+        if world > 1:
+            t = torch.tensor([dt_alt], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_alt = float(t)
+        alt = {"gemm_precision": args.alt_precision, "value": per_gpu * world * args.steps / dt_alt, "ms_per_step": 1e3 * dt_alt / args.steps}
+        be.set_gemm_precision(default_precision)
+        log(f"alt precision {args.alt_precision}: {alt['ms_per_step']:.1f} ms/step")
     if rank == 0:
         n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
         achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
@@ -172,8 +234,13 @@ def main():
                 traffic_src = "profiles/pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)"
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<*> (v_mfma_f32_32x32x2_f32)", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        kname, nprod = GEMM_KERNELS[be.gemm_precision_name]
+        # `achieved` counts the ALGORITHMIC fp32 FLOPs (2MNK); the split kernel issues `nprod` bf16 MFMAs per fp32 product, so
+        # its ceiling in the same unit is the bf16 dense peak / nprod
+        peak = PEAK_F32_MFMA_TFLOPS if nprod == 0 else PEAK_BF16_MFMA_TFLOPS / nprod
+        roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "frac_of_native_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                "gemm_precision": be.gemm_precision_name, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": by / max(n, 1),
                 "launches_per_step": n / args.steps, "avg_launch_us": 1e3 * ms / max(n, 1), "gflop_per_launch": fl / max(n, 1) / 1e9,
                 "kernel_ms_per_step": ms / args.steps}
@@ -191,13 +258,15 @@ def main():
                                    f"production GrappaModel 40.8M params random-init, train mode (dropout on), Adam + clip 10",
                        "molecules_per_gpu": per_gpu, "global_batch": per_gpu * world, "conformations": 32, "atoms_rank0": plan.N,
                        "tuples_rank0": {k: int(v) for k, v in plan.T.items()}, "parallelism": f"dp{world}"},
+            "gemm_arithmetic": {"default": be.gemm_precision_name,
+                                "note": "inputs, outputs, accumulation and every non-GEMM kernel are fp32; f32_bf16x6 splits each fp32 operand "
+                                        "exactly into 3 bf16 pieces and sums the 6 largest partial products on the bf16 matrix cores "
+                                        "(error vs a float64 product <= that of the native fp32 MFMA: tests/test_gpu_ops.py::"
+                                        "test_gemm_precision_modes; end-to-end parity: tests/test_gpu_e2e.py)",
+                                "native_f32_mfma": alt},
             "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": 1e3 * dt_prof / args.steps, "final_loss": final_loss,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            log("cpu baseline (oracle) ...")
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, 2)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgrappa_hip.so")
 
 ABI_VERSION = 2
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
-GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4, "dbg_x6": 0x102, "dbg_bf16": 0x104, "dbg2_x6": 0x202, "dbg3_x6": 0x302, "dbg4_x6": 0x402}
+GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4}
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -48,7 +48,8 @@ SIGNATURES = {
     "grappa_abi_version": (_i, []),
     "grappa_build_arch": (C.c_char_p, []),
     "grappa_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
-    "grappa_gemm_f32_plan": (_i, [_i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "grappa_gemm_f32_plan": (_i, [_i, _i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "grappa_gemm_f32_set_plan_override": (None, [_i, _i, _i]),
     "grappa_gemm_f32": (_i, [_vp, C.POINTER(GemmDesc), _vp, _sz]),
     "grappa_colsum_workspace_bytes": (_sz, [_i, _i]),
     "grappa_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz]),

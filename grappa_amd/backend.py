@@ -65,6 +65,9 @@ def _flat(t: torch.Tensor, name: str, dev, dtype=torch.float32) -> None:
         raise ValueError(f"{name}: expected a contiguous {dtype} tensor on {dev}")
 
 
+DEFAULT_GEMM_PRECISION = "f32_bf16x6"
+
+
 class HipBackend:
     name = "hip"
 
@@ -73,8 +76,17 @@ class HipBackend:
             raise RuntimeError("grappa_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self._ws = {}
-        self.gemm_precision = _lib.GEMM_PRECISIONS[os.environ.get("GRAPPA_GEMM_PRECISION", "f32")]
+        # arithmetic of the dense products (include/grappa_hip.h GRAPPA_GEMM_*): "f32_bf16x6" = fp32 operands split into three
+        # bf16 pieces on the bf16 matrix cores with fp32 accumulation -- at least as close to the exact product as the native
+        # fp32 MFMA (tests/test_gpu_ops.py::test_gemm_precision_modes) at ~1.7x its speed; "f32" = native fp32 MFMA
+        self.set_gemm_precision(os.environ.get("GRAPPA_GEMM_PRECISION", DEFAULT_GEMM_PRECISION))
         self._prof = None      # list of (kernel family, algorithmic flops, algorithmic bytes, start event, end event) when profiling
+
+    def set_gemm_precision(self, name: str) -> None:
+        if name not in _lib.GEMM_PRECISIONS:
+            raise ValueError(f"gemm precision {name!r}: expected one of {sorted(_lib.GEMM_PRECISIONS)}")
+        self.gemm_precision_name = name
+        self.gemm_precision = _lib.GEMM_PRECISIONS[name]
 
     # ------------------------------------------------------------------ in-process kernel timing (bench.py roofline)
     def start_profile(self) -> None:

@@ -290,10 +290,32 @@ constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256};
 constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128};
 constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
 
-// Tile choice by a small cost model: the busiest of the 256 CUs gets ceil(workgroups / 256) of them, each costing
-// BM*BN*k_per_split MFMA work divided by the tile's efficiency (smaller tiles re-read LDS more per MFMA); split-K (only when
-// K is long) adds the slab round trip.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
 bool use_bf16x(int M, int N, int precision) { return precision != GRAPPA_GEMM_F32_MFMA && M > 32 && N > 32; }
+
+// tuning / tests only (grappa_gemm_f32_set_plan_override): force the tile configuration, split-K factor and tail use
+struct PlanOverride { int cfg = -1, nsplit = 0, tail = -1; };
+PlanOverride g_override;
+
+// Tile choice by a small cost model in CU-cycles.  A workgroup of tile c over k_per_split columns of K costs
+// BM*BN*(k + K0_c) / RATE_c; a CU runs CONC_c of them at once (each then CONC_c times slower), the chip drains the grid in
+// ceil(workgroups / (256*CONC_c)) such rounds.  Split-K adds the slab round trip and two launches.  With an unsplit K the
+// tiles beyond the last full 256 can run as a second, split-K "tail" launch (rem * ts workgroups, each 1/ts long) instead of
+// costing a whole extra round.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
+struct CostModel {
+    // MACs per cycle per CU sustained in the main loop, and the per-tile prologue + epilogue expressed in columns of K
+    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0};
+    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0};
+    double grid(int c, long wgs, int kps) const {
+        const int conc = CFG_CONC[c];
+        const double t = (double)CFG_BM[c] * CFG_BN[c] * (kps + k0[c]) / rate[c];
+        if (wgs <= 256L * conc) {
+            const double per_cu = (double)((wgs + 255) / 256);
+            return per_cu * t * (per_cu < 2 && conc > 1 ? 1.3 : 1.0);   // a lone workgroup of a multi-resident tile cannot hide its barrier bubbles
+        }
+        return (double)((wgs + 256L * conc - 1) / (256L * conc)) * conc * t;
+    }
+    static double splitk(int nsplit, double elems) { return 12000.0 + nsplit * elems / 200.0; }   // two launches + slab write / reduce
+};
 
 Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false) {
     Plan best;
@@ -304,62 +326,55 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false) {
     best.tail_nsplit = 0;
     best.tail_k_per_split = 0;
     double best_cost = 1e300;
-    const int cands[NCFG] = {0, 4, 1, 2, 3, 6, 5};
-    // indexed by cfg; the bf16-split tiles run ~2-3x the MAC rate of the native ones (same cost unit, so that the split-K
-    // slab terms below weigh correctly against them)
-    const double eff[NCFG] = {1.00, 0.70, 0.55, 0.55, 0.93, 1.60, 2.40};
+    const CostModel cm;
     int max_split = K >= 16 * BK ? K / (8 * BK) : 1;
     if (max_split > 64) max_split = 64;
-    for (int ci = 0; ci < NCFG; ++ci) {
-        const int c = cands[ci];
+    int max_tail_split = K >= 8 * BK ? K / (4 * BK) : 1;      // the tail may be cut finer than a full split-K GEMM
+    if (max_tail_split > 64) max_tail_split = 64;
+    for (int c = 0; c < NCFG; ++c) {
+        if (g_override.cfg >= 0 && c != g_override.cfg) continue;
         if (bf16x != (c >= 5)) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
         if ((c == 0 || c == 4 || c == 1) && (N <= 32 || M <= 32)) continue;
         const long tiles = (long)((M + CFG_BM[c] - 1) / CFG_BM[c]) * ((N + CFG_BN[c] - 1) / CFG_BN[c]);
+        const double te = (double)CFG_BM[c] * CFG_BN[c];
         for (int ns = 1; ns <= max_split; ns = ns < 4 ? ns + 1 : ns + (ns + 3) / 4) {
+            if (g_override.nsplit > 0 && ns != g_override.nsplit) continue;
             int kps = (K + ns - 1) / ns;
             kps = (kps + BK - 1) / BK * BK;
             const int nsplit = (K + kps - 1) / kps;
-            const long wgs = tiles * nsplit;
-            // unit = one MAC on one CU (128 MAC/cycle/CU).  A CU runs `conc` workgroups of this tile at once (LDS/VGPR limit),
-            // each then `conc` times slower; the chip drains the grid in ceil(wgs / (256*conc)) such rounds.
-            const int conc = CFG_CONC[c];
-            const double tile_cost = (double)CFG_BM[c] * CFG_BN[c] * (kps + 3.0 * BK) / eff[c];   // + pipeline fill / epilogue
-            double cost;
-            if (wgs <= 256L * conc) {
-                const double per_cu = (double)((wgs + 255) / 256);
-                cost = per_cu * tile_cost * (per_cu < 2 ? 1.3 : 1.0);     // a lone workgroup cannot hide its barrier / LDS-store bubbles
-            } else {
-                cost = (double)((wgs + 256L * conc - 1) / (256L * conc)) * conc * tile_cost;
+            double cost = cm.grid(c, tiles * nsplit, kps);
+            if (nsplit > 1) cost += CostModel::splitk(nsplit, (double)M * N);
+            Plan cand = best;
+            cand.cfg = c;
+            cand.nsplit = nsplit;
+            cand.k_per_split = kps;
+            cand.main_tiles = (int)tiles;
+            cand.tail_nsplit = 0;
+            cand.tail_k_per_split = 0;
+            const long rem = tiles % 256;
+            if (nsplit == 1 && tiles > 256 && rem > 0 && rem <= 160 && g_override.tail != 0) {
+                int ts = (int)(256 / rem);
+                if (ts > max_tail_split) ts = max_tail_split;
+                int tkps = (K + ts - 1) / ts;
+                tkps = (tkps + BK - 1) / BK * BK;
+                const int tns = (K + tkps - 1) / tkps;
+                if (tns >= 2) {
+                    const double with_tail = cm.grid(c, tiles - rem, kps) + cm.grid(c, rem * tns, tkps) + CostModel::splitk(tns, rem * te);
+                    if (with_tail < cost || g_override.tail == 1) {
+                        cost = with_tail;
+                        cand.main_tiles = (int)(tiles - rem);
+                        cand.tail_nsplit = tns;
+                        cand.tail_k_per_split = tkps;
+                    }
+                }
             }
-            if (nsplit > 1) cost += 1.5e6 + (double)nsplit * M * N * 0.5;
             if (cost < best_cost) {
                 best_cost = cost;
-                best.cfg = c;
-                best.nsplit = nsplit;
-                best.k_per_split = kps;
+                best = cand;
             }
-        }
-    }
-    // Tail: with an unsplit K the grid is tiles = 256*q + rem workgroups; the rem tiles would cost the chip a whole extra
-    // round.  Run them as a second, split-K launch instead (rem * tail_nsplit ~ one workgroup per CU, each 1/tail_nsplit long).
-    const long tiles = (long)((M + CFG_BM[best.cfg] - 1) / CFG_BM[best.cfg]) * ((N + CFG_BN[best.cfg] - 1) / CFG_BN[best.cfg]);
-    best.main_tiles = (int)tiles;
-    if (best.nsplit == 1 && tiles > 256) {
-        const long rem = tiles % 256;
-        int ts = rem > 0 ? (int)(256 / rem) : 0;
-        const int max_tail_split = K >= 8 * BK ? K / (4 * BK) : 1;     // the tail may be cut finer than a full split-K GEMM
-        if (ts > max_tail_split) ts = max_tail_split;
-        if (ts > 64) ts = 64;
-        if (rem > 0 && rem <= 160 && ts >= 2) {
-            int kps = (K + ts - 1) / ts;
-            kps = (kps + BK - 1) / BK * BK;
-            best.tail_nsplit = (K + kps - 1) / kps;
-            best.tail_k_per_split = kps;
-            best.main_tiles = (int)(tiles - rem);
-            if (best.tail_nsplit < 2) { best.tail_nsplit = 0; best.main_tiles = (int)tiles; }
         }
     }
     return best;
@@ -409,9 +424,10 @@ extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
     return a * sizeof(float);
 }
 
-extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
+extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
     if (M <= 0 || N <= 0 || K <= 0 || !tile_m || !tile_n || !nsplit || !tail_tiles || !tail_nsplit) return GRAPPA_ERR_ARG;
-    Plan pl = make_plan(M, N, K);
+    if (precision < GRAPPA_GEMM_F32_MFMA || precision > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
+    Plan pl = make_plan(M, N, K, true, use_bf16x(M, N, precision));
     *tile_m = CFG_BM[pl.cfg];
     *tile_n = CFG_BN[pl.cfg];
     *nsplit = pl.nsplit;
@@ -419,6 +435,12 @@ extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_
     *tail_tiles = pl.tail_nsplit > 1 ? (int)(tiles - pl.main_tiles) : 0;
     *tail_nsplit = pl.tail_nsplit;
     return GRAPPA_OK;
+}
+
+extern "C" void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail) {
+    g_override.cfg = cfg;
+    g_override.nsplit = nsplit;
+    g_override.tail = tail;
 }
 
 extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes) {
@@ -441,9 +463,8 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
     auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
     p.vec_io = al16(d->C, d->ldc) && al16(d->C2, d->ldc2) && al16(d->pre, d->ldpre) && al16(d->res, d->ldres) && al16(d->aux, d->ldaux);
-    const int prec = d->precision & 0xff;   // DEBUG
-    if (prec < GRAPPA_GEMM_F32_MFMA || prec > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
-    const bool bf16x = use_bf16x(d->M, d->N, prec);
+    if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
+    const bool bf16x = use_bf16x(d->M, d->N, d->precision);
     Plan pl = make_plan(d->M, d->N, d->K, vec, bf16x);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
@@ -467,7 +488,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             p.cs_slab = p.slab + (size_t)nsplit * ntiles * te;
         }
         int rc;
-        if (bf16x) rc = grappa_launch_gemm_bf16x(st, p, prec, vec);
+        if (bf16x) rc = grappa_launch_gemm_bf16x(st, p, d->precision, vec);
         else if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
         else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
         else rc = dispatch<false, false>(st, p, pl.cfg, vec);

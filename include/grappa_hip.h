@@ -92,7 +92,10 @@ typedef struct grappa_gemm_desc {
 size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);
 /* host-only: the tile (tile_m x tile_n x 32) and split-K factor the launcher will use for this shape, and the "tail": when the
  * tile grid is 256*q + rem workgroups, the rem tiles run as a second launch with their K range split tail_nsplit ways */
-int grappa_gemm_f32_plan(int M, int N, int K, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit);
+int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit);
+/* tuning and tests only, not thread safe: force the tile configuration index (0..6, -1 = model's choice), the split-K factor
+ * (0 = model's choice) and the tail launch (1 on, 0 off, -1 = model's choice) of every following plan */
+void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail);
 int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes);
 
 /* out[n] (+)= sum_m x[m*ldx + n]   (bias gradients) */
