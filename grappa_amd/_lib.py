@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgrappa_hip.so")
+LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hip.so")   # override: kernel A/B builds (tools/)
 
 ABI_VERSION = 2
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
@@ -75,6 +75,7 @@ SIGNATURES = {
     "grappa_mm_bwd_f32": (_i, [_vp, C.POINTER(MMDesc), _vp, _vp, C.POINTER(VP4), C.POINTER(VP4)]),
     "grappa_loss_ef_fwd_bwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp]),
     "grappa_loss_param_fwd_bwd_f32": (_i, [_vp, C.POINTER(PLossDesc), _vp, C.POINTER(VP6)]),
+    "grappa_eval_se_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "grappa_sumsq_workspace_bytes": (_sz, [_sz]),
     "grappa_sumsq_f32": (_i, [_vp, _sz, _vp, _vp, _i, _vp, _sz]),
     "grappa_adam_step_f32": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _f]),

@@ -442,6 +442,15 @@ class HipBackend:
                                                  _ptr(is_dummy), _ptr(grad), _ptr(grad_ref), float(wE), float(wG), float(inv_B),
                                                  loss_mol.data_ptr(), _ptr(gE), _ptr(gG)), "grappa_loss_ef_fwd_bwd_f32")
 
+    def eval_se(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, out) -> None:
+        """out (B,4) = per molecule {se_E, n_E, se_G, n_G} (include/grappa_hip.h grappa_eval_se_f32)"""
+        dev = out.device
+        for t, n in ((energy, "energy"), (energy_ref, "energy_ref"), (is_dummy, "is_dummy"), (grad, "grad"), (grad_ref, "grad_ref"), (out, "out")):
+            if t is not None:
+                _flat(t, n, dev)
+        _chk(self.lib.grappa_eval_se_f32(self._stream(), plan.B, energy.shape[1], plan.N, plan.atom_molptr.data_ptr(), energy.data_ptr(),
+                                         energy_ref.data_ptr(), _ptr(is_dummy), _ptr(grad), _ptr(grad_ref), out.data_ptr()), "grappa_eval_se_f32")
+
     def loss_param(self, plan, params, refs, fac, reg, pw, inv_B, loss_mol, gps) -> None:
         """params/refs/gps: lists of 6 tensors-or-None in the order n2_k, n2_eq, n3_k, n3_eq, n4_k, n4_improper_k."""
         dev = loss_mol.device

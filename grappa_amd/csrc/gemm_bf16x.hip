@@ -18,6 +18,10 @@
 // Epilogue, split-K slabs, XCD-aware order and the tail launch are shared with the native kernel (gemm_common.h).
 #include "gemm_common.h"
 
+#ifndef GRAPPA_EXP
+#define GRAPPA_EXP 0
+#endif
+
 using namespace grappa_gemm;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -26,7 +30,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int SK = 16;                  // k-slab per pipeline step (one 32x32x16 MFMA deep)
-constexpr int NT = 512;
 constexpr int ROWB = 48;                // LDS row: 16 bf16 (32 B) + 16 B pad -> conflict-free ds_read_b128 per 16-lane group
 constexpr int AHEAD = 4;                // register sets: slab s+4 is loaded while slab s is multiplied
 
@@ -40,10 +43,10 @@ struct Quad { float x[4]; };
 
 // slab element (row, kq..kq+3) owned by this thread for quad slot j of an operand with ROWS rows.
 // K-contiguous source: 4 lanes cover the 64 bytes of one row; k-major source: 64 lanes cover 64 consecutive rows of one k.
-template <int ROWS, bool KCONT>
+template <int NT, int ROWS, bool KCONT>
 __device__ inline void quad_coords(int j, int& row, int& kq) {
     if (KCONT) {
-        row = (threadIdx.x >> 2) + 128 * j;
+        row = (threadIdx.x >> 2) + (NT / 4) * j;
         kq = (threadIdx.x & 3) << 2;
     } else {
         const int f = threadIdx.x + j * NT;
@@ -54,12 +57,12 @@ __device__ inline void quad_coords(int j, int& row, int& kq) {
 
 // Loads never wait for their data: out-of-range rows and k are only CLAMPED here (the addresses stay inside the operand);
 // the k tail is zeroed when the slab is split and stored (store_quads<MASK>), AHEAD - 1 steps later.
-template <int ROWS, bool KCONT, bool VEC>
-__device__ inline void load_quads(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend, Quad (&q)[ROWS / 128]) {
+template <int NT, int ROWS, bool KCONT, bool VEC>
+__device__ inline void load_quads(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend, Quad (&q)[ROWS * 4 / NT]) {
 #pragma unroll
-    for (int j = 0; j < ROWS / 128; ++j) {
+    for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
-        quad_coords<ROWS, KCONT>(j, row, kq);
+        quad_coords<NT, ROWS, KCONT>(j, row, kq);
         const int gr = min(row0 + row, R - 1);          // out-of-range rows are clamped: their results are never stored
         const int gk = k0 + kq;
         if (KCONT && VEC) {
@@ -80,12 +83,12 @@ __device__ inline float u2f(unsigned x) { return __uint_as_float(x); }
 // split 4 consecutive-k fp32 values into NP bf16 pieces (round to nearest even; the residual r - float(piece) is exact in
 // fp32) and store each piece's 4 values as one 8-byte LDS write.  krem = valid k of this slab counted from its first column
 // (MASK: a slab at the end of a K range, whose tail is zero-filled here).
-template <int NP, int ROWS, bool KCONT, bool MASK>
-__device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[ROWS / 128], int krem) {
+template <int NT, int NP, int ROWS, bool KCONT, bool MASK>
+__device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[ROWS * 4 / NT], int krem) {
 #pragma unroll
-    for (int j = 0; j < ROWS / 128; ++j) {
+    for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
-        quad_coords<ROWS, KCONT>(j, row, kq);
+        quad_coords<NT, ROWS, KCONT>(j, row, kq);
         float r[4] = {q[j].x[0], q[j].x[1], q[j].x[2], q[j].x[3]};
         if (MASK) {
 #pragma unroll
@@ -99,7 +102,11 @@ __device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[RO
             h23[0] = (__bf16)r[2]; h23[1] = (__bf16)r[3];
             const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
             *reinterpret_cast<uint2*>(dst + p * (ROWS * ROWB)) = make_uint2(u01, u23);
+#if GRAPPA_EXP & 4
+            if (false) {
+#else
             if (p + 1 < NP) {                       // float(bf16) is the 16 bits moved to the top half of the word
+#endif
                 r[0] -= u2f(u01 << 16); r[1] -= u2f(u01 & 0xffff0000u);
                 r[2] -= u2f(u23 << 16); r[3] -= u2f(u23 & 0xffff0000u);
             }
@@ -115,13 +122,13 @@ __device__ inline float quad_sum(const Quad (&q)[NQ]) {
     return s;
 }
 
-template <int ROWS, bool KCONT>
-__device__ inline float quad_sum_masked(const Quad (&q)[ROWS / 128], int krem) {
+template <int NT, int ROWS, bool KCONT>
+__device__ inline float quad_sum_masked(const Quad (&q)[ROWS * 4 / NT], int krem) {
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < ROWS / 128; ++j) {
+    for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
-        quad_coords<ROWS, KCONT>(j, row, kq);
+        quad_coords<NT, ROWS, KCONT>(j, row, kq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += kq + e < krem ? q[j].x[e] : 0.f;
     }
@@ -186,6 +193,21 @@ struct PhaseOrder<NMFMA, NMFMA, NWRITE, NVALU> {
     static __device__ inline void emit() {}
 };
 
+// sched_group_barrier sequence for NMFMA x { 1 MFMA, a share of NREAD LDS reads }
+template <int G, int NMFMA, int NREAD>
+struct ReadOrder {
+    static __device__ inline void emit() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int R = (G + 1) * NREAD / NMFMA - G * NREAD / NMFMA;
+        if (R > 0) __builtin_amdgcn_sched_group_barrier(0x100, R > 0 ? R : 1, 0);
+        ReadOrder<G + 1, NMFMA, NREAD>::emit();
+    }
+};
+template <int NMFMA, int NREAD>
+struct ReadOrder<NMFMA, NMFMA, NREAD> {
+    static __device__ inline void emit() {}
+};
+
 struct KRange {
     int kbeg, kend, nsteps;
     __device__ inline int k_of(int s) const { return kbeg + s * SK; }
@@ -196,10 +218,10 @@ struct KRange {
 //   (registers S) into the other stage | barrier | fragment reads of slab s+1 -> fn | second half of the MFMAs on fc
 // TAIL = one of the last steps of the K range: loads / stores happen only while slabs remain and the stored slab is masked to
 // the valid k; main-loop steps do both unconditionally.
-template <int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool TAIL>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool TAIL>
 __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict__ smem, f32x16 (&acc)[2][BN / WN / 32], int m0, int n0,
-                                     const KRange& kr, int s, int wm0, int wn0, int lr, int lh, Quad (&la)[BM / 128], Quad (&lb)[BN / 128],
-                                     const Quad (&sa)[BM / 128], const Quad (&sb)[BN / 128],
+                                     const KRange& kr, int s, int wm0, int wn0, int lr, int lh, Quad (&la)[BM * 4 / NT], Quad (&lb)[BN * 4 / NT],
+                                     const Quad (&sa)[BM * 4 / NT], const Quad (&sb)[BN * 4 / NT],
                                      const Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fc, Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fn,
                                      float& cs, bool do_cs) {
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
@@ -208,37 +230,59 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     const bool do_store = !TAIL || s + 1 < kr.nsteps;
     const bool do_load = !TAIL || s + AHEAD < kr.nsteps;
     if (do_load) {
-        load_quads<BM, AK, VEC>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
-        load_quads<BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
+        load_quads<NT, BM, AK, VEC>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
+        load_quads<NT, BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
     }
     __builtin_amdgcn_sched_barrier(0);
     char* nxt = smem + ((s + 1) & 1) * STAGE;
     mfma_range<MODE, TM, TN, 0, NM / 2>(fc, acc);
+#if GRAPPA_EXP & 8
+    if (do_store && TAIL) {
+#else
     if (do_store) {
+#endif
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
-        store_quads<NP, BM, AK, TAIL>(nxt, sa, krem);
-        store_quads<NP, BN, BKC, TAIL>(nxt + NP * BM * ROWB, sb, krem);
-        if (!AK && do_cs) cs += TAIL ? quad_sum_masked<BM, AK>(sa, krem) : quad_sum(sa);
+        store_quads<NT, NP, BM, AK, TAIL>(nxt, sa, krem);
+        store_quads<NT, NP, BN, BKC, TAIL>(nxt + NP * BM * ROWB, sb, krem);
+        if (!AK && do_cs) cs += TAIL ? quad_sum_masked<NT, BM, AK>(sa, krem) : quad_sum(sa);
     }
     if (!TAIL) {
         // issue order of this phase: one MFMA, then a slice of the split arithmetic and of the LDS stores, so that the matrix
         // pipe runs under the vector work instead of before it (left alone the compiler bunches all MFMAs after the barrier)
-        constexpr int NQ = BM / 128 + BN / 128;
+        constexpr int NQ = (BM + BN) * 4 / NT;
         PhaseOrder<0, NM / 2, NQ * NP, NQ * (NP == 3 ? 30 : NP == 2 ? 18 : 6)>::emit();
     }
     __builtin_amdgcn_sched_barrier(0);
+#if GRAPPA_EXP & 16
+    if (TAIL)
+#endif
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (do_store) read_frags<NP, BM, BN, TM, TN>(nxt, wm0, wn0, lr, lh, fn);
+#if GRAPPA_EXP & 1
+    mfma_range<MODE, TM, TN, NM / 2, NM>(fc, acc);
+    if (!TAIL) {
+        // the next slab's fragment reads ride between these MFMAs instead of all eight wavefronts bursting them at the LDS
+        // right after the barrier (an MFMA issues only once its wavefront's reads are queued)
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#if GRAPPA_EXP & 2
+        ReadOrder<0, NM / 4, (TM + TN) * NP>::emit();        // two reads per MFMA gap, all queued by the middle of the half
+#else
+        ReadOrder<0, NM / 2, (TM + TN) * NP>::emit();
+#endif
+    }
+#else
     __builtin_amdgcn_sched_barrier(0);                 // the next slab's fragment reads are in flight before these MFMAs issue
     mfma_range<MODE, TM, TN, NM / 2, NM>(fc, acc);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
-__global__ __launch_bounds__(NT) void gemm_bf16x_kernel(GemmParams p) {
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16x_kernel(GemmParams p) {
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
-    constexpr int NQA = BM / 128, NQB = BN / 128;
+    constexpr int NQA = BM * 4 / NT, NQB = BN * 4 / NT;
+    static_assert((NT / 64 / WN) * 64 == BM, "wavefront grid must cover the tile");
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
     const TileCoord tc = map_workgroup(p);
@@ -267,22 +311,22 @@ __global__ __launch_bounds__(NT) void gemm_bf16x_kernel(GemmParams p) {
         Quad a0[NQA], b0[NQB], a1[NQA], b1[NQB], a2[NQA], b2[NQB], a3[NQA], b3[NQB];
         Frags<NP, TM, TN> fe, fo;      // fragments of even / odd slabs
 #define GRAPPA_LOAD(S, QA, QB)                                                                      \
-    load_quads<BM, AK, VEC>(d.A, d.lda, m0, kr.k_of((S) < nsteps ? (S) : 0), d.M, kr.kend, QA); \
-    load_quads<BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of((S) < nsteps ? (S) : 0), d.N, kr.kend, QB)
+    load_quads<NT, BM, AK, VEC>(d.A, d.lda, m0, kr.k_of((S) < nsteps ? (S) : 0), d.M, kr.kend, QA); \
+    load_quads<NT, BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of((S) < nsteps ? (S) : 0), d.N, kr.kend, QB)
         GRAPPA_LOAD(0, a0, b0);
         GRAPPA_LOAD(1, a1, b1);
         GRAPPA_LOAD(2, a2, b2);
         GRAPPA_LOAD(3, a3, b3);
 #undef GRAPPA_LOAD
-        store_quads<NP, BM, AK, true>(smem, a0, kr.kend - kr.kbeg);
-        store_quads<NP, BN, BKC, true>(smem + NP * BM * ROWB, b0, kr.kend - kr.kbeg);
-        if (!AK && do_cs) cs += quad_sum_masked<BM, AK>(a0, kr.kend - kr.kbeg);
+        store_quads<NT, NP, BM, AK, true>(smem, a0, kr.kend - kr.kbeg);
+        store_quads<NT, NP, BN, BKC, true>(smem + NP * BM * ROWB, b0, kr.kend - kr.kbeg);
+        if (!AK && do_cs) cs += quad_sum_masked<NT, BM, AK>(a0, kr.kend - kr.kbeg);
         __syncthreads();
         read_frags<NP, BM, BN, TM, TN>(smem, wm0, wn0, lr, lh, fe);
         int s = 0;
         // step s stores slab s+1 (register set (s+1) % 4) and loads slab s+4 into the set slab s occupied
 #define GRAPPA_STEP(TAIL, LA, LB, SA, SB, FC, FN) \
-    pipeline_step<MODE, BM, BN, WN, AK, BKC, VEC, TAIL>(d, smem, acc, m0, n0, kr, s, wm0, wn0, lr, lh, LA, LB, SA, SB, FC, FN, cs, do_cs)
+    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, TAIL>(d, smem, acc, m0, n0, kr, s, wm0, wn0, lr, lh, LA, LB, SA, SB, FC, FN, cs, do_cs)
         // main loop: four steps per trip (the register sets rotate); never stores the last slab of the range and every load
         // it issues is for an existing slab
         for (; s + 7 < nsteps; s += 4) {
@@ -337,11 +381,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16x_kernel(GemmParams p) {
                                        p.vec_io != 0);
 }
 
-template <int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
 int launch_mode(hipStream_t st, GemmParams& p) {
     constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (BM + BN) * ROWB, staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
     constexpr size_t smem = stages > staging ? stages : staging;
-    auto kern = gemm_bf16x_kernel<MODE, BM, BN, WN, AK, BKC, VEC>;
+    auto kern = gemm_bf16x_kernel<NT, MODE, BM, BN, WN, AK, BKC, VEC>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -352,18 +396,19 @@ int launch_mode(hipStream_t st, GemmParams& p) {
     return grappa_launch_status();
 }
 
-template <int MODE, int BM, int BN, int WN>
+template <int NT, int MODE, int BM, int BN, int WN>
 int launch_layout(hipStream_t st, GemmParams& p, bool vec) {
     const grappa_gemm_desc& d = p.d;
-    if (d.a_kcontig && d.b_kcontig) return vec ? launch_mode<MODE, BM, BN, WN, true, true, true>(st, p) : launch_mode<MODE, BM, BN, WN, true, true, false>(st, p);
-    if (d.a_kcontig) return vec ? launch_mode<MODE, BM, BN, WN, true, false, true>(st, p) : launch_mode<MODE, BM, BN, WN, true, false, false>(st, p);
-    return launch_mode<MODE, BM, BN, WN, false, false, false>(st, p);     // row-contiguous operands never use the float4 path
+    if (d.a_kcontig && d.b_kcontig) return vec ? launch_mode<NT, MODE, BM, BN, WN, true, true, true>(st, p) : launch_mode<NT, MODE, BM, BN, WN, true, true, false>(st, p);
+    if (d.a_kcontig) return vec ? launch_mode<NT, MODE, BM, BN, WN, true, false, true>(st, p) : launch_mode<NT, MODE, BM, BN, WN, true, false, false>(st, p);
+    return launch_mode<NT, MODE, BM, BN, WN, false, false, false>(st, p);     // row-contiguous operands never use the float4 path
 }
 
 template <int MODE>
 int launch_tile(hipStream_t st, GemmParams& p, bool vec) {
-    if (p.bm == 256 && p.bn == 128) return launch_layout<MODE, 256, 128, 2>(st, p, vec);     // 4 x 2 wavefronts of 64 x 64
-    if (p.bm == 128 && p.bn == 128) return launch_layout<MODE, 128, 128, 4>(st, p, vec);     // 2 x 4 wavefronts of 64 x 32
+    if (p.bm == 256 && p.bn == 128) return launch_layout<512, MODE, 256, 128, 2>(st, p, vec);                         // 4 x 2 wavefronts of 64 x 64
+    if (p.bm == 128 && p.bn == 128 && p.wg_threads == 256) return launch_layout<256, MODE, 128, 128, 2>(st, p, vec);   // 2 x 2 of 64 x 64, two workgroups per CU
+    if (p.bm == 128 && p.bn == 128) return launch_layout<512, MODE, 128, 128, 4>(st, p, vec);                         // 2 x 4 wavefronts of 64 x 32
     return GRAPPA_ERR_ARG;
 }
 

@@ -70,6 +70,52 @@ __global__ __launch_bounds__(256) void loss_ef_kernel(int B, int C, const int* _
     if (tid == 0) loss_mol[b] = loss;
 }
 
+// FastEvaluator.step (training/evaluation.py:53-113): per molecule the sums the reference takes after dgl.unbatch --
+// sum_c ((E - mean E) - (E_ref - mean E_ref))^2 over the real conformations (get_energies centres per molecule,
+// utils/graph_utils.py:35-63), sum over atoms, real conformations and xyz of (G - G_ref)^2, and the two counts
+// (conformations; atoms x conformations = 3-vectors).  out[b] = {se_E, n_E, se_G, n_G}.
+__global__ __launch_bounds__(256) void eval_se_kernel(int B, int C, const int* __restrict__ atom_molptr, const float* __restrict__ energy,
+                                                      const float* __restrict__ energy_ref, const float* __restrict__ is_dummy,
+                                                      const float* __restrict__ grad, const float* __restrict__ grad_ref, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float nr = 0.f, se = 0.f, sr = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float m = (is_dummy && is_dummy[(size_t)b * C + c] != 0.f) ? 0.f : 1.f;
+        nr += m;
+        se += m * energy[(size_t)b * C + c];
+        sr += m * energy_ref[(size_t)b * C + c];
+    }
+    const float nreal = block_sum(nr, red);
+    const float me = block_sum(se, red) / nreal, mr = block_sum(sr, red) / nreal;
+    float sq = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float m = (is_dummy && is_dummy[(size_t)b * C + c] != 0.f) ? 0.f : 1.f;
+        const float diff = (energy[(size_t)b * C + c] - me) - (energy_ref[(size_t)b * C + c] - mr);
+        sq += m * diff * diff;
+    }
+    const float se_e = block_sum(sq, red);
+    float se_g = 0.f;
+    const int a0 = atom_molptr[b], a1 = atom_molptr[b + 1];
+    if (grad && grad_ref) {
+        const size_t base = (size_t)a0 * C * 3, n = (size_t)(a1 - a0) * C * 3;
+        float gq = 0.f;
+        for (size_t i = tid; i < n; i += 256) {
+            const int c = (int)((i / 3) % C);
+            const float m = (is_dummy && is_dummy[(size_t)b * C + c] != 0.f) ? 0.f : 1.f;
+            const float diff = grad[base + i] - grad_ref[base + i];
+            gq += m * diff * diff;
+        }
+        se_g = block_sum(gq, red);
+    }
+    if (tid == 0) {
+        out[4 * (size_t)b] = se_e;
+        out[4 * (size_t)b + 1] = nreal;
+        out[4 * (size_t)b + 2] = se_g;
+        out[4 * (size_t)b + 3] = (grad && grad_ref) ? (float)(a1 - a0) * nreal : 0.f;
+    }
+}
+
 struct PLArgs {
     grappa_ploss_desc d;
     float* loss_mol;
@@ -146,5 +192,14 @@ extern "C" int grappa_loss_param_fwd_bwd_f32(void* stream, const grappa_ploss_de
         if (d->ref[l] && d->ref_width[l] < 1) return GRAPPA_ERR_ARG;
     }
     hipLaunchKernelGGL(loss_param_kernel, dim3(d->B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_eval_se_f32(void* stream, int B, int C, int N, const int* atom_molptr, const float* energy, const float* energy_ref,
+                                  const float* is_dummy, const float* grad, const float* grad_ref, float* out) {
+    if (B <= 0 || C <= 0 || N < 0 || !atom_molptr || !energy || !energy_ref || !out) return GRAPPA_ERR_ARG;
+    if ((grad == nullptr) != (grad_ref == nullptr)) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(eval_se_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), B, C, atom_molptr, energy, energy_ref, is_dummy,
+                       grad, grad_ref, out);
     return grappa_launch_status();
 }

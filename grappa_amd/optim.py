@@ -66,6 +66,12 @@ class FusedAdam:
         be.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                      self.step_count, grad_scale, sumsq, self.max_grad_norm if self.max_grad_norm is not None else 0.0)
 
+    def reset_state(self):
+        """what re-creating torch.optim.Adam does at a restart epoch (training/lightning_model.py:144-151)"""
+        self.m.zero_()
+        self.v.zero_()
+        self.step_count = 0
+
     def grad_norm(self) -> torch.Tensor:
         return torch.sqrt(self.sumsq[0])
 

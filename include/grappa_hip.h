@@ -246,6 +246,13 @@ typedef struct grappa_ploss_desc {
 } grappa_ploss_desc;
 int grappa_loss_param_fwd_bwd_f32(void* stream, const grappa_ploss_desc* d, float* loss_mol, float* const gp[6]);
 
+/* FastEvaluator.step (training/evaluation.py:53-113; get_energies / get_gradients utils/graph_utils.py:35-86), one workgroup
+ * per molecule instead of dgl.unbatch + a Python loop:  out[b*4 + {0,1,2,3}] = { sum over real conformations of the squared
+ * difference of the per-molecule-centred energies, number of real conformations, sum over atoms x real conformations x xyz of
+ * (G - G_ref)^2, atoms x real conformations }.  grad / grad_ref may both be NULL (FastEvaluator(gradients=False)). */
+int grappa_eval_se_f32(void* stream, int B, int C, int N, const int* atom_molptr, const float* energy, const float* energy_ref,
+                       const float* is_dummy, const float* grad, const float* grad_ref, float* out);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser (training/lightning_model.py:297-299 Adam; lightning_trainer.py:92 gradient_clip_val=10):
  * sumsq: out[0] (+)= sum x^2.  adam: p -= lr * mhat/(sqrt(vhat)+eps) with g scaled by

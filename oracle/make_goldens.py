@@ -310,5 +310,46 @@ def main():
     save("ref_energy.npz", {}, mols, out)
 
 
+def make_eval_golden():
+    """FastEvaluator (N4): the reference's own evaluator on two batches (one with padded dummy conformations), three dataset
+    names.  matplotlib (plot helpers only, never called here) is absent offline: an empty module object satisfies the import."""
+    import types
+    for name in ("matplotlib", "matplotlib.pyplot"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from grappa.training.evaluation import FastEvaluator as RefFastEvaluator
+    cfg = small_config(n_conv=1, gated=False, n_att=1)
+    ev, ev_nograd = RefFastEvaluator(), RefFastEvaluator(gradients=False)
+    d, batches = {}, []
+    specs = [dict(ids=pick_small(4, 10, 30, start=40), n_confs=5, seed=23, pad={1: 2, 3: 4}, names=["dsA", "dsB", "dsA", "dsC"]),
+             dict(ids=pick_small(3, 8, 24, start=500), n_confs=7, seed=29, pad=None, names=["dsB", "dsB", "dsA"])]
+    sd = None
+    for bi, sp in enumerate(specs):
+        mols = build_inputs(sp["ids"], n_confs=sp["n_confs"], seed=sp["seed"], charge_model="amber99", pad_confs_of=sp["pad"])
+        out, sd, g = run_reference(cfg, mols, sp["n_confs"], state_dict=sd, loss_kwargs=dict(gradient_weight=0.5, energy_weight=1.0, param_weight=0.0),
+                                   with_param_refs=False, grads="none")
+        with torch.no_grad():
+            ev.step(g, sp["names"])
+            ev_nograd.step(g, sp["names"])
+        d[f"b{bi}::energy"] = to_np(g.nodes["g"].data["energy"])
+        d[f"b{bi}::energy_ref"] = to_np(g.nodes["g"].data["energy_ref"])
+        d[f"b{bi}::is_dummy"] = to_np(g.nodes["g"].data["is_dummy"])
+        d[f"b{bi}::gradient"] = to_np(g.nodes["n1"].data["gradient"])
+        d[f"b{bi}::gradient_ref"] = to_np(g.nodes["n1"].data["gradient_ref"])
+        d[f"b{bi}::atoms_per_mol"] = np.array([len(m["z"]) for m in mols])
+        d[f"b{bi}::dsnames"] = np.array(sp["names"])
+    for tag, e in (("full", ev), ("nograd", ev_nograd)):
+        m = e.pool()
+        for ds, mm in m.items():
+            for k, v in mm.items():
+                d[f"metrics::{tag}::{ds}::{k}"] = np.array([np.nan if v is None else float(v)])
+    d["n_batches"] = np.array([len(specs)])
+    np.savez_compressed(os.path.join(OUT, "ref_eval.npz"), **d)
+    print("wrote ref_eval.npz", {k: float(v[0]) for k, v in d.items() if k.startswith("metrics::full")})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        make_eval_golden()
+    else:
+        main()
+        make_eval_golden()

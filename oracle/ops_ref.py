@@ -409,6 +409,26 @@ class RefBackend:
                 gks[l].view(T, n_per[l]).copy_(v.sum(-1))
 
     # ------------------------------------------------------------------ loss
+    def eval_se(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, out):
+        """training/evaluation.py:53-113 per molecule (after unbatch: dummy conformations deleted, energies centred)"""
+        B, dev = plan.B, out.device
+        m = torch.ones_like(energy) if is_dummy is None else (is_dummy == 0).float()
+        nreal = m.sum(1)
+        me = (m * energy).sum(1, keepdim=True) / nreal[:, None]
+        mr = (m * energy_ref).sum(1, keepdim=True) / nreal[:, None]
+        diff = (energy - me) - (energy_ref - mr)
+        out[:, 0] = (m * diff * diff).sum(1)
+        out[:, 1] = nreal
+        out[:, 2:] = 0
+        if grad is not None:
+            ptr = plan.atom_molptr.long()
+            cnt = ptr[1:] - ptr[:-1]
+            seg = torch.repeat_interleave(torch.arange(B, device=dev), cnt)
+            d = grad - grad_ref
+            sq = (m[seg][..., None] * d * d).sum((1, 2))
+            out[:, 2] = torch.zeros(B, device=dev).index_add(0, seg, sq)
+            out[:, 3] = cnt.float() * nreal
+
     def loss_ef(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, wE, wG, inv_B, loss_mol, gE, gG):
         B = plan.B
         dev = loss_mol.device

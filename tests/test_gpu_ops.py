@@ -153,6 +153,33 @@ def test_gemm_wgrad_with_fused_bias_gradient(hip, ref, M, N, K, precision):
     _cmp(b_h, b_r, 2e-5, f"fused bias gradient[{precision}] {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("cfg", [5, 6, 7])
+@pytest.mark.parametrize("M,N,K,ak,bk", [(1000, 512, 512, 1, 1), (257, 511, 256, 1, 1), (700, 384, 1536, 1, 0), (512, 512, 5000, 0, 0),
+                                         (130, 64, 85, 1, 1), (1536, 512, 3001, 0, 0)])
+def test_gemm_bf16x_tile_configurations(hip, ref, M, N, K, ak, bk, cfg):
+    """every tile configuration of the bf16-split kernel (5: 128x128 / 8 wavefronts, 6: 256x128, 7: 128x128 / 4 wavefronts, two
+    workgroups per CU), forced through the plan override, with a fused epilogue and (wgrad layout) the fused bias gradient"""
+    g = torch.Generator().manual_seed(M + 3 * N + K + cfg)
+    A = torch.randn((M, K) if ak else (K, M), generator=g)
+    B = torch.randn((N, K) if bk else (K, N), generator=g) / math.sqrt(K)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    wgrad = not ak and not bk
+    kw = dict(accumulate=True) if wgrad else dict(bias=bias, act=1, res=res)
+    o_r, o_h = torch.full((M, N), 0.25), torch.full((M, N), 0.25, device="cuda")
+    cs_r, cs_h = (torch.ones(M), torch.ones(M, device="cuda")) if wgrad else (None, None)
+    ref.gemm(A, B, o_r, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), a_colsum=cs_r, **kw)
+    kw_h = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    hip.lib.grappa_gemm_f32_set_plan_override(cfg, 0, -1)
+    try:
+        hip.gemm(A.cuda(), B.cuda(), o_h, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), a_colsum=cs_h, precision="f32_bf16x6", **kw_h)
+        torch.cuda.synchronize()
+    finally:
+        hip.lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+    _cmp(o_h, o_r, 2e-5, f"gemm[f32_bf16x6, cfg {cfg}] {M}x{N}x{K} ak={ak} bk={bk}")
+    if wgrad:
+        _cmp(cs_h, cs_r, 2e-5, f"fused bias gradient[cfg {cfg}] {M}x{N}x{K}")
+
+
 def test_gemm_strided_views(hip, ref):
     g = torch.Generator().manual_seed(2)
     N_, R, Wp = 200, 256, 511
