@@ -18,10 +18,6 @@
 // Epilogue, split-K slabs, XCD-aware order and the tail launch are shared with the native kernel (gemm_common.h).
 #include "gemm_common.h"
 
-#ifndef GRAPPA_EXP
-#define GRAPPA_EXP 0
-#endif
-
 using namespace grappa_gemm;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -102,11 +98,7 @@ __device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[RO
             h23[0] = (__bf16)r[2]; h23[1] = (__bf16)r[3];
             const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
             *reinterpret_cast<uint2*>(dst + p * (ROWS * ROWB)) = make_uint2(u01, u23);
-#if GRAPPA_EXP & 4
-            if (false) {
-#else
             if (p + 1 < NP) {                       // float(bf16) is the 16 bits moved to the top half of the word
-#endif
                 r[0] -= u2f(u01 << 16); r[1] -= u2f(u01 & 0xffff0000u);
                 r[2] -= u2f(u23 << 16); r[3] -= u2f(u23 & 0xffff0000u);
             }
@@ -236,11 +228,7 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     __builtin_amdgcn_sched_barrier(0);
     char* nxt = smem + ((s + 1) & 1) * STAGE;
     mfma_range<MODE, TM, TN, 0, NM / 2>(fc, acc);
-#if GRAPPA_EXP & 8
-    if (do_store && TAIL) {
-#else
     if (do_store) {
-#endif
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
         store_quads<NT, NP, BM, AK, TAIL>(nxt, sa, krem);
         store_quads<NT, NP, BN, BKC, TAIL>(nxt + NP * BM * ROWB, sb, krem);
@@ -253,28 +241,16 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
         PhaseOrder<0, NM / 2, NQ * NP, NQ * (NP == 3 ? 30 : NP == 2 ? 18 : 6)>::emit();
     }
     __builtin_amdgcn_sched_barrier(0);
-#if GRAPPA_EXP & 16
-    if (TAIL)
-#endif
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (do_store) read_frags<NP, BM, BN, TM, TN>(nxt, wm0, wn0, lr, lh, fn);
-#if GRAPPA_EXP & 1
     mfma_range<MODE, TM, TN, NM / 2, NM>(fc, acc);
     if (!TAIL) {
         // the next slab's fragment reads ride between these MFMAs instead of all eight wavefronts bursting them at the LDS
-        // right after the barrier (an MFMA issues only once its wavefront's reads are queued)
+        // right after the barrier (an MFMA issues only once its wavefront's reads are queued): +1.7 % on the workload's shapes
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-#if GRAPPA_EXP & 2
-        ReadOrder<0, NM / 4, (TM + TN) * NP>::emit();        // two reads per MFMA gap, all queued by the middle of the half
-#else
         ReadOrder<0, NM / 2, (TM + TN) * NP>::emit();
-#endif
     }
-#else
-    __builtin_amdgcn_sched_barrier(0);                 // the next slab's fragment reads are in flight before these MFMAs issue
-    mfma_range<MODE, TM, TN, NM / 2, NM>(fc, acc);
-#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -407,7 +383,6 @@ int launch_layout(hipStream_t st, GemmParams& p, bool vec) {
 template <int MODE>
 int launch_tile(hipStream_t st, GemmParams& p, bool vec) {
     if (p.bm == 256 && p.bn == 128) return launch_layout<512, MODE, 256, 128, 2>(st, p, vec);                         // 4 x 2 wavefronts of 64 x 64
-    if (p.bm == 128 && p.bn == 128 && p.wg_threads == 256) return launch_layout<256, MODE, 128, 128, 2>(st, p, vec);   // 2 x 2 of 64 x 64, two workgroups per CU
     if (p.bm == 128 && p.bn == 128) return launch_layout<512, MODE, 128, 128, 4>(st, p, vec);                         // 2 x 4 wavefronts of 64 x 32
     return GRAPPA_ERR_ARG;
 }

@@ -21,7 +21,6 @@ struct GemmParams {
     int ntiles_launch;
     int bm, bn;            // tile shape (for the reduce kernel)
     int vec_io;            // every epilogue tensor is 16-byte aligned with a leading dimension % 4 == 0 (float4 epilogue)
-    int wg_threads;        // bf16-split kernel: 512 (one workgroup per CU) or 256 (128x128 tile, two workgroups per CU)
 };
 
 __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v) {

@@ -285,18 +285,16 @@ struct Plan {
 
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
 // cfg 5, 6: the 128x128 and 256x128 tiles of the bf16-split kernel (gemm_bf16x.hip), one 512-thread workgroup per CU
-// cfg 7: the bf16-split kernel's 128x128 tile as a 256-thread workgroup (2 x 2 wavefronts of 64x64), two workgroups per CU
-constexpr int NCFG = 8;
-constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256, 128};
-constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128, 128};
-constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1, 2};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 / 72 KB, VGPR budget)
+constexpr int NCFG = 7;
+constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256};
+constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128};
+constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
 
 bool use_bf16x(int M, int N, int precision) { return precision != GRAPPA_GEMM_F32_MFMA && M > 32 && N > 32; }
 
 // tuning / tests only (grappa_gemm_f32_set_plan_override): force the tile configuration, split-K factor and tail use
 struct PlanOverride { int cfg = -1, nsplit = 0, tail = -1; };
 PlanOverride g_override;
-bool g_cfg7_enabled = false;
 
 // Tile choice by a small cost model in CU-cycles.  A workgroup of tile c over k_per_split columns of K costs
 // BM*BN*(k + K0_c) / RATE_c; a CU runs CONC_c of them at once (each then CONC_c times slower), the chip drains the grid in
@@ -305,8 +303,8 @@ bool g_cfg7_enabled = false;
 // costing a whole extra round.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
 struct CostModel {
     // MACs per cycle per CU sustained in the main loop, and the per-tile prologue + epilogue expressed in columns of K
-    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0, 300.0};
-    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0, 64.0};
+    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0};
+    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0};
     double grid(int c, long wgs, int kps) const {
         const int conc = CFG_CONC[c];
         const double t = (double)CFG_BM[c] * CFG_BN[c] * (kps + k0[c]) / rate[c];
@@ -336,7 +334,6 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false) {
     for (int c = 0; c < NCFG; ++c) {
         if (g_override.cfg >= 0 && c != g_override.cfg) continue;
         if (bf16x != (c >= 5)) continue;
-        if (c == 7 && g_override.cfg != 7 && !g_cfg7_enabled) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
@@ -474,7 +471,6 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     if (need > 0 && (!ws || ws_bytes < need)) return GRAPPA_ERR_WORKSPACE;
     p.bm = CFG_BM[pl.cfg];
     p.bn = CFG_BN[pl.cfg];
-    p.wg_threads = pl.cfg == 7 ? 256 : 512;
     p.tiles_m = (d->M + p.bm - 1) / p.bm;
     p.tiles_n = (d->N + p.bn - 1) / p.bn;
     const int tiles = p.tiles_m * p.tiles_n;

@@ -15,6 +15,7 @@ learnable_statistics=False -- the only values the reference's shipped configurat
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Union
 
 import torch
@@ -418,11 +419,35 @@ class WriteParameters(nn.Module):
                                                       cfg["improper_symmetriser_depth"], drop, cfg["improper_symmetriser_width"], stats, pos,
                                                       cfg["gated_torsion"], cfg["wrong_symmetry"], cfg["torsion_cutoff"])
 
+        # The four writers read the same atom embedding and write disjoint tuple levels: on the GPU each runs on its own HIP stream
+        # (largest first), so that the tail rounds and launch gaps of one head's kernels are filled by another head's.  autograd
+        # replays every backward node on the stream of its forward, which gives the same overlap in the backward pass.
+        self.head_streams = int(os.environ.get("GRAPPA_HEAD_STREAMS", "4"))
+        self._streams = None
+
+    def _writers_largest_first(self):
+        return [self.proper_writer, self.angle_writer, self.improper_writer, self.bond_writer]
+
     def forward(self, g):
-        g = self.bond_writer(g)
-        g = self.angle_writer(g)
-        g = self.proper_writer(g)
-        g = self.improper_writer(g)
+        h = g.nodes["n1"].data["h"]
+        if self.head_streams <= 1 or not h.is_cuda:
+            g = self.bond_writer(g)
+            g = self.angle_writer(g)
+            g = self.proper_writer(g)
+            g = self.improper_writer(g)
+            return g
+        main = torch.cuda.current_stream(h.device)
+        if self._streams is None or self._streams[0].device != h.device:
+            self._streams = [torch.cuda.Stream(device=h.device) for _ in range(min(self.head_streams, 4) - 1)]
+        lanes = [main] + self._streams                     # the largest head stays on the caller's stream
+        writers = self._writers_largest_first()
+        for s in self._streams:
+            s.wait_stream(main)
+        for i, w in enumerate(writers):
+            with torch.cuda.stream(lanes[i % len(lanes)]):
+                g = w(g)
+        for s in self._streams:
+            main.wait_stream(s)
         return g
 
 

@@ -153,12 +153,12 @@ def test_gemm_wgrad_with_fused_bias_gradient(hip, ref, M, N, K, precision):
     _cmp(b_h, b_r, 2e-5, f"fused bias gradient[{precision}] {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("cfg", [5, 6, 7])
+@pytest.mark.parametrize("cfg", [5, 6])
 @pytest.mark.parametrize("M,N,K,ak,bk", [(1000, 512, 512, 1, 1), (257, 511, 256, 1, 1), (700, 384, 1536, 1, 0), (512, 512, 5000, 0, 0),
                                          (130, 64, 85, 1, 1), (1536, 512, 3001, 0, 0)])
 def test_gemm_bf16x_tile_configurations(hip, ref, M, N, K, ak, bk, cfg):
-    """every tile configuration of the bf16-split kernel (5: 128x128 / 8 wavefronts, 6: 256x128, 7: 128x128 / 4 wavefronts, two
-    workgroups per CU), forced through the plan override, with a fused epilogue and (wgrad layout) the fused bias gradient"""
+    """both tile configurations of the bf16-split kernel (5: 128x128, 6: 256x128), forced through the plan override, with a fused
+    epilogue and (wgrad layout) the fused bias gradient"""
     g = torch.Generator().manual_seed(M + 3 * N + K + cfg)
     A = torch.randn((M, K) if ak else (K, M), generator=g)
     B = torch.randn((N, K) if bk else (K, N), generator=g) / math.sqrt(K)
