@@ -135,7 +135,7 @@ def main():
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.backend import get_backend
     from grappa_amd.datasets import WORKLOADS, build_workload
-    from grappa_amd.dist import all_reduce_gradients
+    from grappa_amd.dist import BucketedGradReducer
     from grappa_amd.optim import FlatParams, FusedAdam
 
     log("imports done; building model")
@@ -147,6 +147,7 @@ def main():
     model = model.to(dev).train()
     flat = FlatParams(model)
     opt = FusedAdam(flat, lr=1.5e-5, max_grad_norm=10.0)
+    reducer = BucketedGradReducer(model, flat)
     energy = Energy()
     loss_fn = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
     per_gpu = WORKLOADS[args.workload][0]
@@ -164,7 +165,7 @@ def main():
                 g.nodes[lvl].data.pop(k, None)
         loss = loss_fn(energy(model(g)))
         loss.backward()
-        all_reduce_gradients(flat.grad)
+        reducer.finish()               # writer-head bucket was sent from inside the backward pass; GNN bucket + wait here
         opt.step()
         return loss
 
@@ -189,13 +190,19 @@ def main():
     final_loss = float(loss.detach())
     log(f"timed region done: {1e3 * dt / args.steps:.1f} ms/step; instrumented pass")
 
-    # instrumented repetition of the same steps: HIP events around every GEMM / GAT launch on the launch stream
+    # instrumented repetition of the same steps: HIP events around every GEMM / GAT launch on the launch stream.  The writer
+    # heads run on ONE stream here (GRAPPA_HEAD_STREAMS=1 semantics): with the heads on four streams a kernel shares the chip with
+    # another head's kernels and an event pair measures the sharing, not the kernel; profiles/ rocprof runs use the same setting.
+    head_streams = model.parameter_writer.head_streams
+    model.parameter_writer.head_streams = 1
+    step()
     be.start_profile()
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
     prof = be.stop_profile()
     dt_prof = time.perf_counter() - t1
+    model.parameter_writer.head_streams = head_streams
 
     log("instrumented pass done")
     # the same K steps with the dense products on the native fp32 matrix instruction, for reference next to the default
@@ -257,7 +264,8 @@ def main():
             "config": {"workload": f"{args.workload}: {per_gpu} molecules/GPU (20-40 atoms, Espaloma pool), 32 conformations, "
                                    f"production GrappaModel 40.8M params random-init, train mode (dropout on), Adam + clip 10",
                        "molecules_per_gpu": per_gpu, "global_batch": per_gpu * world, "conformations": 32, "atoms_rank0": plan.N,
-                       "tuples_rank0": {k: int(v) for k, v in plan.T.items()}, "parallelism": f"dp{world}"},
+                       "tuples_rank0": {k: int(v) for k, v in plan.T.items()}, "parallelism": f"dp{world}",
+                       "writer_head_streams": head_streams},
             "gemm_arithmetic": {"default": be.gemm_precision_name,
                                 "note": "inputs, outputs, accumulation and every non-GEMM kernel are fp32; f32_bf16x6 splits each fp32 operand "
                                         "exactly into 3 bf16 pieces and sums the 6 largest partial products on the bf16 matrix cores "

@@ -3,7 +3,8 @@
 The reference is single-device.  Molecules never interact (block-diagonal graph,
 loss = mean over molecules), so the batch is dealt to the ranks after sorting by size (round-robin,
 balances tuples per GPU), every rank runs the same kernels on its shard with the loss scaled by
-1/B_global, and the gradients are summed with ONE collective per step over xGMI.
+1/B_global, and the gradients are summed over xGMI: one collective of the flat buffer (`all_reduce_gradients`), or two
+buckets with the first overlapped with the rest of the backward pass (`BucketedGradReducer`).
 """
 import os
 from typing import List, Sequence
@@ -33,3 +34,45 @@ def all_reduce_gradients(flat_grad: torch.Tensor) -> None:
     """sum over ranks; each rank's loss is already scaled by 1/B_global (MolwiseLoss.global_batch_size)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+
+
+class BucketedGradReducer:
+    """Gradient all-reduce in two buckets of the flat buffer, the first overlapped with the backward pass.
+
+    The backward pass finishes the writer heads (55 % of the parameters: 22.2 M of 40.8 M in the production model) before it enters
+    the GNN (18.6 M).  The moment the gradient of the atom embedding `h` is complete (`GrappaModel.on_heads_backward_done`) every writer
+    gradient is final, so its slice of the flat buffer is handed to an ASYNCHRONOUS all-reduce (RCCL runs it on its own stream,
+    ordered after the compute stream's work so far) while the GNN backward keeps the matrix cores busy; `finish()` reduces the
+    GNN slice and waits for both.  Same sums as `all_reduce_gradients`, so results are identical."""
+
+    def __init__(self, model, flat):
+        self.flat = flat
+        self.model = model
+        self.head_range = flat.range_of(model.parameter_writer)
+        self._work = []
+        self._heads_sent = False
+        model.on_heads_backward_done = self._on_heads_done
+
+    @staticmethod
+    def _active() -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _on_heads_done(self) -> None:
+        if self._active() and not self._heads_sent:
+            a, b = self.head_range
+            self._work.append(dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self._heads_sent = True
+
+    def finish(self) -> None:
+        """call after loss.backward(): reduces what is left and waits for every bucket"""
+        if self._active():
+            a, b = self.head_range
+            if not self._heads_sent:                       # the hook did not fire (e.g. heads without gradient): one bucket
+                a, b = 0, 0
+            for lo, hi in ((0, a), (b, self.flat.numel)):
+                if hi > lo:
+                    self._work.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            for w in self._work:
+                w.wait()
+        self._work = []
+        self._heads_sent = False

@@ -431,10 +431,8 @@ class WriteParameters(nn.Module):
     def forward(self, g):
         h = g.nodes["n1"].data["h"]
         if self.head_streams <= 1 or not h.is_cuda:
-            g = self.bond_writer(g)
-            g = self.angle_writer(g)
-            g = self.proper_writer(g)
-            g = self.improper_writer(g)
+            for w in self._writers_largest_first():         # same host order (hence dropout seeds) as the multi-stream path
+                g = w(g)
             return g
         main = torch.cuda.current_stream(h.device)
         if self._streams is None or self._streams[0].device != h.device:
@@ -482,10 +480,16 @@ class GrappaModel(nn.Module):
                              final_dropout=gnn_dropout_final, initial_dropout=gnn_dropout_initial)
         self.parameter_writer = WriteParameters(cfg, param_statistics)
         self.field_of_view = gnn_attentional_layers + gnn_convolutions + 3
+        self.on_heads_backward_done = None      # optional callback (dist.BucketedGradReducer): overlap of the gradient all-reduce
 
     def forward(self, g):
         # tuple-index consistency (reference grappa.py:122-128) is validated once per batch, on the host, when the plan is built
         g.plan()
         g = self.gnn(g)
+        h = g.nodes["n1"].data["h"]
+        if self.on_heads_backward_done is not None and h.requires_grad:
+            # fires when the gradient of the atom embedding is complete = every writer head has finished its backward pass
+            cb = self.on_heads_backward_done
+            h.register_hook(lambda grad: (cb(), None)[1])
         g = self.parameter_writer(g)
         return g

@@ -38,6 +38,18 @@ class FlatParams:
             off += sz
         self.params: List[torch.nn.Parameter] = params
         self.numel = total
+        self._offsets = {id(p): (o, o + sz) for p, o, sz in zip(params, [sum(sizes[:i]) for i in range(len(sizes))], sizes)}
+
+    def range_of(self, module: torch.nn.Module):
+        """[start, end) of the contiguous slice of the flat buffers that holds `module`'s parameters (registration order keeps a
+        sub-module's parameters together); raises if they are not contiguous."""
+        spans = sorted(self._offsets[id(p)] for p in module.parameters() if id(p) in self._offsets)
+        if not spans:
+            raise ValueError("module has no parameters in this buffer")
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            if a1 != b0:
+                raise ValueError("the module's parameters are not contiguous in the flat buffer")
+        return spans[0][0], spans[-1][1]
 
     def zero_grad(self):
         self.grad.zero_()

@@ -216,6 +216,81 @@ def test_properties_at_c2_size():
     assert not torch.allclose(ka, g.nodes["n2"].data["k"])
 
 
+def test_c3_batch_1024_bf16_arithmetic():
+    """BASELINE.json configs[2]: 1024 molecules drawn from the whole Espaloma pool (~39 k atoms, ~0.75 M tokens), 32 conformations,
+    production model, dense products in bf16 arithmetic on the matrix cores (fp32 accumulate; LayerNorm / softmax / energy in
+    fp32).  No CPU recomputation at this size: the bf16 modes are checked against the fp32-grade default ON THE SAME BATCH with
+    the tolerance SURVEY section 8(d) states for the bf16 configuration (2e-2 relative on parameters, stated floors), bf16x3
+    (two bf16 pieces per operand, ~2^-16) an order of magnitude tighter; one train step in bf16x3 must give a finite loss and
+    finite, non-zero gradients."""
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_workload
+    from grappa_amd.optim import FlatParams
+    be = get_backend()
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").eval()
+    g_cpu = build_workload("C3-espaloma-b1024", seed=0)
+    assert g_cpu.plan().B == 1024
+    default = be.gemm_precision_name
+    outs = {}
+    try:
+        for mode in (default, "bf16x3", "bf16"):
+            be.set_gemm_precision(mode)
+            with torch.no_grad():
+                g = Energy()(model(g_cpu.to("cuda")))
+            outs[mode] = {(lvl, k): g.nodes[lvl].data[k].float().cpu() for lvl in ("n2", "n3", "n4", "n4_improper") for k in ("k", "eq")
+                          if k in g.nodes[lvl].data}
+            outs[mode]["E"] = g.nodes["g"].data["energy"].cpu()
+            assert all(torch.isfinite(v).all() for v in outs[mode].values()), mode
+        for mode, tol in (("bf16x3", 2e-3), ("bf16", 2e-2)):
+            for key, ref in outs[default].items():
+                if key == "E":
+                    continue
+                lvl, k = key
+                # floors = half the output scale of the head (k = c * k_std + k_mean: std 0.5 / 1.2 proper, 4.1 improper; bond/angle k ~ 1e2)
+                floor = FLOORS["eq"] if k == "eq" else {"n4": 0.5, "n4_improper": 2.0}.get(lvl, 1.0)
+                assert gu.rel_err(outs[mode][key], ref.numpy(), floor) < tol, (mode, key)
+        # one bf16x3 train step at this size
+        be.set_gemm_precision("bf16x3")
+        model.train()
+        flat = FlatParams(model)
+        flat.zero_grad()
+        loss = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)(Energy()(model(g_cpu.to("cuda"))))
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss) and torch.isfinite(flat.grad).all() and float(flat.grad.abs().max()) > 0
+    finally:
+        be.set_gemm_precision(default)
+
+
+def test_writer_heads_on_streams_equal_single_stream():
+    """the four writer heads on four HIP streams (default) give bit-identical parameters, loss and gradients to the single-stream
+    order: every kernel is deterministic and the heads touch disjoint tensors"""
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.datasets import build_batch_from_pool
+    from grappa_amd.optim import FlatParams
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").train()
+    flat = FlatParams(model)
+    g_cpu = build_batch_from_pool(list(range(100, 148)), n_confs=8, seed=3)
+    res = []
+    for streams in (1, 4, 4):
+        model.parameter_writer.head_streams = streams
+        ops.manual_seed(77)
+        flat.zero_grad()
+        g = Energy()(model(g_cpu.to("cuda")))
+        loss = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)(g)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.detach().clone(), flat.grad.clone(), g.nodes["n4"].data["k"].detach().clone(), g.nodes["n2"].data["eq"].detach().clone()))
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a, b)
+
+
 def test_predict_drop_in():
     from grappa_amd import Grappa, Molecule, get_default_model_config, model_from_config
     from grappa_amd.datasets import molecule_from_pool

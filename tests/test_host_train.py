@@ -110,7 +110,16 @@ def _dp_worker(rank, world, port, ids, sd, out_q):
     sizes = [int(pool_atom_counts()[i]) for i in ids]
     mine = [ids[j] for j in shard_indices(sizes, world, rank)]
     _loss(model, mine, 5, global_b=len(ids)).backward()
-    all_reduce_gradients(flat.grad)
+    one_bucket = flat.grad.clone()
+    all_reduce_gradients(one_bucket)
+    # the same step again through the two-bucket reducer (writer-head slice sent from inside the backward pass)
+    from grappa_amd.dist import BucketedGradReducer
+    reducer = BucketedGradReducer(model, flat)
+    flat.zero_grad()
+    _loss(model, mine, 5, global_b=len(ids)).backward()
+    assert reducer._heads_sent and len(reducer._work) == 1
+    reducer.finish()
+    assert torch.equal(flat.grad, one_bucket)
     if rank == 0:
         out_q.put(flat.grad.clone().numpy())
     dist.barrier()
