@@ -1,0 +1,80 @@
+"""ctypes binding of libgrappa_host.so (the C ABI of include/grappa_host.h): host-side tuple enumeration and graph features.
+Built in-tree next to libgrappa_hip.so by `make -C grappa_amd/csrc` / `__graft_entry__.build()`."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrappa_host.so")
+ABI_VERSION = 1
+
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i64 = C.POINTER(C.c_int64)
+SIGNATURES = {
+    "grappa_host_abi_version": (C.c_int, []),
+    "grappa_topo_enumerate": (C.c_int, [C.c_int, _i32p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _i64, _i64]),
+    "grappa_degree_encoding": (C.c_int, [C.c_int, C.c_int, _i32p, _f32p]),
+    "grappa_ring_encoding": (C.c_int, [C.c_int, C.c_int, _i32p, _f32p]),
+}
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C grappa_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.grappa_host_abi_version() != ABI_VERSION:
+        raise RuntimeError("libgrappa_host.so: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _bonds32(bonds) -> np.ndarray:
+    b = np.ascontiguousarray(np.asarray(bonds, dtype=np.int64).reshape(-1, 2))
+    if b.size and (b.min() < 0 or b.max() >= 2 ** 31):
+        raise ValueError("atom ids must be non-negative 32-bit integers")
+    return np.ascontiguousarray(b.astype(np.int32))
+
+
+def enumerate_tuples(bonds):
+    """-> (angles (n,3) int32, propers (n,4) int32) in the reference's row order (include/grappa_host.h grappa_topo_enumerate)"""
+    lib = load()
+    b = _bonds32(bonds)
+    na, npr = C.c_int64(0), C.c_int64(0)
+    rc = lib.grappa_topo_enumerate(len(b), b, None, 0, None, 0, C.byref(na), C.byref(npr))
+    if rc != 0:
+        if len(b) and (b[:, 0] == b[:, 1]).any():
+            raise AssertionError("Encountered self-bond")                  # the reference asserts (utils/tuple_indices.py:72)
+        raise RuntimeError(f"grappa_topo_enumerate failed with status {rc}")
+    angles, propers = np.empty((na.value, 3), dtype=np.int32), np.empty((npr.value, 4), dtype=np.int32)
+    rc = lib.grappa_topo_enumerate(len(b), b, angles.ctypes.data_as(C.c_void_p), na.value, propers.ctypes.data_as(C.c_void_p), npr.value,
+                                   C.byref(na), C.byref(npr))
+    if rc != 0:
+        raise RuntimeError(f"grappa_topo_enumerate failed with status {rc}")
+    return angles, propers
+
+
+def degree_encoding(n_atoms: int, bonds) -> np.ndarray:
+    enc = np.empty((n_atoms, 6), dtype=np.float32)
+    b = _bonds32(bonds)
+    rc = load().grappa_degree_encoding(n_atoms, len(b), b, enc)
+    if rc != 0:
+        raise RuntimeError(f"grappa_degree_encoding failed with status {rc}")
+    return enc
+
+
+def ring_encoding(n_atoms: int, bonds) -> np.ndarray:
+    enc = np.empty((n_atoms, 7), dtype=np.float32)
+    b = _bonds32(bonds)
+    rc = load().grappa_ring_encoding(n_atoms, len(b), b, enc)
+    if rc != 0:
+        raise RuntimeError(f"grappa_ring_encoding failed with status {rc}")
+    return enc

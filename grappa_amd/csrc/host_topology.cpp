@@ -1,0 +1,294 @@
+// libgrappa_host.so: host-side graph preparation (include/grappa_host.h) -- tuple enumeration and ring / degree features in O(atoms).
+#include "../../include/grappa_host.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr int OK = 0, ERR_ARG = -1, ERR_WORKSPACE = -2;   // include/grappa_hip.h GRAPPA_OK / GRAPPA_ERR_ARG / GRAPPA_ERR_WORKSPACE
+constexpr int MAX_RING = 8;
+
+// CSR adjacency over ids 0..n-1; every bond appears in both lists (duplicates kept, as the reference's dict of lists keeps them)
+struct Adjacency {
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> nbr;
+    void build(int n, int n_bonds, const int32_t* bonds, bool sort_lists) {
+        ptr.assign((size_t)n + 1, 0);
+        for (int b = 0; b < n_bonds; ++b) {
+            ++ptr[bonds[2 * b] + 1];
+            ++ptr[bonds[2 * b + 1] + 1];
+        }
+        for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+        nbr.resize((size_t)ptr[n]);
+        std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int b = 0; b < n_bonds; ++b) {
+            const int32_t u = bonds[2 * b], v = bonds[2 * b + 1];
+            nbr[fill[u]++] = v;
+            nbr[fill[v]++] = u;
+        }
+        if (sort_lists)
+            for (int i = 0; i < n; ++i) std::sort(nbr.begin() + ptr[i], nbr.begin() + ptr[i + 1]);
+    }
+    const int32_t* begin(int v) const { return nbr.data() + ptr[v]; }
+    const int32_t* end(int v) const { return nbr.data() + ptr[v + 1]; }
+};
+
+// dynamic bitset over the edges of one ring system
+struct Bits {
+    std::vector<uint64_t> w;
+    explicit Bits(int nbits = 0) : w((size_t)(nbits + 63) / 64, 0) {}
+    void flip(int i) { w[i >> 6] ^= 1ull << (i & 63); }
+    int top() const {
+        for (int k = (int)w.size() - 1; k >= 0; --k)
+            if (w[k]) return k * 64 + 63 - __builtin_clzll(w[k]);
+        return -1;
+    }
+    void operator^=(const Bits& o) {
+        for (size_t k = 0; k < w.size(); ++k) w[k] ^= o.w[k];
+    }
+    bool operator<(const Bits& o) const { return w < o.w; }
+    bool operator==(const Bits& o) const { return w == o.w; }
+};
+
+struct Cycle {
+    int len;
+    Bits bits;
+    int atoms[MAX_RING];
+};
+
+}  // namespace
+
+extern "C" int grappa_host_abi_version(void) { return 1; }
+
+extern "C" int grappa_topo_enumerate(int n_bonds, const int32_t* bonds, int32_t* angles, int64_t cap_angles, int32_t* propers,
+                                     int64_t cap_propers, int64_t* n_angles, int64_t* n_propers) {
+    if (n_bonds < 0 || (n_bonds > 0 && !bonds) || !n_angles || !n_propers) return ERR_ARG;
+    int32_t max_id = -1;
+    for (int b = 0; b < n_bonds; ++b) {
+        const int32_t u = bonds[2 * b], v = bonds[2 * b + 1];
+        if (u < 0 || v < 0 || u == v) return ERR_ARG;                    // the reference asserts on self-bonds
+        max_id = std::max(max_id, std::max(u, v));
+    }
+    const int n = max_id + 1;
+    // atoms in order of first appearance in the bond list (the iteration order of the reference's neighbour dict)
+    std::vector<int32_t> order;
+    order.reserve((size_t)n);
+    std::vector<char> seen((size_t)n, 0);
+    for (int b = 0; b < n_bonds; ++b)
+        for (int e = 0; e < 2; ++e) {
+            const int32_t a = bonds[2 * b + e];
+            if (!seen[a]) {
+                seen[a] = 1;
+                order.push_back(a);
+            }
+        }
+    Adjacency adj;
+    adj.build(n, n_bonds, bonds, true);
+    int64_t na = 0, np = 0;
+    bool overflow = false;
+    for (const int32_t a1 : order)
+        for (const int32_t* p2 = adj.begin(a1); p2 != adj.end(a1); ++p2) {
+            const int32_t a2 = *p2;
+            for (const int32_t* p3 = adj.begin(a2); p3 != adj.end(a2); ++p3) {
+                const int32_t a3 = *p3;
+                if (a3 == a1) continue;
+                if (a1 < a3) {
+                    if (angles) {
+                        if (na < cap_angles) {
+                            int32_t* r = angles + 3 * na;
+                            r[0] = a1; r[1] = a2; r[2] = a3;
+                        } else {
+                            overflow = true;
+                        }
+                    }
+                    ++na;
+                }
+                for (const int32_t* p4 = adj.begin(a3); p4 != adj.end(a3); ++p4) {
+                    const int32_t a4 = *p4;
+                    if (a4 >= a1) break;                                    // neighbour lists ascend: nothing smaller follows
+                    if (a4 == a2) continue;
+                    if (propers) {
+                        if (np < cap_propers) {
+                            int32_t* r = propers + 4 * np;
+                            r[0] = a4; r[1] = a3; r[2] = a2; r[3] = a1;
+                        } else {
+                            overflow = true;
+                        }
+                    }
+                    ++np;
+                }
+            }
+        }
+    *n_angles = na;
+    *n_propers = np;
+    return overflow ? ERR_WORKSPACE : OK;
+}
+
+extern "C" int grappa_degree_encoding(int n_atoms, int n_bonds, const int32_t* bonds, float* enc) {
+    if (n_atoms < 0 || n_bonds < 0 || (n_bonds > 0 && !bonds) || (n_atoms > 0 && !enc)) return ERR_ARG;
+    std::vector<int32_t> deg((size_t)n_atoms, 0);
+    for (int b = 0; b < 2 * n_bonds; ++b) {
+        if (bonds[b] < 0 || bonds[b] >= n_atoms) return ERR_ARG;
+        ++deg[bonds[b]];
+    }
+    std::memset(enc, 0, sizeof(float) * 6 * (size_t)n_atoms);
+    for (int i = 0; i < n_atoms; ++i)
+        if (deg[i] >= 1 && deg[i] <= 6) enc[6 * (size_t)i + deg[i] - 1] = 1.0f;
+    return OK;
+}
+
+extern "C" int grappa_ring_encoding(int n_atoms, int n_bonds, const int32_t* bonds, float* enc) {
+    if (n_atoms < 0 || n_bonds < 0 || (n_bonds > 0 && !bonds) || (n_atoms > 0 && !enc)) return ERR_ARG;
+    for (int b = 0; b < 2 * n_bonds; ++b)
+        if (bonds[b] < 0 || bonds[b] >= n_atoms) return ERR_ARG;
+    std::memset(enc, 0, sizeof(float) * 7 * (size_t)n_atoms);
+    Adjacency adj;
+    adj.build(n_atoms, n_bonds, bonds, true);
+    // ---- bridges (iterative lowlink DFS; parallel edges to the DFS parent are ignored, as one bond) -> atoms on a cycle
+    std::vector<int32_t> disc((size_t)n_atoms, -1), low((size_t)n_atoms, 0), parent((size_t)n_atoms, -1);
+    std::vector<int64_t> it((size_t)n_atoms, 0);
+    std::vector<char> in_ring((size_t)n_atoms, 0), tree_bridge((size_t)n_atoms, 1);   // tree_bridge[v]: edge (parent[v], v) is a bridge
+    std::vector<int32_t> stack;
+    int32_t timer = 0;
+    for (int root = 0; root < n_atoms; ++root) {
+        if (disc[root] != -1) continue;
+        disc[root] = low[root] = timer++;
+        it[root] = adj.ptr[root];
+        stack.push_back(root);
+        while (!stack.empty()) {
+            const int32_t v = stack.back();
+            if (it[v] < adj.ptr[v + 1]) {
+                const int32_t w = adj.nbr[it[v]++];
+                if (w == parent[v]) continue;
+                if (disc[w] == -1) {
+                    disc[w] = low[w] = timer++;
+                    parent[w] = v;
+                    it[w] = adj.ptr[w];
+                    stack.push_back(w);
+                } else {
+                    low[v] = std::min(low[v], disc[w]);
+                }
+            } else {
+                stack.pop_back();
+                const int32_t p = parent[v];
+                if (p != -1) {
+                    low[p] = std::min(low[p], low[v]);
+                    if (low[v] <= disc[p]) {                                  // (p, v) lies on a cycle
+                        tree_bridge[v] = 0;
+                        in_ring[v] = in_ring[p] = 1;
+                    }
+                }
+            }
+        }
+    }
+    auto is_ring_edge = [&](int32_t a, int32_t b) {
+        if (!in_ring[a] || !in_ring[b]) return false;
+        if (parent[b] == a) return !tree_bridge[b];
+        if (parent[a] == b) return !tree_bridge[a];
+        return true;                                                           // a non-tree edge always closes a cycle
+    };
+    // ---- ring systems = connected components over ring edges; local edge numbering per system
+    std::vector<int32_t> comp((size_t)n_atoms, -1);
+    std::vector<int32_t> members, queue;
+    std::vector<char> on_path((size_t)n_atoms, 0);     // every mark is cleared when its frame pops
+    for (int s = 0; s < n_atoms; ++s) {
+        enc[7 * (size_t)s] = in_ring[s] ? 1.0f : 0.0f;
+        if (!in_ring[s] || comp[s] != -1) continue;
+        members.clear();
+        queue.assign(1, s);
+        comp[s] = s;
+        while (!queue.empty()) {
+            const int32_t v = queue.back();
+            queue.pop_back();
+            members.push_back(v);
+            for (const int32_t* p = adj.begin(v); p != adj.end(v); ++p)
+                if (comp[*p] == -1 && is_ring_edge(v, *p)) {
+                    comp[*p] = s;
+                    queue.push_back(*p);
+                }
+        }
+        std::sort(members.begin(), members.end());
+        std::unordered_map<uint64_t, int> edge_id;
+        for (const int32_t a : members)
+            for (const int32_t* p = adj.begin(a); p != adj.end(a); ++p)
+                if (a < *p && is_ring_edge(a, *p)) edge_id.emplace(((uint64_t)(uint32_t)a << 32) | (uint32_t)*p, (int)edge_id.size());
+        const int ne = (int)edge_id.size();
+        auto eid = [&](int32_t a, int32_t b) {
+            if (a > b) std::swap(a, b);
+            return edge_id.at(((uint64_t)(uint32_t)a << 32) | (uint32_t)b);
+        };
+        // ---- every simple cycle of length 3..8 once: found from its smallest atom, orientation fixed by path[1] < path[last]
+        std::vector<Cycle> cycles;
+        int path[MAX_RING];
+        struct Frame { int32_t v; int64_t next; };
+        std::vector<Frame> fr;
+        for (const int32_t start : members) {
+            int depth = 0;
+            path[depth++] = start;
+            on_path[start] = 1;
+            fr.assign(1, Frame{start, adj.ptr[start]});
+            while (!fr.empty()) {
+                Frame& f = fr.back();
+                if (f.next == adj.ptr[f.v + 1]) {
+                    on_path[f.v] = 0;
+                    --depth;
+                    fr.pop_back();
+                    continue;
+                }
+                const int32_t w = adj.nbr[f.next++];
+                if (w == start && depth >= 3) {
+                    if (path[1] < path[depth - 1] && is_ring_edge(f.v, w)) {
+                        Cycle c;
+                        c.len = depth;
+                        c.bits = Bits(ne);
+                        bool ok = true;
+                        for (int i = 0; i < depth && ok; ++i) {
+                            const int32_t a = path[i], b = path[(i + 1) % depth];
+                            if (!is_ring_edge(a, b)) ok = false;
+                            else c.bits.flip(eid(a, b));
+                            c.atoms[i] = a;
+                        }
+                        if (ok) cycles.push_back(std::move(c));
+                    }
+                } else if (w > start && comp[w] == s && !on_path[w] && depth < MAX_RING && is_ring_edge(f.v, w)) {
+                    path[depth++] = w;
+                    on_path[w] = 1;
+                    fr.push_back(Frame{w, adj.ptr[w]});
+                }
+            }
+        }
+        // parallel bonds can produce the same edge set twice: keep one per edge set (the reference graph has no parallel bonds)
+        std::sort(cycles.begin(), cycles.end(), [](const Cycle& x, const Cycle& y) { return x.len != y.len ? x.len < y.len : x.bits < y.bits; });
+        cycles.erase(std::unique(cycles.begin(), cycles.end(), [](const Cycle& x, const Cycle& y) { return x.len == y.len && x.bits == y.bits; }),
+                     cycles.end());
+        // ---- relevant cycles: not a GF(2) sum of strictly shorter cycles (basis grows only after a whole length class is tested)
+        std::unordered_map<int, Bits> basis;
+        auto reduce = [&](Bits v) {
+            for (int t = v.top(); t >= 0; t = v.top()) {
+                auto f = basis.find(t);
+                if (f == basis.end()) break;
+                v ^= f->second;
+            }
+            return v;
+        };
+        for (size_t i = 0; i < cycles.size();) {
+            size_t j = i;
+            while (j < cycles.size() && cycles[j].len == cycles[i].len) ++j;
+            std::vector<size_t> keep;
+            for (size_t c = i; c < j; ++c)
+                if (reduce(cycles[c].bits).top() >= 0) keep.push_back(c);
+            for (const size_t c : keep) {
+                for (int a = 0; a < cycles[c].len; ++a) enc[7 * (size_t)cycles[c].atoms[a] + cycles[c].len - 2] = 1.0f;
+                Bits r = reduce(cycles[c].bits);
+                const int t = r.top();
+                if (t >= 0) basis.emplace(t, std::move(r));
+            }
+            i = j;
+        }
+    }
+    return OK;
+}

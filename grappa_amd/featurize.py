@@ -115,6 +115,12 @@ def _relevant(cycles):
 
 
 def ring_encoding(n_atoms: int, bonds: Sequence[Tuple[int, int]]) -> np.ndarray:
+    """native (libgrappa_host.so grappa_ring_encoding: per ring system, O(atoms)); `ring_encoding_py` is the same definition in Python"""
+    from . import _hostlib
+    return _hostlib.ring_encoding(n_atoms, bonds)
+
+
+def ring_encoding_py(n_atoms: int, bonds: Sequence[Tuple[int, int]]) -> np.ndarray:
     bonds = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
     adj = _adjacency(n_atoms, bonds)
     in_ring = _ring_atoms(n_atoms, adj)
@@ -127,6 +133,11 @@ def ring_encoding(n_atoms: int, bonds: Sequence[Tuple[int, int]]) -> np.ndarray:
 
 
 def degree_encoding(n_atoms: int, bonds: Sequence[Tuple[int, int]]) -> np.ndarray:
+    from . import _hostlib
+    return _hostlib.degree_encoding(n_atoms, bonds)
+
+
+def degree_encoding_py(n_atoms: int, bonds: Sequence[Tuple[int, int]]) -> np.ndarray:
     bonds = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
     deg = np.bincount(bonds.reshape(-1), minlength=n_atoms)
     enc = np.zeros((n_atoms, 6), dtype=np.float32)

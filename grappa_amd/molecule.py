@@ -52,11 +52,11 @@ class Molecule:
 
     def __post_init__(self):
         if self.angles is None or self.propers is None:
-            is_sorted = False
             if self.neighbor_dict is None:
-                self.neighbor_dict = tuple_indices.get_neighbor_dict(self.bonds, sort=True)
-                is_sorted = True
-            d = tuple_indices.get_idx_tuples(self.bonds, self.neighbor_dict, is_sorted=is_sorted)
+                # the usual case (no caller-supplied neighbour lists): native O(atoms) enumeration, reference row order
+                d = tuple_indices.get_idx_tuples(self.bonds)
+            else:
+                d = tuple_indices.get_idx_tuples(self.bonds, self.neighbor_dict, is_sorted=False)
             if self.angles is None:
                 self.angles = d["angles"]
             if self.propers is None:

@@ -28,7 +28,20 @@ def get_neighbor_dict(bonds: Sequence[Tuple[int, int]], sort: bool = True) -> Di
 
 
 def get_idx_tuples(bonds, neighbor_dict=None, is_sorted: bool = False):
-    """-> {'bonds','angles','propers'} with angle[0] < angle[2] and proper[0] < proper[3]."""
+    """-> {'bonds','angles','propers'} with angle[0] < angle[2] and proper[0] < proper[3].
+    Without caller-supplied neighbour lists the enumeration runs natively (libgrappa_host.so, include/grappa_host.h
+    grappa_topo_enumerate: O(atoms), same sets and row order); with them the dict's own iteration order is honoured here."""
+    if neighbor_dict is None:
+        from . import _hostlib
+        angles, propers = _hostlib.enumerate_tuples(bonds)
+        if not is_sorted:
+            bonds = [tuple(int(x) for x in sorted(b)) for b in bonds]
+        return {"bonds": bonds, "angles": [tuple(r) for r in angles.tolist()], "propers": [tuple(r) for r in propers.tolist()]}
+    return get_idx_tuples_py(bonds, neighbor_dict, is_sorted)
+
+
+def get_idx_tuples_py(bonds, neighbor_dict=None, is_sorted: bool = False):
+    """the same enumeration on Python dicts (caller-supplied neighbour lists; cross-check of the native path in the tests)"""
     if neighbor_dict is None:
         neighbor_dict = get_neighbor_dict(bonds, sort=True)
     elif not is_sorted:

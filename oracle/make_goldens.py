@@ -347,9 +347,39 @@ def make_eval_golden():
     print("wrote ref_eval.npz", {k: float(v[0]) for k, v in d.items() if k.startswith("metrics::full")})
 
 
+def make_tuple_golden():
+    """angles / propers of 36 pool molecules from the reference's own enumeration (utils/tuple_indices.py:7-63), incl. scrambled
+    bond order and orientation (first-appearance order != index order) and sparse atom ids: pins the ROW ORDER of the native
+    enumerator (include/grappa_host.h grappa_topo_enumerate)."""
+    from grappa.utils import tuple_indices as ref_ti
+    rng = np.random.default_rng(0)
+    d = {}
+    n_pool = len(POOL["atom_ptr"]) - 1
+    ids = list(range(0, n_pool, 97))[:36]
+    for j, i in enumerate(ids):
+        _, bonds, _ = pool_molecule(i)
+        bonds = bonds.copy()
+        if j % 3 == 1:
+            bonds = bonds[rng.permutation(len(bonds))]
+            flip = rng.random(len(bonds)) < 0.5
+            bonds[flip] = bonds[flip][:, ::-1]
+        if j % 3 == 2:
+            bonds = bonds * 3 + 5
+        out = ref_ti.get_idx_tuples([tuple(int(x) for x in b) for b in bonds])
+        d[f"m{j}::bonds"] = bonds.astype(np.int64)
+        d[f"m{j}::angles"] = np.asarray(out["angles"], dtype=np.int64).reshape(-1, 3)
+        d[f"m{j}::propers"] = np.asarray(out["propers"], dtype=np.int64).reshape(-1, 4)
+    d["n"] = np.array([len(ids)])
+    np.savez_compressed(os.path.join(OUT, "ref_tuples.npz"), **d)
+    print("wrote ref_tuples.npz")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "eval":
         make_eval_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tuples":
+        make_tuple_golden()
     else:
         main()
         make_eval_golden()
+        make_tuple_golden()

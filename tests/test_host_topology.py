@@ -1,0 +1,102 @@
+"""CPU: native host-side graph preparation (libgrappa_host.so, include/grappa_host.h).
+Tuple enumeration is pinned -- sets AND row order -- to tests/golden/ref_tuples.npz, the output of the reference's own
+utils/tuple_indices.get_idx_tuples (oracle/make_goldens.py tuples).  Ring / degree features have no runnable reference offline
+(RDKit): the native code is checked against the Python statement of the same definition and against known ring systems."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_utils as gu
+from grappa_amd import _hostlib, featurize, tuple_indices
+from grappa_amd.datasets import pool_molecule, pool_size
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_library_exports_every_declared_symbol():
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "grappa_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(grappa_[a-z0-9_]+)\s*\(", text)))
+    lib = ctypes.CDLL(_hostlib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_hostlib.SIGNATURES) == names and _hostlib.load().grappa_host_abi_version() == 1
+
+
+def test_tuple_enumeration_matches_reference_rows_and_order():
+    fx = gu.load("ref_tuples.npz")
+    for j in range(int(fx["n"][0])):
+        bonds = fx[f"m{j}::bonds"]
+        angles, propers = _hostlib.enumerate_tuples(bonds)
+        assert angles.dtype == np.int32 and np.array_equal(angles, fx[f"m{j}::angles"]), j
+        assert np.array_equal(propers, fx[f"m{j}::propers"]), j
+        blist = [tuple(int(x) for x in b) for b in bonds]
+        d = tuple_indices.get_idx_tuples(blist)                       # product entry point (native)
+        dp = tuple_indices.get_idx_tuples_py(blist)                   # dict-based statement of the same loops
+        for key, want in (("angles", fx[f"m{j}::angles"]), ("propers", fx[f"m{j}::propers"])):
+            assert [list(t) for t in d[key]] == want.tolist() and [list(t) for t in dp[key]] == want.tolist(), (j, key)
+        assert d["bonds"] == [tuple(sorted(b)) for b in blist]
+
+
+def test_tuple_enumeration_edge_cases():
+    a, p = _hostlib.enumerate_tuples(np.zeros((0, 2), dtype=np.int64))
+    assert a.shape == (0, 3) and p.shape == (0, 4)
+    a, p = _hostlib.enumerate_tuples([(0, 1)])
+    assert a.shape == (0, 3) and p.shape == (0, 4)
+    a, p = _hostlib.enumerate_tuples([(2, 1), (1, 0), (2, 3)])           # butane skeleton, atoms first seen as 2, 1, 0, 3
+    assert a.tolist() == [[1, 2, 3], [0, 1, 2]] and p.tolist() == [[0, 1, 2, 3]]
+    with pytest.raises(AssertionError):
+        _hostlib.enumerate_tuples([(0, 1), (2, 2)])
+    # capacity too small: status GRAPPA_ERR_WORKSPACE (-2), counts still reported
+    lib = _hostlib.load()
+    b = np.array([[0, 1], [1, 2], [2, 3]], dtype=np.int32)
+    na, npr = ctypes.c_int64(0), ctypes.c_int64(0)
+    small = np.empty((1, 3), dtype=np.int32)
+    rc = lib.grappa_topo_enumerate(3, b, small.ctypes.data_as(ctypes.c_void_p), 1, None, 0, ctypes.byref(na), ctypes.byref(npr))
+    assert rc == -2 and na.value == 2 and npr.value == 1
+
+
+def _ring(n, bonds):
+    return _hostlib.ring_encoding(n, np.asarray(bonds, dtype=np.int64).reshape(-1, 2))
+
+
+def test_ring_and_degree_features_on_known_ring_systems():
+    cyc = lambda ids: [(ids[i], ids[(i + 1) % len(ids)]) for i in range(len(ids))]   # noqa: E731
+    # benzene + methyl: ring atoms flagged in-ring and size 6 only
+    enc = _ring(7, cyc(list(range(6))) + [(0, 6)])
+    assert enc[:6].tolist() == [[1, 0, 0, 0, 1, 0, 0]] * 6 and enc[6].tolist() == [0] * 7
+    # naphthalene: two fused six-rings; the 10-ring envelope is not a ring of size <= 8, and is a sum of the two anyway
+    naph = cyc([0, 1, 2, 3, 4, 5]) + [(4, 6), (6, 7), (7, 8), (8, 9), (9, 5)]
+    enc = _ring(10, naph)
+    assert (enc[:, 0] == 1).all() and (enc[:, 4] == 1).all() and enc[:, [1, 2, 3, 5, 6]].sum() == 0
+    # bicyclo[2.2.1]: two five-rings are relevant, the six-ring envelope is their sum -> no size-6 flag
+    norb = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 0), (0, 6), (6, 3)]
+    enc = _ring(7, norb)
+    assert (enc[:, 3] == 1).all() and enc[:, 4].sum() == 0
+    # cubane: six four-rings, all relevant; spiro[2.2]pentane: two three-rings sharing atom 0
+    cube = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+    enc = _ring(8, cube)
+    assert (enc[:, 2] == 1).all() and enc[:, [1, 3, 4, 5, 6]].sum() == 0
+    enc = _ring(5, [(0, 1), (1, 2), (2, 0), (0, 3), (3, 4), (4, 0)])
+    assert (enc[:, 1] == 1).all() and (enc[:, 0] == 1).all()
+    # 12-membered macrocycle: in a ring, but no size flag (sizes 3..8 only); biphenyl link is a bridge
+    enc = _ring(12, cyc(list(range(12))))
+    assert (enc[:, 0] == 1).all() and enc[:, 1:].sum() == 0
+    biph = cyc([0, 1, 2, 3, 4, 5]) + cyc([6, 7, 8, 9, 10, 11]) + [(0, 6)]
+    enc = _ring(12, biph)
+    assert (enc[:, 4] == 1).all() and enc[:, [1, 2, 3, 5, 6]].sum() == 0
+    # degree one-hot 1..6 (0 and > 6 give all zeros), empty graph
+    deg = _hostlib.degree_encoding(9, np.array([(0, i) for i in range(1, 8)]))
+    assert deg[0].sum() == 0 and (deg[1:8, 0] == 1).all() and deg[8].sum() == 0
+    assert _hostlib.ring_encoding(3, np.zeros((0, 2))).sum() == 0
+    with pytest.raises(RuntimeError):
+        _hostlib.ring_encoding(2, np.array([(0, 5)]))
+
+
+def test_native_features_equal_the_python_definition_on_the_molecule_pool():
+    for i in range(0, pool_size(), 11):
+        z, bonds, _ = pool_molecule(i)
+        assert np.array_equal(featurize.ring_encoding(len(z), bonds), featurize.ring_encoding_py(len(z), bonds)), i
+        assert np.array_equal(featurize.degree_encoding(len(z), bonds), featurize.degree_encoding_py(len(z), bonds)), i
