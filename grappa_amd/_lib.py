@@ -39,6 +39,13 @@ class PLossDesc(C.Structure):
                 ("pw", C.c_void_p), ("inv_B", C.c_float)]
 
 
+class CollateDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_row", C.c_void_p), ("dst_row", C.c_void_p), ("p0", C.c_void_p),
+                ("p1", C.c_void_p), ("c0", C.c_int64), ("width", C.c_int32), ("mode", C.c_int32)]
+
+
+COLLATE_MODES = {"copy": 0, "add": 1, "inv_rows": 2, "inc_code": 3, "conf": 4}
+
 VP4 = C.c_void_p * 4
 VP6 = C.c_void_p * 6
 
@@ -76,6 +83,7 @@ SIGNATURES = {
     "grappa_loss_ef_fwd_bwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp]),
     "grappa_loss_param_fwd_bwd_f32": (_i, [_vp, C.POINTER(PLossDesc), _vp, C.POINTER(VP6)]),
     "grappa_eval_se_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "grappa_collate_batch": (_i, [_vp, _vp, C.POINTER(CollateDesc), _i, _i]),
     "grappa_sumsq_workspace_bytes": (_sz, [_sz]),
     "grappa_sumsq_f32": (_i, [_vp, _sz, _vp, _vp, _i, _vp, _sz]),
     "grappa_adam_step_f32": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _f]),

@@ -442,6 +442,30 @@ class HipBackend:
                                                  _ptr(is_dummy), _ptr(grad), _ptr(grad_ref), float(wE), float(wG), float(inv_B),
                                                  loss_mol.data_ptr(), _ptr(gE), _ptr(gG)), "grappa_loss_ef_fwd_bwd_f32")
 
+    def collate_gather(self, tables, B: int) -> None:
+        """one launch for all tables of a batch (include/grappa_hip.h grappa_collate_batch).  tables: dicts with the tensors
+        src, dst (4-byte element types), src_row (B,) int64, dst_row (B+1,) int64, optional p0 / p1 (int32), and width, mode, c0."""
+        if not tables or B == 0:
+            return
+        dev = tables[0]["dst"].device
+        arr = (_lib.CollateDesc * len(tables))()
+        for d, t in zip(arr, tables):
+            for k in ("src", "dst"):
+                if t[k].element_size() not in (4, 8) or t[k].device != dev or not t[k].is_contiguous():
+                    raise ValueError(f"collate table {k}: expected a contiguous 4- or 8-byte tensor on {dev}")
+            for k, dt in (("src_row", torch.int64), ("dst_row", torch.int64), ("p0", torch.int32), ("p1", torch.int32)):
+                v = t.get(k)
+                if v is not None and (v.dtype != dt or v.device != dev or not v.is_contiguous()):
+                    raise ValueError(f"collate table {k}: expected a contiguous {dt} tensor on {dev}")
+            d.src, d.dst = t["src"].data_ptr(), t["dst"].data_ptr()
+            d.src_row, d.dst_row = t["src_row"].data_ptr(), t["dst_row"].data_ptr()
+            d.p0, d.p1 = _ptr(t.get("p0")), _ptr(t.get("p1"))
+            d.c0, d.width, d.mode = int(t.get("c0", 0)), int(t["width"]), _lib.COLLATE_MODES[t["mode"]]
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        descs = host.to(dev)
+        _chk(self.lib.grappa_collate_batch(self._stream(), descs.data_ptr(), arr, len(tables), int(B)), "grappa_collate_batch")
+        self._keep = descs                 # the kernel reads the descriptors asynchronously: keep them alive until the next call
+
     def eval_se(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, out) -> None:
         """out (B,4) = per molecule {se_E, n_E, se_G, n_G} (include/grappa_hip.h grappa_eval_se_f32)"""
         dev = out.device

@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int OK = 0, ERR_ARG = -1, ERR_WORKSPACE = -2;   // include/grappa_hip.h GRAPPA_OK / GRAPPA_ERR_ARG / GRAPPA_ERR_WORKSPACE
+constexpr int OK = 0, ERR_ARG = -1, ERR_WORKSPACE = -3;   // include/grappa_hip.h GRAPPA_OK / GRAPPA_ERR_ARG / GRAPPA_ERR_WORKSPACE
 constexpr int MAX_RING = 8;
 
 // CSR adjacency over ids 0..n-1; every bond appears in both lists (duplicates kept, as the reference's dict of lists keeps them)

@@ -246,6 +246,40 @@ typedef struct grappa_ploss_desc {
 } grappa_ploss_desc;
 int grappa_loss_param_fwd_bwd_f32(void* stream, const grappa_ploss_desc* d, float* loss_mol, float* const gp[6]);
 
+/* Device-side collate (replaces the per-batch host work of data/GraphDataLoader.py:23-73 collate_fn,
+ * utils/dgl_utils.py:11-60 batch and :132-171 set_number_confs for a dataset that is resident in HBM).
+ * A table is an array of 4-byte elements (int32 / float32; an int64 column counts as two) with `width` elements per row.
+ * Workgroup (j, t) copies the rows of batch slot j of table t:
+ *   rows  dst_row[j] .. dst_row[j+1]-1 of dst   <-   rows src_row[j] .. of src          (all arrays are DEVICE pointers)
+ * and transforms them according to `mode`:
+ *   COPY      verbatim (features, charges, reference parameters)
+ *   ADD       int32 + p0[j]                       (CSR columns / tuple indices + atom offset, reverse-edge slots + edge offset)
+ *   INV_ROWS  local token row pos*p0[j] + t  ->  pos*c0 + p1[j] + t     (p0 = tuples of the molecule, p1 = tuple offset of the
+ *             slot, c0 = tuples of the batch at this level; width 1)
+ *   INC_CODE  packed incidence code (tuple << 4 | level << 2 | pos) + (p0[4*j + level] << 4)
+ *   CONF      conformation selection: a source row holds (p0[j], width) values, a batch row (c0, width);
+ *             dst[row][c][e] = src[src_row[j] + (row*p0[j] + p1[j*c0 + c])*width + e]  -- src_row[j] is an ELEMENT offset here;
+ *             p1 = selected conformation per (slot, output conformation): sub-sampling and dummy padding alike. */
+#define GRAPPA_COLLATE_COPY 0
+#define GRAPPA_COLLATE_ADD 1
+#define GRAPPA_COLLATE_INV_ROWS 2
+#define GRAPPA_COLLATE_INC_CODE 3
+#define GRAPPA_COLLATE_CONF 4
+typedef struct grappa_collate_desc {
+    const int32_t* src;
+    int32_t* dst;
+    const int64_t* src_row;   /* [B] */
+    const int64_t* dst_row;   /* [B+1] */
+    const int32_t* p0;
+    const int32_t* p1;
+    int64_t c0;
+    int32_t width;
+    int32_t mode;
+} grappa_collate_desc;
+/* descs_device: the n_tables descriptors in device memory (read by the kernel); descs_host: the same array in host memory
+ * (validated before the launch).  One launch, grid (B, n_tables). */
+int grappa_collate_batch(void* stream, const grappa_collate_desc* descs_device, const grappa_collate_desc* descs_host, int n_tables, int B);
+
 /* FastEvaluator.step (training/evaluation.py:53-113; get_energies / get_gradients utils/graph_utils.py:35-86), one workgroup
  * per molecule instead of dgl.unbatch + a Python loop:  out[b*4 + {0,1,2,3}] = { sum over real conformations of the squared
  * difference of the per-molecule-centred energies, number of real conformations, sum over atoms x real conformations x xyz of

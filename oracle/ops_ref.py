@@ -409,6 +409,34 @@ class RefBackend:
                 gks[l].view(T, n_per[l]).copy_(v.sum(-1))
 
     # ------------------------------------------------------------------ loss
+    def collate_gather(self, tables, B):
+        """include/grappa_hip.h grappa_collate_batch, table by table and slot by slot (4-byte elements viewed as int32)"""
+        for t in tables:
+            w, mode = int(t["width"]), t["mode"]
+            src, dst = t["src"].view(torch.int32).reshape(-1), t["dst"].view(torch.int32).reshape(-1)
+            for j in range(B):
+                r0, r1, s0 = int(t["dst_row"][j]), int(t["dst_row"][j + 1]), int(t["src_row"][j])
+                n = r1 - r0
+                if n == 0:
+                    continue
+                if mode == "conf":
+                    c_src, c_out = int(t["p0"][j]), int(t["c0"])
+                    sel = t["p1"][j * c_out:(j + 1) * c_out].long()
+                    blk = src[s0:s0 + n * c_src * w].reshape(n, c_src, w)
+                    dst[r0 * c_out * w:r1 * c_out * w] = blk[:, sel].reshape(-1)
+                    continue
+                v = src[s0 * w:(s0 + n) * w]
+                if mode == "add":
+                    v = v + int(t["p0"][j])
+                elif mode == "inv_rows":
+                    t_mol, t_off, t_batch = int(t["p0"][j]), int(t["p1"][j]), int(t["c0"])
+                    pos = torch.div(v, t_mol, rounding_mode="floor")
+                    v = pos * t_batch + t_off + (v - pos * t_mol)
+                elif mode == "inc_code":
+                    off = t["p0"][4 * j:4 * j + 4]
+                    v = v + (off[((v >> 2) & 3).long()] << 4)
+                dst[r0 * w:r1 * w] = v
+
     def eval_se(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, out):
         """training/evaluation.py:53-113 per molecule (after unbatch: dummy conformations deleted, energies centred)"""
         B, dev = plan.B, out.device

@@ -49,13 +49,13 @@ def test_tuple_enumeration_edge_cases():
     assert a.tolist() == [[1, 2, 3], [0, 1, 2]] and p.tolist() == [[0, 1, 2, 3]]
     with pytest.raises(AssertionError):
         _hostlib.enumerate_tuples([(0, 1), (2, 2)])
-    # capacity too small: status GRAPPA_ERR_WORKSPACE (-2), counts still reported
+    # capacity too small: status GRAPPA_ERR_WORKSPACE (-3), counts still reported
     lib = _hostlib.load()
     b = np.array([[0, 1], [1, 2], [2, 3]], dtype=np.int32)
     na, npr = ctypes.c_int64(0), ctypes.c_int64(0)
     small = np.empty((1, 3), dtype=np.int32)
     rc = lib.grappa_topo_enumerate(3, b, small.ctypes.data_as(ctypes.c_void_p), 1, None, 0, ctypes.byref(na), ctypes.byref(npr))
-    assert rc == -2 and na.value == 2 and npr.value == 1
+    assert rc == -3 and na.value == 2 and npr.value == 1
 
 
 def _ring(n, bonds):
