@@ -8,7 +8,9 @@ namespace {
 
 constexpr int LN_MAX_CHUNKS = 8;   // 8 float4 per lane * 64 lanes = 2048 floats
 
-template <bool STORE_STATS>
+// NCH = float4 chunks per lane (row width <= 256 * NCH): the row lives in registers, so the chunk count is a template parameter --
+// sized for the widest row (8 chunks) every width would carry ~130 live registers and run at 3 wavefronts per SIMD
+template <int NCH, bool STORE_STATS>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, int ldy, float* __restrict__ mean_out,
@@ -19,10 +21,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
     const int nvec = W >> 2;
     for (int row = wave_global; row < M; row += nwaves) {
         const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
-        float4 v[LN_MAX_CHUNKS];
+        float4 v[NCH];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nvec) {
                 v[i] = xr[c];
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
         const float mean = wave_sum(s) / (float)W;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nvec) {
                 const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
         float4* yr = reinterpret_cast<float4*>(y + (size_t)row * ldy);
 #pragma unroll
-        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nvec) {
                 const float4 g = reinterpret_cast<const float4*>(gamma)[c];
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
 }
 
 // dx per row; per-block partial dgamma/dbeta into part[block][2][W]
+template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const float* __restrict__ dy, int lddy,
                                                             const float* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -72,9 +75,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
     const int wave_global = blockIdx.x * 4 + wave;
     const int nwaves = gridDim.x * 4;
     const int nvec = W >> 2;
-    float4 dg[LN_MAX_CHUNKS], db[LN_MAX_CHUNKS];
+    float4 dg[NCH], db[NCH];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -82,10 +85,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
         const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
         const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * lddy);
         const float mu = mean[row], rs = rstd[row];
-        float4 xh[LN_MAX_CHUNKS], g[LN_MAX_CHUNKS];
+        float4 xh[NCH], g[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nvec) {
                 const float4 xv = xr[c], dv = dyr[c], gm = reinterpret_cast<const float4*>(gamma)[c];
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
         const float m1 = wave_sum(s1) / (float)W, m2 = wave_sum(s2) / (float)W;
         float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * lddx);
 #pragma unroll
-        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nvec) {
                 float4 o;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
     }
     // block reduction of the per-wave partials (fixed order -> reproducible)
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c < nvec) {
             reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 0) * W)[c] = dg[i];
@@ -258,7 +261,7 @@ inline int grid_for(size_t n, int cap = 2048) {
 }
 inline int ln_blocks(int M) {
     int b = (M + 3) / 4;
-    if (b > 1024) b = 1024;
+    if (b > 1024) b = 1024;          // 4 wavefronts per SIMD on 256 CUs (2048 measured no faster)
     if (b < 1) b = 1;
     return b;
 }
@@ -279,11 +282,17 @@ extern "C" int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float*
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
         return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int blocks = ln_blocks(M) > 2048 ? 2048 : ln_blocks(M);
-    if (mean && rstd)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd);
-    else
-        hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd);
+    const int blocks = ln_blocks(M);
+#define GRAPPA_LN_FWD(NCH)                                                                                                              \
+    if (mean && rstd)                                                                                                                   \
+        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, true>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd); \
+    else                                                                                                                                \
+        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, false>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd)
+    if (W <= 256) { GRAPPA_LN_FWD(1); }
+    else if (W <= 512) { GRAPPA_LN_FWD(2); }
+    else if (W <= 1024) { GRAPPA_LN_FWD(4); }
+    else { GRAPPA_LN_FWD(8); }
+#undef GRAPPA_LN_FWD
     return grappa_launch_status();
 }
 
@@ -306,7 +315,12 @@ extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float*
     float* part = reinterpret_cast<float*>(ws);
     float* scratch = part + (size_t)blocks * 2 * W;
     const size_t smem = (size_t)4 * 2 * W * sizeof(float);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part);
+#define GRAPPA_LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part)
+    if (W <= 256) GRAPPA_LN_BWD(1);
+    else if (W <= 512) GRAPPA_LN_BWD(2);
+    else if (W <= 1024) GRAPPA_LN_BWD(4);
+    else GRAPPA_LN_BWD(8);
+#undef GRAPPA_LN_BWD
     int rc = grappa_launch_status();
     if (rc) return rc;
     reduce_rows(st, blocks, 2 * W, W, part, dgamma, accumulate, scratch);
