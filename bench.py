@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_bf16x6)")
     ap.add_argument("--alt-precision", default="f32", help="also time K steps with this GEMM arithmetic (reported beside the default); '' to skip")
+    ap.add_argument("--bwd-precision", default="bf16x3", help="also time K steps with the backward-pass products in this arithmetic (reported beside the default, never as `value`); '' to skip")
     ap.add_argument("--cpu-sample", type=int, default=8, help="molecules in the CPU baseline sample")
     ap.add_argument("--cpu-limit", type=float, default=150.0, help="wall-clock limit of the CPU baseline child, seconds")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (functional test of the N>1 path on one GPU)")
@@ -228,6 +229,30 @@ def main():
         alt = {"gemm_precision": args.alt_precision, "value": per_gpu * world * args.steps / dt_alt, "ms_per_step": 1e3 * dt_alt / args.steps}
         be.set_gemm_precision(default_precision)
         log(f"alt precision {args.alt_precision}: {alt['ms_per_step']:.1f} ms/step")
+    # optional third timing: forward products unchanged (fp32-grade), backward products (dgrad / wgrad) in --bwd-precision
+    bwd = None
+    if args.bwd_precision:
+        be.set_gemm_precision_bwd(args.bwd_precision)
+        step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_bwd = time.perf_counter() - t3
+        if world > 1:
+            t = torch.tensor([dt_bwd], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_bwd = float(t)
+        bwd = {"backward_gemm_precision": args.bwd_precision, "value": per_gpu * world * args.steps / dt_bwd, "ms_per_step": 1e3 * dt_bwd / args.steps,
+               "note": "NOT the headline configuration: forward products as in `default`, dgrad/wgrad products in the named arithmetic "
+                       "(GRAPPA_GEMM_PRECISION_BWD); parameters / energies / forces / loss are bit-identical to the default"}
+        be.set_gemm_precision_bwd(None)
+        log(f"backward precision {args.bwd_precision}: {bwd['ms_per_step']:.1f} ms/step")
     if rank == 0:
         n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
         achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
@@ -271,7 +296,7 @@ def main():
                                         "exactly into 3 bf16 pieces and sums the 6 largest partial products on the bf16 matrix cores "
                                         "(error vs a float64 product <= that of the native fp32 MFMA: tests/test_gpu_ops.py::"
                                         "test_gemm_precision_modes; end-to-end parity: tests/test_gpu_e2e.py)",
-                                "native_f32_mfma": alt},
+                                "native_f32_mfma": alt, "backward_reduced": bwd},
             "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": 1e3 * dt_prof / args.steps, "final_loss": final_loss,
         }
         out["cpu_baseline"] = cpu_base

@@ -80,6 +80,10 @@ class HipBackend:
         # bf16 pieces on the bf16 matrix cores with fp32 accumulation -- at least as close to the exact product as the native
         # fp32 MFMA (tests/test_gpu_ops.py::test_gemm_precision_modes) at ~1.7x its speed; "f32" = native fp32 MFMA
         self.set_gemm_precision(os.environ.get("GRAPPA_GEMM_PRECISION", DEFAULT_GEMM_PRECISION))
+        # optional, OFF by default: a separate arithmetic for the products of the BACKWARD pass (dgrad / wgrad layouts), e.g.
+        # "bf16x3" (two bf16 pieces per operand, 2^-16 per product).  The forward pass -- parameters, energies, forces, loss -- is
+        # untouched by it; the reference itself trains with torch.set_float32_matmul_precision('medium') (training/trainrun.py:3).
+        self.set_gemm_precision_bwd(os.environ.get("GRAPPA_GEMM_PRECISION_BWD") or None)
         self._prof = None      # list of (kernel family, algorithmic flops, algorithmic bytes, start event, end event) when profiling
 
     def set_gemm_precision(self, name: str) -> None:
@@ -87,6 +91,12 @@ class HipBackend:
             raise ValueError(f"gemm precision {name!r}: expected one of {sorted(_lib.GEMM_PRECISIONS)}")
         self.gemm_precision_name = name
         self.gemm_precision = _lib.GEMM_PRECISIONS[name]
+
+    def set_gemm_precision_bwd(self, name) -> None:
+        if name is not None and name not in _lib.GEMM_PRECISIONS:
+            raise ValueError(f"gemm precision {name!r}: expected one of {sorted(_lib.GEMM_PRECISIONS)}")
+        self.gemm_precision_bwd_name = name
+        self.gemm_precision_bwd = None if name is None else _lib.GEMM_PRECISIONS[name]
 
     # ------------------------------------------------------------------ in-process kernel timing (bench.py roofline)
     def start_profile(self) -> None:
@@ -166,7 +176,12 @@ class HipBackend:
                 raise ValueError("gemm: a_colsum needs the row-contiguous A layout and length M")
             d.a_colsum = a_colsum.data_ptr()
         d.act, d.drop_p, d.drop_seed, d.accumulate = int(act), float(drop_p), int(drop_seed) & (2 ** 64 - 1), int(accumulate)
-        d.precision = self.gemm_precision if precision is None else _lib.GEMM_PRECISIONS[precision]
+        if precision is not None:
+            d.precision = _lib.GEMM_PRECISIONS[precision]
+        elif a_kcontig and b_kcontig or self.gemm_precision_bwd is None:
+            d.precision = self.gemm_precision
+        else:
+            d.precision = self.gemm_precision_bwd      # dgrad (B row-contiguous) and wgrad (both row-contiguous) products: backward pass only
         if M == 0 or N == 0:
             return
         if K == 0:

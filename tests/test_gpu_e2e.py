@@ -265,6 +265,36 @@ def test_c3_batch_1024_bf16_arithmetic():
         be.set_gemm_precision(default)
 
 
+def test_backward_products_in_bf16x3_leave_the_forward_untouched():
+    """optional GRAPPA_GEMM_PRECISION_BWD=bf16x3: loss / parameters bit-identical (forward GEMMs keep the default arithmetic), every
+    parameter gradient within 1e-3 of its tensor's max of the default's (2^-16 per product, averaged over 10^4..10^5 summands)"""
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    from grappa_amd.optim import FlatParams
+    be = get_backend()
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").eval()
+    flat = FlatParams(model)
+    g_cpu = build_batch_from_pool(list(range(100, 132)), n_confs=8, seed=3)
+    res = []
+    try:
+        for bwd in (None, "bf16x3"):
+            be.set_gemm_precision_bwd(bwd)
+            flat.zero_grad()
+            g = Energy()(model(g_cpu.to("cuda")))
+            loss = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)(g)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), g.nodes["n3"].data["k"].detach().clone(), [p.grad.detach().clone() for p in flat.params]))
+    finally:
+        be.set_gemm_precision_bwd(None)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    worst = max(float((a - b).abs().max() / a.abs().max().clamp_min(1e-20)) for a, b in zip(res[0][2], res[1][2]) if float(a.abs().max()) > 0)
+    assert 0 < worst < 1e-3, worst
+
+
 def test_writer_heads_on_streams_equal_single_stream():
     """the four writer heads on four HIP streams (default) give bit-identical parameters, loss and gradients to the single-stream
     order: every kernel is deterministic and the heads touch disjoint tensors"""
