@@ -1,7 +1,7 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` into per-kernel-family HBM traffic per launch.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc/bench_FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc/bench_WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc/bench_FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --alt-precision '' --bwd-precision ''
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc/bench_WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --alt-precision '' --bwd-precision ''
     python tools/pmc_traffic.py gpurun_out/pmc/bench_FETCH_SIZE gpurun_out/pmc/bench_WRITE_SIZE > gpurun_out/pmc_traffic_c2.json
 
 Units and corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
@@ -14,7 +14,7 @@ import json
 import re
 import sys
 
-FAMILIES = {"gemm_f32": r"gemm_f32_kernel", "gemm_splitk_reduce": r"gemm_splitk_reduce_kernel", "gat_fwd": r"gat_fwd_kernel",
+FAMILIES = {"gemm_f32": r"gemm_f32_kernel|gemm_bf16x_kernel", "gemm_bf16x": r"gemm_bf16x_kernel", "gemm_splitk_reduce": r"gemm_splitk_reduce_kernel", "gat_fwd": r"gat_fwd_kernel",
             "gat_bwd": r"gat_bwd_kernel|gat_delta_kernel", "layernorm": r"layernorm_", "seqattn": r"seqattn_"}
 
 
