@@ -1,0 +1,133 @@
+"""`Trainer`: the reference's training loop (training/lightning_model.py `LitModel` + data/GraphDataLoader.py sampling) on the
+MI355X path, without Lightning: dataset resident in HBM (`DeviceDataset`), batches assembled on the device, one train step =
+GrappaModel -> Energy -> MolwiseLoss -> backward -> (bucketed all-reduce) -> fused clip + Adam, per-dataset RMSEs from
+`FastEvaluator`, learning-rate warm-up / restarts / decay from `TrainSchedule`.  Nothing in the loop copies a tensor to the host
+except the scalar loss that is logged once per epoch and the pooled metrics.
+
+Sampling follows GraphDataLoader (data/GraphDataLoader.py:100-138): plain shuffling (a `torch.randperm` per epoch) or, with
+per-dataset `weights` / `balance_factor`, weighted sampling with replacement.  Under `torch.distributed` every rank draws the SAME
+global batch (same seed) and keeps its size-balanced share of it (`dist.shard_indices`).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.distributed as tdist
+
+from .device_dataset import DeviceDataset
+from .dist import BucketedGradReducer, shard_indices
+from .energy import Energy
+from .evaluation import FastEvaluator
+from .loss import MolwiseLoss
+from .optim import FlatParams, FusedAdam
+from .schedule import TrainSchedule
+
+
+def epoch_batches(names: List[str], batch_size: int, shuffle: bool = True, weights: Dict[str, float] = {}, balance_factor: float = 0.,
+                  generator: Optional[torch.Generator] = None) -> List[np.ndarray]:
+    """molecule ids of every batch of one epoch (the last batch may be smaller), GraphDataLoader semantics"""
+    n = len(names)
+    assert 0 <= balance_factor <= 1, f"balance_factor must be between 0 and 1, but got {balance_factor}"
+    if shuffle and (len(weights) or balance_factor > 0):
+        w = np.array([weights.get(x, 1.0) for x in names], dtype=np.float64)
+        if balance_factor > 0:
+            occ = {x: names.count(x) / n for x in set(names)}
+            balanced = 1.0 / float(len(occ))
+            ratio = {x: float((1.0 - balance_factor) * balanced + balance_factor * occ[x]) for x in occ}
+            w = w * np.array([1.0 / ratio[x] for x in names])
+        order = torch.multinomial(torch.as_tensor(w, dtype=torch.double), n, replacement=True, generator=generator).numpy()
+    elif len(weights) > 0:
+        raise ValueError("Weights are only supported with shuffle=True")
+    elif shuffle:
+        order = torch.randperm(n, generator=generator).numpy()
+    else:
+        order = np.arange(n)
+    return [order[i:i + batch_size] for i in range(0, n, batch_size)]
+
+
+class Trainer:
+    def __init__(self, model, train_set: DeviceDataset, val_set: Optional[DeviceDataset] = None, batch_size: int = 32,
+                 conf_strategy: Union[str, int] = 32, val_batch_size: int = 32, val_conf_strategy: Union[str, int] = "max",
+                 lr: float = 1.5e-5, weight_decay: float = 0., gradient_clip_val: Optional[float] = 10.0,
+                 proper_regularisation: float = 1e-3, improper_regularisation: float = 0., param_weights_by_dataset: Dict[str, float] = {},
+                 weights: Dict[str, float] = {}, balance_factor: float = 0., seed: int = 0, **schedule_kwargs):
+        self.model, self.train_set, self.val_set = model, train_set, val_set
+        self.batch_size, self.conf_strategy = batch_size, conf_strategy
+        self.val_batch_size, self.val_conf_strategy = val_batch_size, val_conf_strategy
+        self.weights, self.balance_factor = dict(weights), balance_factor
+        self.schedule = TrainSchedule(lr=lr, **schedule_kwargs)
+        self.loss_fn = MolwiseLoss(proper_regularisation=proper_regularisation, improper_regularisation=improper_regularisation,
+                                   param_weights_by_dataset=param_weights_by_dataset, **self.schedule.initial_loss_weights())
+        self.energy = Energy()
+        self.flat = FlatParams(model)
+        self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay, max_grad_norm=gradient_clip_val)
+        self.reducer = BucketedGradReducer(model, self.flat)
+        self.evaluator = FastEvaluator()
+        self.gen = torch.Generator().manual_seed(seed)
+        self.world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
+        self.rank = tdist.get_rank() if self.world > 1 else 0
+        self.history: List[Dict] = []
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _my_share(self, ids: np.ndarray) -> np.ndarray:
+        if self.world == 1:
+            return ids
+        sizes = self.train_set.count["n1"][ids]
+        return ids[shard_indices(sizes.tolist(), self.world, self.rank)]
+
+    def train_step(self, ids: np.ndarray) -> torch.Tensor:
+        self.opt.lr = self.schedule.next_lr()
+        mine = self._my_share(np.asarray(ids))
+        g, names = self.train_set.collate(mine, self.conf_strategy)
+        self.loss_fn.global_batch_size = len(ids) if self.world > 1 else None
+        self.opt.zero_grad()
+        loss = self.loss_fn(self.energy(self.model(g)), list(names))
+        loss.backward()
+        self.reducer.finish()
+        self.opt.step()
+        return loss.detach()
+
+    def train_epoch(self, epoch: int) -> float:
+        self.model.train()
+        self.schedule.on_train_epoch_start(epoch, self.loss_fn, self.opt)
+        total, count = None, 0
+        for ids in epoch_batches(self.train_set.names, self.batch_size, True, self.weights, self.balance_factor, self.gen):
+            loss = self.train_step(ids)
+            total = loss * len(ids) if total is None else total + loss * len(ids)      # stays on the device
+            count += len(ids)
+        return float(total) / max(count, 1)                                            # the epoch's only host sync
+
+    @torch.no_grad()
+    def validate(self, epoch: int):
+        if self.val_set is None:
+            return None
+        self.model.eval()
+        for ids in epoch_batches(self.val_set.names, self.val_batch_size, shuffle=False):
+            g, names = self.val_set.collate(ids, self.val_conf_strategy)
+            self.evaluator.step(self.energy(self.model(g)), list(names))
+        metrics = self.evaluator.pool()
+        es = self.schedule.on_validation_epoch_end(epoch, metrics)
+        return metrics, es
+
+    def fit(self, max_epochs: int, log=None) -> List[Dict]:
+        for epoch in range(max_epochs):
+            rec = {"epoch": epoch, "train_loss": self.train_epoch(epoch), "lr": self.schedule.lr}
+            val = self.validate(epoch)
+            if val is not None:
+                rec["val_metrics"], rec["early_stopping_loss"] = val
+            self.history.append(rec)
+            if log is not None:
+                log(rec)
+            if self.schedule.should_stop:
+                break
+        return self.history
+
+    # ---- export in the reference's container format (utils/loading_utils.py:64-73, training/export_model.py:84-97)
+    def model_dict(self) -> Dict:
+        return {"state_dict": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                "config": {"model_config": dict(self.model.model_config)}, "split_names": None}
+
+    def save(self, path: str) -> None:
+        torch.save(self.model_dict(), path)

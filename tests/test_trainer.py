@@ -1,0 +1,72 @@
+"""The training loop on a resident dataset (grappa_amd/trainer.py): sampling semantics of the reference's GraphDataLoader, loss
+decreasing over epochs, validation metrics feeding the schedule, export in the reference's container format.
+CPU: through the test-only backend (tiny model); GPU (-m gpu): the same loop on the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+from test_host_train import TINY
+
+
+def _items(ids, n_confs=4):
+    from grappa_amd.datasets import graph_from_pool
+    return [(graph_from_pool(i, n_confs=n_confs + (j % 3), seed=2), f"ds{j % 2}") for j, i in enumerate(ids)]
+
+
+def test_epoch_batches_follow_the_reference_samplers():
+    from grappa_amd.trainer import epoch_batches
+    names = ["a"] * 9 + ["b"] * 3
+    g = torch.Generator().manual_seed(0)
+    b = epoch_batches(names, 5, shuffle=True, generator=g)
+    assert [len(x) for x in b] == [5, 5, 2] and sorted(np.concatenate(b).tolist()) == list(range(12))     # RandomSampler: a permutation
+    assert np.concatenate(epoch_batches(names, 5, shuffle=False)).tolist() == list(range(12))
+    # balance_factor 1: every dataset is drawn equally often (weights ~ 1 / occurrence, GraphDataLoader.py:106-131); -> 0: per molecule
+    g = torch.Generator().manual_seed(1)
+    draws = np.concatenate([np.concatenate(epoch_batches(names, 12, True, {}, 1.0, g)) for _ in range(400)])
+    assert 0.45 < np.mean(draws >= 9) < 0.55                     # the 3 molecules of 'b' make up half of the draws
+    draws = np.concatenate([np.concatenate(epoch_batches(names, 12, True, {}, 1e-9, g)) for _ in range(400)])
+    assert 0.21 < np.mean(draws >= 9) < 0.29                     # 3 of 12
+    draws = np.concatenate([np.concatenate(epoch_batches(names, 12, True, {"b": 3.0}, 0.0, g)) for _ in range(400)])
+    assert 0.45 < np.mean(draws >= 9) < 0.55                     # weight 3 on 'b': 9 of 18
+    with pytest.raises(ValueError):
+        epoch_batches(names, 5, shuffle=False, weights={"a": 2.0})
+
+
+def _run(device, epochs=4):
+    from grappa_amd import GrappaModel, model_from_dict, ops
+    from grappa_amd.device_dataset import DeviceDataset
+    from grappa_amd.trainer import Trainer
+    torch.manual_seed(0)
+    ops.manual_seed(5)
+    model = GrappaModel(**TINY).to(device)
+    train = DeviceDataset(_items(list(range(300, 324))), device=device)
+    val = DeviceDataset(_items(list(range(340, 348))), device=device)
+    tr = Trainer(model, train, val, batch_size=8, conf_strategy=4, val_batch_size=4, val_conf_strategy="min", lr=2e-3,
+                 proper_regularisation=1e-3, start_qm_epochs=0, warmup_steps=2, energy_weight=1.0, gradient_weight=0.8, param_weight=0.0,
+                 patience=1, lr_decay=0.5)
+    hist = tr.fit(epochs)
+    assert len(hist) == epochs and all(np.isfinite(h["train_loss"]) for h in hist)
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"]
+    m = hist[-1]["val_metrics"]
+    assert set(m) == {"ds0", "ds1", "avg"} and m["avg"]["rmse_gradients"] > 0
+    assert hist[0]["early_stopping_loss"] is None and hist[1]["early_stopping_loss"] > 0      # counted only after start_qm_epochs (:257)
+    # export / reload in the reference's container format: identical predictions
+    md = tr.model_dict()
+    assert set(md) >= {"state_dict", "config"} and "gnn.blocks.0.layer_norm.weight" in md["state_dict"]
+    clone = model_from_dict(md).to(device).eval()
+    model.eval()
+    g, _ = val.collate([0, 1, 2], "min")
+    g2, _ = val.collate([0, 1, 2], "min")
+    with torch.no_grad():
+        a, b = model(g), clone(g2)
+    assert torch.equal(a.nodes["n3"].data["k"], b.nodes["n3"].data["k"])
+    return hist
+
+
+def test_trainer_cpu(ref_backend):
+    _run("cpu")
+
+
+@pytest.mark.gpu
+def test_trainer_gpu():
+    _run("cuda")
