@@ -342,7 +342,14 @@ class AngleWriter(nn.Module):
         self.to_eq = _ToRange(math.pi, stats["std"]["n3_eq"].item() + eps)
 
     def forward(self, g):
-        c = self.angle_model(self.rep_projector(g.nodes["n1"].data["h"], g.nodes["n3"].data["idxs"]))
+        x = self.rep_projector(g.nodes["n1"].data["h"], g.nodes["n3"].data["idxs"])
+        if x.shape[1] == 0:
+            # no angle in the whole batch (diatomics only).  The reference guards only the torsion writers
+            # (interaction_parameters.py:531-532) and has no such molecules; the same empty result is the natural extension.
+            g.nodes["n3"].data["eq"] = torch.zeros(0, dtype=x.dtype, device=x.device)
+            g.nodes["n3"].data["k"] = torch.zeros(0, dtype=x.dtype, device=x.device)
+            return g
+        c = self.angle_model(x)
         g.nodes["n3"].data["eq"] = self.to_eq(c[:, 0])
         g.nodes["n3"].data["k"] = self.to_k(c[:, 1])
         return g
