@@ -122,3 +122,25 @@ def protein_like_graph(n_atoms_min: int = 50000, seed: int = 0) -> MolBatch:
     data = {nt: dict(g.nodes[nt].data) for nt in g.ntypes}
     data["g"] = {}
     return MolBatch(g._src, g._dst, data, one)
+
+
+_T4_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "t4_lysozyme.npz")
+
+
+def t4_lysozyme_molecule() -> Molecule:
+    """the all-atom T4 lysozyme graph (2,634 atoms, amber99 template charges; data/build_t4.py made it from the structure and
+    residue templates the reference ships).  Impropers follow the planar-centre rule of the synthetic workloads."""
+    d = np.load(_T4_PATH)
+    return Molecule.from_graph(d["z"].astype(np.int64).tolist(), d["bonds"].astype(np.int64).tolist(), d["charges"].astype(np.float32).tolist(),
+                               charge_model="amber99")
+
+
+def protein_graph_t4(copies: int = 19) -> MolBatch:
+    """BASELINE.json configs[4] / SURVEY 8(d) C5: ONE graph of `copies` disjoint T4 lysozymes (19 -> 50,046 atoms), inference only"""
+    one = t4_lysozyme_molecule().to_dgl()
+    g = batch([one] * copies)
+    counts = {nt: np.array([g.num_nodes(nt)]) for nt in g.ntypes}
+    counts["g"] = np.array([1])
+    data = {nt: dict(g.nodes[nt].data) for nt in g.ntypes}
+    data["g"] = {}
+    return MolBatch(g._src, g._dst, data, counts)
