@@ -19,16 +19,15 @@ class FastEvaluator:
                  gradients: bool = True):
         if log_parameters:
             raise NotImplementedError("Logging of parameters is not supported anymore.")      # evaluation.py:33-34
-        if log_classical_values:
-            raise NotImplementedError("classical force-field values are not part of the MI355X path (SURVEY.md section 8)")
-        self.log_classical_values = False
+        self.log_classical_values = log_classical_values
         self.metric_names = metric_names
         self.gradients = gradients
         self.init_storage()
 
     def init_storage(self):
         self._ds_index: Dict[str, int] = {}
-        self._acc: Optional[torch.Tensor] = None          # (n_datasets, 4) float64 on the graphs' device: se_E, n_E, se_G, n_G
+        self._acc: Optional[torch.Tensor] = None          # (n_datasets, 8) float64 on the graphs' device: se_E, n_E, se_G, n_G, then the
+        #                                                   same four for the classical force field vs the PREDICTION (evaluation.py:80-87)
 
     def _index_of(self, dsnames: List[str], device) -> torch.Tensor:
         for n in dsnames:
@@ -36,9 +35,9 @@ class FastEvaluator:
                 self._ds_index[n] = len(self._ds_index)
         need = len(self._ds_index)
         if self._acc is None:
-            self._acc = torch.zeros((max(need, 8), 4), dtype=torch.float64, device=device)
+            self._acc = torch.zeros((max(need, 8), 8), dtype=torch.float64, device=device)
         elif self._acc.shape[0] < need:
-            grown = torch.zeros((2 * need, 4), dtype=torch.float64, device=device)
+            grown = torch.zeros((2 * need, 8), dtype=torch.float64, device=device)
             grown[: self._acc.shape[0]] = self._acc
             self._acc = grown
         return torch.tensor([self._ds_index[n] for n in dsnames], dtype=torch.int64).to(device, non_blocking=True)
@@ -57,8 +56,16 @@ class FastEvaluator:
             assert grad.dim() == 3, f"gradients must be a tensor of shape (n_atoms,n_confs, 3) but is {tuple(grad.shape)}"
             assert grad.shape == grad_ref.shape, f"gradients and gradients_ref must have the same shape but are {grad.shape} and {grad_ref.shape}"
         is_dummy = gd["is_dummy"].float().contiguous() if "is_dummy" in gd else None
-        out = torch.empty((plan.B, 4), dtype=torch.float32, device=energy.device)
-        get_backend().eval_se(plan, energy, energy_ref, is_dummy, grad, grad_ref, out)
+        out = torch.zeros((plan.B, 8), dtype=torch.float32, device=energy.device)
+        be = get_backend()
+        first = torch.empty((plan.B, 4), dtype=torch.float32, device=energy.device)
+        be.eval_se(plan, energy, energy_ref, is_dummy, grad, grad_ref, first)
+        out[:, :4] = first
+        if self.log_classical_values:
+            e_cl = gd["energy_classical_ff"].detach().float().contiguous()
+            g_cl = n1["gradient_classical_ff"].detach().float().contiguous() if self.gradients else None
+            be.eval_se(plan, e_cl, energy, is_dummy, g_cl, grad, first)
+            out[:, 4:] = first
         idx = self._index_of(list(dsnames), energy.device)
         self._acc.index_add_(0, idx, out.double())
 
@@ -66,12 +73,15 @@ class FastEvaluator:
         """per-dataset metrics (energies: per conformation; gradients: per 3-vector; crmse: per component) and their unweighted
         average over datasets; resets the storage (evaluation.py:115-159)."""
         metrics: Dict[str, Dict[str, Optional[float]]] = {}
-        acc = self._acc.cpu().numpy() if self._acc is not None else np.zeros((0, 4))
+        acc = self._acc.cpu().numpy() if self._acc is not None else np.zeros((0, 8))
         for dsname, i in self._ds_index.items():
-            se_e, n_e, se_g, n_g = (float(x) for x in acc[i])
+            se_e, n_e, se_g, n_g, cse_e, _, cse_g, _ = (float(x) for x in acc[i])
             m = {"rmse_energies": float(np.sqrt(np.float32(se_e) / np.float32(n_e))),
                  "rmse_gradients": float(np.sqrt(np.float32(se_g) / np.float32(n_g))) if self.gradients else None,
                  "crmse_gradients": float(np.sqrt(np.float32(se_g) / np.float32(n_g) / np.float32(3.0))) if self.gradients else None}
+            if self.log_classical_values:
+                m["rmse_classical_gradients"] = float(np.sqrt(np.float32(cse_g) / np.float32(n_g))) if self.gradients else None
+                m["rmse_classical_energies"] = float(np.sqrt(np.float32(cse_e) / np.float32(n_e)))
             if self.metric_names is not None:
                 m = {k: v for k, v in m.items() if k in self.metric_names}
             metrics[dsname] = m

@@ -318,7 +318,7 @@ def make_eval_golden():
         sys.modules.setdefault(name, types.ModuleType(name))
     from grappa.training.evaluation import FastEvaluator as RefFastEvaluator
     cfg = small_config(n_conv=1, gated=False, n_att=1)
-    ev, ev_nograd = RefFastEvaluator(), RefFastEvaluator(gradients=False)
+    ev, ev_nograd, ev_cl = RefFastEvaluator(), RefFastEvaluator(gradients=False), RefFastEvaluator(log_classical_values=True)
     d, batches = {}, []
     specs = [dict(ids=pick_small(4, 10, 30, start=40), n_confs=5, seed=23, pad={1: 2, 3: 4}, names=["dsA", "dsB", "dsA", "dsC"]),
              dict(ids=pick_small(3, 8, 24, start=500), n_confs=7, seed=29, pad=None, names=["dsB", "dsB", "dsA"])]
@@ -327,9 +327,26 @@ def make_eval_golden():
         mols = build_inputs(sp["ids"], n_confs=sp["n_confs"], seed=sp["seed"], charge_model="amber99", pad_confs_of=sp["pad"])
         out, sd, g = run_reference(cfg, mols, sp["n_confs"], state_dict=sd, loss_kwargs=dict(gradient_weight=0.5, energy_weight=1.0, param_weight=0.0),
                                    with_param_refs=False, grads="none")
+        # classical force-field values: an Energy pass on seeded 'classical' parameters (suffix _ref), written with the
+        # suffix the evaluator reads (_classical_ff)
+        rng = np.random.default_rng(100 + bi)
+        with torch.no_grad(), zero_dihedral_noise():
+            for lvl, scale in (("n2", 0.05), ("n3", 0.05)):
+                for kk in ("k", "eq"):
+                    v = g.nodes[lvl].data[kk].detach()
+                    g.nodes[lvl].data[kk + "_ref"] = v * torch.from_numpy(1.0 + scale * rng.normal(size=tuple(v.shape))).float()
+            for lvl in ("n4", "n4_improper"):
+                v = g.nodes[lvl].data["k"].detach()
+                g.nodes[lvl].data["k_ref"] = v + torch.from_numpy(0.1 * rng.normal(size=tuple(v.shape))).float()
+        g.nodes["n1"].data["xyz"] = g.nodes["n1"].data["xyz"].detach().clone()       # a fresh leaf: the first pass's graph is freed
+        with zero_dihedral_noise():
+            g = RefEnergy(suffix="_ref", write_suffix="_classical_ff", gradients=True)(g)
         with torch.no_grad():
             ev.step(g, sp["names"])
             ev_nograd.step(g, sp["names"])
+            ev_cl.step(g, sp["names"])
+        d[f"b{bi}::energy_classical_ff"] = to_np(g.nodes["g"].data["energy_classical_ff"])
+        d[f"b{bi}::gradient_classical_ff"] = to_np(g.nodes["n1"].data["gradient_classical_ff"])
         d[f"b{bi}::energy"] = to_np(g.nodes["g"].data["energy"])
         d[f"b{bi}::energy_ref"] = to_np(g.nodes["g"].data["energy_ref"])
         d[f"b{bi}::is_dummy"] = to_np(g.nodes["g"].data["is_dummy"])
@@ -337,7 +354,7 @@ def make_eval_golden():
         d[f"b{bi}::gradient_ref"] = to_np(g.nodes["n1"].data["gradient_ref"])
         d[f"b{bi}::atoms_per_mol"] = np.array([len(m["z"]) for m in mols])
         d[f"b{bi}::dsnames"] = np.array(sp["names"])
-    for tag, e in (("full", ev), ("nograd", ev_nograd)):
+    for tag, e in (("full", ev), ("nograd", ev_nograd), ("classical", ev_cl)):
         m = e.pool()
         for ds, mm in m.items():
             for k, v in mm.items():

@@ -21,15 +21,17 @@ class _Graph:
         counts = fx[f"b{bi}::atoms_per_mol"]
         ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(device)
         self._plan = types.SimpleNamespace(B=len(counts), N=int(counts.sum()), atom_molptr=ptr, device=device)
-        self.nodes = {"g": types.SimpleNamespace(data={"energy": t("energy"), "energy_ref": t("energy_ref"), "is_dummy": t("is_dummy")}),
-                      "n1": types.SimpleNamespace(data={"gradient": t("gradient"), "gradient_ref": t("gradient_ref")})}
+        self.nodes = {"g": types.SimpleNamespace(data={"energy": t("energy"), "energy_ref": t("energy_ref"), "is_dummy": t("is_dummy"),
+                                                       "energy_classical_ff": t("energy_classical_ff")}),
+                      "n1": types.SimpleNamespace(data={"gradient": t("gradient"), "gradient_ref": t("gradient_ref"),
+                                                        "gradient_classical_ff": t("gradient_classical_ff")})}
 
     def plan(self):
         return self._plan
 
 
 def _check(fx, device):
-    for tag, ev in (("full", FastEvaluator()), ("nograd", FastEvaluator(gradients=False))):
+    for tag, ev in (("full", FastEvaluator()), ("nograd", FastEvaluator(gradients=False)), ("classical", FastEvaluator(log_classical_values=True))):
         for bi in range(int(fx["n_batches"][0])):
             ev.step(_Graph(fx, bi, device), [str(x) for x in fx[f"b{bi}::dsnames"]])
         m = ev.pool()
