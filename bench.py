@@ -7,10 +7,12 @@ backward -> all-reduce -> fused Adam with grad clipping) on N MI355X of one node
 Workload (BASELINE.json configs[1]): 256 molecules of 20-40 atoms PER GPU drawn from the Espaloma
 molecule pool, 32 conformations, production model (40.8 M parameters, random init), fp32, train mode (dropout on),
 synthetic charges / coordinates / reference energies+forces.  Weak scaling: every rank gets its own 256 molecules,
-gradients are summed with one RCCL all-reduce of the flat gradient buffer.
-The JSON line also carries `roofline` (fp32 MFMA GEMM family: algorithmic 2MNK FLOPs / HIP-event kernel time, measured
-in an instrumented repetition of the same steps right after the timed region; plus the GAT kernels vs HBM) and
-`cpu_baseline` (the oracle's CPU restatement of the same train step on a bounded sample, rank 0, N=1 only).
+gradients are summed with a two-bucket RCCL all-reduce of the flat gradient buffer (the writer-head bucket overlaps the GNN backward).
+The JSON line also carries `roofline` (the GEMM family -- by default fp32 products as six bf16 MFMAs, `gemm_bf16x_kernel`:
+algorithmic 2MNK FLOPs / HIP-event time per call, measured in an instrumented single-stream repetition of the same steps right
+after the timed region; plus the GAT kernels vs HBM), `gemm_arithmetic` (the same steps with the native fp32 MFMA, and with the
+optional reduced backward arithmetic -- neither is ever `value`) and `cpu_baseline` (the oracle's CPU restatement of the same
+train step on a bounded sample, rank 0, N=1 only).
 """
 import argparse
 import json

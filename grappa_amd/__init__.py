@@ -8,6 +8,11 @@ from .energy import Energy
 from .loss import MolwiseLoss
 from .deploy import get_default_model_config, model_from_config, model_from_dict
 from .grappa import Grappa
+from .evaluation import FastEvaluator
+from .schedule import TrainSchedule
+from .device_dataset import DeviceDataset
+from .trainer import Trainer
 
 __all__ = ["MolBatch", "batch", "unbatch", "set_number_confs", "delete_dummy_confs", "Molecule", "Parameters", "GrappaModel",
-           "Energy", "MolwiseLoss", "get_default_model_config", "model_from_config", "model_from_dict", "Grappa"]
+           "Energy", "MolwiseLoss", "get_default_model_config", "model_from_config", "model_from_dict", "Grappa", "FastEvaluator",
+           "TrainSchedule", "DeviceDataset", "Trainer"]

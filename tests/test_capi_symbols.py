@@ -57,5 +57,6 @@ def test_product_has_no_cpu_fallback():
         backend.set_backend(old)
     # and the product package never imports the oracle
     import subprocess, sys
-    code = "import sys, grappa_amd, grappa_amd.ops, grappa_amd.datasets, grappa_amd.optim, grappa_amd.dist; assert not any(m.startswith('oracle') for m in sys.modules)"
+    code = ("import sys, grappa_amd, grappa_amd.ops, grappa_amd.datasets, grappa_amd.optim, grappa_amd.dist, grappa_amd.trainer, grappa_amd.pdb, "
+            "grappa_amd.moldata, grappa_amd.dataloader; assert not any(m.startswith('oracle') for m in sys.modules)")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
