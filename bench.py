@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_bf16x6)")
     ap.add_argument("--alt-precision", default="f32", help="also time K steps with this GEMM arithmetic (reported beside the default); '' to skip")
     ap.add_argument("--bwd-precision", default="bf16x3", help="also time K steps with the backward-pass products in this arithmetic (reported beside the default, never as `value`); '' to skip")
+    ap.add_argument("--strong-global-batch", type=int, default=0, help="strong-scaling run: this many molecules in total, dealt to the ranks (default 0 = weak scaling, the workload's batch per GPU)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="molecules in the CPU baseline sample")
     ap.add_argument("--cpu-limit", type=float, default=150.0, help="wall-clock limit of the CPU baseline child, seconds")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (functional test of the N>1 path on one GPU)")
@@ -154,10 +155,21 @@ def main():
     energy = Energy()
     loss_fn = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
     per_gpu = WORKLOADS[args.workload][0]
-    loss_fn.global_batch_size = per_gpu * world
+    mol_ids = None
+    if args.strong_global_batch:
+        # strong scaling (not the default contract line): ONE global batch of the workload's molecule range, dealt to the ranks by
+        # size (dist.shard_indices); per-GPU work shrinks as N grows
+        from grappa_amd.datasets import pool_atom_counts, select_molecules
+        from grappa_amd.dist import shard_indices
+        _, lo, hi, _ = WORKLOADS[args.workload]
+        all_ids = select_molecules(args.strong_global_batch, seed=0, min_atoms=lo, max_atoms=hi)
+        sizes = [int(pool_atom_counts()[i]) for i in all_ids]
+        mol_ids = [all_ids[j] for j in shard_indices(sizes, world, rank)]
+        per_gpu = args.strong_global_batch / world
+    loss_fn.global_batch_size = int(round(per_gpu * world))
     ops.manual_seed(1234 + rank)
     log("model ready; building workload")
-    g = build_workload(args.workload, seed=rank).to(dev)
+    g = build_workload(args.workload, seed=rank, mol_ids=mol_ids).to(dev)
     plan = g.plan()
     log(f"workload ready: atoms {plan.N} tuples {plan.T}; warmup")
 
@@ -287,7 +299,7 @@ def main():
         out = {
             "metric": "molecules/sec (train step, energy+force loss)", "value": per_gpu * world * args.steps / dt, "unit": "molecules/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.strong_global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {per_gpu} molecules/GPU (20-40 atoms, Espaloma pool), 32 conformations, "
                                    f"production GrappaModel 40.8M params random-init, train mode (dropout on), Adam + clip 10",
                        "molecules_per_gpu": per_gpu, "global_batch": per_gpu * world, "conformations": 32, "atoms_rank0": plan.N,
