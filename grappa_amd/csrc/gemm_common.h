@@ -234,21 +234,30 @@ static __global__ __launch_bounds__(REDUCE_THREADS) void gemm_splitk_reduce_kern
             }
         }
     }
-    for (size_t i = (size_t)blockIdx.x * REDUCE_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * REDUCE_THREADS) {
+    // four consecutive columns of one tile row per thread (tiles are 16-byte aligned and bn % 4 == 0): 16-byte slab loads, several
+    // in flight (the sum keeps its fixed order s = 0, 1, ...: reproducible)
+    for (size_t i = ((size_t)blockIdx.x * REDUCE_THREADS + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * REDUCE_THREADS * 4) {
         const int tl = (int)(i / tile_elems), rem = (int)(i - (size_t)tl * tile_elems);
         const int tile = p.tile_begin + tl;
         const int m = (tile / p.tiles_n) * p.bm + rem / p.bn, n = (tile % p.tiles_n) * p.bn + rem % p.bn;
         if (m >= p.d.M || n >= p.d.N) continue;
-        float v = 0.0f;
-        for (int s = 0; s < p.nsplit; ++s) v += p.slab[(size_t)s * split_stride + i];
-        epilogue_store(p, m, n, v);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int s = 0; s < p.nsplit; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(p.slab + (size_t)s * split_stride + i);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (n + q < p.d.N) epilogue_store(p, m, n + q, ve[q]);
     }
 }
 
 
 inline int launch_splitk_reduce(hipStream_t st, const GemmParams& p) {
     const size_t total = (size_t)p.ntiles_launch * p.bm * p.bn;
-    int blocks = (int)((total + REDUCE_THREADS - 1) / REDUCE_THREADS);
+    int blocks = (int)((total / 4 + REDUCE_THREADS - 1) / REDUCE_THREADS);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(REDUCE_THREADS), 0, st, p);
     return grappa_launch_status();
