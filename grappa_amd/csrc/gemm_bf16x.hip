@@ -241,7 +241,7 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
         // issue order of this phase: one MFMA, then a slice of the split arithmetic and of the LDS stores, so that the matrix
         // pipe runs under the vector work instead of before it (left alone the compiler bunches all MFMAs after the barrier)
         constexpr int NQ = (BM + BN) * 4 / NT;
-        PhaseOrder<0, NFIRST, NQ * NP, NQ * (NP == 3 ? 30 : NP == 2 ? 18 : 6)>::emit();
+        PhaseOrder<0, NFIRST, NQ * NP, NQ * (NP == 3 ? 26 : NP == 2 ? 16 : 6)>::emit();      // vector ops per quad as counted in the ISA (an over-estimate leaves the last MFMAs bare)
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
