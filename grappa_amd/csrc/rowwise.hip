@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
 
 // out[g*out_stride + j] (+)= sum over rows b in group g of part[b*stride + j]   (grid.y = number of groups)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(int nrows, int stride, int n, const float* __restrict__ part,
-                                                          float* __restrict__ out, int out_stride, int accumulate, int rows_per_group) {
+                                                          float* __restrict__ out, int out_stride, int accumulate, int rows_per_group,
+                                                          float* __restrict__ out2, int n_first) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const int b0 = blockIdx.y * rows_per_group;
@@ -152,22 +153,25 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int nrows, int stride,
     for (; b < b1; ++b) s0 += part[(size_t)b * stride + j];
     const float s = (s0 + s1) + (s2 + s3);
     float* o = out + (size_t)blockIdx.y * out_stride + j;
+    if (out2 && j >= n_first) o = out2 + (j - n_first);          // final stage with two destinations: columns [n_first, n) go to out2
     *o = accumulate ? *o + s : s;
 }
 
 constexpr int REDUCE_GROUPS = 32;
 
 // fixed-order two-stage reduction of per-block partials; scratch holds REDUCE_GROUPS * n floats
-inline void reduce_rows(hipStream_t st, int nrows, int stride, int n, const float* part, float* out, int accumulate, float* scratch) {
+// out2 != nullptr: the n columns are two vectors back to back, [0, n_first) -> out and [n_first, n) -> out2 (LayerNorm's dgamma | dbeta)
+inline void reduce_rows(hipStream_t st, int nrows, int stride, int n, const float* part, float* out, int accumulate, float* scratch,
+                        float* out2 = nullptr, int n_first = 0) {
     const dim3 gx((n + 255) / 256);
     if (nrows <= 2 * REDUCE_GROUPS) {
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, nrows, stride, n, part, out, 0, accumulate, nrows);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, nrows, stride, n, part, out, 0, accumulate, nrows, out2, n_first);
         return;
     }
     const int rpg = (nrows + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
     const int groups = (nrows + rpg - 1) / rpg;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, groups), dim3(256), 0, st, nrows, stride, n, part, scratch, n, 0, rpg);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, groups, n, n, scratch, out, 0, accumulate, groups);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, groups), dim3(256), 0, st, nrows, stride, n, part, scratch, n, 0, rpg, (float*)nullptr, 0);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, groups, n, n, scratch, out, 0, accumulate, groups, out2, n_first);
 }
 
 // column sums: block = 256 threads = 64 columns x 4 row-lanes... simple: each block owns a row stripe,
@@ -297,7 +301,7 @@ extern "C" int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float*
 }
 
 extern "C" size_t grappa_layernorm_bwd_workspace_bytes(int M, int W) {
-    return ((size_t)ln_blocks(M) * 2 * W + (size_t)REDUCE_GROUPS * W) * sizeof(float);
+    return ((size_t)ln_blocks(M) * 2 * W + (size_t)REDUCE_GROUPS * 2 * W) * sizeof(float);
 }
 
 extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
@@ -309,7 +313,7 @@ extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float*
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(gamma)) & 15)
         return GRAPPA_ERR_ARG;
     const int blocks = ln_blocks(M);
-    const size_t need = ((size_t)blocks * 2 * W + (size_t)REDUCE_GROUPS * W) * sizeof(float);
+    const size_t need = ((size_t)blocks * 2 * W + (size_t)REDUCE_GROUPS * 2 * W) * sizeof(float);
     if (!ws || ws_bytes < need) return GRAPPA_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* part = reinterpret_cast<float*>(ws);
@@ -323,8 +327,7 @@ extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float*
 #undef GRAPPA_LN_BWD
     int rc = grappa_launch_status();
     if (rc) return rc;
-    reduce_rows(st, blocks, 2 * W, W, part, dgamma, accumulate, scratch);
-    reduce_rows(st, blocks, 2 * W, W, part + W, dbeta, accumulate, scratch);     // stream order makes the scratch reuse safe
+    reduce_rows(st, blocks, 2 * W, 2 * W, part, dgamma, accumulate, scratch, dbeta, W);     // dgamma | dbeta in one pass (two launches, not four)
     return grappa_launch_status();
 }
 
