@@ -200,6 +200,31 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(int M, int N, cons
     }
 }
 
+// the same with 16-byte accesses: N, the leading dimensions and the base addresses are multiples of 4 floats (host-checked)
+__global__ __launch_bounds__(256) void act_dropout_bwd_vec_kernel(int M, int N, const float* __restrict__ dy, int lddy,
+                                                                  const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
+                                                                  float* __restrict__ dz, int lddz) {
+    const int n4 = N >> 2;
+    const size_t total = (size_t)M * n4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) << 2;
+        float4 v = *reinterpret_cast<const float4*>(dy + (size_t)m * lddy + n);
+        if (p > 0.f) {
+            const uint64_t idx = (uint64_t)m * (uint64_t)N + (uint64_t)n;          // element index of the forward's mask
+            v.x = grappa_keep(seed, idx, p) ? v.x * scale : 0.f;
+            v.y = grappa_keep(seed, idx + 1, p) ? v.y * scale : 0.f;
+            v.z = grappa_keep(seed, idx + 2, p) ? v.z * scale : 0.f;
+            v.w = grappa_keep(seed, idx + 3, p) ? v.w * scale : 0.f;
+        }
+        if (y) {
+            const float4 t = *reinterpret_cast<const float4*>(y + (size_t)m * ldy + n);
+            v.x *= grappa_elu_grad_from_out(t.x); v.y *= grappa_elu_grad_from_out(t.y);
+            v.z *= grappa_elu_grad_from_out(t.z); v.w *= grappa_elu_grad_from_out(t.w);
+        }
+        *reinterpret_cast<float4*>(dz + (size_t)m * lddz + n) = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(size_t n, const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i] + z[i];
 }
@@ -359,8 +384,14 @@ extern "C" int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const floa
     if (M == 0 || N == 0) return GRAPPA_OK;
     if (!dy || !dz) return GRAPPA_ERR_ARG;
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
+    const bool vec = (N & 3) == 0 && (lddy & 3) == 0 && (lddz & 3) == 0 && (!y || (ldy & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(act_dropout_bwd_vec_kernel, dim3(grid_for((size_t)M * (N >> 2))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
+    else
+        hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
     return grappa_launch_status();
 }
 
