@@ -295,9 +295,11 @@ def test_backward_products_in_bf16x3_leave_the_forward_untouched():
     assert 0 < worst < 1e-3, worst
 
 
-def test_writer_heads_on_streams_equal_single_stream():
-    """the four writer heads on four HIP streams (default) give bit-identical parameters, loss and gradients to the single-stream
-    order: every kernel is deterministic and the heads touch disjoint tensors"""
+def test_writer_heads_on_streams_match_single_stream():
+    """opt-in GRAPPA_HEAD_STREAMS=4 (the default is one stream): loss, parameters and gradients agree with the single-stream
+    result to the path's tolerance.  Bit-identity holds in most runs but not all (a sporadic ~1e-4 relative deviation in a few
+    rows when the heads execute concurrently), which is why the option is off by default; single-stream
+    runs must be bit-reproducible."""
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.datasets import build_batch_from_pool
     from grappa_amd.optim import FlatParams
@@ -307,7 +309,7 @@ def test_writer_heads_on_streams_equal_single_stream():
     flat = FlatParams(model)
     g_cpu = build_batch_from_pool(list(range(100, 148)), n_confs=8, seed=3)
     res = []
-    for streams in (1, 4, 4):
+    for streams in (1, 1, 4):
         model.parameter_writer.head_streams = streams
         ops.manual_seed(77)
         flat.zero_grad()
@@ -316,9 +318,14 @@ def test_writer_heads_on_streams_equal_single_stream():
         loss.backward()
         torch.cuda.synchronize()
         res.append((loss.detach().clone(), flat.grad.clone(), g.nodes["n4"].data["k"].detach().clone(), g.nodes["n2"].data["eq"].detach().clone()))
-    for r in res[1:]:
-        for a, b in zip(res[0], r):
-            assert torch.equal(a, b)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)                                   # one stream: bit-reproducible
+    loss1, grad1, k41, eq1 = res[0]
+    loss4, grad4, k44, eq4 = res[2]
+    assert abs(float(loss4) - float(loss1)) <= 1e-4 * abs(float(loss1))
+    assert gu.rel_err(k44.cpu(), k41.cpu().numpy(), 5e-2) < 2e-3 and gu.rel_err(eq4.cpu(), eq1.cpu().numpy(), 1e-4) < 2e-3
+    assert float((grad4 - grad1).abs().max()) <= 2e-3 * float(grad1.abs().max())
+    model.parameter_writer.head_streams = 1
 
 
 def test_predict_drop_in():
