@@ -7,7 +7,8 @@ backward -> all-reduce -> fused Adam with grad clipping) on N MI355X of one node
 Workload (BASELINE.json configs[1]): 256 molecules of 20-40 atoms PER GPU drawn from the Espaloma
 molecule pool, 32 conformations, production model (40.8 M parameters, random init), fp32, train mode (dropout on),
 synthetic charges / coordinates / reference energies+forces.  Weak scaling: every rank gets its own 256 molecules,
-gradients are summed with a two-bucket RCCL all-reduce of the flat gradient buffer (the writer-head bucket overlaps the GNN backward).
+gradients are summed with a two-bucket RCCL all-reduce of the flat gradient buffer after backward() (GRAPPA_OVERLAP_ALLREDUCE=1 sends
+the writer-head bucket from inside the backward pass).
 The JSON line also carries `roofline` (the GEMM family -- by default fp32 products as six bf16 MFMAs, `gemm_bf16x_kernel`:
 algorithmic 2MNK FLOPs / HIP-event time per call, measured in an instrumented single-stream repetition of the same steps right
 after the timed region; plus the GAT kernels vs HBM), `gemm_arithmetic` (the same steps with the native fp32 MFMA, and with the
@@ -180,7 +181,7 @@ def main():
                 g.nodes[lvl].data.pop(k, None)
         loss = loss_fn(energy(model(g)))
         loss.backward()
-        reducer.finish()               # writer-head bucket was sent from inside the backward pass; GNN bucket + wait here
+        reducer.finish()               # all-reduce of the flat gradient buffer (both buckets here unless the overlap is switched on)
         opt.step()
         return loss
 

@@ -4,7 +4,7 @@ The reference is single-device.  Molecules never interac
 loss = mean over molecules), so the batch is dealt to the ranks after sorting by size (round-robin,
 balances tuples per GPU), every rank runs the same kernels on its shard with the loss scaled by
 1/B_global, and the gradients are summed over xGMI: one collective of the flat buffer (`all_reduce_gradients`), or two
-buckets with the first overlapped with the rest of the backward pass (`BucketedGradReducer`).
+buckets, the first optionally overlapped with the rest of the backward pass (`BucketedGradReducer`).
 """
 import os
 from typing import List, Sequence
@@ -37,7 +37,7 @@ def all_reduce_gradients(flat_grad: torch.Tensor) -> None:
 
 
 class BucketedGradReducer:
-    """Gradient all-reduce in two buckets of the flat buffer, the first overlapped with the backward pass.
+    """Gradient all-reduce in two buckets of the flat buffer, the first optionally overlapped with the backward pass.
 
     The backward pass finishes the writer heads (55 % of the parameters: 22.2 M of 40.8 M in the production model) before it enters
     the GNN (18.6 M).  The moment the gradient of the atom embedding `h` is complete (`GrappaModel.on_heads_backward_done`) every writer
@@ -45,13 +45,19 @@ class BucketedGradReducer:
     ordered after the compute stream's work so far) while the GNN backward keeps the matrix cores busy; `finish()` reduces the
     GNN slice and waits for both.  Same sums as `all_reduce_gradients`, so results are identical."""
 
-    def __init__(self, model, flat):
+    def __init__(self, model, flat, overlap=None):
         self.flat = flat
         self.model = model
         self.head_range = flat.range_of(model.parameter_writer)
         self._work = []
         self._heads_sent = False
-        model.on_heads_backward_done = self._on_heads_done
+        # overlap=True sends the writer-head bucket from inside the backward pass.  OFF by default (GRAPPA_OVERLAP_ALLREDUCE=1 turns
+        # it on): on this platform kernels of THIS library running on two hardware queues at once were seen to break the
+        # producer -> consumer order inside a stream (DESIGN.md section 6, "Streams"); RCCL's kernels on a second queue are probably
+        # harmless (unrelated library kernels were), but that cannot be verified on a one-GPU box, so the default keeps the
+        # compute stream alone: both buckets are reduced after backward().
+        self.overlap = (os.environ.get("GRAPPA_OVERLAP_ALLREDUCE", "0") not in ("0", "")) if overlap is None else bool(overlap)
+        model.on_heads_backward_done = self._on_heads_done if self.overlap else None
 
     @staticmethod
     def _active() -> bool:

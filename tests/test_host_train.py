@@ -114,11 +114,18 @@ def _dp_worker(rank, world, port, ids, sd, out_q):
     all_reduce_gradients(one_bucket)
     # the same step again through the two-bucket reducer (writer-head slice sent from inside the backward pass)
     from grappa_amd.dist import BucketedGradReducer
-    reducer = BucketedGradReducer(model, flat)
+    reducer = BucketedGradReducer(model, flat, overlap=True)
     flat.zero_grad()
     _loss(model, mine, 5, global_b=len(ids)).backward()
     assert reducer._heads_sent and len(reducer._work) == 1
     reducer.finish()
+    assert torch.equal(flat.grad, one_bucket)
+    # and the default (no overlap: both buckets after backward)
+    plain = BucketedGradReducer(model, flat)
+    assert plain.overlap is False and model.on_heads_backward_done is None
+    flat.zero_grad()
+    _loss(model, mine, 5, global_b=len(ids)).backward()
+    plain.finish()
     assert torch.equal(flat.grad, one_bucket)
     if rank == 0:
         out_q.put(flat.grad.clone().numpy())
