@@ -19,114 +19,49 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int nvec = W >> 2;
-    if constexpr (NCH <= 2) {
-        // two rows per trip: the second row's loads and shuffle reductions fill the latency of the first's (a row is two dependent
-        // wave-wide reductions, and a wavefront walks ~20 rows)
-        for (int row0 = wave_global; row0 < M; row0 += 2 * nwaves) {
-            const int row1 = row0 + nwaves;
-            const bool two = row1 < M;
-            const float4* xr0 = reinterpret_cast<const float4*>(x + (size_t)row0 * ldx);
-            const float4* xr1 = reinterpret_cast<const float4*>(x + (size_t)(two ? row1 : row0) * ldx);
-            float4 v0[NCH], v1[NCH];
-            float s0 = 0.f, s1 = 0.f;
-    #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nvec) {
-                    v0[i] = xr0[c];
-                    v1[i] = xr1[c];
-                    s0 += (v0[i].x + v0[i].y) + (v0[i].z + v0[i].w);
-                    s1 += (v1[i].x + v1[i].y) + (v1[i].z + v1[i].w);
-                }
-            }
-            const float mean0 = wave_sum(s0) / (float)W, mean1 = wave_sum(s1) / (float)W;
-            float q0 = 0.f, q1 = 0.f;
-    #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nvec) {
-                    const float a = v0[i].x - mean0, b = v0[i].y - mean0, cc = v0[i].z - mean0, d = v0[i].w - mean0;
-                    q0 += (a * a + b * b) + (cc * cc + d * d);
-                    const float e = v1[i].x - mean1, f = v1[i].y - mean1, g = v1[i].z - mean1, h = v1[i].w - mean1;
-                    q1 += (e * e + f * f) + (g * g + h * h);
-                }
-            }
-            const float rstd0 = 1.0f / sqrtf(wave_sum(q0) / (float)W + 1e-5f), rstd1 = 1.0f / sqrtf(wave_sum(q1) / (float)W + 1e-5f);
-            float4* yr0 = reinterpret_cast<float4*>(y + (size_t)row0 * ldy);
-            float4* yr1 = reinterpret_cast<float4*>(y + (size_t)(two ? row1 : row0) * ldy);
-    #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nvec) {
-                    const float4 g = reinterpret_cast<const float4*>(gamma)[c];
-                    const float4 b = reinterpret_cast<const float4*>(beta)[c];
-                    float4 o;
-                    o.x = (v0[i].x - mean0) * rstd0 * g.x + b.x;
-                    o.y = (v0[i].y - mean0) * rstd0 * g.y + b.y;
-                    o.z = (v0[i].z - mean0) * rstd0 * g.z + b.z;
-                    o.w = (v0[i].w - mean0) * rstd0 * g.w + b.w;
-                    yr0[c] = o;
-                    if (two) {
-                        o.x = (v1[i].x - mean1) * rstd1 * g.x + b.x;
-                        o.y = (v1[i].y - mean1) * rstd1 * g.y + b.y;
-                        o.z = (v1[i].z - mean1) * rstd1 * g.z + b.z;
-                        o.w = (v1[i].w - mean1) * rstd1 * g.w + b.w;
-                        yr1[c] = o;
-                    }
-                }
-            }
-            if (STORE_STATS && lane == 0) {
-                mean_out[row0] = mean0;
-                rstd_out[row0] = rstd0;
-                if (two) {
-                    mean_out[row1] = mean1;
-                    rstd_out[row1] = rstd1;
-                }
+    // one row per wavefront and trip.  (Two rows per trip measured 20 % faster on the widest tables, but that kernel is the one
+    // that returned deviating rows when several queues ran this library's kernels at once -- DESIGN.md section 6 -- so it is not used.)
+    for (int row = wave_global; row < M; row += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+        float4 v[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                v[i] = xr[c];
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
         }
-    } else {       // wide rows: a second row in flight costs occupancy (measured slower at W = 2048)
-        for (int row = wave_global; row < M; row += nwaves) {
-            const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
-            float4 v[NCH];
-            float s = 0.f;
-    #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nvec) {
-                    v[i] = xr[c];
-                    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-                }
+        const float mean = wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + b * b) + (cc * cc + d * d);
             }
-            const float mean = wave_sum(s) / (float)W;
-            float q = 0.f;
-    #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nvec) {
-                    const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-                    q += (a * a + b * b) + (cc * cc + d * d);
-                }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
+        float4* yr = reinterpret_cast<float4*>(y + (size_t)row * ldy);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+                const float4 b = reinterpret_cast<const float4*>(beta)[c];
+                float4 o;
+                o.x = (v[i].x - mean) * rstd * g.x + b.x;
+                o.y = (v[i].y - mean) * rstd * g.y + b.y;
+                o.z = (v[i].z - mean) * rstd * g.z + b.z;
+                o.w = (v[i].w - mean) * rstd * g.w + b.w;
+                yr[c] = o;
             }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
-            float4* yr = reinterpret_cast<float4*>(y + (size_t)row * ldy);
-    #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nvec) {
-                    const float4 g = reinterpret_cast<const float4*>(gamma)[c];
-                    const float4 b = reinterpret_cast<const float4*>(beta)[c];
-                    float4 o;
-                    o.x = (v[i].x - mean) * rstd * g.x + b.x;
-                    o.y = (v[i].y - mean) * rstd * g.y + b.y;
-                    o.z = (v[i].z - mean) * rstd * g.z + b.z;
-                    o.w = (v[i].w - mean) * rstd * g.w + b.w;
-                    yr[c] = o;
-                }
-            }
-            if (STORE_STATS && lane == 0) {
-                mean_out[row] = mean;
-                rstd_out[row] = rstd;
-            }
+        }
+        if (STORE_STATS && lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
         }
     }
 }

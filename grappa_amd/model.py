@@ -422,9 +422,10 @@ class WriteParameters(nn.Module):
         # The four writers read the same atom embedding and write disjoint tuple levels: on the GPU each CAN run on its own HIP stream
         # (largest first), so that the tail rounds and launch gaps of one head's kernels are filled by another head's; autograd
         # replays every backward node on the stream of its forward, which gives the same overlap in the backward pass (+2.8 % at C2).
-        # OFF by default (GRAPPA_HEAD_STREAMS=1): with the heads truly concurrent (>= 2 hardware queues) a forward sporadically
-        # differs from the single-stream result in some rows (~1e-4 relative with the default arithmetic); DESIGN.md section 6
-        # lists what was ruled out (tools/head_stream_check.py reproduces it) -- not root-caused, so not the default.
+        # OFF by default (GRAPPA_HEAD_STREAMS=1).  With a two-rows-per-trip LayerNorm kernel (since removed) concurrent heads gave
+        # sporadically deviating rows; the cause sits below this library and is not understood.  With the
+        # shipped kernels 20 of 20 four-stream train steps were bit-identical to the single-stream ones, but until the mechanism is
+        # known the default path keeps compute on one queue.
         self.head_streams = int(os.environ.get("GRAPPA_HEAD_STREAMS", "1"))
         self._streams = None
 

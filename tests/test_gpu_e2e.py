@@ -297,9 +297,9 @@ def test_backward_products_in_bf16x3_leave_the_forward_untouched():
 
 def test_writer_heads_on_streams_match_single_stream():
     """opt-in GRAPPA_HEAD_STREAMS=4 (the default is one stream): loss, parameters and gradients agree with the single-stream
-    result to the path's tolerance.  Bit-identity holds in most runs but not all (a sporadic ~1e-4 relative deviation in a few
-    rows when the heads execute concurrently), which is why the option is off by default; single-stream
-    runs must be bit-reproducible."""
+    result to the path's tolerance (with the shipped kernels the runs have been bit-identical; the tolerance is there because a
+    since-removed LayerNorm kernel deviated under concurrent queues for reasons below this library, DESIGN.md section 6, which is
+    also why the option is off by default); single-stream runs must be bit-reproducible."""
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.datasets import build_batch_from_pool
     from grappa_amd.optim import FlatParams
