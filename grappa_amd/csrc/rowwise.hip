@@ -313,7 +313,8 @@ extern "C" int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float*
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
         return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int blocks = ln_blocks(M);
+    // the forward kernel is light (<= 54 registers up to W = 1024): 2048 blocks = 8 wavefronts per SIMD keep twice the rows in flight
+    const int blocks = W <= 1024 ? ((M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4) : ln_blocks(M);
 #define GRAPPA_LN_FWD(NCH)                                                                                                              \
     if (mean && rstd)                                                                                                                   \
         hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, true>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd); \
