@@ -12,21 +12,24 @@ def model_from_config(model_config: Dict, param_statistics: Dict = None):
     return GrappaModel(param_statistics=param_statistics, **model_config)
 
 
+_HEADS = ("bond", "angle", "proper", "improper")
+
+
 def get_default_model_config():
-    return {
-        "graph_node_features": 256, "in_feats": None,
-        "in_feat_name": ["atomic_number", "partial_charge", "ring_encoding", "degree", "charge_model"], "in_feat_dims": {},
-        "gnn_width": 512, "gnn_attentional_layers": 7, "gnn_convolutions": 0, "gnn_attention_heads": 16,
-        "gnn_dropout_attention": 0.3, "gnn_dropout_initial": 0.0, "gnn_dropout_conv": 0.1, "gnn_dropout_final": 0.1,
-        "parameter_dropout": 0.5,
-        "bond_transformer_depth": 3, "bond_n_heads": 8, "bond_transformer_width": 512, "bond_symmetriser_depth": 3, "bond_symmetriser_width": 256,
-        "angle_transformer_depth": 3, "angle_n_heads": 8, "angle_transformer_width": 512, "angle_symmetriser_depth": 3, "angle_symmetriser_width": 256,
-        "proper_transformer_depth": 3, "proper_n_heads": 8, "proper_transformer_width": 512, "proper_symmetriser_depth": 3, "proper_symmetriser_width": 256,
-        "improper_transformer_depth": 3, "improper_n_heads": 8, "improper_transformer_width": 512, "improper_symmetriser_depth": 3,
-        "improper_symmetriser_width": 256,
-        "n_periodicity_proper": 6, "n_periodicity_improper": 3, "gated_torsion": True, "wrong_symmetry": False,
-        "positional_encoding": True, "layer_norm": True, "self_interaction": True, "learnable_statistics": False, "torsion_cutoff": 1e-4,
-    }
+    """hyper-parameters of the production model (grappa-1.x): 7 attention blocks of width 512 with 16 heads on 256 atom features;
+    four writer heads with 3 transformer layers (8 heads, width 512) and a 3-layer symmetriser of width 256 each"""
+    cfg = {"graph_node_features": 256, "in_feats": None, "in_feat_dims": {},
+           "in_feat_name": ["atomic_number", "partial_charge", "ring_encoding", "degree", "charge_model"]}
+    cfg.update(gnn_width=512, gnn_attentional_layers=7, gnn_convolutions=0, gnn_attention_heads=16)
+    for part, p in (("attention", 0.3), ("initial", 0.0), ("conv", 0.1), ("final", 0.1)):
+        cfg[f"gnn_dropout_{part}"] = p
+    cfg["parameter_dropout"] = 0.5
+    for head in _HEADS:
+        cfg[f"{head}_transformer_depth"], cfg[f"{head}_n_heads"], cfg[f"{head}_transformer_width"] = 3, 8, 512
+        cfg[f"{head}_symmetriser_depth"], cfg[f"{head}_symmetriser_width"] = 3, 256
+    cfg.update(n_periodicity_proper=6, n_periodicity_improper=3, gated_torsion=True, wrong_symmetry=False, positional_encoding=True,
+               layer_norm=True, self_interaction=True, learnable_statistics=False, torsion_cutoff=1e-4)
+    return cfg
 
 
 def model_from_dict(model_dict: Dict):
