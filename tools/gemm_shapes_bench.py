@@ -1,6 +1,8 @@
-"""Per-shape timing of the fp32 MFMA GEMM on the GPU box: every distinct (M,N,K,layout) the production model issues in one
-train step of the C2 workload, timed with HIP events (10 repetitions after 2 warm-ups).  Prints TFLOP/s per shape and the
-step-weighted total.  Usage: python tools/gemm_shapes_bench.py [--record]"""
+"""Per-shape timing of the GEMM on the GPU box: every distinct (M,N,K,layout) the production model issues in one train step of the C2
+workload, timed with HIP events (10 repetitions after 2 warm-ups).  Prints TFLOP/s per shape and the step-weighted total.
+    python tools/gemm_shapes_bench.py --precisions=f32_bf16x6,f32            # arithmetic modes side by side, one process
+    python tools/gemm_shapes_bench.py --precisions=f32_bf16x6,f32_bf16x6@5   # "@cfg": force a tile configuration (plan override)
+    GRAPPA_HIP_LIB=/path/to/variant.so python tools/gemm_shapes_bench.py ... # A/B a kernel variant built into another library"""
 import collections
 import os
 import sys
