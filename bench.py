@@ -4,18 +4,21 @@ backward -> all-reduce -> fused Adam with grad clipping) on N MI355X of one node
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): 256 molecules of 20-40 atoms PER GPU drawn from the Espaloma
-molecule pool, 32 conformations, production model (40.8 M parameters, random init), fp32, train mode (dropout on),
-synthetic charges / coordinates / reference energies+forces.  Weak scaling: every rank gets its own 256 molecules,
-gradients are summed with a two-bucket RCCL all-reduce of the flat gradient buffer after backward() (GRAPPA_OVERLAP_ALLREDUCE=1 sends
-the writer-head bucket from inside the backward pass).
-The JSON line also carries `roofline` (the GEMM family -- by default fp32 products as six bf16 MFMAs, `gemm_bf16x_kernel`:
-algorithmic 2MNK FLOPs / HIP-event time per call, measured in an instrumented single-stream repetition of the same steps right
-after the timed region; plus the GAT kernels vs HBM), `gemm_arithmetic` (the same steps with the native fp32 MFMA, and with the
-optional reduced backward arithmetic -- neither is ever `value`) and `cpu_baseline` (the oracle's CPU restatement of the same
-train step on a bounded sample, rank 0, N=1 only).
+N = 1 (the headline line): BASELINE.json configs[1]: 256 molecules of 20-40 atoms drawn from the Espaloma
+molecule pool, 32 conformations, production model (40.8 M parameters, keyed init), fp32-grade arithmetic, train mode (dropout on),
+synthetic charges / coordinates / reference energies+forces, inputs resident in HBM.  The same JSON line also carries
+  `roofline`      the dominant kernel family (the dense products): algorithmic 2MNK FLOPs / HIP-event time per call, measured in an
+                  instrumented repetition of the same steps right after the timed region; plus the GAT kernels vs HBM,
+  `cpu_baseline`  the oracle's CPU restatement of the same train step on a bounded sample (rank 0, N = 1 only),
+  `c3`            BASELINE configs[2] (1024 molecules of the whole pool) timed right after C2 with the same arithmetic,
+  `c4_strong_n1`  BASELINE configs[3]'s 4096-molecule global batch on ONE GPU (4 chunks of 1024, gradients accumulated, one
+                  optimiser step) -- the N = 1 point of the strong-scaling curve below.
+N > 1 (default): STRONG scaling of BASELINE configs[3] (C4): ONE global batch of 4096 molecules dealt to the ranks by size
+(dist.shard_indices), loss scaled by 1/4096 on every rank, gradients summed with a two-bucket RCCL all-reduce of the flat gradient
+buffer after backward(); `--weak` switches to weak scaling of C2 (256 molecules per GPU).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,6 +38,7 @@ GEMM_KERNELS = {"f32": ("gemm_f32_kernel<*> (v_mfma_f32_32x32x2_f32)", 0),
                 "f32_bf16x6": ("gemm_bf16x_kernel<6,*> (fp32 operands as 3 bf16 pieces, 6 partial products, v_mfma_f32_32x32x16_bf16)", 6),
                 "bf16x3": ("gemm_bf16x_kernel<3,*>", 3), "bf16": ("gemm_bf16x_kernel<1,*>", 1)}
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+LOSS_KW = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
 
 
 def keyed_init(model):
@@ -44,7 +48,28 @@ def keyed_init(model):
     model.load_state_dict(gu.keyed_state_dict(model))
 
 
-def cpu_baseline_child(workload: str, n_mols: int, steps: int, threads: int):
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: ties a committed PMC summary to the code it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "grappa_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_child(workload: str, n_mols: int, steps: int, warmup: int, threads: int):
     """the oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same workload; runs in
     a child process of its own (`bench.py --cpu-baseline-child ...`) that never touches the GPU"""
     from grappa_amd import get_default_model_config
@@ -58,10 +83,10 @@ def cpu_baseline_child(workload: str, n_mols: int, steps: int, threads: int):
     model.load_state_dict(gu.keyed_state_dict(model))
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1.5e-5)
-    loss_fn = cpu_ref.RefMolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
+    loss_fn = cpu_ref.RefMolwiseLoss(**LOSS_KW)
     energy = cpu_ref.RefEnergy()
     times = []
-    for it in range(steps + 1):
+    for it in range(steps + warmup):
         g = build_batch_from_pool(ids, n_confs=32, seed=0)
         t0 = time.perf_counter()
         opt.zero_grad()
@@ -69,29 +94,46 @@ def cpu_baseline_child(workload: str, n_mols: int, steps: int, threads: int):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
-        if it > 0:
+        if it >= warmup:
             times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
-    print(json.dumps({"value": n_mols / t, "unit": "molecules/s", "cores": int(torch.get_num_threads()), "kind": "port",
-                      "sample": f"{n_mols} molecules of {workload} x 32 conformations, production model fp32, median of {steps} train "
-                                f"step(s) after one warm-up (oracle/cpu_ref.py, torch {torch.__version__} CPU, {threads} threads)"}), flush=True)
+    print(json.dumps({"value": n_mols / t, "threads": int(torch.get_num_threads()), "median_step_s": t, "steps": steps, "warmup": warmup}), flush=True)
 
 
-def cpu_baseline(workload: str, n_mols: int, steps: int, limit_s: float):
-    """run the bounded CPU sample in a child process (started before this process touches the GPU) under a wall-clock limit"""
+def cpu_baseline(workload: str, n_mols: int, steps: int, warmup: int, limit_s: float):
+    """the bounded CPU sample in child processes (started before this process touches the GPU): once on 16 threads, once on every
+    core the box reports; the faster one is the baseline (all cores, core count and CPU model recorded)"""
     import subprocess
-    threads = max(1, min(16, os.cpu_count() or 1))       # more threads than this only oversubscribe the oracle's small per-op work
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", workload, str(n_mols), str(steps), str(threads)]
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
-    try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=env)
-        for line in reversed(out.stdout.splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
-        return {"value": None, "unit": "molecules/s", "cores": threads, "kind": "port", "sample": f"child failed: {out.stderr[-300:]}"}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "molecules/s", "cores": threads, "kind": "port",
-                "sample": f"{n_mols} molecules x {steps + 1} train steps did not finish within {limit_s:.0f} s on {threads} threads"}
+    ncpu = os.cpu_count() or 1
+    settings = sorted({min(16, ncpu), ncpu})
+    tried, best = [], None
+    t_start = time.time()
+    for threads in settings:
+        left = limit_s - (time.time() - t_start)
+        if left < 10:
+            tried.append({"threads": threads, "value": None, "note": "skipped: time limit"})
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", workload, str(n_mols), str(steps), str(warmup), str(threads)]
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=left, env=env)
+            rec = None
+            for line in reversed(out.stdout.splitlines()):
+                if line.startswith("{"):
+                    rec = json.loads(line)
+                    break
+            if rec is None:
+                rec = {"threads": threads, "value": None, "note": f"child failed: {out.stderr[-200:]}"}
+        except subprocess.TimeoutExpired:
+            rec = {"threads": threads, "value": None, "note": f"did not finish within {left:.0f} s"}
+        tried.append(rec)
+        if rec.get("value") and (best is None or rec["value"] > best["value"]):
+            best = rec
+    sample = (f"{n_mols} molecules of {workload} x 32 conformations, production model fp32, full train step (forward, energy+force loss, "
+              f"backward, clip, Adam), median of {steps} steps after {warmup} warm-up (oracle/cpu_ref.py, torch {torch.__version__} CPU); "
+              f"thread settings tried: " + ", ".join(f"{r.get('threads')} -> {r['value']:.1f} mol/s" if r.get("value") else f"{r.get('threads')} -> {r.get('note')}" for r in tried))
+    return {"value": best["value"] if best else None, "unit": "molecules/s", "cores": ncpu, "threads_used": best["threads"] if best else None,
+            "cpu_model": cpu_model_name(), "kind": "port", "sample": sample}
 
 
 def log(*a):
@@ -100,31 +142,36 @@ def log(*a):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
-        cpu_baseline_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+        cpu_baseline_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="C2-pubchem-b256")
+    ap.add_argument("--workload", default=None, help="default: C2-pubchem-b256 at N = 1 (and with --weak), C4-espaloma-b4096 (strong scaling) at N > 1")
+    ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling, the workload's batch on every GPU (default at N > 1 is strong scaling of C4)")
+    ap.add_argument("--strong-global-batch", type=int, default=0, help="strong scaling of this many molecules of the workload's molecule range (default at N > 1: 4096 of C4)")
+    ap.add_argument("--chunk", type=int, default=1024, help="molecules per forward/backward pass of a rank (larger shards are accumulated over chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the C3 and C4-on-one-GPU timings that follow the headline measurement")
     ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_bf16x6)")
     ap.add_argument("--alt-precision", default="f32", help="also time K steps with this GEMM arithmetic (reported beside the default); '' to skip")
-    ap.add_argument("--bwd-precision", default="bf16x3", help="also time K steps with the backward-pass products in this arithmetic (reported beside the default, never as `value`); '' to skip")
-    ap.add_argument("--strong-global-batch", type=int, default=0, help="strong-scaling run: this many molecules in total, dealt to the ranks (default 0 = weak scaling, the workload's batch per GPU)")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="molecules in the CPU baseline sample")
-    ap.add_argument("--cpu-limit", type=float, default=150.0, help="wall-clock limit of the CPU baseline child, seconds")
+    ap.add_argument("--bwd-precision", default="", help="also time K steps with the backward-pass products in this arithmetic (reported beside the default, never as `value`); '' to skip")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="molecules in the CPU baseline sample")
+    ap.add_argument("--cpu-limit", type=float, default=150.0, help="wall-clock limit of the CPU baseline children, seconds")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (functional test of the N>1 path on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # CPU baseline first, in a child process, before this process initialises the GPU (rank 0 at N = 1 only)
+    strong = world > 1 and not args.weak or args.strong_global_batch > 0
+    workload = args.workload or ("C4-espaloma-b4096" if strong else "C2-pubchem-b256")
+    # CPU baseline first, in child processes, before this process initialises the GPU (rank 0 at N = 1 only)
     cpu_base = None
     if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
         log(f"cpu baseline (oracle, {args.cpu_sample} molecules, limit {args.cpu_limit:.0f} s) ...")
-        cpu_base = cpu_baseline(args.workload, args.cpu_sample, 1, args.cpu_limit)
+        cpu_base = cpu_baseline(workload, args.cpu_sample, 3, 2, args.cpu_limit)
         log(f"cpu baseline: {cpu_base}")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -139,8 +186,8 @@ def main():
 
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.backend import get_backend
-    from grappa_amd.datasets import WORKLOADS, build_workload
-    from grappa_amd.dist import BucketedGradReducer
+    from grappa_amd.datasets import WORKLOADS, WORKLOAD_DESCRIPTIONS, build_batch_from_pool, pool_atom_counts, select_molecules, workload_molecule_ids
+    from grappa_amd.dist import BucketedGradReducer, shard_indices
     from grappa_amd.optim import FlatParams, FusedAdam
 
     log("imports done; building model")
@@ -154,131 +201,160 @@ def main():
     opt = FusedAdam(flat, lr=1.5e-5, max_grad_norm=10.0)
     reducer = BucketedGradReducer(model, flat)
     energy = Energy()
-    loss_fn = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
-    per_gpu = WORKLOADS[args.workload][0]
-    mol_ids = None
-    if args.strong_global_batch:
-        # strong scaling (not the default contract line): ONE global batch of the workload's molecule range, dealt to the ranks by
-        # size (dist.shard_indices); per-GPU work shrinks as N grows
-        from grappa_amd.datasets import pool_atom_counts, select_molecules
-        from grappa_amd.dist import shard_indices
-        _, lo, hi, _ = WORKLOADS[args.workload]
-        all_ids = select_molecules(args.strong_global_batch, seed=0, min_atoms=lo, max_atoms=hi)
-        sizes = [int(pool_atom_counts()[i]) for i in all_ids]
-        mol_ids = [all_ids[j] for j in shard_indices(sizes, world, rank)]
-        per_gpu = args.strong_global_batch / world
-    loss_fn.global_batch_size = int(round(per_gpu * world))
     ops.manual_seed(1234 + rank)
+    counts = pool_atom_counts()
+
+    class Job:
+        """one configuration on this rank: its molecules in chunks resident in HBM, and the train step over them"""
+
+        def __init__(self, name, global_batch, ids, seed):
+            self.name, self.global_batch, self.n_local = name, int(global_batch), len(ids)
+            self.loss_fn = MolwiseLoss(**LOSS_KW)
+            self.loss_fn.global_batch_size = int(global_batch)
+            self.graphs = [build_batch_from_pool(ids[i:i + args.chunk], n_confs=WORKLOADS[name][3], seed=seed).to(dev)
+                           for i in range(0, len(ids), args.chunk)]
+            self.atoms = sum(g.plan().N for g in self.graphs)
+            self.tuples = {k: sum(int(g.plan().T[k]) for g in self.graphs) for k in self.graphs[0].plan().T}
+            self.allreduce_events = None
+
+        def step(self):
+            opt.zero_grad()
+            for g in self.graphs:                                      # gradients accumulate in the flat buffer over the chunks
+                for lvl in ("n2", "n3", "n4", "n4_improper"):         # drop last step's outputs
+                    for k in ("k", "eq"):
+                        g.nodes[lvl].data.pop(k, None)
+                loss = self.loss_fn(energy(model(g)))
+                loss.backward()
+            if self.allreduce_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reducer.finish()
+                e1.record()
+                self.allreduce_events.append((e0, e1))
+            else:
+                reducer.finish()       # all-reduce of the flat gradient buffer (both buckets here unless the overlap is switched on)
+            opt.step()
+            return loss
+
+        def timed(self, steps, warmup):
+            """-> (seconds for `steps` steps as the MAX over ranks, last loss)"""
+            for _ in range(warmup):
+                loss = self.step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = self.step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t)
+            return dt, float(loss.detach())
+
+        def describe(self):
+            return {"workload": f"{self.name}: {WORKLOAD_DESCRIPTIONS[self.name]}, {WORKLOADS[self.name][3]} conformations, production "
+                                f"GrappaModel 40.8M params (keyed init), train mode (dropout on), Adam + clip 10"
+                                + (f"; this rank: {self.n_local} molecules in {len(self.graphs)} chunks of <= {args.chunk}, gradients accumulated, one optimiser step"
+                                   if len(self.graphs) > 1 else ""),
+                    "global_batch": self.global_batch, "molecules_rank0": self.n_local, "conformations": WORKLOADS[self.name][3],
+                    "atoms_rank0": self.atoms, "tuples_rank0": self.tuples, "chunks_rank0": len(self.graphs)}
+
+    def strong_job(name, total):
+        _, lo, hi, _ = WORKLOADS[name]
+        all_ids = workload_molecule_ids(name, seed=0) if total == WORKLOADS[name][0] else select_molecules(total, seed=0, min_atoms=lo, max_atoms=hi)
+        sizes = [int(counts[i]) for i in all_ids]
+        mine = [all_ids[j] for j in shard_indices(sizes, world, rank)]
+        return Job(name, total, mine, seed=0)
+
     log("model ready; building workload")
-    g = build_workload(args.workload, seed=rank, mol_ids=mol_ids).to(dev)
-    plan = g.plan()
-    log(f"workload ready: atoms {plan.N} tuples {plan.T}; warmup")
-
-    def step():
-        opt.zero_grad()
-        for lvl in ("n2", "n3", "n4", "n4_improper"):         # drop last step's outputs
-            for k in ("k", "eq"):
-                g.nodes[lvl].data.pop(k, None)
-        loss = loss_fn(energy(model(g)))
-        loss.backward()
-        reducer.finish()               # all-reduce of the flat gradient buffer (both buckets here unless the overlap is switched on)
-        opt.step()
-        return loss
-
-    for _ in range(args.warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    final_loss = float(loss.detach())
+    if strong:
+        job = strong_job(workload, args.strong_global_batch or WORKLOADS[workload][0])
+    else:
+        job = Job(workload, WORKLOADS[workload][0] * world, workload_molecule_ids(workload, seed=rank), seed=rank)
+    log(f"workload {job.name} ready: molecules {job.n_local} atoms {job.atoms} tuples {job.tuples}; warmup")
+    dt, final_loss = job.timed(args.steps, args.warmup)
     log(f"timed region done: {1e3 * dt / args.steps:.1f} ms/step; instrumented pass")
 
-    # instrumented repetition of the same steps: HIP events around every GEMM / GAT launch on the launch stream.  The writer
-    # heads run on ONE stream here (GRAPPA_HEAD_STREAMS=1 semantics): with the heads on four streams a kernel shares the chip with
-    # another head's kernels and an event pair measures the sharing, not the kernel; profiles/ rocprof runs use the same setting.
+    # instrumented repetition of the same steps: HIP events around every GEMM / GAT launch on the launch stream (one stream:
+    # GRAPPA_HEAD_STREAMS=1 semantics; profiles/ rocprof runs use the same setting), and around the gradient all-reduce
     head_streams = model.parameter_writer.head_streams
     model.parameter_writer.head_streams = 1
-    step()
+    job.step()
+    torch.cuda.synchronize()
+    job.allreduce_events = []
     be.start_profile()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        job.step()
     prof = be.stop_profile()
     dt_prof = time.perf_counter() - t1
+    allreduce_ms = sum(a.elapsed_time(b) for a, b in job.allreduce_events) / max(len(job.allreduce_events), 1)
+    job.allreduce_events = None
     model.parameter_writer.head_streams = head_streams
-
     log("instrumented pass done")
+
+    def alt_run(setter, restore):
+        setter()
+        d, _ = job.timed(args.steps, 1)
+        restore()
+        return {"value": job.global_batch * args.steps / d, "ms_per_step": 1e3 * d / args.steps}
+
     # the same K steps with the dense products on the native fp32 matrix instruction, for reference next to the default
     alt = None
     if args.alt_precision and args.alt_precision != be.gemm_precision_name:
         default_precision = be.gemm_precision_name
-        be.set_gemm_precision(args.alt_precision)
-        step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt_alt = time.perf_counter() - t2
-        if world > 1:
-            t = torch.tensor([dt_alt], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_alt = float(t)
-        alt = {"gemm_precision": args.alt_precision, "value": per_gpu * world * args.steps / dt_alt, "ms_per_step": 1e3 * dt_alt / args.steps}
-        be.set_gemm_precision(default_precision)
+        alt = alt_run(lambda: be.set_gemm_precision(args.alt_precision), lambda: be.set_gemm_precision(default_precision))
+        alt["gemm_precision"] = args.alt_precision
         log(f"alt precision {args.alt_precision}: {alt['ms_per_step']:.1f} ms/step")
-    # optional third timing: forward products unchanged (fp32-grade), backward products (dgrad / wgrad) in --bwd-precision
     bwd = None
     if args.bwd_precision:
-        be.set_gemm_precision_bwd(args.bwd_precision)
-        step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt_bwd = time.perf_counter() - t3
-        if world > 1:
-            t = torch.tensor([dt_bwd], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_bwd = float(t)
-        bwd = {"backward_gemm_precision": args.bwd_precision, "value": per_gpu * world * args.steps / dt_bwd, "ms_per_step": 1e3 * dt_bwd / args.steps,
-               "note": "NOT the headline configuration: forward products as in `default`, dgrad/wgrad products in the named arithmetic "
-                       "(GRAPPA_GEMM_PRECISION_BWD); parameters / energies / forces / loss are bit-identical to the default"}
-        be.set_gemm_precision_bwd(None)
+        bwd = alt_run(lambda: be.set_gemm_precision_bwd(args.bwd_precision), lambda: be.set_gemm_precision_bwd(None))
+        bwd.update({"backward_gemm_precision": args.bwd_precision,
+                    "note": "NOT the headline configuration: forward products as in `default`, dgrad/wgrad products in the named arithmetic "
+                            "(GRAPPA_GEMM_PRECISION_BWD); parameters / energies / forces / loss are bit-identical to the default"})
         log(f"backward precision {args.bwd_precision}: {bwd['ms_per_step']:.1f} ms/step")
+
+    # N = 1: the other single-GPU configurations, timed with the same arithmetic right after the headline measurement
+    extras = {}
+    if world == 1 and not args.no_extras and not strong and workload == "C2-pubchem-b256":
+        headline_graphs = job.graphs
+        for key, name, steps in (("c3", "C3-espaloma-b1024", 3), ("c4_strong_n1", "C4-espaloma-b4096", 2)):
+            try:
+                j2 = Job(name, WORKLOADS[name][0], workload_molecule_ids(name, seed=0), seed=0)
+                d2, l2 = j2.timed(steps, 1)
+                extras[key] = {"value": j2.global_batch * steps / d2, "unit": "molecules/s", "ms_per_step": 1e3 * d2 / steps, "steps": steps, "warmup": 1,
+                               "scaling": "strong" if key.startswith("c4") else None, "n_gpus": 1, "gemm_precision": be.gemm_precision_name,
+                               "final_loss": l2, "config": j2.describe()}
+                log(f"{key}: {extras[key]['ms_per_step']:.1f} ms/step = {extras[key]['value']:.0f} molecules/s")
+                del j2
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001  (an extra must never take the headline line down)
+                extras[key] = {"value": None, "error": repr(e)[:300]}
+        job.graphs = headline_graphs
+
     if rank == 0:
         n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
         achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process; the committed
-        # rocprofv3 --pmc summary of this same command (tools/pmc_traffic.py -> profiles/pmc_traffic_c2.json) is reported
+        # rocprofv3 --pmc summary of this same command (tools/pmc_traffic.py -> profiles/pmc_traffic_c2.json) is reported -- only
+        # while the kernel sources it was measured on are the ones running
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
-        if args.workload == "C2-pubchem-b256" and os.path.exists(tpath):
+        if job.name == "C2-pubchem-b256" and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath))["families"]["gemm_f32"]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)"
+                tj = json.load(open(tpath))
+                if tj.get("kernel_source_hash") == kernel_source_hash():
+                    traffic = tj["families"]["gemm_f32"]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch; same kernel sources)"
+                else:
+                    traffic_src = "profiles/pmc_traffic_c2.json was measured on other kernel sources: not reported"
             except Exception:
                 traffic = None
         kname, nprod = GEMM_KERNELS[be.gemm_precision_name]
@@ -297,23 +373,24 @@ def main():
             a = (by_ / (ms_ * 1e-3)) / 1e9 if ms_ > 0 else 0.0
             gat[fam] = {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
                         "avg_launch_us": 1e3 * ms_ / max(n_, 1), "mb_per_launch": by_ / max(n_, 1) / 1e6}
+        cfg = job.describe()
+        cfg.update({"parallelism": f"dp{world}", "world_size": world, "dist_backend": args.dist_backend if world > 1 else None,
+                    "allreduce_ms_per_step": allreduce_ms if world > 1 else None, "allreduce_bytes": 4 * flat.numel if world > 1 else None,
+                    "writer_head_streams": head_streams})
         out = {
-            "metric": "molecules/sec (train step, energy+force loss)", "value": per_gpu * world * args.steps / dt, "unit": "molecules/s",
+            "metric": "molecules/sec (train step, energy+force loss)", "value": job.global_batch * args.steps / dt, "unit": "molecules/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong" if args.strong_global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {per_gpu} molecules/GPU (20-40 atoms, Espaloma pool), 32 conformations, "
-                                   f"production GrappaModel 40.8M params random-init, train mode (dropout on), Adam + clip 10",
-                       "molecules_per_gpu": per_gpu, "global_batch": per_gpu * world, "conformations": 32, "atoms_rank0": plan.N,
-                       "tuples_rank0": {k: int(v) for k, v in plan.T.items()}, "parallelism": f"dp{world}",
-                       "writer_head_streams": head_streams},
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": cfg,
             "gemm_arithmetic": {"default": be.gemm_precision_name,
                                 "note": "inputs, outputs, accumulation and every non-GEMM kernel are fp32; f32_bf16x6 splits each fp32 operand "
                                         "exactly into 3 bf16 pieces and sums the 6 largest partial products on the bf16 matrix cores "
                                         "(error vs a float64 product <= that of the native fp32 MFMA: tests/test_gpu_ops.py::"
-                                        "test_gemm_precision_modes; end-to-end parity: tests/test_gpu_e2e.py)",
+                                        "test_gemm_precision_modes; end-to-end parity: tests/test_gpu_e2e.py, tests/test_gpu_configs.py)",
                                 "native_f32_mfma": alt, "backward_reduced": bwd},
             "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": 1e3 * dt_prof / args.steps, "final_loss": final_loss,
         }
+        out.update(extras)
         out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -84,6 +84,36 @@ def select_molecules(n: int, seed: int = 0, min_atoms: int = 1, max_atoms: int =
     return rng.choice(cand, size=n, replace=True).tolist()
 
 
+@lru_cache(maxsize=1)
+def _amide_counts() -> np.ndarray:
+    """per pool molecule: number of amide carbons (a carbon bonded to a terminal oxygen AND a nitrogen) -- the N-C(=O) motif of
+    a peptide backbone, read off the bond graph alone (the pool stores no bond orders)."""
+    P = pool()
+    z, bonds = P["z"], P["bonds"]
+    n_mol = len(P["atom_ptr"]) - 1
+    out = np.zeros(n_mol, dtype=np.int64)
+    for i in range(n_mol):
+        a0, a1 = P["atom_ptr"][i], P["atom_ptr"][i + 1]
+        b = bonds[P["bond_ptr"][i]:P["bond_ptr"][i + 1]].astype(np.int64)
+        zi = z[a0:a1]
+        deg = np.bincount(b.reshape(-1), minlength=a1 - a0)
+        has_o = np.zeros(a1 - a0, dtype=bool)
+        has_n = np.zeros(a1 - a0, dtype=bool)
+        for u, v in ((b[:, 0], b[:, 1]), (b[:, 1], b[:, 0])):
+            has_o[u[(zi[v] == 8) & (deg[v] == 1)]] = True
+            has_n[u[zi[v] == 7]] = True
+        out[i] = int(np.sum((zi == 6) & has_o & has_n))
+    return out
+
+
+def select_dipeptide_like(n: int, seed: int = 0, min_atoms: int = 25, max_atoms: int = 60) -> List[int]:
+    """pool molecules with >= 2 N-C(=O) motifs and 25-60 atoms, sampled with replacement by a seeded rng"""
+    counts = pool_atom_counts()
+    cand = np.nonzero((counts >= min_atoms) & (counts <= max_atoms) & (_amide_counts() >= 2))[0]
+    rng = np.random.default_rng(seed)
+    return rng.choice(cand, size=n, replace=True).tolist()
+
+
 WORKLOADS = {
     # name: (batch, min_atoms, max_atoms, n_confs)   -- BASELINE.json configs, SURVEY.md section 8(d)
     "C1-dipeptide-b8": (8, 25, 60, 32),
@@ -93,8 +123,18 @@ WORKLOADS = {
 }
 
 
+WORKLOAD_DESCRIPTIONS = {
+    "C1-dipeptide-b8": "8 dipeptide-like molecules (>= 2 amide motifs, 25-60 atoms) of the Espaloma pool",
+    "C2-pubchem-b256": "256 small molecules (20-40 atoms) of the Espaloma pool",
+    "C3-espaloma-b1024": "1024 molecules drawn from the whole Espaloma pool (mean ~38 atoms, up to 126)",
+    "C4-espaloma-b4096": "4096 molecules drawn from the whole Espaloma pool (mean ~38 atoms, up to 126)",
+}
+
+
 def workload_molecule_ids(name: str, seed: int = 0) -> List[int]:
     b, lo, hi, _ = WORKLOADS[name]
+    if name.startswith("C1-dipeptide"):
+        return select_dipeptide_like(b, seed=seed, min_atoms=lo, max_atoms=hi)
     return select_molecules(b, seed=seed, min_atoms=lo, max_atoms=hi)
 
 

@@ -52,7 +52,22 @@ def _zeros(shape, like: torch.Tensor) -> torch.Tensor:
 
 
 def _pgrad(p: torch.Tensor) -> torch.Tensor:
-    """gradient buffer of a parameter (kernels accumulate into it)."""
+    """gradient buffer of a parameter (kernels accumulate into it).  A parameter that lives in a `FlatParams` buffer keeps its
+    gradient INSIDE the flat gradient buffer (the all-reduce and the fused Adam read that buffer, not `p.grad`): if something
+    detached it -- `module.zero_grad()` / `optimizer.zero_grad(set_to_none=True)` set `p.grad = None` -- the view is restored and
+    its slice zeroed (which is what the caller asked for); a foreign tensor in `p.grad` is an error."""
+    home = getattr(p, "_grappa_flat", None)
+    if home is not None:
+        flat_grad, lo = home
+        view = flat_grad[lo:lo + p.numel()].view(p.shape)
+        if p.grad is None:
+            view.zero_()
+            p.grad = view
+        elif p.grad.data_ptr() != view.data_ptr():
+            raise RuntimeError("a parameter of a FlatParams buffer has a .grad outside of the flat gradient buffer; use "
+                               "FlatParams.zero_grad() / FusedAdam.zero_grad() (torch.autograd.grad and optimizers that replace "
+                               ".grad are not supported with flat buffers)")
+        return p.grad
     if p.grad is None:
         p.grad = torch.zeros_like(p)
     return p.grad
@@ -91,7 +106,10 @@ def _ln_bwd(be, dy, x, mean, rstd, w, b):
     dx = _new(x.shape, x)
     if x.shape[0] == 0:
         return dx
-    be.layernorm_bwd(dy, x, mean, rstd, w, dx, _pgrad(w), _pgrad(b), accumulate=True)
+    # a frozen affine pair still needs somewhere to put the reductions the kernel produces
+    dw = _pgrad(w) if w.requires_grad else torch.zeros_like(w)
+    db = _pgrad(b) if b.requires_grad else torch.zeros_like(b)
+    be.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, db, accumulate=True)
     return dx
 
 

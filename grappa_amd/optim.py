@@ -14,7 +14,10 @@ from .backend import get_backend
 
 
 class FlatParams:
-    """Re-points every distinct parameter of a module into one contiguous buffer (and its .grad likewise)."""
+    """Re-points every distinct parameter of a module into one contiguous buffer (and its .grad likewise).
+    Invariant: `p.grad` of every parameter is a view of `self.grad`.  `FlatParams.zero_grad()` / `FusedAdam.zero_grad()` keep it;
+    `module.zero_grad()` (set_to_none) breaks it and the next backward pass restores it (ops._pgrad); `torch.autograd.grad` on these
+    parameters is not supported (the kernels write parameter gradients themselves, autograd sees None)."""
 
     def __init__(self, module: torch.nn.Module):
         params, seen = [], set()
@@ -35,6 +38,7 @@ class FlatParams:
             self.data[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.data[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+            p._grappa_flat = (self.grad, off)          # ops._pgrad keeps the gradient inside the flat buffer
             off += sz
         self.params: List[torch.nn.Parameter] = params
         self.numel = total

@@ -26,8 +26,9 @@ from .schedule import TrainSchedule
 
 
 def epoch_batches(names: List[str], batch_size: int, shuffle: bool = True, weights: Dict[str, float] = {}, balance_factor: float = 0.,
-                  generator: Optional[torch.Generator] = None) -> List[np.ndarray]:
-    """molecule ids of every batch of one epoch (the last batch may be smaller), GraphDataLoader semantics"""
+                  generator: Optional[torch.Generator] = None, min_last: int = 1) -> List[np.ndarray]:
+    """molecule ids of every batch of one epoch (the last batch may be smaller), GraphDataLoader semantics.  A trailing batch of
+    fewer than `min_last` molecules is appended to the batch before it (data parallel: every rank needs at least one molecule)."""
     n = len(names)
     assert 0 <= balance_factor <= 1, f"balance_factor must be between 0 and 1, but got {balance_factor}"
     if shuffle and (len(weights) or balance_factor > 0):
@@ -44,7 +45,13 @@ def epoch_batches(names: List[str], batch_size: int, shuffle: bool = True, weigh
         order = torch.randperm(n, generator=generator).numpy()
     else:
         order = np.arange(n)
-    return [order[i:i + batch_size] for i in range(0, n, batch_size)]
+    batches = [order[i:i + batch_size] for i in range(0, n, batch_size)]
+    if len(batches) > 1 and len(batches[-1]) < min_last:
+        tail = batches.pop()
+        batches[-1] = np.concatenate([batches[-1], tail])
+    if batches and len(batches[-1]) < min_last:
+        raise ValueError(f"{n} molecules cannot be dealt to {min_last} ranks")
+    return batches
 
 
 class Trainer:
@@ -93,10 +100,12 @@ class Trainer:
         self.model.train()
         self.schedule.on_train_epoch_start(epoch, self.loss_fn, self.opt)
         total, count = None, 0
-        for ids in epoch_batches(self.train_set.names, self.batch_size, True, self.weights, self.balance_factor, self.gen):
+        for ids in epoch_batches(self.train_set.names, self.batch_size, True, self.weights, self.balance_factor, self.gen, min_last=self.world):
             loss = self.train_step(ids)
             total = loss * len(ids) if total is None else total + loss * len(ids)      # stays on the device
             count += len(ids)
+        if self.world > 1:                 # a rank's loss is its share of sum_m l_m / B_global: the batch loss is the sum over ranks
+            tdist.all_reduce(total, op=tdist.ReduceOp.SUM)
         return float(total) / max(count, 1)                                            # the epoch's only host sync
 
     @torch.no_grad()

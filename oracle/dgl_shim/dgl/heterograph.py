@@ -179,6 +179,31 @@ class DGLGraph:
             g._batch_num_edges = {k: self._batch_num_edges[k] for k in edges}
         return g
 
+    # --- single-node-type helpers used by the reference's water guard (utils/dgl_utils.py:210-234) -------------------
+    def to_networkx(self):
+        """DGLGraph.to_networkx(): a networkx.MultiDiGraph over node ids 0..n-1 with one edge per stored edge."""
+        import networkx as nx
+        assert len(self.canonical_etypes) == 1
+        src, dst = self._edges[self.canonical_etypes[0]]
+        h = nx.MultiDiGraph()
+        h.add_nodes_from(range(self.num_nodes()))
+        h.add_edges_from(zip(src.tolist(), dst.tolist()))
+        return h
+
+    def subgraph(self, nodes):
+        """node-induced subgraph of a single-node-type graph; node features are carried over (DGL's DGLGraph.subgraph)."""
+        assert len(self.ntypes) == 1 and len(self.canonical_etypes) == 1
+        nt, et = self.ntypes[0], self.canonical_etypes[0]
+        nodes = torch.as_tensor(nodes).long()
+        new_id = torch.full((self._num_nodes[nt],), -1, dtype=torch.long)
+        new_id[nodes] = torch.arange(len(nodes))
+        src, dst = self._edges[et]
+        keep = (new_id[src] >= 0) & (new_id[dst] >= 0)
+        g = DGLGraph({et: (new_id[src[keep]], new_id[dst[keep]])}, {nt: len(nodes)})
+        for f, t in self._ndata[nt].items():
+            g._ndata[nt][f] = t[nodes]
+        return g
+
     def __deepcopy__(self, memo):
         g = DGLGraph({k: (v[0].clone(), v[1].clone()) for k, v in self._edges.items()},
                      self._num_nodes)

@@ -391,12 +391,70 @@ def make_tuple_golden():
     print("wrote ref_tuples.npz")
 
 
+def make_predict_golden():
+    """P1: the reference's own `Grappa.predict` (grappa.py:36-57 -> data/Parameters.py:62-140) on four pool molecules with the
+    production config (weights from the state-dict keys), plus `Parameters.from_dgl` on a hand-filled graph that holds exact
+    zeros and both signs in the torsion tables (the >= / > asymmetry) and the two raise conditions."""
+    from grappa.grappa import Grappa as RefGrappa
+    from grappa.data import Parameters as RefParameters
+    cfg = get_default_model_config()
+    torch.manual_seed(0)
+    model = RefGrappaModel(**cfg)
+    model.load_state_dict(keyed_state_dict(model))
+    wrapper = RefGrappa(model, device="cpu")
+    mols = build_inputs(pick_small(2, 10, 22, start=700) + pick_small(1, 30, 45, start=900) + pick_small(1, 6, 12, start=1500, impropers=False),
+                        n_confs=1, seed=41)
+    d = pack_inputs(mols)
+    fields = ["atoms", "bonds", "bond_k", "bond_eq", "angles", "angle_k", "angle_eq", "propers", "proper_ks", "proper_phases",
+              "impropers", "improper_ks", "improper_phases"]
+    for i, m in enumerate(mols):
+        _, mol = ref_graph(m, 1, False)
+        params = wrapper.predict(mol)
+        for f in fields:
+            d[f"pred{i}::{f}"] = np.asarray(getattr(params, f))
+    # from_dgl alone, on a graph whose parameter tables are set by hand
+    g, _ = ref_graph(mols[0], 1, False)
+    rng = np.random.default_rng(5)
+    for lvl, n in (("n4", 6), ("n4_improper", 3)):
+        k = rng.normal(0, 1, size=(g.num_nodes(lvl), n)).astype(np.float32)
+        k[::2, 0] = 0.0
+        k[1::3, 1] = -0.0
+        g.nodes[lvl].data["k"] = torch.from_numpy(k)
+        d[f"hand::{lvl}_k"] = k
+    for lvl, lo, hi in (("n2", 0.9, 1.6), ("n3", 1.6, 2.2)):
+        g.nodes[lvl].data["k"] = torch.from_numpy(rng.uniform(50, 900, g.num_nodes(lvl)).astype(np.float32))
+        g.nodes[lvl].data["eq"] = torch.from_numpy(rng.uniform(lo, hi, g.num_nodes(lvl)).astype(np.float32))
+        d[f"hand::{lvl}_k"], d[f"hand::{lvl}_eq"] = to_np(g.nodes[lvl].data["k"]), to_np(g.nodes[lvl].data["eq"])
+    params = RefParameters.from_dgl(g)
+    for f in fields:
+        d[f"hand::out::{f}"] = np.asarray(getattr(params, f))
+    raised = []
+    for lvl, bad in (("n3", np.pi / 180 * 44.9), ("n2", 0.499)):
+        keep = g.nodes[lvl].data["eq"].clone()
+        g.nodes[lvl].data["eq"] = keep.clone()
+        g.nodes[lvl].data["eq"][1] = bad
+        try:
+            RefParameters.from_dgl(g)
+            raised.append("none")
+        except Exception as e:  # noqa: BLE001
+            raised.append(type(e).__name__)
+        g.nodes[lvl].data["eq"][1] = bad * 1.01          # just above the limit: accepted
+        RefParameters.from_dgl(g)
+        g.nodes[lvl].data["eq"] = keep
+    d["hand::raises"] = np.array(raised)
+    np.savez_compressed(os.path.join(OUT, "ref_predict.npz"), **d)
+    print("wrote ref_predict.npz; raise conditions ->", raised)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "eval":
         make_eval_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "tuples":
         make_tuple_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "predict":
+        make_predict_golden()
     else:
         main()
         make_eval_golden()
         make_tuple_golden()
+        make_predict_golden()

@@ -60,16 +60,22 @@ def param_refs(m, g, n_per=(6, 3), nan_refs=True):
         g.nodes["n3"].data["k_ref"][:2] = float("nan")
 
 
+def molecule_of(m) -> Molecule:
+    """the product's Molecule for one fixture record (the reference run was fed the same graph, charges and features)."""
+    mol = Molecule(atoms=list(range(len(m["z"]))), bonds=[tuple(int(x) for x in b) for b in m["bonds"]],
+                   impropers=[tuple(int(x) for x in r) for r in m["impropers"]],
+                   atomic_numbers=[int(x) for x in m["z"]], partial_charges=[float(x) for x in m["q"]],
+                   charge_model=str(m["charge_model"]))
+    # the featuriser must reproduce what the reference run was fed
+    assert np.array_equal(mol.additional_features["ring_encoding"], m["ring_encoding"])
+    assert np.array_equal(mol.additional_features["degree"], m["degree"])
+    return mol
+
+
 def build_batch(mols, n_confs, with_param_refs=True, n_per=(6, 3), nan_refs=True):
     graphs = []
     for m in mols:
-        mol = Molecule(atoms=list(range(len(m["z"]))), bonds=[tuple(int(x) for x in b) for b in m["bonds"]],
-                       impropers=[tuple(int(x) for x in r) for r in m["impropers"]],
-                       atomic_numbers=[int(x) for x in m["z"]], partial_charges=[float(x) for x in m["q"]],
-                       charge_model=str(m["charge_model"]))
-        # the featuriser must reproduce what the reference run was fed
-        assert np.array_equal(mol.additional_features["ring_encoding"], m["ring_encoding"])
-        assert np.array_equal(mol.additional_features["degree"], m["degree"])
+        mol = molecule_of(m)
         g = mol.to_dgl()
         g.nodes["n1"].data["xyz"] = torch.from_numpy(m["xyz"].copy())
         g.nodes["g"].data["energy_ref"] = torch.from_numpy(m["energy_ref"].copy())

@@ -1,0 +1,195 @@
+"""GPU (-m gpu): every BASELINE.json configuration on the HIP path, checked against the oracle.
+
+  C1  8 dipeptide-like molecules x 32 conformations: the whole train step (parameters, energies, forces, loss AND every
+      parameter gradient) against oracle/cpu_ref.py on the same batch.
+  C3  1024 molecules x 32 conformations at full size on the GPU; 16 sampled molecules are recomputed by the oracle ALONE
+      (the model is block diagonal over molecules: batching invariance, reference tests/unbatch.py) and must match their rows of
+      the big batch -- default arithmetic at 1e-4, the bf16 modes at the gates SURVEY 8(d) states.
+  C4  4096 molecules dealt to 8 ranks (dist.shard_indices): rank 0's 512-molecule shard at full size with the same sampled
+      check, and the data-parallel identity  sum over 8 shards of grad == sum over 2 shards of grad  for the same 4096 molecules
+      (every shard run on this one GPU, loss scaled by 1/4096 as under DDP).
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+FLOORS = {"k": 1e-3, "kt": 5e-2, "eq": 1e-4}        # tests/test_host_model.py
+LOSS_KW = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
+LEVELS = ["n2", "n3", "n4", "n4_improper"]
+
+
+def _model(train=False):
+    from grappa_amd import get_default_model_config, model_from_config
+    cfg = get_default_model_config()
+    model = model_from_config(cfg)
+    sd = gu.keyed_state_dict(model)
+    model.load_state_dict(sd)
+    model = model.to("cuda")
+    return (model.train() if train else model.eval()), cfg, sd
+
+
+def _oracle(cfg, sd):
+    from oracle import cpu_ref
+    ref = cpu_ref.RefGrappaModel(**cfg)
+    ref.load_state_dict(sd)
+    return ref.eval()
+
+
+def _rows(plan, lvl, b):
+    p = plan.atom_molptr if lvl == "n1" else plan.mol_ptr[lvl]
+    return int(p[b]), int(p[b + 1])
+
+
+def _check_sampled_molecules(g, ids, sample, cfg, sd, tol_k, tol_eq, check_forces=True, floors=FLOORS):
+    """molecules `sample` (positions in the batch) recomputed alone by the oracle == their rows of the big GPU batch"""
+    from grappa_amd.datasets import build_batch_from_pool
+    from oracle import cpu_ref
+    plan = g.plan()
+    ref = _oracle(cfg, sd)
+    C = g.nodes["n1"].data["xyz"].shape[1]
+    worst = {}
+    for b in sample:
+        g1 = build_batch_from_pool([ids[b]], n_confs=C, seed=0)
+        with torch.no_grad():
+            rg = ref(g1)
+        rg = cpu_ref.RefEnergy()(rg) if check_forces else rg
+        for lvl in LEVELS:
+            r0, r1 = _rows(plan, lvl, b)
+            assert r1 - r0 == rg.num_nodes(lvl)
+            e = gu.rel_err(g.nodes[lvl].data["k"][r0:r1].detach().cpu(), rg.nodes[lvl].data["k"].detach().numpy(),
+                           floors["kt" if lvl.startswith("n4") else "k"])
+            worst[lvl + "_k"] = max(worst.get(lvl + "_k", 0.0), e)
+            assert e < tol_k, (b, lvl, e)
+            if lvl in ("n2", "n3"):
+                e = gu.rel_err(g.nodes[lvl].data["eq"][r0:r1].detach().cpu(), rg.nodes[lvl].data["eq"].detach().numpy(), floors["eq"])
+                worst[lvl + "_eq"] = max(worst.get(lvl + "_eq", 0.0), e)
+                assert e < tol_eq, (b, lvl, e)
+        if check_forces:
+            a0, a1 = _rows(plan, "n1", b)
+            eE = gu.rel_err_scaled(g.nodes["g"].data["energy"][b:b + 1].detach().cpu(), rg.nodes["g"].data["energy"].detach().numpy(), 1e-3, 1e-3)
+            eG = gu.rel_err_scaled(g.nodes["n1"].data["gradient"][a0:a1].detach().cpu(), rg.nodes["n1"].data["gradient"].detach().numpy(), 1e-2, 1e-2)
+            worst["E"], worst["G"] = max(worst.get("E", 0.0), eE), max(worst.get("G", 0.0), eG)
+            assert eE < tol_k and eG < tol_k, (b, eE, eG)
+    return worst
+
+
+def test_c1_dipeptide_batch_train_step_against_oracle():
+    """BASELINE configs[0]: 8 dipeptide-like molecules, 32 conformations, production model; dropout off on both sides."""
+    from grappa_amd import Energy, MolwiseLoss
+    from grappa_amd.datasets import build_workload, workload_molecule_ids
+    from grappa_amd.optim import FlatParams
+    from oracle import cpu_ref
+    model, cfg, sd = _model()
+    flat = FlatParams(model)
+    flat.zero_grad()
+    ids = workload_molecule_ids("C1-dipeptide-b8", seed=0)
+    assert len(ids) == 8
+    g = Energy()(model(build_workload("C1-dipeptide-b8", seed=0).to("cuda")))
+    assert g.nodes["n1"].data["xyz"].shape[1] == 32
+    loss = MolwiseLoss(**LOSS_KW)(g)
+    loss.backward()
+    ref = _oracle(cfg, sd)
+    rg = cpu_ref.RefEnergy()(ref(build_workload("C1-dipeptide-b8", seed=0)))
+    rloss = cpu_ref.RefMolwiseLoss(**LOSS_KW)(rg)
+    rloss.backward()
+    for lvl in LEVELS:
+        assert torch.equal(g.nodes[lvl].data["idxs"].cpu(), rg.nodes[lvl].data["idxs"])
+        assert gu.rel_err(g.nodes[lvl].data["k"].detach().cpu(), rg.nodes[lvl].data["k"].detach().numpy(), FLOORS["kt" if lvl.startswith("n4") else "k"]) < TOL, lvl
+        if lvl in ("n2", "n3"):
+            assert gu.rel_err(g.nodes[lvl].data["eq"].detach().cpu(), rg.nodes[lvl].data["eq"].detach().numpy(), FLOORS["eq"]) < TOL, lvl
+    assert gu.rel_err(g.nodes["n1"].data["h"].detach().cpu(), rg.nodes["n1"].data["h"].detach().numpy(), 1e-1) < TOL
+    assert gu.rel_err_scaled(g.nodes["g"].data["energy"].detach().cpu(), rg.nodes["g"].data["energy"].detach().numpy(), 1e-3, 1e-3) < TOL
+    assert gu.rel_err_scaled(g.nodes["n1"].data["gradient"].detach().cpu(), rg.nodes["n1"].data["gradient"].detach().numpy(), 1e-2, 1e-2) < TOL
+    assert abs(float(loss) - float(rloss)) <= TOL * abs(float(rloss))
+    rgrads = dict(ref.named_parameters())
+    worst, n = 0.0, 0
+    for k, p in model.named_parameters():
+        r = rgrads[k].grad
+        if r is None:
+            continue
+        e = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-8)
+        worst, n = max(worst, e), n + 1
+        assert e < TOL, (k, e)               # SURVEY 8(d) gate: 1e-4 of the tensor's scale
+    assert n > 150
+    print("C1: worst parameter-gradient error vs oracle (fraction of the tensor's max):", worst)
+
+
+def test_c3_batch_1024_sampled_molecules_against_oracle():
+    """BASELINE configs[2] at full size; default arithmetic 1e-4, bf16x3 2e-3, bf16 2e-2 against the ORACLE."""
+    from grappa_amd import Energy
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_workload, workload_molecule_ids
+    be = get_backend()
+    model, cfg, sd = _model()
+    ids = workload_molecule_ids("C3-espaloma-b1024", seed=0)
+    g_cpu = build_workload("C3-espaloma-b1024", seed=0)
+    assert g_cpu.plan().B == 1024
+    sample = np.random.default_rng(3).choice(1024, size=16, replace=False).tolist()
+    sample[0] = int(np.argmax(np.diff(g_cpu.plan().atom_molptr.numpy())))      # the largest molecule of the batch is always in
+    default = be.gemm_precision_name
+    try:
+        for mode, tk, teq, forces in ((default, TOL, TOL, True), ("bf16x3", 2e-3, 2e-3, False), ("bf16", 2e-2, 2e-2, False)):
+            be.set_gemm_precision(mode)
+            with torch.no_grad():
+                g = model(g_cpu.to("cuda"))
+                if forces:
+                    g = Energy()(g)
+            # floors of the reduced modes: half the output scale of the head (k = c * k_std + k_mean: std 0.5 .. 4)
+            floors = FLOORS if mode == default else {"k": 1.0, "kt": 0.5, "eq": FLOORS["eq"]}
+            worst = _check_sampled_molecules(g, ids, sample, cfg, sd, tk, teq, check_forces=forces, floors=floors)
+            print(f"C3 [{mode}] worst relative errors vs oracle over 16 sampled molecules:", {k: f"{v:.2e}" for k, v in worst.items()})
+    finally:
+        be.set_gemm_precision(default)
+
+
+def test_c4_shard_of_4096_against_oracle_and_gradient_sum_over_shards():
+    """BASELINE configs[3]: 4096 molecules, 512 per GPU."""
+    from grappa_amd import Energy, MolwiseLoss
+    from grappa_amd.datasets import build_batch_from_pool, pool_atom_counts, workload_molecule_ids
+    from grappa_amd.dist import shard_indices
+    from grappa_amd.optim import FlatParams
+    model, cfg, sd = _model()
+    flat = FlatParams(model)
+    ids = workload_molecule_ids("C4-espaloma-b4096", seed=0)
+    assert len(ids) == 4096
+    sizes = [int(pool_atom_counts()[i]) for i in ids]
+    loss_fn = MolwiseLoss(**LOSS_KW)
+    loss_fn.global_batch_size = 4096
+    sums, losses = {}, {}
+    for world in (8, 2):
+        total = torch.zeros_like(flat.grad)
+        tot_loss = 0.0
+        seen = []
+        for rank in range(world):
+            mine = shard_indices(sizes, world, rank)
+            seen += mine
+            shard_ids = [ids[j] for j in mine]
+            flat.zero_grad()
+            g = Energy()(model(build_batch_from_pool(shard_ids, n_confs=32, seed=0).to("cuda")))
+            loss = loss_fn(g)
+            loss.backward()
+            total += flat.grad
+            tot_loss += float(loss)
+            if world == 8 and rank == 0:
+                assert g.plan().B == 512
+                sample = np.random.default_rng(4).choice(512, size=16, replace=False).tolist()
+                worst = _check_sampled_molecules(g, shard_ids, sample, cfg, sd, TOL, TOL)
+                print("C4 shard 0 (512 molecules) worst relative errors vs oracle over 16 sampled molecules:", {k: f"{v:.2e}" for k, v in worst.items()})
+            del g, loss
+        assert sorted(seen) == list(range(4096))                  # the shards partition the batch
+        sums[world], losses[world] = total, tot_loss
+    assert abs(losses[8] - losses[2]) <= 1e-5 * abs(losses[2])
+    scale = float(sums[2].abs().max())
+    assert scale > 0 and float((sums[8] - sums[2]).abs().max()) <= 1e-4 * scale
+    # per parameter tensor as well (small tensors must not hide behind the largest one)
+    for p in flat.params:
+        lo, hi = flat._offsets[id(p)]
+        a, b = sums[8][lo:hi], sums[2][lo:hi]
+        s = float(b.abs().max())
+        if s > 0:
+            assert float((a - b).abs().max()) <= 1e-3 * s

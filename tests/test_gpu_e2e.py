@@ -54,7 +54,7 @@ def test_small_configs_against_reference_goldens(name, n_confs, refs):
         if ref is None:
             continue
         scale = max(float(np.abs(ref).max()), 1e-8)
-        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / scale < 2e-3, k
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / scale < TOL, k      # 1e-4 of the tensor's scale
         n += 1
     assert n > 50
 
@@ -77,7 +77,7 @@ def test_production_config_against_reference_golden():
     checked = 0
     for k, p in model.named_parameters():
         if k in norms and norms[k] > 1e-6:
-            assert abs(float(p.grad.norm()) - norms[k]) / norms[k] < 5e-3, k
+            assert abs(float(p.grad.norm()) - norms[k]) / norms[k] < TOL, k
             checked += 1
     assert checked > 150
 
@@ -126,7 +126,7 @@ def test_production_config_against_oracle_on_a_larger_batch():
             continue
         scale = max(float(r.abs().max()), 1e-8)
         worst = max(worst, float((p.grad.cpu() - r).abs().max()) / scale)
-        assert float((p.grad.cpu() - r).abs().max()) / scale < 5e-3, k
+        assert float((p.grad.cpu() - r).abs().max()) / scale < TOL, k
     print("worst relative parameter-gradient error vs oracle:", worst)
 
 

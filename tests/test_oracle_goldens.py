@@ -50,7 +50,7 @@ def test_small_config_matches_reference(name, n_confs, refs):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         scale = max(float(np.abs(ref).max()), 1e-8)
-        assert float(np.abs(p.grad.numpy() - ref).max()) / scale < 2e-3, k
+        assert float(np.abs(p.grad.numpy() - ref).max()) / scale < TOL, k      # measured: 1e-6
         n += 1
     assert n > 50
     if "is_dummy" in fx.files:

@@ -26,4 +26,4 @@ def test_production_golden_matches_oracle():
     norms = dict(zip(out["grad_norm_keys"].tolist(), out["grad_norm_vals"].tolist()))
     for k, p in model.named_parameters():
         if k in norms and norms[k] > 1e-6:
-            assert abs(float(p.grad.norm()) - norms[k]) / norms[k] < 2e-3, k
+            assert abs(float(p.grad.norm()) - norms[k]) / norms[k] < 2e-5, k      # measured: 1e-6

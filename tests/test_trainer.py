@@ -70,3 +70,80 @@ def test_trainer_cpu(ref_backend):
 @pytest.mark.gpu
 def test_trainer_gpu():
     _run("cuda")
+
+
+def test_epoch_batches_merge_a_short_tail_for_data_parallel_runs():
+    from grappa_amd.trainer import epoch_batches
+    names = ["a"] * 9
+    assert [len(x) for x in epoch_batches(names, 4, shuffle=False)] == [4, 4, 1]
+    assert [len(x) for x in epoch_batches(names, 4, shuffle=False, min_last=2)] == [4, 5]       # 9 % 4 == 1 < 2 ranks
+    assert [len(x) for x in epoch_batches(names, 4, shuffle=False, min_last=1)] == [4, 4, 1]
+    with pytest.raises(ValueError):
+        epoch_batches(["a"], 4, shuffle=False, min_last=2)
+
+
+def _dp_trainer_worker(rank, world, port, out_q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from grappa_amd import GrappaModel, backend, ops
+    from grappa_amd.device_dataset import DeviceDataset
+    from grappa_amd.dist import init_process_group_from_env
+    from grappa_amd.trainer import Trainer
+    from oracle.ops_ref import RefBackend
+    import torch.distributed as dist
+    backend.set_backend(RefBackend())
+    init_process_group_from_env("gloo")
+    torch.manual_seed(0)
+    ops.manual_seed(5)
+    model = GrappaModel(**TINY)
+    train = DeviceDataset(_items(list(range(300, 309))), device="cpu")          # 9 molecules, batches of 4: 9 % 4 == 1 < 2 ranks
+    tr = Trainer(model, train, None, batch_size=4, conf_strategy=4, lr=2e-3, start_qm_epochs=0, warmup_steps=2, energy_weight=1.0,
+                 gradient_weight=0.8, param_weight=0.0)
+    hist = tr.fit(2)
+    out_q.put((rank, [h["train_loss"] for h in hist], float(tr.flat.data.double().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_gloo_with_a_tail_batch_smaller_than_the_world():
+    """len(dataset) % batch_size == 1 with two ranks used to leave one rank without molecules (hang in the all-reduce).
+    Both ranks must finish, log the same (all-reduced) epoch loss and hold identical parameters."""
+    import torch.multiprocessing as mp
+    from test_host_train import _free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    (_, l0, s0), (_, l1, s1) = res
+    assert l0 == l1 and all(np.isfinite(l0)) and s0 == s1
+
+
+def test_flat_gradient_views_survive_zero_grad_set_to_none(ref_backend):
+    """`module.zero_grad()` (set_to_none) detaches p.grad from the flat gradient buffer; the next backward pass must
+    write into the flat buffer again (fused Adam / the all-reduce read that buffer), starting from zero."""
+    from grappa_amd import GrappaModel
+    from grappa_amd.optim import FlatParams
+    from test_host_train import _loss
+    torch.manual_seed(0)
+    model = GrappaModel(**TINY).eval()
+    flat = FlatParams(model)
+    _loss(model, [30, 31], 5).backward()
+    want = flat.grad.clone()
+    assert float(want.abs().max()) > 0
+    model.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in flat.params)
+    _loss(model, [30, 31], 5).backward()
+    assert torch.equal(flat.grad, want)                       # not doubled, not stale: restored views, slices zeroed first
+    assert all(p.grad.data_ptr() == flat.grad[flat._offsets[id(p)][0]:].data_ptr() for p in flat.params)
+    flat.params[0].grad = torch.zeros_like(flat.params[0])    # a foreign tensor is refused
+    with pytest.raises(RuntimeError):
+        _loss(model, [30, 31], 5).backward()

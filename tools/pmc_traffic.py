@@ -11,8 +11,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FAMILIES = {"gemm_f32": r"gemm_f32_kernel|gemm_bf16x_kernel", "gemm_bf16x": r"gemm_bf16x_kernel", "gemm_splitk_reduce": r"gemm_splitk_reduce_kernel", "gat_fwd": r"gat_fwd_kernel",
             "gat_bwd": r"gat_bwd_kernel|gat_delta_kernel", "layernorm": r"layernorm_", "seqattn": r"seqattn_"}
@@ -35,7 +38,9 @@ def main():
     fdir, wdir = sys.argv[1], sys.argv[2]
     ft, fc = collect(fdir, "FETCH_SIZE")
     wt, wc = collect(wdir, "WRITE_SIZE")
+    from bench import kernel_source_hash
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1",
+           "kernel_source_hash": kernel_source_hash(),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "families": {}}
     for fam in FAMILIES:
         if fc[fam] == 0:
