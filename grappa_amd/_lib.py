@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hip.so")   # override: kernel A/B builds (tools/)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
 GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4}
 
@@ -23,7 +23,12 @@ class GemmDesc(C.Structure):
                 ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
                 ("C2", C.c_void_p), ("ldc2", C.c_int), ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int),
                 ("aux", C.c_void_p), ("ldaux", C.c_int), ("pre", C.c_void_p), ("ldpre", C.c_int), ("a_colsum", C.c_void_p), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
-                ("accumulate", C.c_int), ("precision", C.c_int)]
+                ("accumulate", C.c_int), ("precision", C.c_int),
+                # plane format (ABI 3)
+                ("a_planes", C.c_int), ("b_planes", C.c_int), ("a_plane_stride", C.c_size_t), ("b_plane_stride", C.c_size_t),
+                ("Cp", C.c_void_p), ("ldcp", C.c_int), ("cp_plane_stride", C.c_size_t),
+                ("resp", C.c_void_p), ("ldresp", C.c_int), ("resp_plane_stride", C.c_size_t),
+                ("auxp", C.c_void_p), ("ldauxp", C.c_int), ("auxp_plane_stride", C.c_size_t)]
 
 
 class MMDesc(C.Structure):

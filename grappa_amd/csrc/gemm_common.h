@@ -23,12 +23,52 @@ struct GemmParams {
     int vec_io;            // every epilogue tensor is 16-byte aligned with a leading dimension % 4 == 0 (float4 epilogue)
 };
 
+// ---- plane format (include/grappa_hip.h): X = P0 + P1 + P2, three bf16 planes
+__device__ inline float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+__device__ inline float planes_load1(const uint16_t* __restrict__ p, size_t stride, size_t idx) {
+    return (bf16_bits_to_f32(p[idx]) + bf16_bits_to_f32(p[idx + stride])) + bf16_bits_to_f32(p[idx + 2 * stride]);   // exact: 8 + 8 + 8 bits
+}
+// four consecutive elements (8-byte aligned)
+__device__ inline void planes_load4(const uint16_t* __restrict__ p, size_t stride, size_t idx, float (&v)[4]) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p + idx), b = *reinterpret_cast<const uint2*>(p + idx + stride),
+                c = *reinterpret_cast<const uint2*>(p + idx + 2 * stride);
+    v[0] = (__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16)) + __uint_as_float(c.x << 16);
+    v[1] = (__uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u)) + __uint_as_float(c.x & 0xffff0000u);
+    v[2] = (__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16)) + __uint_as_float(c.y << 16);
+    v[3] = (__uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u)) + __uint_as_float(c.y & 0xffff0000u);
+}
+typedef __bf16 grappa_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ inline void planes_store4(uint16_t* __restrict__ p, size_t stride, size_t idx, const float (&v)[4]) {
+    float r[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        grappa_bf16x2 h01, h23;
+        h01[0] = (__bf16)r[0]; h01[1] = (__bf16)r[1];
+        h23[0] = (__bf16)r[2]; h23[1] = (__bf16)r[3];
+        const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+        *reinterpret_cast<uint2*>(p + idx + pl * stride) = make_uint2(u01, u23);
+        if (pl < 2) {
+            r[0] -= __uint_as_float(u01 << 16); r[1] -= __uint_as_float(u01 & 0xffff0000u);
+            r[2] -= __uint_as_float(u23 << 16); r[3] -= __uint_as_float(u23 & 0xffff0000u);
+        }
+    }
+}
+__device__ inline void planes_store1(uint16_t* __restrict__ p, size_t stride, size_t idx, float v) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const __bf16 h = (__bf16)v;
+        p[idx + pl * stride] = __builtin_bit_cast(uint16_t, h);
+        v -= (float)h;
+    }
+}
+
 __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v) {
     const grappa_gemm_desc& d = p.d;
     if (d.pre) v += d.pre[(size_t)m * d.ldpre + n];
     if (d.bias) v += d.bias[n];
     if (d.act == GRAPPA_ACT_ELU) v = grappa_elu(v);
     if (d.aux) v *= grappa_elu_grad_from_out(d.aux[(size_t)m * d.ldaux + n]);
+    else if (d.auxp) v *= grappa_elu_grad_from_out(planes_load1(d.auxp, d.auxp_plane_stride, (size_t)m * d.ldauxp + n));
     float* out = d.C;
     int ldo = d.ldc;
     if (d.C2) {
@@ -38,9 +78,13 @@ __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v
     }
     if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
     if (d.res) v += d.res[(size_t)m * d.ldres + n];
-    float* o = out + (size_t)m * ldo + n;
-    if (d.accumulate) v += *o;
-    *o = v;
+    else if (d.resp) v += planes_load1(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n);
+    if (out) {
+        float* o = out + (size_t)m * ldo + n;
+        if (d.accumulate) v += *o;
+        *o = v;
+    }
+    if (d.Cp) planes_store1(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v);
 }
 
 
@@ -88,6 +132,12 @@ __device__ inline void tile_epilogue(const GemmParams& p, const f32x16 (&acc)[TM
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     if (ncol[j] < d.N) srow[ncol[j]] = acc[i][j][e];
+                continue;
+            }
+            if (d.Cp || d.resp || d.auxp || !d.C) {                 // plane-format epilogue tensors: element-wise path
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (ncol[j] < d.N) epilogue_store(p, m, ncol[j], acc[i][j][e]);
                 continue;
             }
             const float* pre_r = d.pre ? d.pre + (size_t)m * d.ldpre : nullptr;
@@ -173,8 +223,13 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
             const float4 t = *reinterpret_cast<const float4*>(d.aux + (size_t)m * d.ldaux + n);
             v[0] *= grappa_elu_grad_from_out(t.x); v[1] *= grappa_elu_grad_from_out(t.y);
             v[2] *= grappa_elu_grad_from_out(t.z); v[3] *= grappa_elu_grad_from_out(t.w);
+        } else if (d.auxp) {
+            float t[4];
+            planes_load4(d.auxp, d.auxp_plane_stride, (size_t)m * d.ldauxp + n, t);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] *= grappa_elu_grad_from_out(t[q]);
         }
-        float* o = d.C + (size_t)m * d.ldc + n;
+        float* o = d.C ? d.C + (size_t)m * d.ldc + n : nullptr;
         if (d.C2) {
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
             o = d.C2 + (size_t)m * d.ldc2 + n;
@@ -187,12 +242,19 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
         if (d.res) {
             const float4 t = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
             v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        } else if (d.resp) {
+            float t[4];
+            planes_load4(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, t);
+            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
         }
-        if (d.accumulate) {
-            const float4 t = *reinterpret_cast<const float4*>(o);
-            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        if (o) {
+            if (d.accumulate) {
+                const float4 t = *reinterpret_cast<const float4*>(o);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (d.Cp) planes_store4(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v);
     }
 }
 

@@ -19,6 +19,7 @@
 using namespace grappa_gemm;
 
 int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool vec_kcontig);   // gemm_bf16x.hip
+int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision);                      // gemm_planes.hip
 
 namespace {
 
@@ -317,7 +318,7 @@ struct CostModel {
     static double splitk(int nsplit, double elems) { return 12000.0 + nsplit * elems / 200.0; }   // two launches + slab write / reduce
 };
 
-Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false) {
+Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool planes = false) {
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
@@ -332,8 +333,9 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false) {
     int max_tail_split = K >= 8 * BK ? K / (4 * BK) : 1;      // the tail may be cut finer than a full split-K GEMM
     if (max_tail_split > 64) max_tail_split = 64;
     for (int c = 0; c < NCFG; ++c) {
-        if (g_override.cfg >= 0 && c != g_override.cfg) continue;
+        if (g_override.cfg >= 0 && c != g_override.cfg && !planes) continue;
         if (bf16x != (c >= 5)) continue;
+        if (planes && c != 6) continue;                  // the plane-format kernel has the 256 x 128 tile only
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
@@ -420,6 +422,8 @@ extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
     if (use_bf16x(M, N, GRAPPA_GEMM_F32_BF16X9)) {
         const size_t c = plan_workspace_floats(make_plan(M, N, K, true, true), M, N);
         if (c > a) a = c;
+        const size_t e = plan_workspace_floats(make_plan(M, N, K, true, true, true), M, N);
+        if (e > a) a = e;
     }
     return a * sizeof(float);
 }
@@ -444,7 +448,20 @@ extern "C" void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail)
 }
 
 extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes) {
-    if (!d || !d->A || !d->B || !d->C) return GRAPPA_ERR_ARG;
+    if (!d || !d->A || !d->B || (!d->C && !d->Cp)) return GRAPPA_ERR_ARG;
+    if (!d->C && (d->C2 || d->accumulate)) return GRAPPA_ERR_ARG;
+    if ((d->a_planes != 0) != (d->b_planes != 0)) return GRAPPA_ERR_ARG;
+    const bool planes = d->a_planes != 0;
+    if (planes) {
+        auto ok = [](const void* q, int ld, int cols) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 7) == 0 && ld >= cols; };
+        const int kpad = (d->K + 31) / 32 * 32;
+        if (d->M <= 32 || d->N <= 32 || d->a_kcontig != d->b_kcontig) return GRAPPA_ERR_ARG;
+        if (d->a_kcontig ? !(ok(d->A, d->lda, kpad) && ok(d->B, d->ldb, kpad)) : !(ok(d->A, d->lda, d->M) && ok(d->B, d->ldb, d->N))) return GRAPPA_ERR_ARG;
+        const size_t arows = d->a_kcontig ? (size_t)d->M : (size_t)kpad, brows = d->b_kcontig ? (size_t)d->N : (size_t)kpad;
+        if (arows * d->lda * 2 >= (1ull << 32) || brows * d->ldb * 2 >= (1ull << 32)) return GRAPPA_ERR_ARG;
+    }
+    auto al8 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 7) == 0 && (ld & 3) == 0); };
+    if (!al8(d->Cp, d->ldcp) || !al8(d->resp, d->ldresp) || !al8(d->auxp, d->ldauxp)) return GRAPPA_ERR_ARG;
     if (d->M < 0 || d->N < 0 || d->K < 0) return GRAPPA_ERR_ARG;
     if (d->M == 0 || d->N == 0) return GRAPPA_OK;
     if (d->K == 0) return GRAPPA_ERR_ARG;
@@ -464,8 +481,8 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
     p.vec_io = al16(d->C, d->ldc) && al16(d->C2, d->ldc2) && al16(d->pre, d->ldpre) && al16(d->res, d->ldres) && al16(d->aux, d->ldaux);
     if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
-    const bool bf16x = use_bf16x(d->M, d->N, d->precision);
-    Plan pl = make_plan(d->M, d->N, d->K, vec, bf16x);
+    const bool bf16x = planes || use_bf16x(d->M, d->N, d->precision);
+    Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
     if (need > 0 && (!ws || ws_bytes < need)) return GRAPPA_ERR_WORKSPACE;
@@ -488,7 +505,8 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             p.cs_slab = p.slab + (size_t)nsplit * ntiles * te;
         }
         int rc;
-        if (bf16x) rc = grappa_launch_gemm_bf16x(st, p, d->precision, vec);
+        if (planes) rc = grappa_launch_gemm_planes(st, p, d->precision);
+        else if (bf16x) rc = grappa_launch_gemm_bf16x(st, p, d->precision, vec);
         else if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
         else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
         else rc = dispatch<false, false>(st, p, pl.cfg, vec);

@@ -27,7 +27,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 2
+#define GRAPPA_ABI_VERSION 3
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -87,6 +87,19 @@ typedef struct grappa_gemm_desc {
     uint64_t drop_seed;
     int accumulate;
     int precision;                /* GRAPPA_GEMM_* */
+    /* ---- plane format (ABI 3; everything below may be 0 / NULL).  A matrix X "in planes" is three bf16 matrices P0, P1, P2 of
+     * X's shape, P0 = bf16(X), P1 = bf16(X - P0), P2 = bf16(X - P0 - P1), X == P0 + P1 + P2 exactly; plane p starts
+     * `*_plane_stride` ELEMENTS after plane 0, leading dimensions are in bf16 elements and multiples of 8, bases 16-byte aligned.
+     * a_planes / b_planes != 0: A / B point to plane 0 (the pointer types above are then nominal).  Both or neither.  The planes
+     * must be zero beyond K up to the next multiple of 32 along k (columns of a K-contiguous operand: ld >= round_up(K, 32);
+     * rows of a k-major one), rows * ld * 2 < 2^32, and M, N > 32.  Layouts: a_kcontig = b_kcontig = 1 (forward; dgrad with the
+     * TRANSPOSED weight planes) or both 0 (wgrad).  The operands are split ONCE by their producer (grappa_split_planes_f32,
+     * grappa_weight_planes, the *_planes outputs of the row-wise kernels, Cp below) instead of by every GEMM that reads them. */
+    int a_planes, b_planes;
+    size_t a_plane_stride, b_plane_stride;
+    uint16_t* Cp; int ldcp; size_t cp_plane_stride;               /* planes of the FINAL value (what OUT receives); C may be NULL then */
+    const uint16_t* resp; int ldresp; size_t resp_plane_stride;   /* residual given in planes (instead of res) */
+    const uint16_t* auxp; int ldauxp; size_t auxp_plane_stride;   /* saved ELU output given in planes (instead of aux) */
 } grappa_gemm_desc;
 
 size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);

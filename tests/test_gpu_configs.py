@@ -62,7 +62,7 @@ def _check_sampled_molecules(g, ids, sample, cfg, sd, tol_k, tol_eq, check_force
             r0, r1 = _rows(plan, lvl, b)
             assert r1 - r0 == rg.num_nodes(lvl)
             e = gu.rel_err(g.nodes[lvl].data["k"][r0:r1].detach().cpu(), rg.nodes[lvl].data["k"].detach().numpy(),
-                           floors["kt" if lvl.startswith("n4") else "k"])
+                           floors.get("kti", floors["kt"]) if lvl == "n4_improper" else floors["kt" if lvl == "n4" else "k"])
             worst[lvl + "_k"] = max(worst.get(lvl + "_k", 0.0), e)
             assert e < tol_k, (b, lvl, e)
             if lvl in ("n2", "n3"):
@@ -140,7 +140,7 @@ def test_c3_batch_1024_sampled_molecules_against_oracle():
                 if forces:
                     g = Energy()(g)
             # floors of the reduced modes: half the output scale of the head (k = c * k_std + k_mean: std 0.5 .. 4)
-            floors = FLOORS if mode == default else {"k": 1.0, "kt": 0.5, "eq": FLOORS["eq"]}
+            floors = FLOORS if mode == default else {"k": 1.0, "kt": 0.5, "kti": 2.0, "eq": FLOORS["eq"]}
             worst = _check_sampled_molecules(g, ids, sample, cfg, sd, tk, teq, check_forces=forces, floors=floors)
             print(f"C3 [{mode}] worst relative errors vs oracle over 16 sampled molecules:", {k: f"{v:.2e}" for k, v in worst.items()})
     finally:
