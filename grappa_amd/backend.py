@@ -85,6 +85,13 @@ class HipBackend:
         # untouched by it; the reference itself trains with torch.set_float32_matmul_precision('medium') (training/trainrun.py:3).
         self.set_gemm_precision_bwd(os.environ.get("GRAPPA_GEMM_PRECISION_BWD") or None)
         self._prof = None      # list of (kernel family, algorithmic flops, algorithmic bytes, start event, end event) when profiling
+        # opt-in (GRAPPA_WEIGHT_PLANES=1): forward and dgrad products read the weight matrix from its bf16 planes (split once per
+        # optimiser step, both orientations) through LDS-DMA instead of re-splitting it in every workgroup of every launch
+        # (csrc/gemm_planes.hip gemm_wplanes_kernel).  Results are bit-identical to the default; measured speed is the same within
+        # +-3 %, which is why it is not the default.
+        self.weight_planes = os.environ.get("GRAPPA_WEIGHT_PLANES", "0") not in ("0", "")
+        self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
+        self._wepoch = 0
 
     def set_gemm_precision(self, name: str) -> None:
         if name not in _lib.GEMM_PRECISIONS:
@@ -97,6 +104,30 @@ class HipBackend:
             raise ValueError(f"gemm precision {name!r}: expected one of {sorted(_lib.GEMM_PRECISIONS)}")
         self.gemm_precision_bwd_name = name
         self.gemm_precision_bwd = None if name is None else _lib.GEMM_PRECISIONS[name]
+
+    # ------------------------------------------------------------------ weight planes
+    def invalidate_weight_planes(self) -> None:
+        """the parameters were changed behind torch's back (fused Adam writes the flat buffer through the C ABI)"""
+        self._wepoch += 1
+
+    def _planes_of_weight(self, w: torch.Tensor, transposed: bool) -> torch.Tensor:
+        """bf16 planes (3, rows_pad, cols_pad) of W (rows x cols) or of W^T; zero padded to multiples of 32, cached per weight and
+        refreshed when the weight changed (torch's version counter for in-place torch ops, the epoch for the fused Adam)"""
+        R, Cc = w.shape
+        key = (w.data_ptr(), R, Cc, transposed)
+        ver = (w._version, self._wepoch)
+        hit = self._wplanes.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        rows, cols = (Cc, R) if transposed else (R, Cc)
+        if hit is not None:
+            planes = hit[1]
+        else:
+            planes = torch.zeros((3, (rows + 31) // 32 * 32, (cols + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
+        _chk(self.lib.grappa_split_planes_f32(self._stream(), R, Cc, w.data_ptr(), _f32_2d(w, "W", w.device), planes.data_ptr(), planes.stride(1),
+                                              planes.stride(0), int(transposed)), "grappa_split_planes_f32")
+        self._wplanes[key] = (ver, planes)
+        return planes
 
     # ------------------------------------------------------------------ in-process kernel timing (bench.py roofline)
     def start_profile(self) -> None:
@@ -186,6 +217,12 @@ class HipBackend:
             return
         if K == 0:
             raise ValueError("gemm: K == 0")
+        if (self.weight_planes and a_kcontig and b.requires_grad and M > 32 and N > 32 and K % 32 == 0 and a_colsum is None
+                and d.precision != _lib.GEMM_PRECISIONS["f32"] and a.data_ptr() % 16 == 0 and d.lda % 4 == 0):
+            # B is a weight matrix: forward reads the planes of W[N,K]; dgrad (B given as W[K,N] rows) the planes of W^T
+            planes = self._planes_of_weight(b, transposed=not b_kcontig)
+            d.B, d.ldb, d.b_kcontig = planes.data_ptr(), planes.stride(1), 1
+            d.b_planes, d.b_plane_stride = 1, planes.stride(0)
         need = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
         ws = self._workspace(need, dev) if need else None
         self._timed("gemm_f32", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),

@@ -94,8 +94,7 @@ __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v
 struct TileCoord {
     int split, tile_local, tile_m, tile_n;
 };
-__device__ inline TileCoord map_workgroup(const GemmParams& p) {
-    const int nwg = gridDim.x, orig = blockIdx.x;
+__device__ inline TileCoord map_logical(const GemmParams& p, int nwg, int orig) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     TileCoord t;
@@ -106,6 +105,7 @@ __device__ inline TileCoord map_workgroup(const GemmParams& p) {
     t.tile_n = tile % p.tiles_n;
     return t;
 }
+__device__ inline TileCoord map_workgroup(const GemmParams& p) { return map_logical(p, gridDim.x, blockIdx.x); }
 
 // Epilogue of one wavefront's TM x TN grid of 32x32 accumulators (C/D layout: col = lane & 31,
 // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)).  Row-major walk: the 64-bit row offsets of every epilogue tensor are formed once

@@ -450,15 +450,21 @@ extern "C" void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail)
 extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes) {
     if (!d || !d->A || !d->B || (!d->C && !d->Cp)) return GRAPPA_ERR_ARG;
     if (!d->C && (d->C2 || d->accumulate)) return GRAPPA_ERR_ARG;
-    if ((d->a_planes != 0) != (d->b_planes != 0)) return GRAPPA_ERR_ARG;
-    const bool planes = d->a_planes != 0;
+    if (d->a_planes && !d->b_planes) return GRAPPA_ERR_ARG;
+    const bool planes = d->b_planes != 0;
     if (planes) {
         auto ok = [](const void* q, int ld, int cols) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 7) == 0 && ld >= cols; };
         const int kpad = (d->K + 31) / 32 * 32;
         if (d->M <= 32 || d->N <= 32 || d->a_kcontig != d->b_kcontig) return GRAPPA_ERR_ARG;
-        if (d->a_kcontig ? !(ok(d->A, d->lda, kpad) && ok(d->B, d->ldb, kpad)) : !(ok(d->A, d->lda, d->M) && ok(d->B, d->ldb, d->N))) return GRAPPA_ERR_ARG;
+        if (d->a_planes) {
+            if (d->a_kcontig ? !(ok(d->A, d->lda, kpad) && ok(d->B, d->ldb, kpad)) : !(ok(d->A, d->lda, d->M) && ok(d->B, d->ldb, d->N))) return GRAPPA_ERR_ARG;
+        } else {
+            // fp32 A [M][K] + weight planes B [N][K]: whole slabs of 32 in K (fp32 rows are not zero padded), 16-byte aligned rows
+            if (!d->a_kcontig || (d->K & 31) != 0 || (reinterpret_cast<uintptr_t>(d->A) & 15) != 0 || (d->lda & 3) != 0 || d->lda < d->K) return GRAPPA_ERR_ARG;
+            if (!ok(d->B, d->ldb, kpad)) return GRAPPA_ERR_ARG;
+        }
         const size_t arows = d->a_kcontig ? (size_t)d->M : (size_t)kpad, brows = d->b_kcontig ? (size_t)d->N : (size_t)kpad;
-        if (arows * d->lda * 2 >= (1ull << 32) || brows * d->ldb * 2 >= (1ull << 32)) return GRAPPA_ERR_ARG;
+        if (arows * d->lda * (d->a_planes ? 2 : 4) >= (1ull << 32) || brows * d->ldb * 2 >= (1ull << 32)) return GRAPPA_ERR_ARG;
     }
     auto al8 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 7) == 0 && (ld & 3) == 0); };
     if (!al8(d->Cp, d->ldcp) || !al8(d->resp, d->ldresp) || !al8(d->auxp, d->ldauxp)) return GRAPPA_ERR_ARG;

@@ -81,6 +81,8 @@ class FusedAdam:
             sumsq = self.sumsq
         be.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                      self.step_count, grad_scale, sumsq, self.max_grad_norm if self.max_grad_norm is not None else 0.0)
+        if hasattr(be, "invalidate_weight_planes"):
+            be.invalidate_weight_planes()          # the kernel wrote the parameters through raw pointers: cached bf16 planes are stale
 
     def reset_state(self):
         """what re-creating torch.optim.Adam does at a restart epoch (training/lightning_model.py:144-151)"""

@@ -90,17 +90,25 @@ typedef struct grappa_gemm_desc {
     /* ---- plane format (ABI 3; everything below may be 0 / NULL).  A matrix X "in planes" is three bf16 matrices P0, P1, P2 of
      * X's shape, P0 = bf16(X), P1 = bf16(X - P0), P2 = bf16(X - P0 - P1), X == P0 + P1 + P2 exactly; plane p starts
      * `*_plane_stride` ELEMENTS after plane 0, leading dimensions are in bf16 elements and multiples of 8, bases 16-byte aligned.
-     * a_planes / b_planes != 0: A / B point to plane 0 (the pointer types above are then nominal).  Both or neither.  The planes
-     * must be zero beyond K up to the next multiple of 32 along k (columns of a K-contiguous operand: ld >= round_up(K, 32);
-     * rows of a k-major one), rows * ld * 2 < 2^32, and M, N > 32.  Layouts: a_kcontig = b_kcontig = 1 (forward; dgrad with the
-     * TRANSPOSED weight planes) or both 0 (wgrad).  The operands are split ONCE by their producer (grappa_split_planes_f32,
-     * grappa_weight_planes, the *_planes outputs of the row-wise kernels, Cp below) instead of by every GEMM that reads them. */
+     * a_planes / b_planes != 0: A / B point to plane 0 (the pointer types above are then nominal).  Supported: b_planes alone
+     * ("weight planes": A = fp32 activations [M][K] with K % 32 == 0, a_kcontig = b_kcontig = 1 -- forward with the planes of W,
+     * dgrad with the planes of W^T; results are bit-identical to the split-in-kernel product) or both (a_kcontig = b_kcontig = 1,
+     * or both 0 = the wgrad layout).  Planes must be zero beyond K up to the next multiple of 32 along k (columns of a K-contiguous
+     * operand: ld >= round_up(K, 32); rows of a k-major one), rows * ld * element size < 2^32, and M, N > 32.  The operands are
+     * split ONCE by their producer (grappa_split_planes_f32, Cp below) instead of by every GEMM that reads them. */
     int a_planes, b_planes;
     size_t a_plane_stride, b_plane_stride;
     uint16_t* Cp; int ldcp; size_t cp_plane_stride;               /* planes of the FINAL value (what OUT receives); C may be NULL then */
     const uint16_t* resp; int ldresp; size_t resp_plane_stride;   /* residual given in planes (instead of res) */
     const uint16_t* auxp; int ldauxp; size_t auxp_plane_stride;   /* saved ELU output given in planes (instead of aux) */
 } grappa_gemm_desc;
+
+/* fp32 X[R][C] -> plane format: planes[p][r][c] (transpose == 0) or planes[p][c][r] (transpose != 0), p = 0..2, leading
+ * dimension ldp, `plane_stride` elements between planes.  Only the R x C (C x R) block is written: padding the GEMM relies on
+ * (zeros up to the next multiple of 32 along k) is the caller's (allocate zeroed).  Weights are split once per optimiser step
+ * (grappa_amd/optim.py WeightPlanes), both orientations: W for the forward product, W^T for dgrad. */
+int grappa_split_planes_f32(void* stream, int R, int C, const float* x, int ldx, uint16_t* planes, int ldp, size_t plane_stride,
+                            int transpose);
 
 size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);
 /* host-only: the tile (tile_m x tile_n x 32) and split-K factor the launcher will use for this shape, and the "tail": when the

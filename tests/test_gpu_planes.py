@@ -1,0 +1,82 @@
+"""GPU (-m gpu): the plane-format GEMMs (csrc/gemm_planes.hip) through the C ABI.
+
+  * both operands in planes (forward layout and the k-major wgrad layout with split-K and the fused bias gradient), against a
+    float64 product at the accuracy of the split-in-kernel GEMM;
+  * the epilogue's plane tensors: residual and saved ELU output READ from planes, result WRITTEN as planes;
+  * weight planes (fp32 activations x pre-split weight): bit-identical to the split-in-kernel product, op level and for a whole
+    train step (GRAPPA_WEIGHT_PLANES semantics), including after an optimiser step (stale planes must be refreshed).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+import golden_utils as gu
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_plane_gemms_against_float64():
+    import gemm_planes_check as gp
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for M, N, K, km in [(256, 128, 64, 0), (300, 200, 96, 0), (1000, 512, 512, 0), (83, 77, 160, 0), (8233, 1536, 512, 0),
+                        (256, 128, 64, 1), (512, 512, 8233, 1), (300, 200, 1000, 1), (1536, 512, 20011, 1)]:
+        gp.check(M, N, K, bool(km), gen)           # asserts <= 4e-7 of sum |a||b| and bit-equality of the weight-plane product
+    gp.check_epilogue(gen)
+
+
+def test_split_planes_reconstruct_exactly():
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    w = (torch.randn((511, 300), generator=gen, device="cuda") * torch.logspace(-6, 3, 300, device="cuda")).requires_grad_(True)
+    for transposed in (False, True):
+        pl = be._planes_of_weight(w, transposed)
+        ref = w.detach().t() if transposed else w.detach()
+        R, C = ref.shape
+        assert pl.shape == (3, (R + 31) // 32 * 32, (C + 31) // 32 * 32)
+        got = (pl[0, :R, :C].float() + pl[1, :R, :C].float()) + pl[2, :R, :C].float()
+        assert torch.equal(got, ref)                                   # three round-to-nearest bf16 pieces carry all 24 bits
+        assert float(pl[:, R:].float().abs().max()) == 0 and float(pl[:, :, C:].float().abs().max()) == 0
+    # cache: same tensor, same version -> same planes; an in-place update -> refreshed
+    a = be._planes_of_weight(w, False)
+    assert be._planes_of_weight(w, False) is a
+    with torch.no_grad():
+        w.mul_(2.0)
+    b = be._planes_of_weight(w, False)
+    assert torch.equal((b[0, :511, :300].float() + b[1, :511, :300].float()) + b[2, :511, :300].float(), w.detach())
+
+
+def test_train_steps_with_weight_planes_are_bit_identical():
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    from grappa_amd.optim import FlatParams, FusedAdam
+    be = get_backend()
+    res = []
+    try:
+        for use in (False, True):
+            be.weight_planes = use
+            model = model_from_config(get_default_model_config())
+            model.load_state_dict(gu.keyed_state_dict(model))
+            model = model.to("cuda").train()
+            flat = FlatParams(model)
+            opt = FusedAdam(flat, lr=1e-3, max_grad_norm=10.0)
+            ops.manual_seed(11)
+            out = []
+            for step in range(2):                               # the second step runs on UPDATED weights: planes must follow
+                opt.zero_grad()
+                g = Energy()(model(build_batch_from_pool(list(range(200, 232)), n_confs=8, seed=3).to("cuda")))
+                loss = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)(g)
+                loss.backward()
+                out.append((loss.detach().clone(), flat.grad.clone(), g.nodes["n4"].data["k"].detach().clone()))
+                opt.step()
+            torch.cuda.synchronize()
+            res.append(out)
+    finally:
+        be.weight_planes = False
+    for (l0, g0, k0), (l1, g1, k1) in zip(*res):
+        assert torch.equal(l0, l1) and torch.equal(k0, k1) and torch.equal(g0, g1)
+    assert not torch.equal(res[0][0][0], res[0][1][0])          # the two steps differ (the weights moved)

@@ -36,7 +36,10 @@ def ws_for(M, N, K):
 def gemm(a, b, out, M, N, K, a_kcontig, b_kcontig, planes, precision="f32_bf16x6", **kw):
     d = _lib.GemmDesc()
     d.M, d.N, d.K, d.a_kcontig, d.b_kcontig = M, N, K, int(a_kcontig), int(b_kcontig)
-    if planes:
+    if planes == "b":
+        d.A, d.lda = a.data_ptr(), a.stride(0)
+        d.B, d.ldb, d.b_planes, d.b_plane_stride = b.data_ptr(), b.stride(1), 1, b.stride(0)
+    elif planes:
         d.A, d.lda, d.a_planes, d.a_plane_stride = a.data_ptr(), a.stride(1), 1, a.stride(0)
         d.B, d.ldb, d.b_planes, d.b_plane_stride = b.data_ptr(), b.stride(1), 1, b.stride(0)
     else:
@@ -88,7 +91,15 @@ def check(M, N, K, kmajor, gen):
         gemm(A.t().contiguous(), B.t().contiguous(), out2, M, N, K, False, False, False)
     torch.cuda.synchronize()
     err2 = float(((out2.double() - ref).abs() / scale).max())
-    print(f"  M {M:6d} N {N:5d} K {K:6d} {'k-major' if kmajor else 'k-contig'}: planes err {err:.2e}   split-in-kernel err {err2:.2e}", flush=True)
+    msg = ""
+    if not kmajor and K % 32 == 0:
+        out3 = torch.full((M, N), float("nan"), device=dev)
+        gemm(A, bp, out3, M, N, K, True, True, "b")
+        torch.cuda.synchronize()
+        err3 = float(((out3.double() - ref).abs() / scale).max())
+        msg = f"   fp32 A + weight planes err {err3:.2e} (bit-identical to split-in-kernel: {bool(torch.equal(out3, out2))})"
+        assert err3 < 4e-7, err3
+    print(f"  M {M:6d} N {N:5d} K {K:6d} {'k-major' if kmajor else 'k-contig'}: planes err {err:.2e}   split-in-kernel err {err2:.2e}{msg}", flush=True)
     assert err < 4e-7, err
     return err
 
@@ -152,7 +163,7 @@ def bench(gen):
     shapes = [(83328, 512, 512, 0), (83328, 1536, 512, 0), (83328, 512, 1536, 0), (44325, 512, 512, 0), (28248, 512, 512, 0), (17158, 512, 512, 0),
               (8233, 2048, 512, 0), (8233, 512, 2048, 0), (8233, 512, 512, 0),
               (512, 512, 83328, 1), (1536, 512, 83328, 1), (512, 512, 28248, 1), (2048, 512, 8233, 1), (512, 512, 8233, 1)]
-    tot_p = tot_s = 0.0
+    tot_p = tot_s = tot_w = 0.0
     for M, N, K, kmajor in shapes:
         A = torch.randn((M, K), generator=gen, device=dev)
         B = torch.randn((N, K), generator=gen, device=dev)
@@ -166,14 +177,45 @@ def bench(gen):
             ap, bp = split_planes(A), split_planes(B)
             tp = timeit(lambda: gemm(ap, bp, out, M, N, K, True, True, True))
             ts = timeit(lambda: gemm(A, B, out, M, N, K, True, True, False))
+            tw = timeit(lambda: gemm(A, bp, out, M, N, K, True, True, "b"))
         fl = 2.0 * M * N * K
         tot_p += tp
         tot_s += ts
-        print(f"  M {M:6d} N {N:5d} K {K:6d} {'k-major ' if kmajor else 'k-contig'}: planes {tp:7.3f} ms {fl / tp / 1e9:7.1f} TF   split-in-kernel {ts:7.3f} ms {fl / ts / 1e9:7.1f} TF", flush=True)
-    print(f"  sum: planes {tot_p:.3f} ms, split-in-kernel {tot_s:.3f} ms")
+        tot_w += tw if not kmajor else tp
+        print(f"  M {M:6d} N {N:5d} K {K:6d} {'k-major ' if kmajor else 'k-contig'}: planes {tp:7.3f} ms {fl / tp / 1e9:6.1f} TF  split-in-kernel {ts:7.3f} ms {fl / ts / 1e9:6.1f} TF"
+              + ("" if kmajor else f"  fp32A+Wplanes {tw:7.3f} ms {fl / tw / 1e9:6.1f} TF"), flush=True)
+    print(f"  sum: planes {tot_p:.3f} ms, split-in-kernel {tot_s:.3f} ms, fp32A+Wplanes (k-major rows: planes) {tot_w:.3f} ms")
+
+
+def build_variants(only=None):
+    """libraries with the knock-out switches of csrc/gemm_planes.hip (GP_KNOCK), for `--variants`"""
+    import subprocess
+    csrc = os.path.join(ROOT, "grappa_amd", "csrc")
+    outdir = os.path.join(ROOT, "build", "variants")
+    os.makedirs(outdir, exist_ok=True)
+    objs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".o") and f != "gemm_planes.o"]
+    libs = {}
+    for name, flags in (("nodma", ["-DGP_KNOCK=1"]), ("nomfma", ["-DGP_KNOCK=2"]), ("nodma_noepi", ["-DGP_KNOCK=1", "-DGP_NOEPI=1"]),
+                        ("noepi", ["-DGP_NOEPI=1"]), ("stagger8", ["-DGP_STAGGER=8"]), ("stagger24", ["-DGP_STAGGER=24"]),
+                        ("nodma_stagger8", ["-DGP_KNOCK=1", "-DGP_STAGGER=8"]), ("persist", ["-DGP_PERSIST=1"])):
+        if only and name not in only:
+            continue
+        o = os.path.join(outdir, f"gemm_planes_{name}.o")
+        so = os.path.join(outdir, f"libgrappa_hip_{name}.so")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", *flags, "-c", os.path.join(csrc, "gemm_planes.hip"), "-o", o], check=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, o, *objs], check=True)
+        libs[name] = so
+    return libs
 
 
 if __name__ == "__main__":
+    if "--build-variants" in sys.argv:
+        only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+        print(build_variants(only[0] if only else None))
+        sys.exit(0)
+    if "--bench-only" in sys.argv:
+        bench(torch.Generator(device=dev).manual_seed(0))
+        sys.exit(0)
     gen = torch.Generator(device=dev).manual_seed(0)
     print("correctness (max |err| / sum |a||b|):")
     for M, N, K, km in [(256, 128, 64, 0), (256, 128, 512, 0), (300, 200, 96, 0), (1000, 512, 512, 0), (83, 77, 160, 0), (8233, 1536, 512, 0),
