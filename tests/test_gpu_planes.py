@@ -3,8 +3,9 @@
   * both operands in planes (forward layout and the k-major wgrad layout with split-K and the fused bias gradient), against a
     float64 product at the accuracy of the split-in-kernel GEMM;
   * the epilogue's plane tensors: residual and saved ELU output READ from planes, result WRITTEN as planes;
-  * weight planes (fp32 activations x pre-split weight): bit-identical to the split-in-kernel product, op level and for a whole
-    train step (GRAPPA_WEIGHT_PLANES semantics), including after an optimiser step (stale planes must be refreshed).
+  * weight planes (fp32 activations x pre-split weight): bit-identical to the split-in-kernel product at op level; a whole
+    train step under GRAPPA_WEIGHT_PLANES semantics matches the default to rounding, including after an optimiser step (stale
+    planes must be refreshed).
 """
 import os
 import sys
@@ -49,7 +50,7 @@ def test_split_planes_reconstruct_exactly():
     assert torch.equal((b[0, :511, :300].float() + b[1, :511, :300].float()) + b[2, :511, :300].float(), w.detach())
 
 
-def test_train_steps_with_weight_planes_are_bit_identical():
+def test_train_steps_with_weight_planes_match_the_default():
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.backend import get_backend
     from grappa_amd.datasets import build_batch_from_pool
@@ -77,6 +78,10 @@ def test_train_steps_with_weight_planes_are_bit_identical():
             res.append(out)
     finally:
         be.weight_planes = False
+    # per product the two kernels are bit-identical (test_plane_gemms_against_float64); inside the model the planner may pick
+    # another tile / split-K plan for the plane kernel (256 x 128 only), i.e. another summation order: fp32 rounding noise
     for (l0, g0, k0), (l1, g1, k1) in zip(*res):
-        assert torch.equal(l0, l1) and torch.equal(k0, k1) and torch.equal(g0, g1)
+        assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
+        assert float((k0 - k1).abs().max()) <= 2e-5 * float(k0.abs().max())
+        assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
     assert not torch.equal(res[0][0][0], res[0][1][0])          # the two steps differ (the weights moved)
