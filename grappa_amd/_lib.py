@@ -28,7 +28,8 @@ class GemmDesc(C.Structure):
                 ("a_planes", C.c_int), ("b_planes", C.c_int), ("a_plane_stride", C.c_size_t), ("b_plane_stride", C.c_size_t),
                 ("Cp", C.c_void_p), ("ldcp", C.c_int), ("cp_plane_stride", C.c_size_t),
                 ("resp", C.c_void_p), ("ldresp", C.c_int), ("resp_plane_stride", C.c_size_t),
-                ("auxp", C.c_void_p), ("ldauxp", C.c_int), ("auxp_plane_stride", C.c_size_t)]
+                ("auxp", C.c_void_p), ("ldauxp", C.c_int), ("auxp_plane_stride", C.c_size_t),
+                ("cp_nplanes", C.c_int), ("resp_nplanes", C.c_int), ("auxp_nplanes", C.c_int), ("C1p", C.c_void_p), ("ldc1p", C.c_int)]
 
 
 class MMDesc(C.Structure):
@@ -94,6 +95,20 @@ SIGNATURES = {
     "grappa_sumsq_f32": (_i, [_vp, _sz, _vp, _vp, _i, _vp, _sz]),
     "grappa_adam_step_f32": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _f]),
     "grappa_dropout_keep": (_i, [_u64, _u64, _f]),
+    # bf16 storage configuration: same argument lists as the *_f32 entry points
+    "grappa_layernorm_fwd_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "grappa_layernorm_bwd_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
+    "grappa_act_dropout_bwd_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i]),
+    "grappa_gat_fwd_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "grappa_gat_bwd_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "grappa_tuple_gather_fwd_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i]),
+    "grappa_tuple_gather_bwd_bf16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i]),
+    "grappa_seqattn_fwd_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "grappa_seqattn_bwd_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "grappa_perm_concat_fwd_bf16": (_i, [_vp, _i, _i, _i, _i, c_int_p, _vp, _vp]),
+    "grappa_perm_concat_bwd_bf16": (_i, [_vp, _i, _i, _i, _i, c_int_p, _vp, _vp]),
+    "grappa_convert_f32_to_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _i]),
+    "grappa_convert_bf16_to_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i]),
 }
 
 _lib = None

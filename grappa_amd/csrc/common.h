@@ -35,6 +35,31 @@ __device__ inline float grappa_elu(float x) { return x > 0.0f ? x : expm1f(x); }
 __device__ inline float grappa_elu_grad_from_out(float y) { return y > 0.0f ? 1.0f : y + 1.0f; }
 __device__ inline float grappa_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- element types of activation tensors: fp32, or bf16 storage (uint16_t bit patterns; the "bf16" configuration keeps every
+// activation and activation gradient in bf16 in HBM; arithmetic, statistics and accumulation stay fp32).  ld4 / st4 move four
+// consecutive elements (chunk c of a row whose base is 16-byte (fp32) / 8-byte (bf16) aligned).
+typedef uint16_t grappa_bf16_t;
+__device__ inline float4 ld4(const float* __restrict__ row, int c) { return reinterpret_cast<const float4*>(row)[c]; }
+__device__ inline float4 ld4(const grappa_bf16_t* __restrict__ row, int c) {
+    const uint2 u = reinterpret_cast<const uint2*>(row)[c];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ inline void st4(float* __restrict__ row, int c, const float4& v) { reinterpret_cast<float4*>(row)[c] = v; }
+__device__ inline void st4(grappa_bf16_t* __restrict__ row, int c, const float4& v) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 a, b;
+    a[0] = (__bf16)v.x; a[1] = (__bf16)v.y;               // round to nearest even (v_cvt_pk_bf16_f32)
+    b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
+    reinterpret_cast<uint2*>(row)[c] = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
+__device__ inline float ld1(const float* __restrict__ p, size_t i) { return p[i]; }
+__device__ inline float ld1(const grappa_bf16_t* __restrict__ p, size_t i) { return __uint_as_float((unsigned)p[i] << 16); }
+__device__ inline void st1(float* __restrict__ p, size_t i, float v) { p[i] = v; }
+__device__ inline void st1(grappa_bf16_t* __restrict__ p, size_t i, float v) {
+    const __bf16 h = (__bf16)v;
+    p[i] = __builtin_bit_cast(grappa_bf16_t, h);
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -25,11 +25,18 @@ struct GemmParams {
 
 // ---- plane format (include/grappa_hip.h): X = P0 + P1 + P2, three bf16 planes
 __device__ inline float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
-__device__ inline float planes_load1(const uint16_t* __restrict__ p, size_t stride, size_t idx) {
+__device__ inline float planes_load1(const uint16_t* __restrict__ p, size_t stride, size_t idx, int np = 3) {
+    if (np == 1) return bf16_bits_to_f32(p[idx]);
     return (bf16_bits_to_f32(p[idx]) + bf16_bits_to_f32(p[idx + stride])) + bf16_bits_to_f32(p[idx + 2 * stride]);   // exact: 8 + 8 + 8 bits
 }
 // four consecutive elements (8-byte aligned)
-__device__ inline void planes_load4(const uint16_t* __restrict__ p, size_t stride, size_t idx, float (&v)[4]) {
+__device__ inline void planes_load4(const uint16_t* __restrict__ p, size_t stride, size_t idx, float (&v)[4], int np = 3) {
+    if (np == 1) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p + idx);
+        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+        return;
+    }
     const uint2 a = *reinterpret_cast<const uint2*>(p + idx), b = *reinterpret_cast<const uint2*>(p + idx + stride),
                 c = *reinterpret_cast<const uint2*>(p + idx + 2 * stride);
     v[0] = (__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16)) + __uint_as_float(c.x << 16);
@@ -38,10 +45,11 @@ __device__ inline void planes_load4(const uint16_t* __restrict__ p, size_t strid
     v[3] = (__uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u)) + __uint_as_float(c.y & 0xffff0000u);
 }
 typedef __bf16 grappa_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ inline void planes_store4(uint16_t* __restrict__ p, size_t stride, size_t idx, const float (&v)[4]) {
+__device__ inline void planes_store4(uint16_t* __restrict__ p, size_t stride, size_t idx, const float (&v)[4], int np = 3) {
     float r[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
+        if (pl >= np) break;
         grappa_bf16x2 h01, h23;
         h01[0] = (__bf16)r[0]; h01[1] = (__bf16)r[1];
         h23[0] = (__bf16)r[2]; h23[1] = (__bf16)r[3];
@@ -53,9 +61,10 @@ __device__ inline void planes_store4(uint16_t* __restrict__ p, size_t stride, si
         }
     }
 }
-__device__ inline void planes_store1(uint16_t* __restrict__ p, size_t stride, size_t idx, float v) {
+__device__ inline void planes_store1(uint16_t* __restrict__ p, size_t stride, size_t idx, float v, int np = 3) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
+        if (pl >= np) break;
         const __bf16 h = (__bf16)v;
         p[idx + pl * stride] = __builtin_bit_cast(uint16_t, h);
         v -= (float)h;
@@ -68,7 +77,7 @@ __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v
     if (d.bias) v += d.bias[n];
     if (d.act == GRAPPA_ACT_ELU) v = grappa_elu(v);
     if (d.aux) v *= grappa_elu_grad_from_out(d.aux[(size_t)m * d.ldaux + n]);
-    else if (d.auxp) v *= grappa_elu_grad_from_out(planes_load1(d.auxp, d.auxp_plane_stride, (size_t)m * d.ldauxp + n));
+    else if (d.auxp) v *= grappa_elu_grad_from_out(planes_load1(d.auxp, d.auxp_plane_stride, (size_t)m * d.ldauxp + n, d.auxp_nplanes ? d.auxp_nplanes : 3));
     float* out = d.C;
     int ldo = d.ldc;
     if (d.C2) {
@@ -76,15 +85,16 @@ __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v
         out = d.C2;
         ldo = d.ldc2;
     }
+    if (d.C1p) planes_store1(d.C1p, 0, (size_t)m * d.ldc1p + n, v, 1);
     if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
     if (d.res) v += d.res[(size_t)m * d.ldres + n];
-    else if (d.resp) v += planes_load1(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n);
+    else if (d.resp) v += planes_load1(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, d.resp_nplanes ? d.resp_nplanes : 3);
     if (out) {
         float* o = out + (size_t)m * ldo + n;
         if (d.accumulate) v += *o;
         *o = v;
     }
-    if (d.Cp) planes_store1(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v);
+    if (d.Cp) planes_store1(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v, d.cp_nplanes ? d.cp_nplanes : 3);
 }
 
 
@@ -134,7 +144,7 @@ __device__ inline void tile_epilogue(const GemmParams& p, const f32x16 (&acc)[TM
                     if (ncol[j] < d.N) srow[ncol[j]] = acc[i][j][e];
                 continue;
             }
-            if (d.Cp || d.resp || d.auxp || !d.C) {                 // plane-format epilogue tensors: element-wise path
+            if (d.Cp || d.resp || d.auxp || d.C1p || !d.C) {        // plane-format epilogue tensors: element-wise path
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     if (ncol[j] < d.N) epilogue_store(p, m, ncol[j], acc[i][j][e]);
@@ -225,7 +235,7 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
             v[2] *= grappa_elu_grad_from_out(t.z); v[3] *= grappa_elu_grad_from_out(t.w);
         } else if (d.auxp) {
             float t[4];
-            planes_load4(d.auxp, d.auxp_plane_stride, (size_t)m * d.ldauxp + n, t);
+            planes_load4(d.auxp, d.auxp_plane_stride, (size_t)m * d.ldauxp + n, t, d.auxp_nplanes ? d.auxp_nplanes : 3);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] *= grappa_elu_grad_from_out(t[q]);
         }
@@ -234,6 +244,7 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
             o = d.C2 + (size_t)m * d.ldc2 + n;
         }
+        if (d.C1p) planes_store4(d.C1p, 0, (size_t)m * d.ldc1p + n, v, 1);
         if (d.drop_p > 0.0f) {
             const uint64_t idx = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
 #pragma unroll
@@ -244,7 +255,7 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
             v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
         } else if (d.resp) {
             float t[4];
-            planes_load4(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, t);
+            planes_load4(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, t, d.resp_nplanes ? d.resp_nplanes : 3);
             v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
         }
         if (o) {
@@ -254,7 +265,7 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
             }
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        if (d.Cp) planes_store4(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v);
+        if (d.Cp) planes_store4(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v, d.cp_nplanes ? d.cp_nplanes : 3);
     }
 }
 

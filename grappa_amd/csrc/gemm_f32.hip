@@ -448,8 +448,12 @@ extern "C" void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail)
 }
 
 extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes) {
-    if (!d || !d->A || !d->B || (!d->C && !d->Cp)) return GRAPPA_ERR_ARG;
+    if (!d || !d->A || !d->B || (!d->C && !d->Cp && !d->C1p)) return GRAPPA_ERR_ARG;
     if (!d->C && (d->C2 || d->accumulate)) return GRAPPA_ERR_ARG;
+    if (d->C1p && (d->C || d->C2) ) return GRAPPA_ERR_ARG;        // C1p replaces the (C, C2) pair: the final value then goes to Cp
+    if (d->C1p && !d->Cp) return GRAPPA_ERR_ARG;
+    for (int np : {d->cp_nplanes, d->resp_nplanes, d->auxp_nplanes})
+        if (np != 0 && np != 1 && np != 3) return GRAPPA_ERR_ARG;
     if (d->a_planes && !d->b_planes) return GRAPPA_ERR_ARG;
     const bool planes = d->b_planes != 0;
     if (planes) {
@@ -467,7 +471,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
         if (arows * d->lda * (d->a_planes ? 2 : 4) >= (1ull << 32) || brows * d->ldb * 2 >= (1ull << 32)) return GRAPPA_ERR_ARG;
     }
     auto al8 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 7) == 0 && (ld & 3) == 0); };
-    if (!al8(d->Cp, d->ldcp) || !al8(d->resp, d->ldresp) || !al8(d->auxp, d->ldauxp)) return GRAPPA_ERR_ARG;
+    if (!al8(d->Cp, d->ldcp) || !al8(d->resp, d->ldresp) || !al8(d->auxp, d->ldauxp) || !al8(d->C1p, d->ldc1p)) return GRAPPA_ERR_ARG;
     if (d->M < 0 || d->N < 0 || d->K < 0) return GRAPPA_ERR_ARG;
     if (d->M == 0 || d->N == 0) return GRAPPA_OK;
     if (d->K == 0) return GRAPPA_ERR_ARG;

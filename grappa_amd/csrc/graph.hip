@@ -14,13 +14,13 @@ struct Row {
     float4 v[MAXC];
 };
 
-template <int NC>
-__device__ inline void load_row(const float* __restrict__ base, int node, int F, int lane, int nvec, float4 (&r)[NC]) {
-    const float4* p = reinterpret_cast<const float4*>(base + (size_t)node * F);
+template <int NC, typename T>
+__device__ inline void load_row(const T* __restrict__ base, int node, int F, int lane, int nvec, float4 (&r)[NC]) {
+    const T* p = base + (size_t)node * F;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
-        r[i] = (c < nvec) ? p[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[i] = (c < nvec) ? ld4(p, c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -28,9 +28,9 @@ __device__ inline float dot4(const float4& a, const float4& b) { return (a.x * b
 
 // ---------------------------------------------------------------------------------------------
 // forward: NC = chunks per lane (compile-time: 1, 2, 4, 8); lanes_per_head = D/4
-template <int NC>
+template <int NC, typename T>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(int N, int H, int D, const int* __restrict__ indptr, const int* __restrict__ indices,
-                                                      const float* __restrict__ ft, float* __restrict__ out, float* __restrict__ alpha) {
+                                                      const T* __restrict__ ft, T* __restrict__ out, float* __restrict__ alpha) {
     const int lane = threadIdx.x & 63;
     const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (v >= N) return;
@@ -67,13 +67,13 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(int N, int H, int D, const
             mx[i] = m_new;
         }
     }
-    float4* o = reinterpret_cast<float4*>(out + (size_t)v * F);
+    T* o = out + (size_t)v * F;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nvec) {
             const float inv = den[i] > 0.f ? 1.0f / den[i] : 0.f;
-            o[c] = make_float4(acc[i].x * inv, acc[i].y * inv, acc[i].z * inv, acc[i].w * inv);
+            st4(o, c, make_float4(acc[i].x * inv, acc[i].y * inv, acc[i].z * inv, acc[i].w * inv));
             if ((lane % lph) == 0) {
                 const int h = c / lph;
                 for (int e = e0; e < e1; ++e) {
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(int N, int H, int D, const
 }
 
 // delta[v,h] = <dout_v[h], out_v[h]>
-template <int NC>
-__global__ __launch_bounds__(256) void gat_delta_kernel(int N, int H, int D, const float* __restrict__ out, const float* __restrict__ dout,
+template <int NC, typename T>
+__global__ __launch_bounds__(256) void gat_delta_kernel(int N, int H, int D, const T* __restrict__ out, const T* __restrict__ dout,
                                                         float* __restrict__ delta) {
     const int lane = threadIdx.x & 63;
     const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256) void gat_delta_kernel(int N, int H, int D, con
 //                                          + ( ds(u->w) + ds(w->u) ) * ft_w / sqrt(D)
 //   ds(u->w)[h] = alpha[rev e][h] * (<dout_w[h], ft_u[h]> - delta[w,h])      (u is the source of edge u->w)
 //   ds(w->u)[h] = alpha[e][h]     * (<dout_u[h], ft_w[h]> - delta[u,h])      (u is the destination of edge w->u)
-template <int NC>
+template <int NC, typename T>
 __global__ __launch_bounds__(256) void gat_bwd_kernel(int N, int H, int D, const int* __restrict__ indptr, const int* __restrict__ indices,
-                                                      const int* __restrict__ rev, const float* __restrict__ ft,
-                                                      const float* __restrict__ alpha, const float* __restrict__ dout,
-                                                      const float* __restrict__ delta, float* __restrict__ dft) {
+                                                      const int* __restrict__ rev, const T* __restrict__ ft,
+                                                      const float* __restrict__ alpha, const T* __restrict__ dout,
+                                                      const float* __restrict__ delta, T* __restrict__ dft) {
     const int lane = threadIdx.x & 63;
     const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (u >= N) return;
@@ -150,11 +150,11 @@ __global__ __launch_bounds__(256) void gat_bwd_kernel(int N, int H, int D, const
             acc[i].w += a_uw * dw[i].w + coef * fw[i].w;
         }
     }
-    float4* o = reinterpret_cast<float4*>(dft + (size_t)u * F);
+    T* o = dft + (size_t)u * F;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
-        if (c < nvec) o[c] = acc[i];
+        if (c < nvec) st4(o, c, acc[i]);
     }
 }
 
@@ -210,34 +210,60 @@ inline bool head_shape_ok(int H, int D) {
         case 4: hipLaunchKernelGGL(KERN<4>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
         default: hipLaunchKernelGGL(KERN<8>, grid, dim3(256), 0, st, __VA_ARGS__); break;       \
     }
+#define DISPATCH_NC_T(nc, KERN, T, grid, st, ...)                                                     \
+    switch (nc) {                                                                                     \
+        case 1: hipLaunchKernelGGL((KERN<1, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
+        case 2: hipLaunchKernelGGL((KERN<2, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
+        case 4: hipLaunchKernelGGL((KERN<4, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
+        default: hipLaunchKernelGGL((KERN<8, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;        \
+    }
+
+template <typename T>
+int gat_fwd_impl(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const T* ft, T* out, float* alpha) {
+    if (N < 0 || E < 0 || !head_shape_ok(H, D)) return GRAPPA_ERR_ARG;
+    if (N == 0) return GRAPPA_OK;
+    if (!indptr || !ft || !out || !alpha || (E > 0 && !indices)) return GRAPPA_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(ft) | reinterpret_cast<uintptr_t>(out)) & (sizeof(T) == 4 ? 15 : 7)) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((N + 3) / 4);
+    DISPATCH_NC_T(chunks_for(H * D), gat_fwd_kernel, T, grid, st, N, H, D, indptr, indices, ft, out, alpha);
+    return grappa_launch_status();
+}
+
+template <typename T>
+int gat_bwd_impl(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const int* rev, const T* ft, const T* out,
+                 const float* alpha, const T* dout, T* dft, float* delta) {
+    if (N < 0 || E < 0 || !head_shape_ok(H, D)) return GRAPPA_ERR_ARG;
+    if (N == 0) return GRAPPA_OK;
+    if (!indptr || !ft || !out || !alpha || !dout || !dft || !delta || (E > 0 && (!indices || !rev))) return GRAPPA_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(ft) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dft)) & (sizeof(T) == 4 ? 15 : 7))
+        return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((N + 3) / 4);
+    const int nc = chunks_for(H * D);
+    DISPATCH_NC_T(nc, gat_delta_kernel, T, grid, st, N, H, D, out, dout, delta);
+    DISPATCH_NC_T(nc, gat_bwd_kernel, T, grid, st, N, H, D, indptr, indices, rev, ft, alpha, dout, delta, dft);
+    return grappa_launch_status();
+}
 
 }  // namespace
 
 extern "C" int grappa_gat_fwd_f32(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const float* ft,
                                   float* out, float* alpha) {
-    if (N < 0 || E < 0 || !head_shape_ok(H, D)) return GRAPPA_ERR_ARG;
-    if (N == 0) return GRAPPA_OK;
-    if (!indptr || !ft || !out || !alpha || (E > 0 && !indices)) return GRAPPA_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(ft) | reinterpret_cast<uintptr_t>(out)) & 15) return GRAPPA_ERR_ARG;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((N + 3) / 4);
-    DISPATCH_NC(chunks_for(H * D), gat_fwd_kernel, grid, st, N, H, D, indptr, indices, ft, out, alpha);
-    return grappa_launch_status();
+    return gat_fwd_impl<float>(stream, N, E, H, D, indptr, indices, ft, out, alpha);
+}
+extern "C" int grappa_gat_fwd_bf16(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const uint16_t* ft,
+                                   uint16_t* out, float* alpha) {
+    return gat_fwd_impl<grappa_bf16_t>(stream, N, E, H, D, indptr, indices, ft, out, alpha);
 }
 
 extern "C" int grappa_gat_bwd_f32(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const int* rev,
                                   const float* ft, const float* out, const float* alpha, const float* dout, float* dft, float* delta) {
-    if (N < 0 || E < 0 || !head_shape_ok(H, D)) return GRAPPA_ERR_ARG;
-    if (N == 0) return GRAPPA_OK;
-    if (!indptr || !ft || !out || !alpha || !dout || !dft || !delta || (E > 0 && (!indices || !rev))) return GRAPPA_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(ft) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dft)) & 15)
-        return GRAPPA_ERR_ARG;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((N + 3) / 4);
-    const int nc = chunks_for(H * D);
-    DISPATCH_NC(nc, gat_delta_kernel, grid, st, N, H, D, out, dout, delta);
-    DISPATCH_NC(nc, gat_bwd_kernel, grid, st, N, H, D, indptr, indices, rev, ft, alpha, dout, delta, dft);
-    return grappa_launch_status();
+    return gat_bwd_impl<float>(stream, N, E, H, D, indptr, indices, rev, ft, out, alpha, dout, dft, delta);
+}
+extern "C" int grappa_gat_bwd_bf16(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const int* rev,
+                                   const uint16_t* ft, const uint16_t* out, const float* alpha, const uint16_t* dout, uint16_t* dft, float* delta) {
+    return gat_bwd_impl<grappa_bf16_t>(stream, N, E, H, D, indptr, indices, rev, ft, out, alpha, dout, dft, delta);
 }
 
 extern "C" int grappa_neighbor_mean_f32(void* stream, int N, int F, const int* indptr, const int* indices, const float* x, float* out,

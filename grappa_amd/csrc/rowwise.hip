@@ -10,10 +10,10 @@ constexpr int LN_MAX_CHUNKS = 8;   // 8 float4 per lane * 64 lanes = 2048 floats
 
 // NCH = float4 chunks per lane (row width <= 256 * NCH): the row lives in registers, so the chunk count is a template parameter --
 // sized for the widest row (8 chunks) every width would carry ~130 live registers and run at 3 wavefronts per SIMD
-template <int NCH, bool STORE_STATS>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const float* __restrict__ x, int ldx,
+template <int NCH, bool STORE_STATS, typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const T* __restrict__ x, int ldx,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ y, int ldy, float* __restrict__ mean_out,
+                                                            T* __restrict__ y, int ldy, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -22,14 +22,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
     // one row per wavefront and trip.  (Two rows per trip measured 20 % faster on the widest tables, but that kernel is the one
     // that returned deviating rows when several queues ran this library's kernels at once -- DESIGN.md section 6 -- so it is not used.)
     for (int row = wave_global; row < M; row += nwaves) {
-        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+        const T* xr = x + (size_t)row * ldx;
         float4 v[NCH];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nvec) {
-                v[i] = xr[c];
+                v[i] = ld4(xr, c);
                 s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
         }
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
             }
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
-        float4* yr = reinterpret_cast<float4*>(y + (size_t)row * ldy);
+        T* yr = y + (size_t)row * ldy;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
                 o.y = (v[i].y - mean) * rstd * g.y + b.y;
                 o.z = (v[i].z - mean) * rstd * g.z + b.z;
                 o.w = (v[i].w - mean) * rstd * g.w + b.w;
-                yr[c] = o;
+                st4(yr, c, o);
             }
         }
         if (STORE_STATS && lane == 0) {
@@ -67,11 +67,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
 }
 
 // dx per row; per-block partial dgamma/dbeta into part[block][2][W]
-template <int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const float* __restrict__ dy, int lddy,
-                                                            const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+template <int NCH, typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const T* __restrict__ dy, int lddy,
+                                                            const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                            float* __restrict__ dx, int lddx, float* __restrict__ part) {
+                                                            T* __restrict__ dx, int lddx, float* __restrict__ part) {
     extern __shared__ float red[];   // [4 waves][2][W]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_global = blockIdx.x * 4 + wave;
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
         db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int row = wave_global; row < M; row += nwaves) {
-        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
-        const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * lddy);
+        const T* xr = x + (size_t)row * ldx;
+        const T* dyr = dy + (size_t)row * lddy;
         const float mu = mean[row], rs = rstd[row];
         float4 xh[NCH], g[NCH];
         float s1 = 0.f, s2 = 0.f;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nvec) {
-                const float4 xv = xr[c], dv = dyr[c], gm = reinterpret_cast<const float4*>(gamma)[c];
+                const float4 xv = ld4(xr, c), dv = ld4(dyr, c), gm = reinterpret_cast<const float4*>(gamma)[c];
                 xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
                 g[i].x = dv.x * gm.x; g[i].y = dv.y * gm.y; g[i].z = dv.z * gm.z; g[i].w = dv.w * gm.w;
                 s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
             }
         }
         const float m1 = wave_sum(s1) / (float)W, m2 = wave_sum(s2) / (float)W;
-        float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * lddx);
+        T* dxr = dx + (size_t)row * lddx;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
                 o.y = rs * (g[i].y - m1 - xh[i].y * m2);
                 o.z = rs * (g[i].z - m1 - xh[i].z * m2);
                 o.w = rs * (g[i].w - m1 - xh[i].w * m2);
-                dxr[c] = o;
+                st4(dxr, c, o);
             }
         }
     }
@@ -189,28 +189,30 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const
     }
 }
 
-__global__ __launch_bounds__(256) void act_dropout_bwd_kernel(int M, int N, const float* __restrict__ dy, int lddy,
-                                                              const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
-                                                              float* __restrict__ dz, int lddz) {
+template <typename T>
+__global__ __launch_bounds__(256) void act_dropout_bwd_kernel(int M, int N, const T* __restrict__ dy, int lddy,
+                                                              const T* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
+                                                              T* __restrict__ dz, int lddz) {
     const size_t total = (size_t)M * N;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int m = (int)(i / N), n = (int)(i % N);
-        float v = dy[(size_t)m * lddy + n];
+        float v = ld1(dy, (size_t)m * lddy + n);
         if (p > 0.f) v = grappa_keep(seed, i, p) ? v * scale : 0.f;
-        if (y) v *= grappa_elu_grad_from_out(y[(size_t)m * ldy + n]);
-        dz[(size_t)m * lddz + n] = v;
+        if (y) v *= grappa_elu_grad_from_out(ld1(y, (size_t)m * ldy + n));
+        st1(dz, (size_t)m * lddz + n, v);
     }
 }
 
 // the same with 16-byte accesses: N, the leading dimensions and the base addresses are multiples of 4 floats (host-checked)
-__global__ __launch_bounds__(256) void act_dropout_bwd_vec_kernel(int M, int N, const float* __restrict__ dy, int lddy,
-                                                                  const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
-                                                                  float* __restrict__ dz, int lddz) {
+template <typename T>
+__global__ __launch_bounds__(256) void act_dropout_bwd_vec_kernel(int M, int N, const T* __restrict__ dy, int lddy,
+                                                                  const T* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
+                                                                  T* __restrict__ dz, int lddz) {
     const int n4 = N >> 2;
     const size_t total = (size_t)M * n4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) << 2;
-        float4 v = *reinterpret_cast<const float4*>(dy + (size_t)m * lddy + n);
+        float4 v = ld4(dy + (size_t)m * lddy + n, 0);
         if (p > 0.f) {
             const uint64_t idx = (uint64_t)m * (uint64_t)N + (uint64_t)n;          // element index of the forward's mask
             v.x = grappa_keep(seed, idx, p) ? v.x * scale : 0.f;
@@ -219,11 +221,11 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_vec_kernel(int M, int N, 
             v.w = grappa_keep(seed, idx + 3, p) ? v.w * scale : 0.f;
         }
         if (y) {
-            const float4 t = *reinterpret_cast<const float4*>(y + (size_t)m * ldy + n);
+            const float4 t = ld4(y + (size_t)m * ldy + n, 0);
             v.x *= grappa_elu_grad_from_out(t.x); v.y *= grappa_elu_grad_from_out(t.y);
             v.z *= grappa_elu_grad_from_out(t.z); v.w *= grappa_elu_grad_from_out(t.w);
         }
-        *reinterpret_cast<float4*>(dz + (size_t)m * lddz + n) = v;
+        st4(dz + (size_t)m * lddz + n, 0, v);
     }
 }
 
@@ -305,26 +307,109 @@ inline int colsum_blocks(int M) {
 
 }  // namespace
 
-extern "C" int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
-                                        float* y, int ldy, float* mean, float* rstd) {
+namespace {
+template <typename T>
+int layernorm_fwd_impl(void* stream, int M, int W, const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean,
+                       float* rstd) {
     if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (ldy & 3)) return GRAPPA_ERR_ARG;
     if (M == 0) return GRAPPA_OK;
     if (!x || !gamma || !beta || !y) return GRAPPA_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
+    const uintptr_t amask = sizeof(T) == 4 ? 15 : 7;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & amask) || ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15))
         return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // the forward kernel is light (<= 54 registers up to W = 1024): 2048 blocks = 8 wavefronts per SIMD keep twice the rows in flight
     const int blocks = W <= 1024 ? ((M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4) : ln_blocks(M);
 #define GRAPPA_LN_FWD(NCH)                                                                                                              \
     if (mean && rstd)                                                                                                                   \
-        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, true>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd); \
+        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, true, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, false>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, false, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd)
     if (W <= 256) { GRAPPA_LN_FWD(1); }
     else if (W <= 512) { GRAPPA_LN_FWD(2); }
     else if (W <= 1024) { GRAPPA_LN_FWD(4); }
     else { GRAPPA_LN_FWD(8); }
 #undef GRAPPA_LN_FWD
+    return grappa_launch_status();
+}
+
+template <typename T>
+int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const T* x, int ldx, const float* mean, const float* rstd,
+                       const float* gamma, T* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
+    if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return GRAPPA_ERR_ARG;
+    if (M == 0) return GRAPPA_OK;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return GRAPPA_ERR_ARG;
+    const uintptr_t amask = sizeof(T) == 4 ? 15 : 7;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & amask) || (reinterpret_cast<uintptr_t>(gamma) & 15))
+        return GRAPPA_ERR_ARG;
+    const int blocks = ln_blocks(M);
+    const size_t need = ((size_t)blocks * 2 * W + (size_t)REDUCE_GROUPS * 2 * W) * sizeof(float);
+    if (!ws || ws_bytes < need) return GRAPPA_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    float* scratch = part + (size_t)blocks * 2 * W;
+    const size_t smem = (size_t)4 * 2 * W * sizeof(float);
+#define GRAPPA_LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, T>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part)
+    if (W <= 256) GRAPPA_LN_BWD(1);
+    else if (W <= 512) GRAPPA_LN_BWD(2);
+    else if (W <= 1024) GRAPPA_LN_BWD(4);
+    else GRAPPA_LN_BWD(8);
+#undef GRAPPA_LN_BWD
+    int rc = grappa_launch_status();
+    if (rc) return rc;
+    reduce_rows(st, blocks, 2 * W, 2 * W, part, dgamma, accumulate, scratch, dbeta, W);     // dgamma | dbeta in one pass (two launches, not four)
+    return grappa_launch_status();
+}
+
+template <typename T>
+int act_dropout_bwd_impl(void* stream, int M, int N, const T* dy, int lddy, const T* y, int ldy, float drop_p, uint64_t drop_seed, T* dz, int lddz) {
+    if (M < 0 || N < 0 || drop_p < 0.f || drop_p >= 1.f) return GRAPPA_ERR_ARG;
+    if (M == 0 || N == 0) return GRAPPA_OK;
+    if (!dy || !dz) return GRAPPA_ERR_ARG;
+    const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const uintptr_t amask = sizeof(T) == 4 ? 15 : 7;
+    const bool vec = (N & 3) == 0 && (lddy & 3) == 0 && (lddz & 3) == 0 && (!y || (ldy & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & amask) == 0;
+    if (vec)
+        hipLaunchKernelGGL(act_dropout_bwd_vec_kernel<T>, dim3(grid_for((size_t)M * (N >> 2))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
+    else
+        hipLaunchKernelGGL(act_dropout_bwd_kernel<T>, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
+    return grappa_launch_status();
+}
+
+// element-type conversion of a 2-d view (the rare places where a bf16 tensor meets an fp32-only kernel or the reverse)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void convert_kernel(int M, int N, const TI* __restrict__ x, int ldx, TO* __restrict__ y, int ldy) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        st1(y, (size_t)m * ldy + n, ld1(x, (size_t)m * ldx + n));
+    }
+}
+}  // namespace
+
+extern "C" int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
+                                        float* y, int ldy, float* mean, float* rstd) {
+    return layernorm_fwd_impl<float>(stream, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd);
+}
+extern "C" int grappa_layernorm_fwd_bf16(void* stream, int M, int W, const uint16_t* x, int ldx, const float* gamma, const float* beta,
+                                         uint16_t* y, int ldy, float* mean, float* rstd) {
+    return layernorm_fwd_impl<grappa_bf16_t>(stream, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd);
+}
+extern "C" int grappa_convert_f32_to_bf16(void* stream, int M, int N, const float* x, int ldx, uint16_t* y, int ldy) {
+    if (M < 0 || N < 0) return GRAPPA_ERR_ARG;
+    if (M == 0 || N == 0) return GRAPPA_OK;
+    if (!x || !y) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL((convert_kernel<float, grappa_bf16_t>), dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M, N, x, ldx, y, ldy);
+    return grappa_launch_status();
+}
+extern "C" int grappa_convert_bf16_to_f32(void* stream, int M, int N, const uint16_t* x, int ldx, float* y, int ldy) {
+    if (M < 0 || N < 0) return GRAPPA_ERR_ARG;
+    if (M == 0 || N == 0) return GRAPPA_OK;
+    if (!x || !y) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL((convert_kernel<grappa_bf16_t, float>), dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M, N, x, ldx, y, ldy);
     return grappa_launch_status();
 }
 
@@ -335,28 +420,12 @@ extern "C" size_t grappa_layernorm_bwd_workspace_bytes(int M, int W) {
 extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
                                         const float* mean, const float* rstd, const float* gamma, float* dx, int lddx,
                                         float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
-    if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return GRAPPA_ERR_ARG;
-    if (M == 0) return GRAPPA_OK;
-    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return GRAPPA_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(gamma)) & 15)
-        return GRAPPA_ERR_ARG;
-    const int blocks = ln_blocks(M);
-    const size_t need = ((size_t)blocks * 2 * W + (size_t)REDUCE_GROUPS * 2 * W) * sizeof(float);
-    if (!ws || ws_bytes < need) return GRAPPA_ERR_WORKSPACE;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* part = reinterpret_cast<float*>(ws);
-    float* scratch = part + (size_t)blocks * 2 * W;
-    const size_t smem = (size_t)4 * 2 * W * sizeof(float);
-#define GRAPPA_LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part)
-    if (W <= 256) GRAPPA_LN_BWD(1);
-    else if (W <= 512) GRAPPA_LN_BWD(2);
-    else if (W <= 1024) GRAPPA_LN_BWD(4);
-    else GRAPPA_LN_BWD(8);
-#undef GRAPPA_LN_BWD
-    int rc = grappa_launch_status();
-    if (rc) return rc;
-    reduce_rows(st, blocks, 2 * W, 2 * W, part, dgamma, accumulate, scratch, dbeta, W);     // dgamma | dbeta in one pass (two launches, not four)
-    return grappa_launch_status();
+    return layernorm_bwd_impl<float>(stream, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, accumulate, ws, ws_bytes);
+}
+extern "C" int grappa_layernorm_bwd_bf16(void* stream, int M, int W, const uint16_t* dy, int lddy, const uint16_t* x, int ldx,
+                                         const float* mean, const float* rstd, const float* gamma, uint16_t* dx, int lddx,
+                                         float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
+    return layernorm_bwd_impl<grappa_bf16_t>(stream, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, accumulate, ws, ws_bytes);
 }
 
 extern "C" size_t grappa_colsum_workspace_bytes(int M, int N) {
@@ -383,19 +452,11 @@ extern "C" int grappa_colsum_f32(void* stream, int M, int N, const float* x, int
 
 extern "C" int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
                                           float drop_p, uint64_t drop_seed, float* dz, int lddz) {
-    if (M < 0 || N < 0 || drop_p < 0.f || drop_p >= 1.f) return GRAPPA_ERR_ARG;
-    if (M == 0 || N == 0) return GRAPPA_OK;
-    if (!dy || !dz) return GRAPPA_ERR_ARG;
-    const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    const bool vec = (N & 3) == 0 && (lddy & 3) == 0 && (lddz & 3) == 0 && (!y || (ldy & 3) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
-    if (vec)
-        hipLaunchKernelGGL(act_dropout_bwd_vec_kernel, dim3(grid_for((size_t)M * (N >> 2))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
-    else
-        hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
-    return grappa_launch_status();
+    return act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
+}
+extern "C" int grappa_act_dropout_bwd_bf16(void* stream, int M, int N, const uint16_t* dy, int lddy, const uint16_t* y, int ldy,
+                                           float drop_p, uint64_t drop_seed, uint16_t* dz, int lddz) {
+    return act_dropout_bwd_impl<grappa_bf16_t>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
 }
 
 extern "C" int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float* y) {

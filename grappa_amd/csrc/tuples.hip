@@ -14,51 +14,53 @@ struct Perms {
 };
 
 // ------------------------------------------------------------------------------------------------ gather
-__global__ __launch_bounds__(256) void tuple_gather_fwd_kernel(int T, int s, int W, const float* __restrict__ a, int lda,
+template <typename TA, typename TX>
+__global__ __launch_bounds__(256) void tuple_gather_fwd_kernel(int T, int s, int W, const TA* __restrict__ a, int lda,
                                                                const int* __restrict__ idx, const float* __restrict__ pe,
-                                                               float* __restrict__ x, int ldx) {
+                                                               TX* __restrict__ x, int ldx) {
     const int lane = threadIdx.x & 63;
     const int nrows = s * T, nvec = W >> 2;
     const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int r = wave0; r < nrows; r += nw) {
         const int pos = r / T, t = r - pos * T;
         const int atom = idx[(size_t)t * s + pos];
-        const float4* src = reinterpret_cast<const float4*>(a + (size_t)atom * lda);
-        float4* dst = reinterpret_cast<float4*>(x + (size_t)r * ldx);
+        const TA* src = a + (size_t)atom * lda;
+        TX* dst = x + (size_t)r * ldx;
         const float pev = pe ? pe[pos] : 0.f;
         for (int c = lane; c < nvec; c += 64) {
-            float4 v = src[c];
+            float4 v = ld4(src, c);
             if (pe && c == nvec - 1) v.w = pev;
-            dst[c] = v;
+            st4(dst, c, v);
         }
     }
 }
 
+template <typename TX, typename TA>
 __global__ __launch_bounds__(256) void tuple_gather_bwd_kernel(int N, int W, const int* __restrict__ inv_ptr, const int* __restrict__ inv_rows,
-                                                               const float* __restrict__ dx, int lddx, float* __restrict__ da, int ldda,
+                                                               const TX* __restrict__ dx, int lddx, TA* __restrict__ da, int ldda,
                                                                int has_pe, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int nvec = W >> 2;
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (n >= N) return;
     const int r0 = inv_ptr[n], r1 = inv_ptr[n + 1];
-    float4* dst = reinterpret_cast<float4*>(da + (size_t)n * ldda);
+    TA* dst = da + (size_t)n * ldda;
     for (int c = lane; c < nvec; c += 64) {
-        float4 acc = accumulate ? dst[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc = accumulate ? ld4(dst, c) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = r0; j < r1; ++j) {
-            float4 v = reinterpret_cast<const float4*>(dx + (size_t)inv_rows[j] * lddx)[c];
+            float4 v = ld4(dx + (size_t)inv_rows[j] * lddx, c);
             if (has_pe && c == nvec - 1) v.w = 0.f;
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        dst[c] = acc;
+        st4(dst, c, acc);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ attention
 __device__ inline float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
-template <int S>
-__global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, const float* __restrict__ qkv, float* __restrict__ out) {
+template <int S, typename TE>
+__global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, TE* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (t >= T) return;
@@ -70,10 +72,10 @@ __global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, 
         float4 q[S], k[S], v[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
-            const float4* row = reinterpret_cast<const float4*>(qkv + ((size_t)i * T + t) * 3 * F);
-            q[i] = ok ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            k[i] = ok ? row[nvec + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[i] = ok ? row[2 * nvec + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const TE* row = qkv + ((size_t)i * T + t) * 3 * F;
+            q[i] = ok ? ld4(row, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            k[i] = ok ? ld4(row, nvec + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i] = ok ? ld4(row, 2 * nvec + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < S; ++i) {
@@ -96,14 +98,14 @@ __global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, 
                 const float p = sc[j] * inv;
                 o.x += p * v[j].x; o.y += p * v[j].y; o.z += p * v[j].z; o.w += p * v[j].w;
             }
-            if (ok) reinterpret_cast<float4*>(out + ((size_t)i * T + t) * F)[c] = o;
+            if (ok) st4(out + ((size_t)i * T + t) * F, c, o);
         }
     }
 }
 
-template <int S>
-__global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                          float* __restrict__ dqkv) {
+template <int S, typename TE>
+__global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, const TE* __restrict__ dout,
+                                                          TE* __restrict__ dqkv) {
     const int lane = threadIdx.x & 63;
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (t >= T) return;
@@ -116,11 +118,11 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, 
         float4 q[S], k[S], v[S], go[S], dq[S], dk[S], dv[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
-            const float4* row = reinterpret_cast<const float4*>(qkv + ((size_t)i * T + t) * 3 * F);
-            q[i] = ok ? row[c] : zero;
-            k[i] = ok ? row[nvec + c] : zero;
-            v[i] = ok ? row[2 * nvec + c] : zero;
-            go[i] = ok ? reinterpret_cast<const float4*>(dout + ((size_t)i * T + t) * F)[c] : zero;
+            const TE* row = qkv + ((size_t)i * T + t) * 3 * F;
+            q[i] = ok ? ld4(row, c) : zero;
+            k[i] = ok ? ld4(row, nvec + c) : zero;
+            v[i] = ok ? ld4(row, 2 * nvec + c) : zero;
+            go[i] = ok ? ld4(dout + ((size_t)i * T + t) * F, c) : zero;
             dq[i] = zero; dk[i] = zero; dv[i] = zero;
         }
 #pragma unroll
@@ -156,18 +158,19 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, 
         if (ok) {
 #pragma unroll
             for (int i = 0; i < S; ++i) {
-                float4* row = reinterpret_cast<float4*>(dqkv + ((size_t)i * T + t) * 3 * F);
-                row[c] = dq[i];
-                row[nvec + c] = dk[i];
-                row[2 * nvec + c] = dv[i];
+                TE* row = dqkv + ((size_t)i * T + t) * 3 * F;
+                st4(row, c, dq[i]);
+                st4(row, nvec + c, dk[i]);
+                st4(row, 2 * nvec + c, dv[i]);
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ symmetriser input
-__global__ __launch_bounds__(256) void perm_concat_fwd_kernel(int s, int T, int F, int P, Perms perms, const float* __restrict__ x,
-                                                              float* __restrict__ z) {
+template <typename TE>
+__global__ __launch_bounds__(256) void perm_concat_fwd_kernel(int s, int T, int F, int P, Perms perms, const TE* __restrict__ x,
+                                                              TE* __restrict__ z) {
     const int lane = threadIdx.x & 63;
     const int nvec = F >> 2;
     const long total = (long)P * T * s;
@@ -177,29 +180,30 @@ __global__ __launch_bounds__(256) void perm_concat_fwd_kernel(int s, int T, int 
         const long pt = w / s;
         const int t = (int)(pt % T), p = (int)(pt / T);
         const int src_pos = perms.p[p][j];
-        const float4* src = reinterpret_cast<const float4*>(x + ((size_t)src_pos * T + t) * F);
-        float4* dst = reinterpret_cast<float4*>(z + ((size_t)p * T + t) * ((size_t)s * F) + (size_t)j * F);
-        for (int c = lane; c < nvec; c += 64) dst[c] = src[c];
+        const TE* src = x + ((size_t)src_pos * T + t) * F;
+        TE* dst = z + ((size_t)p * T + t) * ((size_t)s * F) + (size_t)j * F;
+        for (int c = lane; c < nvec; c += 64) st4(dst, c, ld4(src, c));
     }
 }
 
-__global__ __launch_bounds__(256) void perm_concat_bwd_kernel(int s, int T, int F, int P, Perms inv, const float* __restrict__ dz,
-                                                              float* __restrict__ dx) {
+template <typename TE>
+__global__ __launch_bounds__(256) void perm_concat_bwd_kernel(int s, int T, int F, int P, Perms inv, const TE* __restrict__ dz,
+                                                              TE* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
     const int nvec = F >> 2;
     const long total = (long)s * T;
     const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
     for (long w = wave0; w < total; w += nw) {
         const int i = (int)(w / T), t = (int)(w % T);
-        float4* dst = reinterpret_cast<float4*>(dx + (size_t)w * F);
+        TE* dst = dx + (size_t)w * F;
         for (int c = lane; c < nvec; c += 64) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int p = 0; p < P; ++p) {
                 const int j = inv.p[p][i];
-                const float4 v = reinterpret_cast<const float4*>(dz + ((size_t)p * T + t) * ((size_t)s * F) + (size_t)j * F)[c];
+                const float4 v = ld4(dz + ((size_t)p * T + t) * ((size_t)s * F) + (size_t)j * F, c);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-            dst[c] = acc;
+            st4(dst, c, acc);
         }
     }
 }
@@ -302,56 +306,92 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int grappa_tuple_gather_fwd_f32(void* stream, int T, int s, int W, const float* a, int lda, const int* idx, const float* pe,
-                                           float* x, int ldx) {
+namespace {
+template <typename T> inline bool aligned_el(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (sizeof(T) == 4 ? 15 : 7)) == 0; }
+
+template <typename TA, typename TX>
+int tuple_gather_fwd_impl(void* stream, int T, int s, int W, const TA* a, int lda, const int* idx, const float* pe, TX* x, int ldx) {
     if (T < 0 || s < 1 || s > 4 || W <= 0 || (W & 3) || (lda & 3) || (ldx & 3)) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
-    if (!a || !idx || !x || !aligned16(a) || !aligned16(x)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(tuple_gather_fwd_kernel, dim3(wave_grid((long)s * T)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, s, W, a,
+    if (!a || !idx || !x || !aligned_el<TA>(a) || !aligned_el<TX>(x)) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL((tuple_gather_fwd_kernel<TA, TX>), dim3(wave_grid((long)s * T)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, s, W, a,
                        lda, idx, pe, x, ldx);
     return grappa_launch_status();
 }
 
-extern "C" int grappa_tuple_gather_bwd_f32(void* stream, int N, int W, const int* inv_ptr, const int* inv_rows, const float* dx, int lddx,
-                                           float* da, int ldda, int has_pe, int accumulate) {
+template <typename TX, typename TA>
+int tuple_gather_bwd_impl(void* stream, int N, int W, const int* inv_ptr, const int* inv_rows, const TX* dx, int lddx, TA* da, int ldda, int has_pe,
+                          int accumulate) {
     if (N < 0 || W <= 0 || (W & 3) || (lddx & 3) || (ldda & 3)) return GRAPPA_ERR_ARG;
     if (N == 0) return GRAPPA_OK;
-    if (!inv_ptr || !da || !aligned16(da) || (dx && !aligned16(dx))) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(tuple_gather_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), N, W, inv_ptr,
+    if (!inv_ptr || !da || !aligned_el<TA>(da) || (dx && !aligned_el<TX>(dx))) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL((tuple_gather_bwd_kernel<TX, TA>), dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), N, W, inv_ptr,
                        inv_rows, dx, lddx, da, ldda, has_pe, accumulate);
     return grappa_launch_status();
 }
 
-extern "C" int grappa_seqattn_fwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out) {
+template <typename TE>
+int seqattn_fwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* qkv, TE* out) {
     if (s < 1 || s > 4 || T < 0 || nheads <= 0 || dh <= 0 || (dh & 3) || !pow2(dh / 4) || dh / 4 > 64 || nheads * dh > 1024) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
-    if (!qkv || !out || !aligned16(qkv) || !aligned16(out)) return GRAPPA_ERR_ARG;
+    if (!qkv || !out || !aligned_el<TE>(qkv) || !aligned_el<TE>(out)) return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((T + 3) / 4);
     const int F = nheads * dh;
     switch (s) {
-        case 1: hipLaunchKernelGGL(seqattn_fwd_kernel<1>, grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-        case 2: hipLaunchKernelGGL(seqattn_fwd_kernel<2>, grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-        case 3: hipLaunchKernelGGL(seqattn_fwd_kernel<3>, grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-        default: hipLaunchKernelGGL(seqattn_fwd_kernel<4>, grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+        case 1: hipLaunchKernelGGL((seqattn_fwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+        case 2: hipLaunchKernelGGL((seqattn_fwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+        case 3: hipLaunchKernelGGL((seqattn_fwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+        default: hipLaunchKernelGGL((seqattn_fwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
     }
     return grappa_launch_status();
 }
 
-extern "C" int grappa_seqattn_bwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv) {
+template <typename TE>
+int seqattn_bwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* qkv, const TE* dout, TE* dqkv) {
     if (s < 1 || s > 4 || T < 0 || nheads <= 0 || dh <= 0 || (dh & 3) || !pow2(dh / 4) || dh / 4 > 64 || nheads * dh > 1024) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
-    if (!qkv || !dout || !dqkv || !aligned16(qkv) || !aligned16(dout) || !aligned16(dqkv)) return GRAPPA_ERR_ARG;
+    if (!qkv || !dout || !dqkv || !aligned_el<TE>(qkv) || !aligned_el<TE>(dout) || !aligned_el<TE>(dqkv)) return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((T + 3) / 4);
     const int F = nheads * dh;
     switch (s) {
-        case 1: hipLaunchKernelGGL(seqattn_bwd_kernel<1>, grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-        case 2: hipLaunchKernelGGL(seqattn_bwd_kernel<2>, grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-        case 3: hipLaunchKernelGGL(seqattn_bwd_kernel<3>, grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-        default: hipLaunchKernelGGL(seqattn_bwd_kernel<4>, grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+        case 1: hipLaunchKernelGGL((seqattn_bwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+        case 2: hipLaunchKernelGGL((seqattn_bwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+        case 3: hipLaunchKernelGGL((seqattn_bwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+        default: hipLaunchKernelGGL((seqattn_bwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
     }
     return grappa_launch_status();
+}
+}  // namespace
+
+extern "C" int grappa_tuple_gather_fwd_f32(void* stream, int T, int s, int W, const float* a, int lda, const int* idx, const float* pe,
+                                           float* x, int ldx) {
+    return tuple_gather_fwd_impl<float, float>(stream, T, s, W, a, lda, idx, pe, x, ldx);
+}
+extern "C" int grappa_tuple_gather_fwd_bf16(void* stream, int T, int s, int W, const uint16_t* a, int lda, const int* idx, const float* pe,
+                                            uint16_t* x, int ldx) {
+    return tuple_gather_fwd_impl<grappa_bf16_t, grappa_bf16_t>(stream, T, s, W, a, lda, idx, pe, x, ldx);
+}
+extern "C" int grappa_tuple_gather_bwd_f32(void* stream, int N, int W, const int* inv_ptr, const int* inv_rows, const float* dx, int lddx,
+                                           float* da, int ldda, int has_pe, int accumulate) {
+    return tuple_gather_bwd_impl<float, float>(stream, N, W, inv_ptr, inv_rows, dx, lddx, da, ldda, has_pe, accumulate);
+}
+extern "C" int grappa_tuple_gather_bwd_bf16(void* stream, int N, int W, const int* inv_ptr, const int* inv_rows, const uint16_t* dx, int lddx,
+                                            uint16_t* da, int ldda, int has_pe, int accumulate) {
+    return tuple_gather_bwd_impl<grappa_bf16_t, grappa_bf16_t>(stream, N, W, inv_ptr, inv_rows, dx, lddx, da, ldda, has_pe, accumulate);
+}
+extern "C" int grappa_seqattn_fwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out) {
+    return seqattn_fwd_impl<float>(stream, s, T, nheads, dh, qkv, out);
+}
+extern "C" int grappa_seqattn_fwd_bf16(void* stream, int s, int T, int nheads, int dh, const uint16_t* qkv, uint16_t* out) {
+    return seqattn_fwd_impl<grappa_bf16_t>(stream, s, T, nheads, dh, qkv, out);
+}
+extern "C" int grappa_seqattn_bwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv) {
+    return seqattn_bwd_impl<float>(stream, s, T, nheads, dh, qkv, dout, dqkv);
+}
+extern "C" int grappa_seqattn_bwd_bf16(void* stream, int s, int T, int nheads, int dh, const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv) {
+    return seqattn_bwd_impl<grappa_bf16_t>(stream, s, T, nheads, dh, qkv, dout, dqkv);
 }
 
 static int fill_perms(int s, int P, const int* h_perm, Perms& fwd, Perms& inv) {
@@ -370,26 +410,42 @@ static int fill_perms(int s, int P, const int* h_perm, Perms& fwd, Perms& inv) {
     return GRAPPA_OK;
 }
 
-extern "C" int grappa_perm_concat_fwd_f32(void* stream, int s, int T, int F, int P, const int* h_perm, const float* x, float* z) {
+namespace {
+template <typename TE>
+int perm_concat_fwd_impl(void* stream, int s, int T, int F, int P, const int* h_perm, const TE* x, TE* z) {
     Perms fwd, inv;
     if (int rc = fill_perms(s, P, h_perm, fwd, inv)) return rc;
     if (T < 0 || F <= 0 || (F & 3)) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
-    if (!x || !z || !aligned16(x) || !aligned16(z)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(perm_concat_fwd_kernel, dim3(wave_grid((long)P * T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P,
+    if (!x || !z || !aligned_el<TE>(x) || !aligned_el<TE>(z)) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(perm_concat_fwd_kernel<TE>, dim3(wave_grid((long)P * T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P,
                        fwd, x, z);
     return grappa_launch_status();
 }
-
-extern "C" int grappa_perm_concat_bwd_f32(void* stream, int s, int T, int F, int P, const int* h_perm, const float* dz, float* dx) {
+template <typename TE>
+int perm_concat_bwd_impl(void* stream, int s, int T, int F, int P, const int* h_perm, const TE* dz, TE* dx) {
     Perms fwd, inv;
     if (int rc = fill_perms(s, P, h_perm, fwd, inv)) return rc;
     if (T < 0 || F <= 0 || (F & 3)) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
-    if (!dz || !dx || !aligned16(dz) || !aligned16(dx)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(perm_concat_bwd_kernel, dim3(wave_grid((long)T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P, inv,
+    if (!dz || !dx || !aligned_el<TE>(dz) || !aligned_el<TE>(dx)) return GRAPPA_ERR_ARG;
+    hipLaunchKernelGGL(perm_concat_bwd_kernel<TE>, dim3(wave_grid((long)T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P, inv,
                        dz, dx);
     return grappa_launch_status();
+}
+}  // namespace
+
+extern "C" int grappa_perm_concat_fwd_f32(void* stream, int s, int T, int F, int P, const int* h_perm, const float* x, float* z) {
+    return perm_concat_fwd_impl<float>(stream, s, T, F, P, h_perm, x, z);
+}
+extern "C" int grappa_perm_concat_fwd_bf16(void* stream, int s, int T, int F, int P, const int* h_perm, const uint16_t* x, uint16_t* z) {
+    return perm_concat_fwd_impl<grappa_bf16_t>(stream, s, T, F, P, h_perm, x, z);
+}
+extern "C" int grappa_perm_concat_bwd_f32(void* stream, int s, int T, int F, int P, const int* h_perm, const float* dz, float* dx) {
+    return perm_concat_bwd_impl<float>(stream, s, T, F, P, h_perm, dz, dx);
+}
+extern "C" int grappa_perm_concat_bwd_bf16(void* stream, int s, int T, int F, int P, const int* h_perm, const uint16_t* dz, uint16_t* dx) {
+    return perm_concat_bwd_impl<grappa_bf16_t>(stream, s, T, F, P, h_perm, dz, dx);
 }
 
 extern "C" int grappa_param_out_fwd_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff, const float* o, int ldo,

@@ -101,6 +101,10 @@ typedef struct grappa_gemm_desc {
     uint16_t* Cp; int ldcp; size_t cp_plane_stride;               /* planes of the FINAL value (what OUT receives); C may be NULL then */
     const uint16_t* resp; int ldresp; size_t resp_plane_stride;   /* residual given in planes (instead of res) */
     const uint16_t* auxp; int ldauxp; size_t auxp_plane_stride;   /* saved ELU output given in planes (instead of aux) */
+    /* number of planes behind Cp / resp / auxp: 3 (0 means 3) = the exact fp32 split; 1 = a plain bf16 tensor (the bf16 storage
+     * configuration: activations are kept in bf16 in HBM, precision GRAPPA_GEMM_BF16 reads plane 0 of both operands) */
+    int cp_nplanes, resp_nplanes, auxp_nplanes;
+    uint16_t* C1p; int ldc1p;                                     /* bf16 copy of the value C receives when C2 is used (before dropout / residual) */
 } grappa_gemm_desc;
 
 /* fp32 X[R][C] -> plane format: planes[p][r][c] (transpose == 0) or planes[p][c][r] (transpose != 0), p = 0..2, leading
@@ -317,6 +321,37 @@ int grappa_sumsq_f32(void* stream, size_t n, const float* x, float* out, int acc
 int grappa_adam_step_f32(void* stream, size_t n, float* p, const float* g, float* m, float* v,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float grad_scale, const float* sumsq, float max_norm);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 storage configuration (BASELINE configs[2]: "bf16, MFMA dense heads"; the reference's Lightning `precision` / its
+ * torch.set_float32_matmul_precision('medium'), training/trainrun.py:3): activations and activation gradients are kept as bf16
+ * in HBM (uint16_t bit patterns, round to nearest even on every store), half the bytes of every HBM-bound kernel; statistics,
+ * softmax, accumulation, parameters, parameter gradients, energies and forces stay fp32.  Same semantics and argument meaning
+ * as the *_f32 entry points above; rows 8-byte aligned.  The dense products take precision GRAPPA_GEMM_BF16 with a_planes /
+ * b_planes = 1 and *_nplanes = 1 (grappa_gemm_desc): one plane = the bf16 tensor itself. */
+int grappa_layernorm_fwd_bf16(void* stream, int M, int W, const uint16_t* x, int ldx, const float* gamma, const float* beta,
+                              uint16_t* y, int ldy, float* mean, float* rstd);
+int grappa_layernorm_bwd_bf16(void* stream, int M, int W, const uint16_t* dy, int lddy, const uint16_t* x, int ldx,
+                              const float* mean, const float* rstd, const float* gamma, uint16_t* dx, int lddx,
+                              float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes);
+int grappa_act_dropout_bwd_bf16(void* stream, int M, int N, const uint16_t* dy, int lddy, const uint16_t* y, int ldy,
+                                float drop_p, uint64_t drop_seed, uint16_t* dz, int lddz);
+int grappa_gat_fwd_bf16(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices,
+                        const uint16_t* ft, uint16_t* out, float* alpha);
+int grappa_gat_bwd_bf16(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const int* rev,
+                        const uint16_t* ft, const uint16_t* out, const float* alpha, const uint16_t* dout,
+                        uint16_t* dft, float* delta);
+int grappa_tuple_gather_fwd_bf16(void* stream, int T, int s, int W, const uint16_t* a, int lda, const int* idx,
+                                 const float* pe, uint16_t* x, int ldx);
+int grappa_tuple_gather_bwd_bf16(void* stream, int N, int W, const int* inv_ptr, const int* inv_rows,
+                                 const uint16_t* dx, int lddx, uint16_t* da, int ldda, int has_pe, int accumulate);
+int grappa_seqattn_fwd_bf16(void* stream, int s, int T, int nheads, int dh, const uint16_t* qkv, uint16_t* out);
+int grappa_seqattn_bwd_bf16(void* stream, int s, int T, int nheads, int dh, const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv);
+int grappa_perm_concat_fwd_bf16(void* stream, int s, int T, int F, int P, const int* h_perm, const uint16_t* x, uint16_t* z);
+int grappa_perm_concat_bwd_bf16(void* stream, int s, int T, int F, int P, const int* h_perm, const uint16_t* dz, uint16_t* dx);
+/* element-type conversion of a [M,N] view (round to nearest even), for the few places where the two configurations meet */
+int grappa_convert_f32_to_bf16(void* stream, int M, int N, const float* x, int ldx, uint16_t* y, int ldy);
+int grappa_convert_bf16_to_f32(void* stream, int M, int N, const uint16_t* x, int ldx, float* y, int ldy);
 
 /* the dropout decision used by every kernel above, exposed for tests: 1 = keep */
 int grappa_dropout_keep(uint64_t seed, uint64_t index, float p);

@@ -187,6 +187,46 @@ def bench(gen):
     print(f"  sum: planes {tot_p:.3f} ms, split-in-kernel {tot_s:.3f} ms, fp32A+Wplanes (k-major rows: planes) {tot_w:.3f} ms")
 
 
+def bench_epilogues(gen):
+    """cost of the fused epilogue pieces on the split-in-kernel GEMM and the weight-plane GEMM (M x 512 x 512)"""
+    M, N, K = 83328, 512, 512
+    A = torch.randn((M, K), generator=gen, device=dev)
+    W = torch.randn((N, K), generator=gen, device=dev) / K ** 0.5
+    wp = split_planes(W)
+    R = torch.randn((M, N), generator=gen, device=dev)
+    U = torch.randn((M, N), generator=gen, device=dev)
+    bias = torch.randn((N,), generator=gen, device=dev)
+    out = torch.empty((M, N), device=dev)
+    out2 = torch.empty((M, N), device=dev)
+    cases = {"plain": {}, "bias": dict(bias=bias), "bias+res": dict(bias=bias, res=R), "bias+drop+res": dict(bias=bias, res=R, drop_p=0.5, drop_seed=123),
+             "aux (ELU')": dict(aux=U), "bias+ELU+drop+res+C2": dict(bias=bias, res=R, drop_p=0.5, drop_seed=123, act=1, C2=out2.data_ptr(), ldc2=N),
+             "accumulate": dict(accumulate=1)}
+    for name, kw in cases.items():
+        ts = timeit(lambda: gemm(A, W, out, M, N, K, True, True, False, **kw))
+        tw = timeit(lambda: gemm(A, wp, out, M, N, K, True, True, "b", **kw))
+        print(f"  {name:24s} split-in-kernel {ts:7.3f} ms   fp32A+Wplanes {tw:7.3f} ms", flush=True)
+
+
+def bench_bf16(gen):
+    """the plane kernels with ONE plane per operand = a plain bf16 GEMM (fp32 accumulate), against the split-in-kernel GEMM in its
+    bf16 mode (fp32 operands rounded in the kernel)"""
+    for M, N, K, kmajor in [(83328, 512, 512, 0), (83328, 1536, 512, 0), (83328, 512, 1536, 0), (333000, 512, 512, 0), (512, 512, 83328, 1), (1536, 512, 333000, 1)]:
+        A = torch.randn((M, K), generator=gen, device=dev)
+        B = torch.randn((N, K), generator=gen, device=dev)
+        out = torch.empty((M, N), device=dev)
+        if kmajor:
+            Af, Bf = A.t().contiguous(), B.t().contiguous()
+            ap, bp = split_planes(Af), split_planes(Bf)
+            tp = timeit(lambda: gemm(ap, bp, out, M, N, K, False, False, True, precision="bf16"))
+            ts = timeit(lambda: gemm(Af, Bf, out, M, N, K, False, False, False, precision="bf16"))
+        else:
+            ap, bp = split_planes(A), split_planes(B)
+            tp = timeit(lambda: gemm(ap, bp, out, M, N, K, True, True, True, precision="bf16"))
+            ts = timeit(lambda: gemm(A, B, out, M, N, K, True, True, False, precision="bf16"))
+        fl = 2.0 * M * N * K
+        print(f"  M {M:6d} N {N:5d} K {K:6d} {'k-major ' if kmajor else 'k-contig'}: bf16 planes {tp:7.3f} ms {fl / tp / 1e9:6.1f} TF   fp32-in bf16 mode {ts:7.3f} ms {fl / ts / 1e9:6.1f} TF", flush=True)
+
+
 def build_variants(only=None):
     """libraries with the knock-out switches of csrc/gemm_planes.hip (GP_KNOCK), for `--variants`"""
     import subprocess
@@ -212,6 +252,12 @@ if __name__ == "__main__":
     if "--build-variants" in sys.argv:
         only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
         print(build_variants(only[0] if only else None))
+        sys.exit(0)
+    if "--bf16" in sys.argv:
+        bench_bf16(torch.Generator(device=dev).manual_seed(0))
+        sys.exit(0)
+    if "--epilogues" in sys.argv:
+        bench_epilogues(torch.Generator(device=dev).manual_seed(0))
         sys.exit(0)
     if "--bench-only" in sys.argv:
         bench(torch.Generator(device=dev).manual_seed(0))
