@@ -47,10 +47,26 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
-def _f32_2d(t: torch.Tensor, name: str, dev) -> int:
-    """validate a (rows, cols) fp32 view with unit inner stride; return its leading dimension."""
-    if t.dtype != torch.float32 or t.device != dev or t.dim() != 2:
-        raise ValueError(f"{name}: expected a 2-d float32 tensor on {dev}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+_ACT_DTYPES = (torch.float32, torch.bfloat16)
+
+
+def _sfx(t: torch.Tensor) -> str:
+    """suffix of the C entry point for an activation tensor's element type"""
+    return "bf16" if t.dtype == torch.bfloat16 else "f32"
+
+
+def _same_dtype(*ts) -> torch.dtype:
+    dts = {t.dtype for t in ts if t is not None}
+    if len(dts) != 1 or next(iter(dts)) not in _ACT_DTYPES:
+        raise ValueError(f"activation tensors of one kernel must share one element type (float32 or bfloat16), got {sorted(map(str, dts))}")
+    return next(iter(dts))
+
+
+def _f32_2d(t: torch.Tensor, name: str, dev, dtype=torch.float32) -> int:
+    """validate a (rows, cols) view of element type `dtype` (None: float32 or bfloat16) with unit inner stride; return its leading dimension."""
+    ok = t.dtype in _ACT_DTYPES if dtype is None else t.dtype == dtype
+    if not ok or t.device != dev or t.dim() != 2:
+        raise ValueError(f"{name}: expected a 2-d {dtype or 'float32/bfloat16'} tensor on {dev}, got {t.dtype} {tuple(t.shape)} on {t.device}")
     if t.shape[1] > 1 and t.stride(1) != 1:
         raise ValueError(f"{name}: inner stride must be 1")
     if t.shape[0] > 1:
@@ -167,23 +183,116 @@ class HipBackend:
         return ws
 
     # ------------------------------------------------------------------ dense
+    def to_f32(self, t: torch.Tensor) -> torch.Tensor:
+        """fp32 copy of a 2-d bf16 view (the few places where a bf16 tensor meets an fp32-only kernel)"""
+        if t.dtype == torch.float32:
+            return t
+        out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+        if t.numel():
+            _chk(self.lib.grappa_convert_bf16_to_f32(self._stream(), t.shape[0], t.shape[1], t.data_ptr(), _f32_2d(t, "x", t.device, torch.bfloat16),
+                                                     out.data_ptr(), out.shape[1]), "grappa_convert_bf16_to_f32")
+        return out
+
+    def to_bf16(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype == torch.bfloat16:
+            return t
+        out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        if t.numel():
+            _chk(self.lib.grappa_convert_f32_to_bf16(self._stream(), t.shape[0], t.shape[1], t.data_ptr(), _f32_2d(t, "x", t.device), out.data_ptr(),
+                                                     out.shape[1]), "grappa_convert_f32_to_bf16")
+        return out
+
+    @staticmethod
+    def _dma_ok(t: torch.Tensor, ld: int) -> bool:
+        """a bf16 operand the LDS-DMA kernels can read: 16-byte aligned base, rows a multiple of 16 bytes apart"""
+        return t.data_ptr() % 16 == 0 and ld % 8 == 0
+
     def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
              drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None) -> None:
+        """C = epilogue(A B^T) (include/grappa_hip.h).  Operands and epilogue tensors may be float32 or -- the bf16 storage
+        configuration -- bfloat16: a bf16 A (and, for the wgrad layout, B) is read by the LDS-DMA plane kernels as a one-plane
+        operand when the shape allows it, otherwise converted to fp32 first; out / out2 / res / aux are written / read in their own
+        element type by the shared epilogue."""
         dev = out.device
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
-        d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
         ar, ac = (M, K) if a_kcontig else (K, M)
         br, bc = (N, K) if b_kcontig else (K, N)
         if tuple(a.shape) != (ar, ac) or tuple(b.shape) != (br, bc) or tuple(out.shape) != (M, N):
             raise ValueError(f"gemm: shapes A{tuple(a.shape)} B{tuple(b.shape)} C{tuple(out.shape)} do not match M={M} N={N} K={K}")
-        d.A, d.lda = a.data_ptr(), _f32_2d(a, "A", dev)
-        d.B, d.ldb = b.data_ptr(), _f32_2d(b, "B", dev)
-        d.C, d.ldc = out.data_ptr(), _f32_2d(out, "C", dev)
-        if out2 is not None:
-            if tuple(out2.shape) != (M, N):
-                raise ValueError("gemm: out2 shape")
-            d.C2, d.ldc2 = out2.data_ptr(), _f32_2d(out2, "C2", dev)
+        if M == 0 or N == 0:
+            return
+        if K == 0:
+            raise ValueError("gemm: K == 0")
+        if precision is not None:
+            d.precision = _lib.GEMM_PRECISIONS[precision]
+        elif a_kcontig and b_kcontig or self.gemm_precision_bwd is None:
+            d.precision = self.gemm_precision
+        else:
+            d.precision = self.gemm_precision_bwd      # dgrad (B row-contiguous) and wgrad (both row-contiguous) products: backward pass only
+        bf16 = torch.bfloat16
+        big = M > 32 and N > 32
+        # ---- operands
+        planes_a = planes_b = None
+        if a_kcontig:
+            # forward / dgrad: B is a weight matrix (fp32 parameter)
+            if b.dtype != torch.float32:
+                raise ValueError("gemm: the weight operand must be float32")
+            if a.dtype == bf16:
+                if big and K % 32 == 0 and self._dma_ok(a, a.stride(0)) and a_colsum is None:
+                    planes_a = a                                                     # one plane = the bf16 tensor itself
+                    planes_b = self._planes_of_weight(b, transposed=not b_kcontig)
+                    d.precision = _lib.GEMM_PRECISIONS["bf16"]
+                else:
+                    a = self.to_f32(a)
+            if planes_a is None and (self.weight_planes and b.requires_grad and big and K % 32 == 0 and a_colsum is None
+                                     and d.precision != _lib.GEMM_PRECISIONS["f32"] and a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0):
+                planes_b = self._planes_of_weight(b, transposed=not b_kcontig)      # fp32 activations x pre-split weight planes
+        else:
+            if b_kcontig:
+                raise ValueError("gemm: layout a_kcontig=0, b_kcontig=1 is never needed by the path")
+            if a.dtype == bf16 and b.dtype == bf16 and big and self._dma_ok(a, a.stride(0)) and self._dma_ok(b, b.stride(0)):
+                planes_a, planes_b = a, b                                            # wgrad: both operands are bf16 activations
+                d.precision = _lib.GEMM_PRECISIONS["bf16"]
+            else:
+                a, b = self.to_f32(a), self.to_f32(b)
+        if planes_a is not None:
+            d.A, d.lda, d.a_planes, d.a_plane_stride = planes_a.data_ptr(), planes_a.stride(0), 1, 0
+            _f32_2d(planes_a, "A", dev, bf16)
+        else:
+            d.A, d.lda = a.data_ptr(), _f32_2d(a, "A", dev)
+        if planes_b is not None and planes_b.dim() == 3:                             # weight planes (3, rows_pad, cols_pad)
+            d.B, d.ldb, d.b_planes, d.b_plane_stride = planes_b.data_ptr(), planes_b.stride(1), 1, planes_b.stride(0)
+            d.a_kcontig, d.b_kcontig = 1, 1
+        elif planes_b is not None:
+            d.B, d.ldb, d.b_planes, d.b_plane_stride = planes_b.data_ptr(), planes_b.stride(0), 1, 0
+            d.a_kcontig, d.b_kcontig = 0, 0
+        else:
+            d.B, d.ldb = b.data_ptr(), _f32_2d(b, "B", dev)
+            d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
+        # ---- outputs and epilogue tensors, each in its own element type
+        def plane_ok(t, name):
+            ld = _f32_2d(t, name, dev, bf16)
+            if t.data_ptr() % 8 or ld % 4:
+                raise ValueError(f"gemm: bf16 {name} needs 8-byte aligned rows")
+            return ld
+        if out2 is not None and tuple(out2.shape) != (M, N):
+            raise ValueError("gemm: out2 shape")
+        final = out2 if out2 is not None else out
+        if final.dtype == bf16:
+            if accumulate:
+                raise ValueError("gemm: accumulate needs a float32 output")
+            d.Cp, d.ldcp, d.cp_nplanes = final.data_ptr(), plane_ok(final, "out"), 1
+            if out2 is not None:                                                     # (out, out2) = (value before dropout / residual, final value)
+                if out.dtype != bf16:
+                    raise ValueError("gemm: out and out2 must share an element type")
+                d.C1p, d.ldc1p = out.data_ptr(), plane_ok(out, "out (pre-dropout copy)")
+        else:
+            d.C, d.ldc = out.data_ptr(), _f32_2d(out, "C", dev)
+            if out2 is not None:
+                if out2.dtype != torch.float32:
+                    raise ValueError("gemm: out and out2 must share an element type")
+                d.C2, d.ldc2 = out2.data_ptr(), _f32_2d(out2, "C2", dev)
         if bias is not None:
             _flat(bias, "bias", dev)
             if bias.numel() != N:
@@ -192,11 +301,17 @@ class HipBackend:
         if res is not None:
             if tuple(res.shape) != (M, N):
                 raise ValueError("gemm: res shape")
-            d.res, d.ldres = res.data_ptr(), _f32_2d(res, "res", dev)
+            if res.dtype == bf16:
+                d.resp, d.ldresp, d.resp_nplanes = res.data_ptr(), plane_ok(res, "res"), 1
+            else:
+                d.res, d.ldres = res.data_ptr(), _f32_2d(res, "res", dev)
         if aux is not None:
             if tuple(aux.shape) != (M, N):
                 raise ValueError("gemm: aux shape")
-            d.aux, d.ldaux = aux.data_ptr(), _f32_2d(aux, "aux", dev)
+            if aux.dtype == bf16:
+                d.auxp, d.ldauxp, d.auxp_nplanes = aux.data_ptr(), plane_ok(aux, "aux"), 1
+            else:
+                d.aux, d.ldaux = aux.data_ptr(), _f32_2d(aux, "aux", dev)
         if pre is not None:
             if tuple(pre.shape) != (M, N):
                 raise ValueError("gemm: pre shape")
@@ -207,31 +322,18 @@ class HipBackend:
                 raise ValueError("gemm: a_colsum needs the row-contiguous A layout and length M")
             d.a_colsum = a_colsum.data_ptr()
         d.act, d.drop_p, d.drop_seed, d.accumulate = int(act), float(drop_p), int(drop_seed) & (2 ** 64 - 1), int(accumulate)
-        if precision is not None:
-            d.precision = _lib.GEMM_PRECISIONS[precision]
-        elif a_kcontig and b_kcontig or self.gemm_precision_bwd is None:
-            d.precision = self.gemm_precision
-        else:
-            d.precision = self.gemm_precision_bwd      # dgrad (B row-contiguous) and wgrad (both row-contiguous) products: backward pass only
-        if M == 0 or N == 0:
-            return
-        if K == 0:
-            raise ValueError("gemm: K == 0")
-        if (self.weight_planes and a_kcontig and b.requires_grad and M > 32 and N > 32 and K % 32 == 0 and a_colsum is None
-                and d.precision != _lib.GEMM_PRECISIONS["f32"] and a.data_ptr() % 16 == 0 and d.lda % 4 == 0):
-            # B is a weight matrix: forward reads the planes of W[N,K]; dgrad (B given as W[K,N] rows) the planes of W^T
-            planes = self._planes_of_weight(b, transposed=not b_kcontig)
-            d.B, d.ldb, d.b_kcontig = planes.data_ptr(), planes.stride(1), 1
-            d.b_planes, d.b_plane_stride = 1, planes.stride(0)
         need = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
         ws = self._workspace(need, dev) if need else None
-        self._timed("gemm_f32", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
+        el = lambda t: 0 if t is None else t.element_size()      # noqa: E731
+        self._timed("gemm_f32", 2.0 * M * N * K, float(M * K * el(a if planes_a is None else planes_a) + N * K * (2 if planes_b is not None else 4)
+                                                         + M * N * el(final)),
                     lambda: _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0),
                                  "grappa_gemm_f32"))
 
     def colsum(self, x, out, accumulate=False) -> None:
         dev = out.device
         M, N = x.shape
+        x = self.to_f32(x)
         ldx = _f32_2d(x, "x", dev)
         _flat(out, "out", dev)
         if out.numel() != N:
@@ -245,9 +347,10 @@ class HipBackend:
         M, N = dy.shape
         if tuple(dz.shape) != (M, N) or (y is not None and tuple(y.shape) != (M, N)):
             raise ValueError("act_dropout_bwd: shapes")
-        _chk(self.lib.grappa_act_dropout_bwd_f32(self._stream(), M, N, dy.data_ptr(), _f32_2d(dy, "dy", dev), _ptr(y),
-                                                 _f32_2d(y, "y", dev) if y is not None else 0, float(drop_p),
-                                                 int(drop_seed) & (2 ** 64 - 1), dz.data_ptr(), _f32_2d(dz, "dz", dev)), "grappa_act_dropout_bwd_f32")
+        dt = _same_dtype(dy, y, dz)
+        fn = getattr(self.lib, f"grappa_act_dropout_bwd_{_sfx(dz)}")
+        _chk(fn(self._stream(), M, N, dy.data_ptr(), _f32_2d(dy, "dy", dev, dt), _ptr(y), _f32_2d(y, "y", dev, dt) if y is not None else 0,
+                float(drop_p), int(drop_seed) & (2 ** 64 - 1), dz.data_ptr(), _f32_2d(dz, "dz", dev, dt)), "grappa_act_dropout_bwd")
 
     def add(self, x, z, y) -> None:
         dev = y.device
@@ -268,8 +371,10 @@ class HipBackend:
             _flat(mean, "mean", dev), _flat(rstd, "rstd", dev)
             if mean.numel() != M or rstd.numel() != M:
                 raise ValueError("layernorm: stats length")
-        _chk(self.lib.grappa_layernorm_fwd_f32(self._stream(), M, W, x.data_ptr(), _f32_2d(x, "x", dev), gamma.data_ptr(), beta.data_ptr(),
-                                               y.data_ptr(), _f32_2d(y, "y", dev), _ptr(mean), _ptr(rstd)), "grappa_layernorm_fwd_f32")
+        dt = _same_dtype(x, y)
+        fn = getattr(self.lib, f"grappa_layernorm_fwd_{_sfx(x)}")
+        _chk(fn(self._stream(), M, W, x.data_ptr(), _f32_2d(x, "x", dev, dt), gamma.data_ptr(), beta.data_ptr(),
+                y.data_ptr(), _f32_2d(y, "y", dev, dt), _ptr(mean), _ptr(rstd)), "grappa_layernorm_fwd")
 
     def layernorm_bwd(self, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True) -> None:
         dev = dx.device
@@ -280,11 +385,12 @@ class HipBackend:
                 raise ValueError(f"layernorm_bwd: {n} length")
         if tuple(dy.shape) != (M, W) or tuple(dx.shape) != (M, W):
             raise ValueError("layernorm_bwd: shapes")
+        dt = _same_dtype(dy, x, dx)
         ws = self._workspace(self.lib.grappa_layernorm_bwd_workspace_bytes(M, W), dev)
-        _chk(self.lib.grappa_layernorm_bwd_f32(self._stream(), M, W, dy.data_ptr(), _f32_2d(dy, "dy", dev), x.data_ptr(), _f32_2d(x, "x", dev),
-                                               mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _f32_2d(dx, "dx", dev),
-                                               dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()),
-             "grappa_layernorm_bwd_f32")
+        fn = getattr(self.lib, f"grappa_layernorm_bwd_{_sfx(x)}")
+        _chk(fn(self._stream(), M, W, dy.data_ptr(), _f32_2d(dy, "dy", dev, dt), x.data_ptr(), _f32_2d(x, "x", dev, dt),
+                mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _f32_2d(dx, "dx", dev, dt),
+                dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()), "grappa_layernorm_bwd")
 
     # ------------------------------------------------------------------ graph
     def _csr_check(self, plan, N, dev):
@@ -297,29 +403,36 @@ class HipBackend:
         dev = out.device
         N = ft.shape[0]
         self._csr_check(plan, N, dev)
-        _flat(ft, "ft", dev), _flat(out, "out", dev), _flat(alpha, "alpha", dev)
+        dt = _same_dtype(ft, out)
+        _flat(ft, "ft", dev, dt), _flat(out, "out", dev, dt), _flat(alpha, "alpha", dev)
         if ft.shape[1] != H * D or out.shape != ft.shape or alpha.numel() != plan.E * H:
             raise ValueError("gat_fwd: shapes")
-        # algorithmic bytes: one source row per edge + col index, one dst row read + one output row write + indptr per node
-        nbytes = plan.E * (H * D * 4 + 4) + N * (2 * H * D * 4 + 4)
+        # algorithmic bytes (element size b): one source row per edge + col index, one dst row read + one output row write + indptr per node
+        eb = ft.element_size()
+        nbytes = plan.E * (H * D * eb + 4) + N * (2 * H * D * eb + 4)
+        fn = getattr(self.lib, f"grappa_gat_fwd_{_sfx(ft)}")
         self._timed("gat_fwd", 2.0 * plan.E * H * D * 2, nbytes,
-                    lambda: _chk(self.lib.grappa_gat_fwd_f32(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(),
-                                                             ft.data_ptr(), out.data_ptr(), alpha.data_ptr()), "grappa_gat_fwd_f32"))
+                    lambda: _chk(fn(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(),
+                                    ft.data_ptr(), out.data_ptr(), alpha.data_ptr()), "grappa_gat_fwd"))
 
     def gat_bwd(self, plan, ft, out, alpha, dout, H, D, dft) -> None:
         dev = dft.device
         N = ft.shape[0]
         self._csr_check(plan, N, dev)
-        for t, n in ((ft, "ft"), (out, "out"), (alpha, "alpha"), (dout, "dout"), (dft, "dft")):
-            _flat(t, n, dev)
+        dt = _same_dtype(ft, out, dout, dft)
+        for t, n in ((ft, "ft"), (out, "out"), (dout, "dout"), (dft, "dft")):
+            _flat(t, n, dev, dt)
+        _flat(alpha, "alpha", dev)
         if ft.shape[1] != H * D or out.shape != ft.shape or dout.shape != ft.shape or dft.shape != ft.shape or alpha.numel() != plan.E * H:
             raise ValueError("gat_bwd: shapes")
         delta = torch.empty((N, H), dtype=torch.float32, device=dev)
-        nbytes = plan.E * (2 * H * D * 4 + 4) + N * (4 * H * D * 4 + 4)
+        eb = ft.element_size()
+        nbytes = plan.E * (2 * H * D * eb + 4) + N * (4 * H * D * eb + 4)
+        fn = getattr(self.lib, f"grappa_gat_bwd_{_sfx(ft)}")
         self._timed("gat_bwd", 2.0 * plan.E * H * D * 5, nbytes,
-                    lambda: _chk(self.lib.grappa_gat_bwd_f32(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(),
-                                                             plan.rev.data_ptr(), ft.data_ptr(), out.data_ptr(), alpha.data_ptr(), dout.data_ptr(),
-                                                             dft.data_ptr(), delta.data_ptr()), "grappa_gat_bwd_f32"))
+                    lambda: _chk(fn(self._stream(), N, plan.E, H, D, plan.indptr.data_ptr(), plan.indices.data_ptr(),
+                                    plan.rev.data_ptr(), ft.data_ptr(), out.data_ptr(), alpha.data_ptr(), dout.data_ptr(),
+                                    dft.data_ptr(), delta.data_ptr()), "grappa_gat_bwd"))
 
     def neighbor_mean(self, plan, x, out, scale_by_neighbor: bool) -> None:
         dev = out.device
@@ -353,8 +466,10 @@ class HipBackend:
             _flat(pe, "pe", dev)
             if pe.numel() != s:
                 raise ValueError("tuple_gather_fwd: pe length")
-        _chk(self.lib.grappa_tuple_gather_fwd_f32(self._stream(), T, s, W, a.data_ptr(), _f32_2d(a, "a", dev), idx.data_ptr(), _ptr(pe),
-                                                  x.data_ptr(), _f32_2d(x, "x", dev)), "grappa_tuple_gather_fwd_f32")
+        dt = _same_dtype(a, x)
+        fn = getattr(self.lib, f"grappa_tuple_gather_fwd_{_sfx(x)}")
+        _chk(fn(self._stream(), T, s, W, a.data_ptr(), _f32_2d(a, "a", dev, dt), idx.data_ptr(), _ptr(pe),
+                x.data_ptr(), _f32_2d(x, "x", dev, dt)), "grappa_tuple_gather_fwd")
 
     def tuple_gather_bwd(self, inv_ptr, inv_rows, dx, da, has_pe: bool, accumulate=False) -> None:
         dev = da.device
@@ -363,44 +478,53 @@ class HipBackend:
             raise ValueError("tuple_gather_bwd: inverse incidence")
         if da.shape[1] < W or inv_rows.numel() != dx.shape[0]:
             raise ValueError("tuple_gather_bwd: shapes")
-        _chk(self.lib.grappa_tuple_gather_bwd_f32(self._stream(), N, W, inv_ptr.data_ptr(), inv_rows.data_ptr(), dx.data_ptr(),
-                                                  _f32_2d(dx, "dx", dev), da.data_ptr(), _f32_2d(da, "da", dev), int(has_pe), int(accumulate)),
-             "grappa_tuple_gather_bwd_f32")
+        dt = _same_dtype(dx, da)
+        fn = getattr(self.lib, f"grappa_tuple_gather_bwd_{_sfx(da)}")
+        _chk(fn(self._stream(), N, W, inv_ptr.data_ptr(), inv_rows.data_ptr(), dx.data_ptr(),
+                _f32_2d(dx, "dx", dev, dt), da.data_ptr(), _f32_2d(da, "da", dev, dt), int(has_pe), int(accumulate)),
+             "grappa_tuple_gather_bwd")
 
     def seqattn_fwd(self, qkv, s, T, nheads, out) -> None:
         dev = out.device
-        _flat(qkv, "qkv", dev), _flat(out, "out", dev)
+        dt = _same_dtype(qkv, out)
+        _flat(qkv, "qkv", dev, dt), _flat(out, "out", dev, dt)
         F = out.shape[1]
         if qkv.shape != (s * T, 3 * F) or out.shape[0] != s * T or F % nheads:
             raise ValueError("seqattn_fwd: shapes")
-        _chk(self.lib.grappa_seqattn_fwd_f32(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), out.data_ptr()), "grappa_seqattn_fwd_f32")
+        fn = getattr(self.lib, f"grappa_seqattn_fwd_{_sfx(out)}")
+        _chk(fn(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), out.data_ptr()), "grappa_seqattn_fwd")
 
     def seqattn_bwd(self, qkv, dout, s, T, nheads, dqkv) -> None:
         dev = dqkv.device
-        _flat(qkv, "qkv", dev), _flat(dout, "dout", dev), _flat(dqkv, "dqkv", dev)
+        dt = _same_dtype(qkv, dout, dqkv)
+        _flat(qkv, "qkv", dev, dt), _flat(dout, "dout", dev, dt), _flat(dqkv, "dqkv", dev, dt)
         F = dout.shape[1]
         if qkv.shape != (s * T, 3 * F) or dqkv.shape != qkv.shape or dout.shape[0] != s * T:
             raise ValueError("seqattn_bwd: shapes")
-        _chk(self.lib.grappa_seqattn_bwd_f32(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr()),
-             "grappa_seqattn_bwd_f32")
+        fn = getattr(self.lib, f"grappa_seqattn_bwd_{_sfx(dqkv)}")
+        _chk(fn(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr()), "grappa_seqattn_bwd")
 
     def perm_concat_fwd(self, x, s, T, perms: Sequence[Sequence[int]], z) -> None:
         dev = z.device
-        _flat(x, "x", dev), _flat(z, "z", dev)
+        dt = _same_dtype(x, z)
+        _flat(x, "x", dev, dt), _flat(z, "z", dev, dt)
         F, P = x.shape[1], len(perms)
         if x.shape[0] != s * T or z.shape != (P * T, s * F):
             raise ValueError("perm_concat_fwd: shapes")
         arr = (C.c_int * (P * s))(*[int(v) for p in perms for v in p])
-        _chk(self.lib.grappa_perm_concat_fwd_f32(self._stream(), s, T, F, P, arr, x.data_ptr(), z.data_ptr()), "grappa_perm_concat_fwd_f32")
+        fn = getattr(self.lib, f"grappa_perm_concat_fwd_{_sfx(z)}")
+        _chk(fn(self._stream(), s, T, F, P, arr, x.data_ptr(), z.data_ptr()), "grappa_perm_concat_fwd")
 
     def perm_concat_bwd(self, dz, s, T, perms, dx) -> None:
         dev = dx.device
-        _flat(dz, "dz", dev), _flat(dx, "dx", dev)
+        dt = _same_dtype(dz, dx)
+        _flat(dz, "dz", dev, dt), _flat(dx, "dx", dev, dt)
         F, P = dx.shape[1], len(perms)
         if dx.shape[0] != s * T or dz.shape != (P * T, s * F):
             raise ValueError("perm_concat_bwd: shapes")
         arr = (C.c_int * (P * s))(*[int(v) for p in perms for v in p])
-        _chk(self.lib.grappa_perm_concat_bwd_f32(self._stream(), s, T, F, P, arr, dz.data_ptr(), dx.data_ptr()), "grappa_perm_concat_bwd_f32")
+        fn = getattr(self.lib, f"grappa_perm_concat_bwd_{_sfx(dx)}")
+        _chk(fn(self._stream(), s, T, F, P, arr, dz.data_ptr(), dx.data_ptr()), "grappa_perm_concat_bwd")
 
     def param_out_fwd(self, kind, o, T, P, n_per, gated, cutoff, consts, k, eq) -> None:
         dev = k.device

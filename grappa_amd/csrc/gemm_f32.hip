@@ -467,7 +467,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             if (!d->a_kcontig || (d->K & 31) != 0 || (reinterpret_cast<uintptr_t>(d->A) & 15) != 0 || (d->lda & 3) != 0 || d->lda < d->K) return GRAPPA_ERR_ARG;
             if (!ok(d->B, d->ldb, kpad)) return GRAPPA_ERR_ARG;
         }
-        const size_t arows = d->a_kcontig ? (size_t)d->M : (size_t)kpad, brows = d->b_kcontig ? (size_t)d->N : (size_t)kpad;
+        const size_t arows = d->a_kcontig ? (size_t)d->M : (size_t)d->K, brows = d->b_kcontig ? (size_t)d->N : (size_t)d->K;
         if (arows * d->lda * (d->a_planes ? 2 : 4) >= (1ull << 32) || brows * d->ldb * 2 >= (1ull << 32)) return GRAPPA_ERR_ARG;
     }
     auto al8 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 7) == 0 && (ld & 3) == 0); };

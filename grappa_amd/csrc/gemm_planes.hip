@@ -59,6 +59,9 @@ constexpr int B_PLANE = PBN * PSLAB * 2;      // 8 KB
 enum PMode { PX1 = 1, PX3 = 3, PX6 = 6, PX9 = 9 };
 template <int MODE> struct PPieces { static constexpr int NP = MODE == PX1 ? 1 : (MODE == PX3 ? 2 : 3); };
 
+// 16 bytes of zeros in device memory: the LDS-DMA source of k-rows beyond K (k-major operands need no padding in HBM)
+__device__ __attribute__((aligned(16))) unsigned grappa_zero16[4] = {0u, 0u, 0u, 0u};
+
 __device__ inline void glds16(const char* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
@@ -103,6 +106,22 @@ __device__ inline void issue_slab(const char* __restrict__ A, const char* __rest
         glds16(ap + s.a0, stage + p * A_PLANE + wave * 1024);
         glds16(ap + s.a1, stage + p * A_PLANE + (wave + 8) * 1024);
         glds16(bp + s.b, stage + NP * A_PLANE + p * B_PLANE + wave * 1024);
+    }
+}
+
+// the same for the LAST slab of a k-major K range that is not a multiple of 32: k-rows >= krem are fetched from the zero page
+template <int NP>
+__device__ inline void issue_slab_ktail(const char* __restrict__ A, const char* __restrict__ B, size_t a_plane_bytes, size_t b_plane_bytes, size_t a_uni,
+                                        size_t b_uni, const LaneSrc& s, char* __restrict__ stage, int wave, int lane, int krem) {
+    const char* z = reinterpret_cast<const char*>(grappa_zero16);
+    const bool oka0 = 2 * wave + (lane >> 5) < krem, oka1 = 2 * (wave + 8) + (lane >> 5) < krem, okb = 4 * wave + (lane >> 4) < krem;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const char* ap = A + p * a_plane_bytes + a_uni;
+        const char* bp = B + p * b_plane_bytes + b_uni;
+        glds16(oka0 ? ap + s.a0 : z, stage + p * A_PLANE + wave * 1024);
+        glds16(oka1 ? ap + s.a1 : z, stage + p * A_PLANE + (wave + 8) * 1024);
+        glds16(okb ? bp + s.b : z, stage + NP * A_PLANE + p * B_PLANE + wave * 1024);
     }
 }
 
@@ -250,9 +269,18 @@ __global__ __launch_bounds__(PNT, 2) void gemm_planes_kernel(GemmParams p) {
         const ReadOff ro = read_offsets<KMAJOR>(wave, lane);
         PFrags<NP> f0, f1;
 
-        issue_slab<NP>(A, B, apb, bpb, a_base, b_base, src, smem, wave);
+        // k-major operands carry no padding: the last slab of a ragged K range takes its missing k-rows from a page of zeros
+        const int krem_last = KMAJOR ? (kend - kbeg) - (nslab - 1) * PSLAB : PSLAB;
+#define GP_ISSUE(T_, STAGE_)                                                                                                                  \
+    do {                                                                                                                                      \
+        if (KMAJOR && (T_) == nslab - 1 && krem_last < PSLAB)                                                                                 \
+            issue_slab_ktail<NP>(A, B, apb, bpb, a_base + (size_t)(T_) * a_step, b_base + (size_t)(T_) * b_step, src, STAGE_, wave, lane, krem_last); \
+        else                                                                                                                                  \
+            issue_slab<NP>(A, B, apb, bpb, a_base + (size_t)(T_) * a_step, b_base + (size_t)(T_) * b_step, src, STAGE_, wave);                \
+    } while (0)
+        GP_ISSUE(0, smem);
         if (nslab > 1) {
-            issue_slab<NP>(A, B, apb, bpb, a_base + a_step, b_base + b_step, src, smem + STAGE, wave);
+            GP_ISSUE(1, smem + STAGE);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -272,7 +300,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_planes_kernel(GemmParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (GP_KNOCK != 1) issue_slab<NP>(A, B, apb, bpb, a_base + (t + 2) * a_step, b_base + (t + 2) * b_step, src, cur, wave);
+                if (GP_KNOCK != 1) GP_ISSUE(t + 2, cur);
             }
             __builtin_amdgcn_sched_barrier(0);
             pmfma_range<MODE, NM / 2, NM>(f0, acc);
@@ -305,6 +333,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_planes_kernel(GemmParams p) {
         }
     }
 
+#undef GP_ISSUE
     if (do_cs) {
         // lanes (lr, 0) and (lr, 1) hold the two k-halves of row wm0 + i*32 + lr
 #pragma unroll

@@ -132,12 +132,14 @@ class GrappaGNN(nn.Module):
         plan = g.plan()
         x = self.input_features(g)
         p0 = self.p_initial if self.training else 0.0
-        h = ops.LinearFn.apply(x, self.pre_dense[0].weight, self.pre_dense[0].bias, ops.ELU, p0, ops.next_seed() if p0 > 0 else 0)
+        if ops.act_dtype() is not None and len(getattr(self, "conv_blocks", [])):
+            raise NotImplementedError("the bf16 storage configuration covers the attention blocks (no SAGE conv blocks)")
+        h = ops.LinearFn.apply(x, self.pre_dense[0].weight, self.pre_dense[0].bias, ops.ELU, p0, ops.next_seed() if p0 > 0 else 0, ops.act_dtype())
         if not self.no_convs:
             for blk in self.blocks:
                 h = blk(plan, h)
         p1 = self.p_final if self.training else 0.0
-        h = ops.LinearFn.apply(h, self.post_dense[0].weight, self.post_dense[0].bias, 0, p1, ops.next_seed() if p1 > 0 else 0)
+        h = ops.LinearFn.apply(h, self.post_dense[0].weight, self.post_dense[0].bias, 0, p1, ops.next_seed() if p1 > 0 else 0, torch.float32)
         g.nodes["n1"].data["h"] = h
         return g
 
@@ -277,7 +279,7 @@ class _WriterBase(nn.Module):
         if model.grappa_transformer is not None and model.grappa_transformer.positional_encoding is not None:
             pe = model.grappa_transformer.positional_encoding.reshape(-1).contiguous()
         lin = self.rep_projector.mlp[0]
-        x = ops.ProjGatherFn.apply(h, lin.weight, lin.bias, plan.idx32[lvl], plan.inv_ptr[lvl], plan.inv_rows[lvl], self.s, pe)
+        x = ops.ProjGatherFn.apply(h, lin.weight, lin.bias, plan.idx32[lvl], plan.inv_ptr[lvl], plan.inv_rows[lvl], self.s, pe, ops.act_dtype())
         return x, plan.T[lvl]
 
 

@@ -20,6 +20,7 @@ Reference blocks restated (file:line under /root/reference/src/grappa/):
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -43,12 +44,34 @@ def next_seed() -> int:
     return (_SEED["base"] * 6364136223846793005 + _SEED["counter"] * 1442695040888963407) & (2 ** 63 - 1)
 
 
-def _new(shape, like: torch.Tensor) -> torch.Tensor:
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+F32 = torch.float32
+_ACT = {"dtype": torch.bfloat16 if os.environ.get("GRAPPA_ACT_DTYPE", "f32") == "bf16" else None}
 
 
-def _zeros(shape, like: torch.Tensor) -> torch.Tensor:
-    return torch.zeros(shape, dtype=torch.float32, device=like.device)
+def set_activation_dtype(name) -> None:
+    """"f32" (default) or "bf16": the bf16 STORAGE configuration (BASELINE configs[2], "bf16, MFMA dense heads"): every activation
+    and activation gradient of the GNN blocks and the writer heads lives in HBM as bf16 (half the bytes of every HBM-bound kernel,
+    dense products straight from bf16 operands by LDS-DMA); LayerNorm statistics, softmax, accumulation, the atom embedding `h`, the
+    parameters k / eq, energies, forces, the loss, weights and weight gradients stay fp32.  Pair it with
+    `backend.set_gemm_precision("bf16")` so that the few products that still read fp32 operands round them the same way."""
+    if name not in ("f32", "bf16", None):
+        raise ValueError(f"activation dtype {name!r}: expected 'f32' or 'bf16'")
+    _ACT["dtype"] = torch.bfloat16 if name == "bf16" else None
+
+
+def act_dtype():
+    """element type the two entry points of the activation chain (pre_dense, the rep projectors) produce; None = float32"""
+    return _ACT["dtype"]
+
+
+def _new(shape, like: torch.Tensor, dtype=None) -> torch.Tensor:
+    """activation buffer in the element type of `like` (float32, or bfloat16 in the bf16 storage configuration) unless `dtype` says
+    otherwise: statistics, softmax weights, parameters' gradients and everything the user reads stay float32"""
+    return torch.empty(shape, dtype=like.dtype if dtype is None else dtype, device=like.device)
+
+
+def _zeros(shape, like: torch.Tensor, dtype=None) -> torch.Tensor:
+    return torch.zeros(shape, dtype=like.dtype if dtype is None else dtype, device=like.device)
 
 
 def _pgrad(p: torch.Tensor) -> torch.Tensor:
@@ -97,7 +120,7 @@ def _linear_bwd_params(be, dz, x, w, b):
 def _ln_fwd(be, x, w, b):
     M = x.shape[0]
     y = _new(x.shape, x)
-    mean, rstd = _new((M,), x), _new((M,), x)
+    mean, rstd = _new((M,), x, F32), _new((M,), x, F32)
     be.layernorm_fwd(x, w, b, y, mean, rstd)
     return y, mean, rstd
 
@@ -118,9 +141,10 @@ def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip):
     M = x.shape[0]
     xn, mean, rstd = _ln_fwd(be, x, norm_w, norm_b)
     Hd, Nout = w1.shape[0], w2.shape[0]
-    u = _new((M, Hd), x)
+    narrow = Nout <= 32                       # the output maps' last product (2 .. 12 columns): fp32 kernels, fp32 operands and result
+    u = _new((M, Hd), x, F32 if narrow else None)
     be.gemm(xn, w1, u, M=M, N=Hd, K=x.shape[1], bias=b1, act=ELU)
-    out = _new((M, Nout), x)
+    out = _new((M, Nout), x, F32 if narrow else None)
     res = xn if skip else None
     pre = None
     if act2:
@@ -141,7 +165,7 @@ def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed,
     else:
         dz2 = dout
     _linear_bwd_params(be, dz2, u, w2, b2)
-    dz1 = _new(u.shape, u)
+    dz1 = _new(u.shape, xn)                                        # (u is fp32 in front of a narrow output product, xn never)
     be.gemm(dz2, w2, dz1, M=M, N=u.shape[1], K=dz2.shape[1], b_kcontig=False, aux=u)          # fused ELU'(u)
     _linear_bwd_params(be, dz1, xn, w1, b1)
     dxn = _new(xn.shape, xn)
@@ -154,15 +178,15 @@ class LinearFn(Function):
     """y = drop(act(x W^T + b))   (pre_dense / post_dense)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, drop_p, seed):
+    def forward(ctx, x, w, b, act, drop_p, seed, out_dtype=None):
         be = get_backend()
         x = _c(x)
         M, K = x.shape
         N = w.shape[0]
-        y = _new((M, N), x)
+        y = _new((M, N), x, out_dtype)
         pre = None
         if act and drop_p > 0:
-            pre = _new((M, N), x)
+            pre = _new((M, N), x, out_dtype)
             be.gemm(x, w, pre, M=M, N=N, K=K, bias=b, act=act, drop_p=drop_p, drop_seed=seed, out2=y)
         else:
             be.gemm(x, w, y, M=M, N=N, K=K, bias=b, act=act, drop_p=drop_p, drop_seed=seed)
@@ -186,7 +210,7 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = _new(x.shape, x)
             be.gemm(dz, w, dx, M=x.shape[0], N=x.shape[1], K=w.shape[0], b_kcontig=False)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class AttBlockFn(Function):
@@ -199,7 +223,7 @@ class AttBlockFn(Function):
         ft = _new((N, w_fc.shape[0]), h)
         be.gemm(h1, w_fc, ft, M=N, N=w_fc.shape[0], K=Fd)
         m = _new(ft.shape, h)
-        alpha = _new((plan.E, heads), h)
+        alpha = _new((plan.E, heads), h, F32)
         be.gat_fwd(plan, ft, heads, ft.shape[1] // heads, m, alpha)
         h3 = _new((N, Fd), h)
         be.gemm(m, w_r, h3, M=N, N=Fd, K=m.shape[1], bias=b_r, drop_p=drop_p, drop_seed=seed1, res=h1)
@@ -290,16 +314,16 @@ class ProjGatherFn(Function):
     """a = ELU(h W^T + b) (N, Wp); x[pos*T+t] = [a[idx[t,pos]], pe[pos]] (s*T, Wp + has_pe)."""
 
     @staticmethod
-    def forward(ctx, h, w, b, idx32, inv_ptr, inv_rows, s, pe):
+    def forward(ctx, h, w, b, idx32, inv_ptr, inv_rows, s, pe, out_dtype=None):
         be = get_backend()
         h = _c(h)
         N, R = h.shape
         Wp = w.shape[0]
         Fd = Wp + (1 if pe is not None else 0)
         T = idx32.shape[0]
-        a = _zeros((N, Fd), h)
+        a = _zeros((N, Fd), h, out_dtype)
         be.gemm(h, w, a[:, :Wp], M=N, N=Wp, K=R, bias=b, act=ELU)
-        x = _new((s * T, Fd), h)
+        x = _new((s * T, Fd), a)
         if T:
             be.tuple_gather_fwd(a, idx32, s, pe, x)
         ctx.save_for_backward(h, w, b, a, inv_ptr, inv_rows)
@@ -313,7 +337,7 @@ class ProjGatherFn(Function):
         s, T, Wp, has_pe = ctx.cfg
         N, R = h.shape
         if T == 0:
-            return (torch.zeros_like(h),) + (None,) * 7
+            return (torch.zeros_like(h),) + (None,) * 8
         dx = _c(dx)
         da = _new(a.shape, a)
         be.tuple_gather_bwd(inv_ptr, inv_rows, dx, da, has_pe, False)
@@ -322,7 +346,7 @@ class ProjGatherFn(Function):
         _linear_bwd_params(be, dz, h, w, b)
         dh = _new(h.shape, h)
         be.gemm(dz, w, dh, M=N, N=R, K=Wp, b_kcontig=False)
-        return (dh,) + (None,) * 7
+        return (dh,) + (None,) * 8
 
 
 class TransformerLayerFn(Function):
@@ -394,7 +418,7 @@ class SymmetriserFn(Function):
             skip = (i != 0) and (i != n_layers - 1)
             cur, sv = _ff_fwd(be, cur, nw, nb, w1, b1, w2, b2, False, 0.0, 0, skip)
             saved.append(sv)
-        ctx.cfg = (s, T, perms, n_layers, tuple(x.shape))
+        ctx.cfg = (s, T, perms, n_layers, tuple(x.shape), x.dtype)
         ctx.saved_layers = saved
         ctx.layers = layers
         return cur
@@ -402,17 +426,17 @@ class SymmetriserFn(Function):
     @staticmethod
     def backward(ctx, dout):
         be = get_backend()
-        s, T, perms, n_layers, xshape = ctx.cfg
+        s, T, perms, n_layers, xshape, xdtype = ctx.cfg
         nret = 5 + 6 * n_layers
         if T == 0:
-            return (torch.zeros(xshape, dtype=torch.float32, device=dout.device),) + (None,) * (nret - 1)
+            return (torch.zeros(xshape, dtype=xdtype, device=dout.device),) + (None,) * (nret - 1)
         g = _c(dout)
         for i in reversed(range(n_layers)):
             nw, nb, w1, b1, w2, b2 = ctx.layers[i]
             skip = (i != 0) and (i != n_layers - 1)
             g = _ff_bwd(be, ctx.saved_layers[i], g, nw, nb, w1, b1, w2, b2, False, 0.0, 0, skip)
         ctx.saved_layers = None
-        dx = torch.empty(xshape, dtype=torch.float32, device=dout.device)
+        dx = torch.empty(xshape, dtype=xdtype, device=dout.device)
         be.perm_concat_bwd(g, s, T, perms, dx)
         return (dx,) + (None,) * (nret - 1)
 

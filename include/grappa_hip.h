@@ -93,8 +93,8 @@ typedef struct grappa_gemm_desc {
      * a_planes / b_planes != 0: A / B point to plane 0 (the pointer types above are then nominal).  Supported: b_planes alone
      * ("weight planes": A = fp32 activations [M][K] with K % 32 == 0, a_kcontig = b_kcontig = 1 -- forward with the planes of W,
      * dgrad with the planes of W^T; results are bit-identical to the split-in-kernel product) or both (a_kcontig = b_kcontig = 1,
-     * or both 0 = the wgrad layout).  Planes must be zero beyond K up to the next multiple of 32 along k (columns of a K-contiguous
-     * operand: ld >= round_up(K, 32); rows of a k-major one), rows * ld * element size < 2^32, and M, N > 32.  The operands are
+     * or both 0 = the wgrad layout).  K-contiguous planes must be zero beyond K up to the next multiple of 32 (ld >= round_up(K, 32));
+     * k-major operands need no padding (rows beyond K are taken from a page of zeros); rows * ld * element size < 2^32; M, N > 32.  The operands are
      * split ONCE by their producer (grappa_split_planes_f32, Cp below) instead of by every GEMM that reads them. */
     int a_planes, b_planes;
     size_t a_plane_stride, b_plane_stride;

@@ -76,7 +76,8 @@ def check(M, N, K, kmajor, gen):
     if not kmajor:
         ap, bp = split_planes(A), split_planes(B)
     else:
-        ap, bp = split_planes(A.t().contiguous()), split_planes(B.t().contiguous())
+        # k-major operands carry NO row padding (the kernel takes k-rows beyond K from a page of zeros)
+        ap, bp = split_planes(A.t().contiguous(), rows_pad=1), split_planes(B.t().contiguous(), rows_pad=1)
     assert torch.equal(merge(ap, *(A.shape if not kmajor else A.t().shape)), A if not kmajor else A.t())
     out = torch.full((M, N), float("nan"), device=dev)
     gemm(ap, bp, out, M, N, K, not kmajor, not kmajor, True)
@@ -135,7 +136,7 @@ def check_epilogue(gen):
     T, No, Ko = 20000, 512, 512
     dZ = torch.randn((T, No), generator=gen, device=dev)
     X = torch.randn((T, Ko), generator=gen, device=dev)
-    dzp, xp = split_planes(dZ), split_planes(X)
+    dzp, xp = split_planes(dZ, rows_pad=1), split_planes(X, rows_pad=1)
     dW = torch.zeros((No, Ko), device=dev)
     db = torch.zeros((No,), device=dev)
     gemm(dzp, xp, dW, No, Ko, T, False, False, True, a_colsum=db, accumulate=1)
