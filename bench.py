@@ -10,7 +10,8 @@ synthetic charges / coordinates / reference energies+forces, inputs resident in 
   `roofline`      the dominant kernel family (the dense products): algorithmic 2MNK FLOPs / HIP-event time per call, measured in an
                   instrumented repetition of the same steps right after the timed region; plus the GAT kernels vs HBM,
   `cpu_baseline`  the oracle's CPU restatement of the same train step on a bounded sample (rank 0, N = 1 only),
-  `c3`            BASELINE configs[2] (1024 molecules of the whole pool) timed right after C2 with the same arithmetic,
+  `c3`            BASELINE configs[2] (1024 molecules of the whole pool) timed right after C2 with the same fp32-grade arithmetic,
+  `c3_bf16`       the same batch in the bf16 STORAGE configuration that config names ("bf16, MFMA dense heads"): never `value`,
   `c4_strong_n1`  BASELINE configs[3]'s 4096-molecule global batch on ONE GPU (4 chunks of 1024, gradients accumulated, one
                   optimiser step) -- the N = 1 point of the strong-scaling curve below.
 N > 1 (default): STRONG scaling of BASELINE configs[3] (C4): ONE global batch of 4096 molecules dealt to the ranks by size
@@ -284,22 +285,50 @@ def main():
     dt, final_loss = job.timed(args.steps, args.warmup)
     log(f"timed region done: {1e3 * dt / args.steps:.1f} ms/step; instrumented pass")
 
-    # instrumented repetition of the same steps: HIP events around every GEMM / GAT launch on the launch stream (one stream:
-    # GRAPPA_HEAD_STREAMS=1 semantics; profiles/ rocprof runs use the same setting), and around the gradient all-reduce
+    GEMM_PEAK_NOTE = ("achieved = algorithmic 2MNK FLOPs / HIP-event time of the calls; peak = bf16 dense MFMA peak (16 x 157.3 TFLOP/s, "
+                      "MI355X_MICROARCH.md) / partial products issued per fp32 product")
+
+    def instrument(j, steps):
+        """instrumented repetition of a job's steps: HIP events around every GEMM / GAT launch on the launch stream (one stream:
+        GRAPPA_HEAD_STREAMS=1 semantics; profiles/ rocprof runs use the same setting) and around the gradient all-reduce
+        -> (gemm roofline dict, gat roofline dict, ms per instrumented step, all-reduce ms per step)"""
+        hs = model.parameter_writer.head_streams
+        model.parameter_writer.head_streams = 1
+        j.step()
+        torch.cuda.synchronize()
+        j.allreduce_events = []
+        be.start_profile()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            j.step()
+        prof = be.stop_profile()
+        dtp = time.perf_counter() - t1
+        ar_ms = sum(a.elapsed_time(b) for a, b in j.allreduce_events) / max(len(j.allreduce_events), 1)
+        j.allreduce_events = None
+        model.parameter_writer.head_streams = hs
+        n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
+        achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        kname, nprod = GEMM_KERNELS[be.gemm_precision_name]
+        if ops.act_dtype() is not None:
+            kname = "gemm_planes_kernel<1,*> (bf16 operands by LDS-DMA, v_mfma_f32_32x32x16_bf16, fp32 accumulate) + gemm_bf16x_kernel<1,*> for the fp32-operand products"
+        # `achieved` counts the ALGORITHMIC FLOPs (2MNK); the split kernels issue `nprod` bf16 MFMAs per fp32 product, so the
+        # ceiling in the same unit is the bf16 dense peak / nprod
+        peak = PEAK_F32_MFMA_TFLOPS if nprod == 0 else PEAK_BF16_MFMA_TFLOPS / nprod
+        roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "frac_of_native_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "gemm_precision": be.gemm_precision_name,
+                "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": by / max(n, 1),
+                "launches_per_step": n / steps, "avg_launch_us": 1e3 * ms / max(n, 1), "gflop_per_launch": fl / max(n, 1) / 1e9,
+                "kernel_ms_per_step": ms / steps, "note": GEMM_PEAK_NOTE}
+        gat = {}
+        for fam in ("gat_fwd", "gat_bwd"):
+            n_, ms_, fl_, by_ = prof.get(fam, (0, 0.0, 0.0, 0.0))
+            a_ = (by_ / (ms_ * 1e-3)) / 1e9 if ms_ > 0 else 0.0
+            gat[fam] = {"bound": "hbm", "achieved": a_, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a_ / PEAK_HBM_GBS,
+                        "avg_launch_us": 1e3 * ms_ / max(n_, 1), "mb_per_launch": by_ / max(n_, 1) / 1e6}
+        return roof, gat, 1e3 * dtp / steps, ar_ms
+
     head_streams = model.parameter_writer.head_streams
-    model.parameter_writer.head_streams = 1
-    job.step()
-    torch.cuda.synchronize()
-    job.allreduce_events = []
-    be.start_profile()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step()
-    prof = be.stop_profile()
-    dt_prof = time.perf_counter() - t1
-    allreduce_ms = sum(a.elapsed_time(b) for a, b in job.allreduce_events) / max(len(job.allreduce_events), 1)
-    job.allreduce_events = None
-    model.parameter_writer.head_streams = head_streams
+    roof, gat, ms_instr, allreduce_ms = instrument(job, args.steps)
     log("instrumented pass done")
 
     def alt_run(setter, restore):
@@ -323,58 +352,67 @@ def main():
                             "(GRAPPA_GEMM_PRECISION_BWD); parameters / energies / forces / loss are bit-identical to the default"})
         log(f"backward precision {args.bwd_precision}: {bwd['ms_per_step']:.1f} ms/step")
 
-    # N = 1: the other single-GPU configurations, timed with the same arithmetic right after the headline measurement
+    # opt-in kernel (GRAPPA_WEIGHT_PLANES): the same steps with the weights read from their pre-split bf16 planes by LDS-DMA
+    wpl = None
+    if world == 1 and not args.no_extras and not be.weight_planes:
+        be.weight_planes = True
+        d_w, _ = job.timed(args.steps, 1)
+        be.weight_planes = False
+        wpl = {"value": job.global_batch * args.steps / d_w, "ms_per_step": 1e3 * d_w / args.steps,
+               "note": "GRAPPA_WEIGHT_PLANES=1: forward / dgrad products read the weight from bf16 planes split once per optimiser step "
+                       "(csrc/gemm_planes.hip gemm_wplanes_kernel); results equal the default to rounding; not the default"}
+        log(f"weight planes: {wpl['ms_per_step']:.1f} ms/step")
+
+    # N = 1: the other single-GPU configurations, timed right after the headline measurement: C3 in the headline arithmetic, C3 in the
+    # bf16 STORAGE configuration BASELINE configs[2] names (never `value`), and the 4096-molecule batch of C4 on one GPU
     extras = {}
     if world == 1 and not args.no_extras and not strong and workload == "C2-pubchem-b256":
         headline_graphs = job.graphs
-        for key, name, steps in (("c3", "C3-espaloma-b1024", 3), ("c4_strong_n1", "C4-espaloma-b4096", 2)):
+        default_precision = be.gemm_precision_name
+        for key, name, steps, bf16 in (("c3", "C3-espaloma-b1024", 3, False), ("c3_bf16", "C3-espaloma-b1024", 3, True),
+                                       ("c4_strong_n1", "C4-espaloma-b4096", 2, False)):
             try:
+                if bf16:
+                    ops.set_activation_dtype("bf16")
+                    be.set_gemm_precision("bf16")
                 j2 = Job(name, WORKLOADS[name][0], workload_molecule_ids(name, seed=0), seed=0)
                 d2, l2 = j2.timed(steps, 1)
                 extras[key] = {"value": j2.global_batch * steps / d2, "unit": "molecules/s", "ms_per_step": 1e3 * d2 / steps, "steps": steps, "warmup": 1,
                                "scaling": "strong" if key.startswith("c4") else None, "n_gpus": 1, "gemm_precision": be.gemm_precision_name,
-                               "final_loss": l2, "config": j2.describe()}
+                               "activation_storage": "bf16" if bf16 else "f32", "final_loss": l2, "config": j2.describe()}
+                if key != "c4_strong_n1":
+                    r2, g2, _, _ = instrument(j2, 2)
+                    extras[key]["roofline"], extras[key]["roofline_gat"] = r2, g2
+                if bf16:
+                    extras[key]["note"] = ("bf16 STORAGE configuration (BASELINE configs[2]): activations and activation gradients in HBM as bf16, dense "
+                                           "products straight from bf16 operands (fp32 accumulate), LayerNorm statistics / softmax / energies / forces / "
+                                           "weights / weight gradients fp32; parameters within 2e-2 of the oracle (tests/test_gpu_bf16.py); reported "
+                                           "beside, never as, the fp32-grade headline")
                 log(f"{key}: {extras[key]['ms_per_step']:.1f} ms/step = {extras[key]['value']:.0f} molecules/s")
                 del j2
-                torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001  (an extra must never take the headline line down)
                 extras[key] = {"value": None, "error": repr(e)[:300]}
+            finally:
+                ops.set_activation_dtype("f32")
+                be.set_gemm_precision(default_precision)
+                torch.cuda.empty_cache()
         job.graphs = headline_graphs
 
     if rank == 0:
-        n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
-        achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process; the committed
         # rocprofv3 --pmc summary of this same command (tools/pmc_traffic.py -> profiles/pmc_traffic_c2.json) is reported -- only
         # while the kernel sources it was measured on are the ones running
-        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
         if job.name == "C2-pubchem-b256" and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel_source_hash") == kernel_source_hash():
-                    traffic = tj["families"]["gemm_f32"]["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch; same kernel sources)"
+                    roof["traffic"] = tj["families"]["gemm_f32"]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch; same kernel sources)"
                 else:
-                    traffic_src = "profiles/pmc_traffic_c2.json was measured on other kernel sources: not reported"
+                    roof["traffic_source"] = "profiles/pmc_traffic_c2.json was measured on other kernel sources: not reported"
             except Exception:
-                traffic = None
-        kname, nprod = GEMM_KERNELS[be.gemm_precision_name]
-        # `achieved` counts the ALGORITHMIC fp32 FLOPs (2MNK); the split kernel issues `nprod` bf16 MFMAs per fp32 product, so
-        # its ceiling in the same unit is the bf16 dense peak / nprod
-        peak = PEAK_F32_MFMA_TFLOPS if nprod == 0 else PEAK_BF16_MFMA_TFLOPS / nprod
-        roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak, "frac_of_native_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-                "gemm_precision": be.gemm_precision_name, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": by / max(n, 1),
-                "launches_per_step": n / args.steps, "avg_launch_us": 1e3 * ms / max(n, 1), "gflop_per_launch": fl / max(n, 1) / 1e9,
-                "kernel_ms_per_step": ms / args.steps}
-        gat = {}
-        for fam in ("gat_fwd", "gat_bwd"):
-            n_, ms_, fl_, by_ = prof.get(fam, (0, 0.0, 0.0, 0.0))
-            a = (by_ / (ms_ * 1e-3)) / 1e9 if ms_ > 0 else 0.0
-            gat[fam] = {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
-                        "avg_launch_us": 1e3 * ms_ / max(n_, 1), "mb_per_launch": by_ / max(n_, 1) / 1e6}
+                pass
         cfg = job.describe()
         cfg.update({"parallelism": f"dp{world}", "world_size": world, "dist_backend": args.dist_backend if world > 1 else None,
                     "allreduce_ms_per_step": allreduce_ms if world > 1 else None, "allreduce_bytes": 4 * flat.numel if world > 1 else None,
@@ -389,8 +427,8 @@ def main():
                                         "exactly into 3 bf16 pieces and sums the 6 largest partial products on the bf16 matrix cores "
                                         "(error vs a float64 product <= that of the native fp32 MFMA: tests/test_gpu_ops.py::"
                                         "test_gemm_precision_modes; end-to-end parity: tests/test_gpu_e2e.py, tests/test_gpu_configs.py)",
-                                "native_f32_mfma": alt, "backward_reduced": bwd},
-            "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": 1e3 * dt_prof / args.steps, "final_loss": final_loss,
+                                "native_f32_mfma": alt, "backward_reduced": bwd, "weight_planes": wpl},
+            "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": ms_instr, "final_loss": final_loss,
         }
         out.update(extras)
         out["cpu_baseline"] = cpu_base
