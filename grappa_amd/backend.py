@@ -270,6 +270,19 @@ class HipBackend:
         else:
             d.B, d.ldb = b.data_ptr(), _f32_2d(b, "B", dev)
             d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
+        # ---- the native fp32 kernel (precision "f32", or M / N <= 32) has no bf16 epilogue: run it on fp32 copies (tiny or non-default)
+        native = planes_a is None and (not big or d.precision == _lib.GEMM_PRECISIONS["f32"])
+        if native and any(t is not None and t.dtype == bf16 for t in (out, out2, res, aux)):
+            f = lambda t: None if t is None else (self.to_f32(t) if t.dtype == bf16 else t)      # noqa: E731
+            o32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out.dtype == bf16 else out
+            o232 = None if out2 is None else (torch.empty((M, N), dtype=torch.float32, device=dev) if out2.dtype == bf16 else out2)
+            self.gemm(a, b, o32, M=M, N=N, K=K, a_kcontig=a_kcontig, b_kcontig=b_kcontig, bias=bias, res=f(res), aux=f(aux), pre=pre, act=act,
+                      drop_p=drop_p, drop_seed=drop_seed, accumulate=accumulate, out2=o232, a_colsum=a_colsum, precision=precision)
+            for dst, src in ((out, o32), (out2, o232)):
+                if dst is not None and dst is not src:
+                    _chk(self.lib.grappa_convert_f32_to_bf16(self._stream(), M, N, src.data_ptr(), N, dst.data_ptr(), _f32_2d(dst, "out", dev, bf16)),
+                         "grappa_convert_f32_to_bf16")
+            return
         # ---- outputs and epilogue tensors, each in its own element type
         def plane_ok(t, name):
             ld = _f32_2d(t, name, dev, bf16)

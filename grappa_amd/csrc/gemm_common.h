@@ -144,12 +144,6 @@ __device__ inline void tile_epilogue(const GemmParams& p, const f32x16 (&acc)[TM
                     if (ncol[j] < d.N) srow[ncol[j]] = acc[i][j][e];
                 continue;
             }
-            if (d.Cp || d.resp || d.auxp || d.C1p || !d.C) {        // plane-format epilogue tensors: element-wise path
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (ncol[j] < d.N) epilogue_store(p, m, ncol[j], acc[i][j][e]);
-                continue;
-            }
             const float* pre_r = d.pre ? d.pre + (size_t)m * d.ldpre : nullptr;
             const float* aux_r = d.aux ? d.aux + (size_t)m * d.ldaux : nullptr;
             const float* res_r = d.res ? d.res + (size_t)m * d.ldres : nullptr;

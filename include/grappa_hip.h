@@ -103,7 +103,7 @@ typedef struct grappa_gemm_desc {
     const uint16_t* auxp; int ldauxp; size_t auxp_plane_stride;   /* saved ELU output given in planes (instead of aux) */
     /* number of planes behind Cp / resp / auxp: 3 (0 means 3) = the exact fp32 split; 1 = a plain bf16 tensor (the bf16 storage
      * configuration: activations are kept in bf16 in HBM, precision GRAPPA_GEMM_BF16 reads plane 0 of both operands) */
-    int cp_nplanes, resp_nplanes, auxp_nplanes;
+    int cp_nplanes, resp_nplanes, auxp_nplanes;                   /* (Cp / C1p / resp / auxp are not available with F32_MFMA or M, N <= 32) */
     uint16_t* C1p; int ldc1p;                                     /* bf16 copy of the value C receives when C2 is used (before dropout / residual) */
 } grappa_gemm_desc;
 
