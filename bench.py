@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the C3 and C4-on-one-GPU timings that follow the headline measurement")
     ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_bf16x6)")
+    ap.add_argument("--act-dtype", default="f32", choices=["f32", "bf16"], help="bf16: the bf16 STORAGE configuration for the main job (profiling / "
+                    "BASELINE configs[2] runs; the line's dtype then reads bf16 -- never the default)")
     ap.add_argument("--alt-precision", default="f32", help="also time K steps with this GEMM arithmetic (reported beside the default); '' to skip")
     ap.add_argument("--bwd-precision", default="", help="also time K steps with the backward-pass products in this arithmetic (reported beside the default, never as `value`); '' to skip")
     ap.add_argument("--cpu-sample", type=int, default=32, help="molecules in the CPU baseline sample")
@@ -195,6 +197,9 @@ def main():
 
     log("imports done; building model")
     be = get_backend()
+    if args.act_dtype == "bf16":
+        ops.set_activation_dtype("bf16")
+        be.set_gemm_precision("bf16")
     if args.gemm_precision:
         be.set_gemm_precision(args.gemm_precision)
     model = model_from_config(get_default_model_config())
@@ -354,7 +359,7 @@ def main():
 
     # opt-in kernel (GRAPPA_WEIGHT_PLANES): the same steps with the weights read from their pre-split bf16 planes by LDS-DMA
     wpl = None
-    if world == 1 and not args.no_extras and not be.weight_planes:
+    if world == 1 and not args.no_extras and not be.weight_planes and args.act_dtype == "f32":
         be.weight_planes = True
         d_w, _ = job.timed(args.steps, 1)
         be.weight_planes = False
@@ -366,7 +371,7 @@ def main():
     # N = 1: the other single-GPU configurations, timed right after the headline measurement: C3 in the headline arithmetic, C3 in the
     # bf16 STORAGE configuration BASELINE configs[2] names (never `value`), and the 4096-molecule batch of C4 on one GPU
     extras = {}
-    if world == 1 and not args.no_extras and not strong and workload == "C2-pubchem-b256":
+    if world == 1 and not args.no_extras and not strong and workload == "C2-pubchem-b256" and args.act_dtype == "f32":
         headline_graphs = job.graphs
         default_precision = be.gemm_precision_name
         for key, name, steps, bf16 in (("c3", "C3-espaloma-b1024", 3, False), ("c3_bf16", "C3-espaloma-b1024", 3, True),
@@ -420,7 +425,7 @@ def main():
         out = {
             "metric": "molecules/sec (train step, energy+force loss)", "value": job.global_batch * args.steps / dt, "unit": "molecules/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16" if args.act_dtype == "bf16" else "f32", "data": "synthetic",
             "config": cfg,
             "gemm_arithmetic": {"default": be.gemm_precision_name,
                                 "note": "inputs, outputs, accumulation and every non-GEMM kernel are fp32; f32_bf16x6 splits each fp32 operand "
