@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hi
 
 ABI_VERSION = 3
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
+GEMM_GROUP_MAX = 16
 GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4}
 
 c_float_p = C.POINTER(C.c_float)
@@ -65,6 +66,8 @@ SIGNATURES = {
     "grappa_gemm_f32_plan": (_i, [_i, _i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "grappa_gemm_f32_set_plan_override": (None, [_i, _i, _i]),
     "grappa_gemm_f32": (_i, [_vp, C.POINTER(GemmDesc), _vp, _sz]),
+    "grappa_gemm_f32_grouped_workspace_bytes": (_sz, [C.POINTER(GemmDesc), _i]),
+    "grappa_gemm_f32_grouped": (_i, [_vp, C.POINTER(GemmDesc), _i, _vp, _sz]),
     "grappa_colsum_workspace_bytes": (_sz, [_i, _i]),
     "grappa_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz]),
     "grappa_act_dropout_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i]),

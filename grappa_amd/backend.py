@@ -105,6 +105,11 @@ class HipBackend:
         # optimiser step, both orientations) through LDS-DMA instead of re-splitting it in every workgroup of every launch
         # (csrc/gemm_planes.hip gemm_wplanes_kernel).  Results are bit-identical to the default; measured speed is the same within
         # +-3 %, which is why it is not the default.
+        # weight-gradient products of a backward pass are queued and launched together (grappa_gemm_f32_grouped): alone, each must
+        # cut its K (= tokens) 10 - 32 ways to fill the chip and pays for that many partial tiles per output tile
+        self.defer_wgrads = os.environ.get("GRAPPA_DEFER_WGRADS", "1") not in ("0", "")
+        self._wq = []                  # (dz, x, dW, db) kept alive until the flush
+        self._wq_callback = False
         self.weight_planes = os.environ.get("GRAPPA_WEIGHT_PLANES", "0") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
         self._wepoch = 0
@@ -342,6 +347,63 @@ class HipBackend:
                                                          + M * N * el(final)),
                     lambda: _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0),
                                  "grappa_gemm_f32"))
+
+    # ------------------------------------------------------------------ weight gradients, grouped
+    def gemm_wgrad(self, dz, x, dw, db=None) -> None:
+        """dW += dz^T x (dz (tokens, N'), x (tokens, K'), dW (N', K')), db += column sums of dz.  fp32 products with enough rows and
+        columns are queued and launched as ONE grouped grid when 16 are waiting or the backward pass ends (autograd's end-of-pass
+        callback; `flush_wgrads()` is also called by the gradient reducer and the optimiser): results are those of `gemm` up to the
+        summation order of the K chunks."""
+        Np, Kp, T = dz.shape[1], x.shape[1], dz.shape[0]
+        prec = self.gemm_precision if self.gemm_precision_bwd is None else self.gemm_precision_bwd
+        ok = (self.defer_wgrads and dz.dtype == torch.float32 and x.dtype == torch.float32 and Np > 32 and Kp > 32 and T > 0
+              and prec != _lib.GEMM_PRECISIONS["f32"] and torch.cuda.current_stream() == torch.cuda.default_stream())
+        if not ok:
+            self.gemm(dz, x, dw, M=Np, N=Kp, K=T, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=db)
+            return
+        dev = dw.device
+        if tuple(dw.shape) != (Np, Kp) or x.shape[0] != T or (db is not None and db.numel() != Np):
+            raise ValueError("gemm_wgrad: shapes")
+        _f32_2d(dz, "dz", dev), _f32_2d(x, "x", dev), _f32_2d(dw, "dW", dev)
+        if db is not None:
+            _flat(db, "db", dev)
+        self._wq.append((dz, x, dw, db))
+        if not self._wq_callback:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush_wgrads)      # runs when this backward pass ends
+                self._wq_callback = True
+            except RuntimeError:                  # not inside a backward pass: nothing will call back
+                self.flush_wgrads()
+                return
+        if len(self._wq) >= _lib.GEMM_GROUP_MAX:
+            self._launch_wgrad_group()
+
+    def flush_wgrads(self) -> None:
+        self._wq_callback = False
+        if self._wq:
+            self._launch_wgrad_group()
+
+    def _launch_wgrad_group(self) -> None:
+        items, self._wq = self._wq, []
+        n = len(items)
+        dev = items[0][2].device
+        prec = self.gemm_precision if self.gemm_precision_bwd is None else self.gemm_precision_bwd
+        arr = (_lib.GemmDesc * n)()
+        flops = nbytes = 0.0
+        for d, (dz, x, dw, db) in zip(arr, items):
+            d.M, d.N, d.K = dz.shape[1], x.shape[1], dz.shape[0]
+            d.a_kcontig, d.b_kcontig = 0, 0
+            d.A, d.lda = dz.data_ptr(), dz.stride(0)
+            d.B, d.ldb = x.data_ptr(), x.stride(0)
+            d.C, d.ldc = dw.data_ptr(), dw.stride(0)
+            d.a_colsum = None if db is None else db.data_ptr()
+            d.accumulate, d.precision = 1, prec
+            flops += 2.0 * d.M * d.N * d.K
+            nbytes += 4.0 * (d.M * d.K + d.N * d.K + d.M * d.N)
+        need = self.lib.grappa_gemm_f32_grouped_workspace_bytes(arr, n)
+        ws = self._workspace(need, dev)
+        self._timed("gemm_f32", flops, nbytes,
+                    lambda: _chk(self.lib.grappa_gemm_f32_grouped(self._stream(), arr, n, ws.data_ptr(), ws.numel()), "grappa_gemm_f32_grouped"))
 
     def colsum(self, x, out, accumulate=False) -> None:
         dev = out.device

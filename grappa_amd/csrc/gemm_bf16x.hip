@@ -257,14 +257,16 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// one workgroup's tile; (nwg, wgid) = size of the problem's workgroup grid and this workgroup's place in it (a launch of its own:
+// gridDim / blockIdx; a grouped launch: the problem's share of the grid)
 template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16x_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, int wgid) {
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
     constexpr int NQA = BM * 4 / NT, NQB = BN * 4 / NT;
     static_assert((NT / 64 / WN) * 64 == BM, "wavefront grid must cover the tile");
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
-    const TileCoord tc = map_workgroup(p);
+    const TileCoord tc = map_logical(p, nwg, wgid);
     const int split = tc.split, tile_local = tc.tile_local, tile_n = tc.tile_n;
     const int m0 = tc.tile_m * BM, n0 = tile_n * BN;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -361,6 +363,23 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x_kernel(GemmParams p) {
 }
 
 template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16x_kernel(GemmParams p) {
+    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC>(p, gridDim.x, blockIdx.x);
+}
+
+// Grouped launch: ONE grid over several independent products (the weight gradients of a backward pass, deferred and launched
+// together).  A wgrad alone has 8 .. 24 tiles and must cut its K (= tokens) 10 .. 32 ways to fill 256 CUs, i.e. write and re-read
+// 10 .. 32 partial tiles per output tile; sixteen of them together fill the chip with 3 .. 11 cuts each.  Problem descriptors and
+// the prefix of workgroups per problem live in device memory (copied ahead of the launch on the same stream).
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16x_grouped_kernel(const GemmParams* __restrict__ ps, const int* __restrict__ wg_begin, int nprob) {
+    const int wg = blockIdx.x;
+    int g = 0;
+    while (g + 1 < nprob && wg >= wg_begin[g + 1]) ++g;
+    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC>(ps[g], wg_begin[g + 1] - wg_begin[g], wg - wg_begin[g]);
+}
+
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
 int launch_mode(hipStream_t st, GemmParams& p) {
     constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (BM + BN) * ROWB, staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
     constexpr size_t smem = stages > staging ? stages : staging;
@@ -390,7 +409,34 @@ int launch_tile(hipStream_t st, GemmParams& p, bool vec) {
     return GRAPPA_ERR_ARG;
 }
 
+template <int MODE>
+int launch_grouped_wgrad(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs) {
+    constexpr int NT = 512, BM = 256, BN = 128;
+    constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (BM + BN) * ROWB, staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
+    constexpr size_t smem = stages > staging ? stages : staging;
+    auto kern = gemm_bf16x_grouped_kernel<NT, MODE, BM, BN, 2, false, false, false>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return GRAPPA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(total_wgs), dim3(NT), smem, st, d_ps, d_wg_begin, nprob);
+    return grappa_launch_status();
+}
+
 }  // namespace
+
+// grouped weight-gradient products (layout a_kcontig = b_kcontig = 0, tile 256 x 128): called by grappa_gemm_f32_grouped
+int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision) {
+    switch (precision) {
+        case GRAPPA_GEMM_F32_BF16X9: return launch_grouped_wgrad<X9>(st, d_ps, d_wg_begin, nprob, total_wgs);
+        case GRAPPA_GEMM_F32_BF16X6: return launch_grouped_wgrad<X6>(st, d_ps, d_wg_begin, nprob, total_wgs);
+        case GRAPPA_GEMM_BF16X3: return launch_grouped_wgrad<X3>(st, d_ps, d_wg_begin, nprob, total_wgs);
+        case GRAPPA_GEMM_BF16: return launch_grouped_wgrad<X1>(st, d_ps, d_wg_begin, nprob, total_wgs);
+        default: return GRAPPA_ERR_ARG;
+    }
+}
 
 // called by grappa_gemm_f32 (gemm_f32.hip) for precision != GRAPPA_GEMM_F32_MFMA; (p.bm, p.bn) is 256x128 or 128x128
 int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool vec_kcontig) {

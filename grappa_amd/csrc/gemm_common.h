@@ -282,11 +282,24 @@ __device__ inline void tile_epilogue_rows(const GemmParams& p, const f32x16 (&ac
 
 constexpr int REDUCE_THREADS = 256;
 
-static __global__ __launch_bounds__(REDUCE_THREADS) void gemm_splitk_reduce_kernel(GemmParams p) {
+__device__ inline void splitk_reduce_body(const GemmParams& p, int nblocks, int block);
+
+static __global__ __launch_bounds__(REDUCE_THREADS) void gemm_splitk_reduce_kernel(GemmParams p) { splitk_reduce_body(p, gridDim.x, blockIdx.x); }
+
+// grouped: blocks [blk_begin[g], blk_begin[g+1]) reduce problem g (problems with nsplit == 1 own no blocks)
+static __global__ __launch_bounds__(REDUCE_THREADS) void gemm_splitk_reduce_grouped_kernel(const GemmParams* __restrict__ ps,
+                                                                                          const int* __restrict__ blk_begin, int nprob) {
+    const int b = blockIdx.x;
+    int g = 0;
+    while (g + 1 < nprob && b >= blk_begin[g + 1]) ++g;
+    splitk_reduce_body(ps[g], blk_begin[g + 1] - blk_begin[g], b - blk_begin[g]);
+}
+
+__device__ inline void splitk_reduce_body(const GemmParams& p, int nblocks, int block) {
     const int tile_elems = p.bm * p.bn;
     const size_t total = (size_t)p.ntiles_launch * tile_elems;
     const size_t split_stride = total;
-    if (p.d.a_colsum && blockIdx.x == 0) {
+    if (p.d.a_colsum && block == 0) {
         // column-sum partials were written by the tile_n == 0 workgroups of this launch
         for (int tl = 0; tl < p.ntiles_launch; ++tl) {
             const int tile = p.tile_begin + tl;
@@ -303,7 +316,7 @@ static __global__ __launch_bounds__(REDUCE_THREADS) void gemm_splitk_reduce_kern
     }
     // four consecutive columns of one tile row per thread (tiles are 16-byte aligned and bn % 4 == 0): 16-byte slab loads, several
     // in flight (the sum keeps its fixed order s = 0, 1, ...: reproducible)
-    for (size_t i = ((size_t)blockIdx.x * REDUCE_THREADS + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * REDUCE_THREADS * 4) {
+    for (size_t i = ((size_t)block * REDUCE_THREADS + threadIdx.x) * 4; i < total; i += (size_t)nblocks * REDUCE_THREADS * 4) {
         const int tl = (int)(i / tile_elems), rem = (int)(i - (size_t)tl * tile_elems);
         const int tile = p.tile_begin + tl;
         const int m = (tile / p.tiles_n) * p.bm + rem / p.bn, n = (tile % p.tiles_n) * p.bn + rem % p.bn;

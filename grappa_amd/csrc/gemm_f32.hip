@@ -20,6 +20,7 @@ using namespace grappa_gemm;
 
 int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool vec_kcontig);   // gemm_bf16x.hip
 int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision);                      // gemm_planes.hip
+int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision);   // gemm_bf16x.hip
 
 namespace {
 
@@ -445,6 +446,154 @@ extern "C" void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail)
     g_override.cfg = cfg;
     g_override.nsplit = nsplit;
     g_override.tail = tail;
+}
+
+// ------------------------------------------------------------------------------------------------ grouped weight gradients
+namespace {
+constexpr int GROUP_MAX = GRAPPA_GEMM_GROUP_MAX;
+struct GroupUpload {              // kernel-argument carrier: descriptors reach device memory without a host-side copy to wait for
+    GemmParams p[8];
+};
+struct GroupIndex {
+    int wg_begin[GROUP_MAX + 1], blk_begin[GROUP_MAX + 1];
+};
+__global__ void group_upload_kernel(GroupUpload u, int n, GemmParams* dst) {
+    const int words = (int)(sizeof(GemmParams) / 4);
+    for (int i = threadIdx.x; i < n * words; i += blockDim.x)
+        reinterpret_cast<unsigned*>(dst)[i] = reinterpret_cast<const unsigned*>(u.p)[i];
+}
+__global__ void group_index_kernel(GroupIndex ix, int n, int* dst_wg, int* dst_blk) {
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        dst_wg[i] = ix.wg_begin[i];
+        dst_blk[i] = ix.blk_begin[i];
+    }
+}
+
+struct GroupPlan {
+    int kps;
+    int nsplit[GROUP_MAX], tiles[GROUP_MAX];
+    int total_wgs;
+    size_t slab_floats[GROUP_MAX], cs_floats[GROUP_MAX];
+    size_t header_bytes, total_bytes;
+};
+
+bool group_desc_ok(const grappa_gemm_desc& d, int precision) {
+    if (d.a_kcontig || d.b_kcontig || d.a_planes || d.b_planes) return false;          // the wgrad layout, fp32 operands
+    if (!d.A || !d.B || !d.C || d.Cp || d.C1p || d.resp || d.auxp) return false;
+    if (d.M <= 32 || d.N <= 32 || d.K <= 0) return false;
+    if (d.precision != precision || d.precision == GRAPPA_GEMM_F32_MFMA) return false;
+    if (d.drop_p < 0.0f || d.drop_p >= 1.0f) return false;
+    return true;
+}
+
+// one K chunk for every problem of the group: the chunk that minimises rounds x tile time + the slab round trips (same cost units
+// as CostModel: CU-cycles)
+GroupPlan plan_group(const grappa_gemm_desc* descs, int n) {
+    GroupPlan g;
+    double work = 0;
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) {
+        g.tiles[i] = ((descs[i].M + 255) / 256) * ((descs[i].N + 127) / 128);
+        work += (double)g.tiles[i] * descs[i].K;
+        kmax = descs[i].K > kmax ? descs[i].K : kmax;
+    }
+    double best = 1e300;
+    g.kps = (kmax + 31) / 32 * 32;
+    for (int R = 1; R <= 12; ++R) {
+        int kps = (int)(work / (256.0 * R));
+        kps = (kps + 31) / 32 * 32;
+        if (kps < 1024) kps = 1024;
+        if (kps > (kmax + 31) / 32 * 32) kps = (kmax + 31) / 32 * 32;
+        long wgs = 0;
+        double slab = 0;
+        for (int i = 0; i < n; ++i) {
+            const int ns = (descs[i].K + kps - 1) / kps;
+            wgs += (long)g.tiles[i] * ns;
+            if (ns > 1) slab += (double)ns * descs[i].M * descs[i].N / 200.0;
+        }
+        const double cost = (double)((wgs + 255) / 256) * 32768.0 * (kps + 160.0) / 307.0 + slab;
+        if (cost < best) {
+            best = cost;
+            g.kps = kps;
+        }
+    }
+    g.total_wgs = 0;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        g.nsplit[i] = (descs[i].K + g.kps - 1) / g.kps;
+        g.total_wgs += g.tiles[i] * g.nsplit[i];
+        g.slab_floats[i] = g.nsplit[i] > 1 ? (size_t)g.nsplit[i] * g.tiles[i] * 256 * 128 : 0;
+        g.cs_floats[i] = g.nsplit[i] > 1 ? (size_t)g.nsplit[i] * descs[i].M : 0;
+        off += g.slab_floats[i] + g.cs_floats[i];
+    }
+    g.header_bytes = ((size_t)n * sizeof(GemmParams) + 2 * (GROUP_MAX + 1) * sizeof(int) + 255) / 256 * 256;
+    g.total_bytes = g.header_bytes + off * sizeof(float);
+    return g;
+}
+}  // namespace
+
+extern "C" size_t grappa_gemm_f32_grouped_workspace_bytes(const grappa_gemm_desc* descs, int n) {
+    if (!descs || n <= 0 || n > GROUP_MAX) return 0;
+    return plan_group(descs, n).total_bytes;
+}
+
+extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* descs, int n, void* ws, size_t ws_bytes) {
+    if (!descs || n <= 0 || n > GROUP_MAX) return GRAPPA_ERR_ARG;
+    const int precision = descs[0].precision;
+    for (int i = 0; i < n; ++i)
+        if (!group_desc_ok(descs[i], precision)) return GRAPPA_ERR_ARG;
+    const GroupPlan g = plan_group(descs, n);
+    if (!ws || ws_bytes < g.total_bytes) return GRAPPA_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GemmParams* d_ps = reinterpret_cast<GemmParams*>(ws);
+    int* d_wg = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)n * sizeof(GemmParams));
+    int* d_blk = d_wg + (GROUP_MAX + 1);
+    float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + g.header_bytes);
+    GroupIndex ix;
+    GroupUpload up;
+    ix.wg_begin[0] = ix.blk_begin[0] = 0;
+    auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
+    int total_blocks = 0;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        const int cnt = n - i0 < 8 ? n - i0 : 8;
+        for (int j = 0; j < cnt; ++j) {
+            const int i = i0 + j;
+            const grappa_gemm_desc& d = descs[i];
+            GemmParams& p = up.p[j];
+            p.d = d;
+            p.k_per_split = g.kps;
+            p.nsplit = g.nsplit[i];
+            p.slab = p.nsplit > 1 ? slab : nullptr;
+            p.cs_slab = p.nsplit > 1 ? slab + g.slab_floats[i] : nullptr;
+            slab += g.slab_floats[i] + g.cs_floats[i];
+            p.drop_scale = d.drop_p > 0.0f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+            p.bm = 256;
+            p.bn = 128;
+            p.tiles_m = (d.M + 255) / 256;
+            p.tiles_n = (d.N + 127) / 128;
+            p.tile_begin = 0;
+            p.ntiles_launch = g.tiles[i];
+            p.vec_io = al16(d.C, d.ldc) && al16(d.C2, d.ldc2) && al16(d.pre, d.ldpre) && al16(d.res, d.ldres) && al16(d.aux, d.ldaux);
+            ix.wg_begin[i + 1] = ix.wg_begin[i] + g.tiles[i] * g.nsplit[i];
+            int blocks = 0;
+            if (p.nsplit > 1) {
+                blocks = (int)(((size_t)g.tiles[i] * 256 * 128 / 4 + REDUCE_THREADS - 1) / REDUCE_THREADS);
+                if (blocks > 1024) blocks = 1024;
+            }
+            ix.blk_begin[i + 1] = ix.blk_begin[i] + blocks;
+            total_blocks = ix.blk_begin[i + 1];
+        }
+        hipLaunchKernelGGL(group_upload_kernel, dim3(1), dim3(256), 0, st, up, cnt, d_ps + i0);
+    }
+    hipLaunchKernelGGL(group_index_kernel, dim3(1), dim3(64), 0, st, ix, n, d_wg, d_blk);
+    if (grappa_launch_status() != GRAPPA_OK) return GRAPPA_ERR_LAUNCH;
+    int rc = grappa_launch_gemm_bf16x_grouped(st, d_ps, d_wg, n, g.total_wgs, precision);
+    if (rc != GRAPPA_OK) return rc;
+    if (total_blocks > 0) {
+        hipLaunchKernelGGL(gemm_splitk_reduce_grouped_kernel, dim3(total_blocks), dim3(REDUCE_THREADS), 0, st, d_ps, d_blk, n);
+        rc = grappa_launch_status();
+    }
+    return rc;
 }
 
 extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes) {

@@ -63,14 +63,23 @@ class BucketedGradReducer:
     def _active() -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
+    @staticmethod
+    def _flush_queued_wgrads() -> None:
+        from .backend import get_backend
+        be = get_backend()
+        if hasattr(be, "flush_wgrads"):
+            be.flush_wgrads()                      # weight gradients still queued for a grouped launch belong in the buffer first
+
     def _on_heads_done(self) -> None:
         if self._active() and not self._heads_sent:
+            self._flush_queued_wgrads()
             a, b = self.head_range
             self._work.append(dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
             self._heads_sent = True
 
     def finish(self) -> None:
         """call after loss.backward(): reduces what is left and waits for every bucket"""
+        self._flush_queued_wgrads()
         if self._active():
             a, b = self.head_range
             if not self._heads_sent:                       # the hook did not fire (e.g. heads without gradient): one bucket

@@ -110,9 +110,13 @@ def _linear_bwd_params(be, dz, x, w, b):
         return
     want_b = b is not None and b.requires_grad
     if w.requires_grad:
-        # the bias gradient colsum(dz) is produced by the same kernel from the dz tiles it stages anyway
-        be.gemm(dz, x, _pgrad(w), M=N, N=K, K=M, a_kcontig=False, b_kcontig=False, accumulate=True,
-                a_colsum=_pgrad(b) if want_b else None)
+        # the bias gradient colsum(dz) is produced by the same kernel from the dz tiles it stages anyway; on the GPU the products of
+        # one backward pass are queued and launched as a group (backend.gemm_wgrad)
+        if hasattr(be, "gemm_wgrad"):
+            be.gemm_wgrad(dz, x, _pgrad(w), _pgrad(b) if want_b else None)
+        else:
+            be.gemm(dz, x, _pgrad(w), M=N, N=K, K=M, a_kcontig=False, b_kcontig=False, accumulate=True,
+                    a_colsum=_pgrad(b) if want_b else None)
     elif want_b:
         be.colsum(dz, _pgrad(b), accumulate=True)
 

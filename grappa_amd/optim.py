@@ -74,6 +74,8 @@ class FusedAdam:
 
     def step(self, grad_scale: float = 1.0):
         be = get_backend()
+        if hasattr(be, "flush_wgrads"):
+            be.flush_wgrads()                      # (normally empty: the backward pass's end-of-pass callback launched them)
         self.step_count += 1
         sumsq = None
         if self.max_grad_norm is not None:

@@ -123,6 +123,16 @@ int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* t
 void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail);
 int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes);
 
+/* Grouped weight gradients: n <= GRAPPA_GEMM_GROUP_MAX independent products in the wgrad layout (a_kcontig = b_kcontig = 0, fp32
+ * operands, M, N > 32, one common precision other than F32_MFMA) as ONE grid + one reduction.  A weight gradient alone has 8 - 24
+ * output tiles and must cut its K (= tokens) 10 - 32 ways to fill the chip, i.e. write and re-read that many partial tiles per
+ * output tile; a backward pass's gradients launched together need 3 - 11 cuts each.  Results per product are those of
+ * grappa_gemm_f32 up to the summation order of the K chunks (fixed, reproducible).  The workspace also carries the device copies of
+ * the descriptors.  Replaces nothing in the reference (torch.autograd runs one addmm per weight); used by ops._WgradQueue. */
+#define GRAPPA_GEMM_GROUP_MAX 16
+size_t grappa_gemm_f32_grouped_workspace_bytes(const grappa_gemm_desc* descs, int n);
+int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* descs, int n, void* ws, size_t ws_bytes);
+
 /* out[n] (+)= sum_m x[m*ldx + n]   (bias gradients) */
 size_t grappa_colsum_workspace_bytes(int M, int N);
 int grappa_colsum_f32(void* stream, int M, int N, const float* x, int ldx, float* out, int accumulate,

@@ -85,3 +85,66 @@ def test_train_steps_with_weight_planes_match_the_default():
         assert float((k0 - k1).abs().max()) <= 2e-5 * float(k0.abs().max())
         assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
     assert not torch.equal(res[0][0][0], res[0][1][0])          # the two steps differ (the weights moved)
+
+
+def test_grouped_weight_gradients_match_single_launches():
+    """grappa_gemm_f32_grouped (the queued weight gradients of a backward pass as ONE grid + one reduction): every product equals its
+    own grappa_gemm_f32 launch up to the summation order of the K chunks; bias gradients ride along; `accumulate` semantics kept."""
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *s: torch.randn(s, generator=gen, device="cuda")      # noqa: E731
+    shapes = [(17158, 512, 512), (44325, 1536, 512), (83328, 512, 512), (28248, 512, 2048), (8233, 2048, 512), (5000, 256, 300), (40, 64, 64)]
+    probs = [(rnd(T, Np), rnd(T, Kp)) for T, Np, Kp in shapes]
+    want, got = [], []
+    old = be.defer_wgrads
+    try:
+        for defer in (False, True):
+            be.defer_wgrads = defer
+            outs = []
+            for dz, x in probs:
+                dw, db = torch.full((dz.shape[1], x.shape[1]), 0.5, device="cuda"), torch.full((dz.shape[1],), -1.0, device="cuda")
+                be.gemm_wgrad(dz, x, dw, db)
+                outs.append((dw, db))
+            be.flush_wgrads()                              # (outside a backward pass every push is launched at once: a group of one)
+            torch.cuda.synchronize()
+            (got if defer else want).append(outs)
+    finally:
+        be.defer_wgrads = old
+    for (dz, x), (w0, b0), (w1, b1) in zip(probs, want[0], got[0]):
+        ref = dz.double().t() @ x.double() + 0.5
+        s = float(ref.abs().max())
+        assert float((w0.double() - ref).abs().max()) < 2e-6 * s and float((w1.double() - ref).abs().max()) < 2e-6 * s
+        rb = dz.double().sum(0) - 1.0
+        assert float((b1.double() - rb).abs().max()) < 2e-6 * float(rb.abs().max())
+        assert float((b0 - b1).abs().max()) < 2e-6 * float(rb.abs().max())
+
+
+def test_train_step_with_and_without_grouped_weight_gradients():
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    from grappa_amd.optim import FlatParams
+    be = get_backend()
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").train()
+    flat = FlatParams(model)
+    res = []
+    old = be.defer_wgrads
+    try:
+        for defer in (False, True, True):
+            be.defer_wgrads = defer
+            ops.manual_seed(3)
+            flat.zero_grad()
+            g = Energy()(model(build_batch_from_pool(list(range(900, 964)), n_confs=8, seed=3).to("cuda")))
+            loss = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)(g)
+            loss.backward()
+            assert not be._wq                       # the end-of-pass callback launched everything that was queued
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), flat.grad.clone()))
+    finally:
+        be.defer_wgrads = old
+    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[0][1].abs().max())
+    assert torch.equal(res[1][1], res[2][1])           # grouped launches are bit-reproducible
