@@ -14,6 +14,7 @@
 // take the scalar-load kernel.  Workgroup order is XCD-aware: consecutive logical ids (= one XCD's L2) are the column tiles
 // of one row panel and, for split-K, the tiles of one K-slice.  Split-K (weight gradients: K = #tokens) writes fp32 slabs
 // that a second kernel sums in a fixed order (bitwise reproducible) before applying the epilogue.
+#include <cstdlib>
 #include "gemm_common.h"
 
 using namespace grappa_gemm;
@@ -499,7 +500,8 @@ GroupPlan plan_group(const grappa_gemm_desc* descs, int n) {
     }
     double best = 1e300;
     g.kps = (kmax + 31) / 32 * 32;
-    for (int R = 1; R <= 12; ++R) {
+    static const int forced = getenv("GRAPPA_GROUP_KPS") ? atoi(getenv("GRAPPA_GROUP_KPS")) : 0;      // tuning only (tools/)
+    for (int R = 1; R <= 12 && !forced; ++R) {
         int kps = (int)(work / (256.0 * R));
         kps = (kps + 31) / 32 * 32;
         if (kps < 1024) kps = 1024;
@@ -517,6 +519,7 @@ GroupPlan plan_group(const grappa_gemm_desc* descs, int n) {
             g.kps = kps;
         }
     }
+    if (forced) g.kps = (forced + 31) / 32 * 32;
     g.total_wgs = 0;
     size_t off = 0;
     for (int i = 0; i < n; ++i) {

@@ -268,7 +268,9 @@ class DeviceDataset:
             data[lvl]["idxs"] = plan.idx32[lvl].long()
         if self.has_confs:
             data["g"]["is_dummy"] = torch.from_numpy(is_dummy).to(dev)
-        dst = torch.repeat_interleave(torch.arange(N, device=dev), (plan.indptr[1:] - plan.indptr[:-1]).long()) if N else torch.zeros(0, dtype=torch.long, device=dev)
+        # (output_size: without it repeat_interleave reads the total back from the device -- the one host sync of a collate)
+        dst = (torch.repeat_interleave(torch.arange(N, device=dev), (plan.indptr[1:] - plan.indptr[:-1]).long(), output_size=int(plan.E))
+               if N else torch.zeros(0, dtype=torch.long, device=dev))
         g = MolBatch(plan.indices.long(), dst, data, {nt: cnt[nt] for nt in NTYPES})
         g._plan = plan
         return g, tuple(self.names[i] for i in ids.tolist())

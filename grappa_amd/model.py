@@ -442,6 +442,9 @@ class WriteParameters(nn.Module):
             return g
         main = torch.cuda.current_stream(h.device)
         if self._streams is None or self._streams[0].device != h.device:
+            import warnings
+            warnings.warn("GRAPPA_HEAD_STREAMS > 1: the writer heads run on several HIP streams.  This opt-in is not the validated "
+                          "configuration (DESIGN.md section 6, multi-queue deviation); the default of one stream is.")
             self._streams = [torch.cuda.Stream(device=h.device) for _ in range(min(self.head_streams, 4) - 1)]
         lanes = [main] + self._streams                     # the largest head stays on the caller's stream
         writers = self._writers_largest_first()
@@ -452,6 +455,11 @@ class WriteParameters(nn.Module):
                 g = w(g)
         for s in self._streams:
             main.wait_stream(s)
+        # the parameters were allocated on the side streams and are consumed on the caller's: tell the caching allocator
+        for lvl in ("n2", "n3", "n4", "n4_improper"):
+            for key, t in g.nodes[lvl].data.items():
+                if key.startswith(("k", "eq")) and torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
         return g
 
 

@@ -309,6 +309,9 @@ def test_writer_heads_on_streams_match_single_stream():
     flat = FlatParams(model)
     g_cpu = build_batch_from_pool(list(range(100, 148)), n_confs=8, seed=3)
     res = []
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    defer, be.defer_wgrads = be.defer_wgrads, False        # grouped weight gradients exist on the caller's stream only: another summation order
     for streams in (1, 1, 4):
         model.parameter_writer.head_streams = streams
         ops.manual_seed(77)
@@ -322,10 +325,11 @@ def test_writer_heads_on_streams_match_single_stream():
         assert torch.equal(a, b)                                   # one stream: bit-reproducible
     loss1, grad1, k41, eq1 = res[0]
     loss4, grad4, k44, eq4 = res[2]
-    assert abs(float(loss4) - float(loss1)) <= 1e-4 * abs(float(loss1))
-    assert gu.rel_err(k44.cpu(), k41.cpu().numpy(), 5e-2) < 2e-3 and gu.rel_err(eq4.cpu(), eq1.cpu().numpy(), 1e-4) < 2e-3
-    assert float((grad4 - grad1).abs().max()) <= 2e-3 * float(grad1.abs().max())
     model.parameter_writer.head_streams = 1
+    be.defer_wgrads = defer
+    # with the shipped kernels the four-stream step has always been bit-identical; anything else is the multi-queue deviation of
+    # DESIGN.md section 6 coming back and must be seen, not absorbed by a tolerance
+    assert torch.equal(loss4, loss1) and torch.equal(k44, k41) and torch.equal(eq4, eq1) and torch.equal(grad4, grad1)
 
 
 def test_predict_drop_in():

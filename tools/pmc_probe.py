@@ -42,5 +42,31 @@ def gat():
           "bwd algorithmic MB", (plan.E * (2 * H * D * 4 + 4) + plan.N * (4 * H * D * 4 + 4)) / 1e6)
 
 
+def gemm3():
+    """the three fp32-grade GEMM designs of round 2 on M x 512 x 512 (forward layout) and the wgrad layout: split in the kernel
+    (gemm_bf16x_kernel), both operands in planes (gemm_planes_kernel), fp32 A + weight planes (gemm_wplanes_kernel)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gemm_planes_check as gp
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    M, N, K = 83328, 512, 512
+    A = torch.randn((M, K), generator=gen, device="cuda")
+    B = torch.randn((N, K), generator=gen, device="cuda")
+    out = torch.empty((M, N), device="cuda")
+    ap, bp = gp.split_planes(A), gp.split_planes(B)
+    for _ in range(6):
+        gp.gemm(A, B, out, M, N, K, True, True, False)
+        gp.gemm(ap, bp, out, M, N, K, True, True, True)
+        gp.gemm(A, bp, out, M, N, K, True, True, "b")
+    T = 83328
+    dZ = torch.randn((T, 512), generator=gen, device="cuda")
+    X = torch.randn((T, 512), generator=gen, device="cuda")
+    dzp, xp = gp.split_planes(dZ, rows_pad=1), gp.split_planes(X, rows_pad=1)
+    dW = torch.empty((512, 512), device="cuda")
+    for _ in range(6):
+        gp.gemm(dZ, X, dW, 512, 512, T, False, False, False)
+        gp.gemm(dzp, xp, dW, 512, 512, T, False, False, True)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
-    {"gemm": gemm, "gat": gat}[sys.argv[1]]()
+    {"gemm": gemm, "gat": gat, "gemm3": gemm3}[sys.argv[1]]()
