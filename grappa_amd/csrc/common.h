@@ -60,6 +60,55 @@ __device__ inline void st1(grappa_bf16_t* __restrict__ p, size_t i, float v) {
     p[i] = __builtin_bit_cast(grappa_bf16_t, h);
 }
 
+// A lane's chunk of E consecutive elements held as fp32.  E = 4: 16 B of fp32 or 8 B of bf16; E = 8 (bf16 only): 16 B per lane --
+// the bf16 kernels are otherwise bound by the NUMBER of memory instructions, not by bytes (same launch time as fp32 with half the bytes)
+template <int E> struct Chunk { float v[E]; };
+template <int E> __device__ inline Chunk<E> chunk_zero() {
+    Chunk<E> c;
+#pragma unroll
+    for (int e = 0; e < E; ++e) c.v[e] = 0.f;
+    return c;
+}
+template <int E, typename T> __device__ inline Chunk<E> ldc(const T* __restrict__ row, int c);
+template <> __device__ inline Chunk<4> ldc<4, float>(const float* __restrict__ row, int c) {
+    const float4 f = reinterpret_cast<const float4*>(row)[c];
+    return Chunk<4>{{f.x, f.y, f.z, f.w}};
+}
+template <> __device__ inline Chunk<4> ldc<4, grappa_bf16_t>(const grappa_bf16_t* __restrict__ row, int c) {
+    const float4 f = ld4(row, c);
+    return Chunk<4>{{f.x, f.y, f.z, f.w}};
+}
+template <> __device__ inline Chunk<8> ldc<8, grappa_bf16_t>(const grappa_bf16_t* __restrict__ row, int c) {
+    const uint4 u = reinterpret_cast<const uint4*>(row)[c];
+    return Chunk<8>{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
+                     __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)}};
+}
+template <int E, typename T> __device__ inline void stc(T* __restrict__ row, int c, const Chunk<E>& x);
+template <> __device__ inline void stc<4, float>(float* __restrict__ row, int c, const Chunk<4>& x) {
+    reinterpret_cast<float4*>(row)[c] = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+}
+template <> __device__ inline void stc<4, grappa_bf16_t>(grappa_bf16_t* __restrict__ row, int c, const Chunk<4>& x) {
+    st4(row, c, make_float4(x.v[0], x.v[1], x.v[2], x.v[3]));
+}
+template <> __device__ inline void stc<8, grappa_bf16_t>(grappa_bf16_t* __restrict__ row, int c, const Chunk<8>& x) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        bf2 h;
+        h[0] = (__bf16)x.v[2 * e];
+        h[1] = (__bf16)x.v[2 * e + 1];
+        w[e] = __builtin_bit_cast(unsigned, h);
+    }
+    reinterpret_cast<uint4*>(row)[c] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <int E> __device__ inline float cdot(const Chunk<E>& a, const Chunk<E>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; e += 2) s += a.v[e] * b.v[e] + a.v[e + 1] * b.v[e + 1];
+    return s;
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -158,6 +158,144 @@ __global__ __launch_bounds__(256) void gat_bwd_kernel(int N, int H, int D, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 rows with EIGHT elements (16 bytes) per lane: the same algorithms as above on Chunk<8>.  With 4 elements per lane a bf16 row
+// costs as many memory instructions as an fp32 row and the kernel runs no faster on half the bytes; with 8 it needs half of them.
+template <int NC, int E, typename T>
+__device__ inline void load_row_e(const T* __restrict__ base, int node, int F, int lane, int nvec, Chunk<E> (&r)[NC]) {
+    const T* p = base + (size_t)node * F;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        r[i] = (c < nvec) ? ldc<E, T>(p, c) : chunk_zero<E>();
+    }
+}
+
+template <int NC, int E, typename T>
+__global__ __launch_bounds__(256) void gat_fwd_kernel_e(int N, int H, int D, const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                        const T* __restrict__ ft, T* __restrict__ out, float* __restrict__ alpha) {
+    const int lane = threadIdx.x & 63;
+    const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (v >= N) return;
+    const int F = H * D, nvec = F / E, lph = D / E;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    Chunk<E> fv[NC], cur[NC], nxt[NC], acc[NC];
+    float mx[NC], den[NC];
+    load_row_e<NC, E>(ft, v, F, lane, nvec, fv);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        acc[i] = chunk_zero<E>();
+        mx[i] = -INFINITY;
+        den[i] = 0.f;
+    }
+    const int e0 = indptr[v], e1 = indptr[v + 1];
+    if (e0 < e1) load_row_e<NC, E>(ft, indices[e0], F, lane, nvec, nxt);
+    for (int e = e0; e < e1; ++e) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) cur[i] = nxt[i];
+        if (e + 1 < e1) load_row_e<NC, E>(ft, indices[e + 1], F, lane, nvec, nxt);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const float s = group_sum(cdot<E>(cur[i], fv[i]), lph) * inv_sqrt_d;
+            const int c = lane + 64 * i;
+            if (c < nvec && (lane % lph) == 0) alpha[(size_t)e * H + (c / lph)] = s;   // raw score, normalised below
+            const float m_new = fmaxf(mx[i], s);
+            const float corr = expf(mx[i] - m_new);
+            const float w = expf(s - m_new);
+            den[i] = den[i] * corr + w;
+#pragma unroll
+            for (int q = 0; q < E; ++q) acc[i].v[q] = acc[i].v[q] * corr + w * cur[i].v[q];
+            mx[i] = m_new;
+        }
+    }
+    T* o = out + (size_t)v * F;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            const float inv = den[i] > 0.f ? 1.0f / den[i] : 0.f;
+            Chunk<E> r;
+#pragma unroll
+            for (int q = 0; q < E; ++q) r.v[q] = acc[i].v[q] * inv;
+            stc<E, T>(o, c, r);
+            if ((lane % lph) == 0) {
+                const int h = c / lph;
+                for (int e = e0; e < e1; ++e) {
+                    const size_t a = (size_t)e * H + h;
+                    alpha[a] = expf(alpha[a] - mx[i]) * inv;
+                }
+            }
+        }
+    }
+}
+
+template <int NC, int E, typename T>
+__global__ __launch_bounds__(256) void gat_delta_kernel_e(int N, int H, int D, const T* __restrict__ out, const T* __restrict__ dout,
+                                                          float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (v >= N) return;
+    const int F = H * D, nvec = F / E, lph = D / E;
+    Chunk<E> a[NC], b[NC];
+    load_row_e<NC, E>(out, v, F, lane, nvec, a);
+    load_row_e<NC, E>(dout, v, F, lane, nvec, b);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const float s = group_sum(cdot<E>(a[i], b[i]), lph);
+        const int c = lane + 64 * i;
+        if (c < nvec && (lane % lph) == 0) delta[(size_t)v * H + c / lph] = s;
+    }
+}
+
+template <int NC, int E, typename T>
+__global__ __launch_bounds__(256) void gat_bwd_kernel_e(int N, int H, int D, const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                        const int* __restrict__ rev, const T* __restrict__ ft,
+                                                        const float* __restrict__ alpha, const T* __restrict__ dout,
+                                                        const float* __restrict__ delta, T* __restrict__ dft) {
+    const int lane = threadIdx.x & 63;
+    const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (u >= N) return;
+    const int F = H * D, nvec = F / E, lph = D / E;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    Chunk<E> fu[NC], du[NC], fw[NC], dw[NC], acc[NC];
+    float delta_u[NC];
+    load_row_e<NC, E>(ft, u, F, lane, nvec, fu);
+    load_row_e<NC, E>(dout, u, F, lane, nvec, du);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        acc[i] = chunk_zero<E>();
+        const int c = lane + 64 * i;
+        delta_u[i] = (c < nvec) ? delta[(size_t)u * H + c / lph] : 0.f;
+    }
+    const int e0 = indptr[u], e1 = indptr[u + 1];
+    for (int e = e0; e < e1; ++e) {
+        const int w = indices[e];
+        const int er = rev[e];
+        load_row_e<NC, E>(ft, w, F, lane, nvec, fw);
+        load_row_e<NC, E>(dout, w, F, lane, nvec, dw);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            const int h = (c < nvec) ? c / lph : 0;
+            const float a_uw = (c < nvec) ? alpha[(size_t)er * H + h] : 0.f;
+            const float a_wu = (c < nvec) ? alpha[(size_t)e * H + h] : 0.f;
+            const float d_w = (c < nvec) ? delta[(size_t)w * H + h] : 0.f;
+            const float dot_src = group_sum(cdot<E>(dw[i], fu[i]), lph);
+            const float dot_dst = group_sum(cdot<E>(du[i], fw[i]), lph);
+            const float coef = (a_uw * (dot_src - d_w) + a_wu * (dot_dst - delta_u[i])) * inv_sqrt_d;
+#pragma unroll
+            for (int q = 0; q < E; ++q) acc[i].v[q] += a_uw * dw[i].v[q] + coef * fw[i].v[q];
+        }
+    }
+    T* o = dft + (size_t)u * F;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) stc<E, T>(o, c, acc[i]);
+    }
+}
+
 template <int NC>
 __global__ __launch_bounds__(256) void neighbor_mean_kernel(int N, int F, const int* __restrict__ indptr, const int* __restrict__ indices,
                                                             const float* __restrict__ x, float* __restrict__ out, int scale_by_neighbor) {
@@ -197,6 +335,15 @@ inline int chunks_for(int F) {
     return nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : 8;
 }
 inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+inline int chunks_for8(int F) {
+    const int nc = (F / 8 + 63) / 64;
+    return nc <= 1 ? 1 : nc <= 2 ? 2 : 4;
+}
+// 8 bf16 per lane: a head = D/8 adjacent lanes, rows 16-byte aligned
+inline bool wide_ok(int H, int D, const void* a, const void* b) {
+    return (D & 7) == 0 && D / 8 > 0 && (((D / 8) & (D / 8 - 1)) == 0) && H * D <= 2048 &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
 inline bool head_shape_ok(int H, int D) {
     if (H <= 0 || D <= 0 || (D & 3)) return false;
     const int lph = D / 4;
@@ -226,6 +373,15 @@ int gat_fwd_impl(void* stream, int N, int E, int H, int D, const int* indptr, co
     if ((reinterpret_cast<uintptr_t>(ft) | reinterpret_cast<uintptr_t>(out)) & (sizeof(T) == 4 ? 15 : 7)) return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((N + 3) / 4);
+    if constexpr (sizeof(T) == 2) {
+        if (wide_ok(H, D, ft, out)) {               // 16-byte accesses: 8 bf16 per lane
+            const int nc8 = chunks_for8(H * D);
+            if (nc8 == 1) hipLaunchKernelGGL((gat_fwd_kernel_e<1, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
+            else if (nc8 == 2) hipLaunchKernelGGL((gat_fwd_kernel_e<2, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
+            else hipLaunchKernelGGL((gat_fwd_kernel_e<4, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
+            return grappa_launch_status();
+        }
+    }
     DISPATCH_NC_T(chunks_for(H * D), gat_fwd_kernel, T, grid, st, N, H, D, indptr, indices, ft, out, alpha);
     return grappa_launch_status();
 }
@@ -240,6 +396,19 @@ int gat_bwd_impl(void* stream, int N, int E, int H, int D, const int* indptr, co
         return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((N + 3) / 4);
+    if constexpr (sizeof(T) == 2) {
+        if (wide_ok(H, D, ft, out) && wide_ok(H, D, dout, dft)) {
+            const int nc8 = chunks_for8(H * D);
+#define GRAPPA_GAT_BWD8(NC8)                                                                                                                  \
+    hipLaunchKernelGGL((gat_delta_kernel_e<NC8, 8, T>), grid, dim3(256), 0, st, N, H, D, out, dout, delta);                                    \
+    hipLaunchKernelGGL((gat_bwd_kernel_e<NC8, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, rev, ft, alpha, dout, delta, dft)
+            if (nc8 == 1) { GRAPPA_GAT_BWD8(1); }
+            else if (nc8 == 2) { GRAPPA_GAT_BWD8(2); }
+            else { GRAPPA_GAT_BWD8(4); }
+#undef GRAPPA_GAT_BWD8
+            return grappa_launch_status();
+        }
+    }
     const int nc = chunks_for(H * D);
     DISPATCH_NC_T(nc, gat_delta_kernel, T, grid, st, N, H, D, out, dout, delta);
     DISPATCH_NC_T(nc, gat_bwd_kernel, T, grid, st, N, H, D, indptr, indices, rev, ft, alpha, dout, delta, dft);

@@ -167,6 +167,119 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, 
     }
 }
 
+
+// ---- the same with E elements per lane (E = 8: 16-byte accesses of bf16 rows, see Chunk<E> in common.h)
+template <int S, int E, typename TE>
+__global__ __launch_bounds__(256) void seqattn_fwd_kernel_e(int T, int F, int dh, const TE* __restrict__ qkv, TE* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= T) return;
+    const int nvec = F / E, lph = dh / E;
+    const float scale = 1.0f / sqrtf((float)dh);
+    for (int c0 = 0; c0 < nvec; c0 += 64) {
+        const int c = c0 + lane;
+        const bool ok = c < nvec;
+        Chunk<E> q[S], k[S], v[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const TE* row = qkv + ((size_t)i * T + t) * 3 * F;
+            q[i] = ok ? ldc<E, TE>(row, c) : chunk_zero<E>();
+            k[i] = ok ? ldc<E, TE>(row, nvec + c) : chunk_zero<E>();
+            v[i] = ok ? ldc<E, TE>(row, 2 * nvec + c) : chunk_zero<E>();
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            float sc[S], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                sc[j] = group_sum(cdot<E>(q[i], k[j]), lph) * scale;
+                mx = fmaxf(mx, sc[j]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                sc[j] = expf(sc[j] - mx);
+                den += sc[j];
+            }
+            const float inv = 1.0f / den;
+            Chunk<E> o = chunk_zero<E>();
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const float p = sc[j] * inv;
+#pragma unroll
+                for (int e = 0; e < E; ++e) o.v[e] += p * v[j].v[e];
+            }
+            if (ok) stc<E, TE>(out + ((size_t)i * T + t) * F, c, o);
+        }
+    }
+}
+
+template <int S, int E, typename TE>
+__global__ __launch_bounds__(256) void seqattn_bwd_kernel_e(int T, int F, int dh, const TE* __restrict__ qkv, const TE* __restrict__ dout,
+                                                            TE* __restrict__ dqkv) {
+    const int lane = threadIdx.x & 63;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= T) return;
+    const int nvec = F / E, lph = dh / E;
+    const float scale = 1.0f / sqrtf((float)dh);
+    for (int c0 = 0; c0 < nvec; c0 += 64) {
+        const int c = c0 + lane;
+        const bool ok = c < nvec;
+        Chunk<E> q[S], k[S], v[S], go[S], dq[S], dk[S], dv[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const TE* row = qkv + ((size_t)i * T + t) * 3 * F;
+            q[i] = ok ? ldc<E, TE>(row, c) : chunk_zero<E>();
+            k[i] = ok ? ldc<E, TE>(row, nvec + c) : chunk_zero<E>();
+            v[i] = ok ? ldc<E, TE>(row, 2 * nvec + c) : chunk_zero<E>();
+            go[i] = ok ? ldc<E, TE>(dout + ((size_t)i * T + t) * F, c) : chunk_zero<E>();
+            dq[i] = chunk_zero<E>(); dk[i] = chunk_zero<E>(); dv[i] = chunk_zero<E>();
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            float p[S], dp[S], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                p[j] = group_sum(cdot<E>(q[i], k[j]), lph) * scale;
+                mx = fmaxf(mx, p[j]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                p[j] = expf(p[j] - mx);
+                den += p[j];
+            }
+            const float inv = 1.0f / den;
+            float dsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                p[j] *= inv;
+                dp[j] = group_sum(cdot<E>(go[i], v[j]), lph);
+                dsum += p[j] * dp[j];
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const float ds = p[j] * (dp[j] - dsum) * scale;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    dq[i].v[e] += ds * k[j].v[e];
+                    dk[j].v[e] += ds * q[i].v[e];
+                    dv[j].v[e] += p[j] * go[i].v[e];
+                }
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                TE* row = dqkv + ((size_t)i * T + t) * 3 * F;
+                stc<E, TE>(row, c, dq[i]);
+                stc<E, TE>(row, nvec + c, dk[i]);
+                stc<E, TE>(row, 2 * nvec + c, dv[i]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ symmetriser input
 template <typename TE>
 __global__ __launch_bounds__(256) void perm_concat_fwd_kernel(int s, int T, int F, int P, Perms perms, const TE* __restrict__ x,
@@ -338,6 +451,17 @@ int seqattn_fwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* q
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((T + 3) / 4);
     const int F = nheads * dh;
+    if constexpr (sizeof(TE) == 2) {
+        if ((dh & 7) == 0 && pow2(dh / 8) && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {      // 8 bf16 per lane
+            switch (s) {
+                case 1: hipLaunchKernelGGL((seqattn_fwd_kernel_e<1, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+                case 2: hipLaunchKernelGGL((seqattn_fwd_kernel_e<2, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+                case 3: hipLaunchKernelGGL((seqattn_fwd_kernel_e<3, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+                default: hipLaunchKernelGGL((seqattn_fwd_kernel_e<4, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+            }
+            return grappa_launch_status();
+        }
+    }
     switch (s) {
         case 1: hipLaunchKernelGGL((seqattn_fwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
         case 2: hipLaunchKernelGGL((seqattn_fwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
@@ -355,6 +479,18 @@ int seqattn_bwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* q
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((T + 3) / 4);
     const int F = nheads * dh;
+    if constexpr (sizeof(TE) == 2) {
+        if ((dh & 7) == 0 && pow2(dh / 8) &&
+            ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dqkv)) & 15) == 0) {
+            switch (s) {
+                case 1: hipLaunchKernelGGL((seqattn_bwd_kernel_e<1, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+                case 2: hipLaunchKernelGGL((seqattn_bwd_kernel_e<2, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+                case 3: hipLaunchKernelGGL((seqattn_bwd_kernel_e<3, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+                default: hipLaunchKernelGGL((seqattn_bwd_kernel_e<4, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+            }
+            return grappa_launch_status();
+        }
+    }
     switch (s) {
         case 1: hipLaunchKernelGGL((seqattn_bwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
         case 2: hipLaunchKernelGGL((seqattn_bwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
