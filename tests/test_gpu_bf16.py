@@ -28,7 +28,7 @@ def _one_ulp(a16, ref32):
     same = (a16 == want).float().mean()
     assert float(same) > 0.98, float(same)
     d = (a16.float() - ref32).abs()
-    assert bool((d <= ref32.abs() * 2.0 ** -7 + 1e-30).all())
+    assert bool((d <= ref32.abs() * 2.0 ** -7 + 1e-6 * ref32.abs().max()).all())      # one bf16 step; sums that cancel keep the absolute noise
 
 
 def test_rowwise_graph_and_tuple_kernels_in_bf16_equal_rounded_fp32_kernels():
