@@ -56,14 +56,8 @@ constexpr int PBM = 256, PBN = 128, PSLAB = 32, PNT = 512;
 constexpr int A_PLANE = PBM * PSLAB * 2;      // bytes of one plane of the A tile in a stage (16 KB)
 constexpr int B_PLANE = PBN * PSLAB * 2;      // 8 KB
 
-// PX1W ("wide", the bf16 storage configuration): ONE plane per operand, but the three plane slots of a stage hold three CONSECUTIVE
-// k-slabs of it (96 k per stage): 24 MFMAs per wavefront between barriers instead of the 8 a one-plane slab of 32 gives
-enum PMode { PX1 = 1, PX3 = 3, PX6 = 6, PX9 = 9, PX1W = 13 };
-template <int MODE> struct PPieces {
-    static constexpr int NP = MODE == PX1 ? 1 : (MODE == PX3 ? 2 : 3);
-    static constexpr int NPROD = MODE == PX1W ? 3 : MODE;          // MFMAs per (sub tile pair, k16 step)
-    static constexpr int KSTAGE = MODE == PX1W ? 3 * PSLAB : PSLAB;  // k per stage
-};
+enum PMode { PX1 = 1, PX3 = 3, PX6 = 6, PX9 = 9 };
+template <int MODE> struct PPieces { static constexpr int NP = MODE == PX1 ? 1 : (MODE == PX3 ? 2 : 3); };
 
 // 16 bytes of zeros in device memory: the LDS-DMA source of k-rows beyond K (k-major operands need no padding in HBM)
 __device__ __attribute__((aligned(16))) unsigned grappa_zero16[4] = {0u, 0u, 0u, 0u};
@@ -99,37 +93,6 @@ __device__ inline LaneSrc lane_sources(const grappa_gemm_desc& d, int m0, int n0
         s.b = ((unsigned)kb * (unsigned)d.ldb + (unsigned)cb) * 2u;
     }
     return s;
-}
-
-// a plane slot whose k-slab lies beyond K: every lane fetches the zero page
-template <int NP>
-__device__ inline void issue_zero_slot(char* __restrict__ stage, int slot, int wave) {
-    const char* z = reinterpret_cast<const char*>(grappa_zero16);
-    glds16(z, stage + slot * A_PLANE + wave * 1024);
-    glds16(z, stage + slot * A_PLANE + (wave + 8) * 1024);
-    glds16(z, stage + NP * A_PLANE + slot * B_PLANE + wave * 1024);
-}
-
-// one plane slot (slot p of the stage) from the given (already slab- and plane-offset) operand bases; krem < 32 (k-major only): the
-// k-rows >= krem come from the zero page
-template <int NP, bool KMAJOR>
-__device__ inline void issue_slot(const char* __restrict__ ap, const char* __restrict__ bp, const LaneSrc& s, char* __restrict__ stage, int slot,
-                                  int wave, int lane, int krem) {
-    if (krem <= 0) {
-        issue_zero_slot<NP>(stage, slot, wave);
-        return;
-    }
-    if (KMAJOR && krem < PSLAB) {
-        const char* z = reinterpret_cast<const char*>(grappa_zero16);
-        const bool oka0 = 2 * wave + (lane >> 5) < krem, oka1 = 2 * (wave + 8) + (lane >> 5) < krem, okb = 4 * wave + (lane >> 4) < krem;
-        glds16(oka0 ? ap + s.a0 : z, stage + slot * A_PLANE + wave * 1024);
-        glds16(oka1 ? ap + s.a1 : z, stage + slot * A_PLANE + (wave + 8) * 1024);
-        glds16(okb ? bp + s.b : z, stage + NP * A_PLANE + slot * B_PLANE + wave * 1024);
-        return;
-    }
-    glds16(ap + s.a0, stage + slot * A_PLANE + wave * 1024);
-    glds16(ap + s.a1, stage + slot * A_PLANE + (wave + 8) * 1024);
-    glds16(bp + s.b, stage + NP * A_PLANE + slot * B_PLANE + wave * 1024);
 }
 
 // LDS-DMA of one slab into `stage`: 3 pieces per plane per wavefront
@@ -238,7 +201,6 @@ __device__ inline void pmfma_range(const PFrags<PPieces<MODE>::NP>& f, f32x16 (&
             if (pb < 0 || pb >= NP) continue;
             if (MODE == PX6 && s > 2) continue;
             if (MODE == PX3 && s > 1) continue;
-            if (MODE == PX1W && pa != pb) continue;                // slot p of A meets slot p of B: three k-slabs of one plane
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -268,8 +230,7 @@ template <int MODE, bool KMAJOR>
 __global__ __launch_bounds__(PNT, 2) void gemm_planes_kernel(GemmParams p) {
     constexpr int NP = PPieces<MODE>::NP;
     constexpr int STAGE = NP * (A_PLANE + B_PLANE);
-    constexpr int NM = PPieces<MODE>::NPROD * 4;  // MFMAs per k-half and wavefront
-    constexpr int KSTAGE = PPieces<MODE>::KSTAGE;
+    constexpr int NM = MODE * 4;                  // MFMAs per k-half and wavefront
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
     const TileCoord tc = map_workgroup(p);
@@ -279,7 +240,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_planes_kernel(GemmParams p) {
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
     const int kbeg = split * p.k_per_split;
     const int kend = min(d.K, kbeg + p.k_per_split);
-    const int nslab = (kend - kbeg + KSTAGE - 1) / KSTAGE;     // (K-contiguous planes are zero-padded to whole slabs of 32 by their producer)
+    const int nslab = (kend - kbeg + PSLAB - 1) / PSLAB;       // K ranges are zero-padded to whole slabs by the producer of the planes
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -301,11 +262,9 @@ __global__ __launch_bounds__(PNT, 2) void gemm_planes_kernel(GemmParams p) {
         const char* B = reinterpret_cast<const char*>(d.B);
         const size_t apb = d.a_plane_stride * 2, bpb = d.b_plane_stride * 2;
         // uniform byte offset of slab s: K-contiguous rows advance by 64 B, k-major operands by 32 rows
-        // byte distance of one k-slab of 32 along k
-        const size_t a_slab = KMAJOR ? (size_t)PSLAB * d.lda * 2 : (size_t)PSLAB * 2;
-        const size_t b_slab = KMAJOR ? (size_t)PSLAB * d.ldb * 2 : (size_t)PSLAB * 2;
-        const size_t a_step = a_slab * (KSTAGE / PSLAB), b_step = b_slab * (KSTAGE / PSLAB);
-        const size_t a_base = (size_t)kbeg / PSLAB * a_slab, b_base = (size_t)kbeg / PSLAB * b_slab;
+        const size_t a_step = KMAJOR ? (size_t)PSLAB * d.lda * 2 : (size_t)PSLAB * 2;
+        const size_t b_step = KMAJOR ? (size_t)PSLAB * d.ldb * 2 : (size_t)PSLAB * 2;
+        const size_t a_base = (size_t)kbeg / PSLAB * a_step, b_base = (size_t)kbeg / PSLAB * b_step;
         const LaneSrc src = lane_sources<KMAJOR>(d, m0, n0, wave, lane);
         const ReadOff ro = read_offsets<KMAJOR>(wave, lane);
         PFrags<NP> f0, f1;
@@ -314,13 +273,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_planes_kernel(GemmParams p) {
         const int krem_last = KMAJOR ? (kend - kbeg) - (nslab - 1) * PSLAB : PSLAB;
 #define GP_ISSUE(T_, STAGE_)                                                                                                                  \
     do {                                                                                                                                      \
-        if (MODE == PX1W) {                                                                                                                   \
-            _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                                                \
-                const int krem_ = (kend - kbeg) - ((T_) * 3 + q_) * PSLAB;                                                                    \
-                issue_slot<NP, KMAJOR>(A + a_base + ((size_t)(T_) * 3 + q_) * a_slab, B + b_base + ((size_t)(T_) * 3 + q_) * b_slab, src, STAGE_, q_, \
-                                       wave, lane, krem_ < PSLAB ? krem_ : PSLAB);                                                           \
-            }                                                                                                                                 \
-        } else if (KMAJOR && (T_) == nslab - 1 && krem_last < PSLAB)                                                                          \
+        if (KMAJOR && (T_) == nslab - 1 && krem_last < PSLAB)                                                                                 \
             issue_slab_ktail<NP>(A, B, apb, bpb, a_base + (size_t)(T_) * a_step, b_base + (size_t)(T_) * b_step, src, STAGE_, wave, lane, krem_last); \
         else                                                                                                                                  \
             issue_slab<NP>(A, B, apb, bpb, a_base + (size_t)(T_) * a_step, b_base + (size_t)(T_) * b_step, src, STAGE_, wave);                \
@@ -719,7 +672,7 @@ int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision) {
         case GRAPPA_GEMM_F32_MFMA:                      // plane operands carry no fp32 copy: the fp32-grade product is the x6 one
         case GRAPPA_GEMM_F32_BF16X6: return launch_planes_layout<PX6>(st, p);
         case GRAPPA_GEMM_BF16X3: return launch_planes_layout<PX3>(st, p);
-        case GRAPPA_GEMM_BF16: return launch_planes_layout<PX1W>(st, p);        // one plane per operand, three k-slabs per stage
+        case GRAPPA_GEMM_BF16: return launch_planes_layout<PX1>(st, p);
         default: return GRAPPA_ERR_ARG;
     }
 }
