@@ -288,11 +288,10 @@ struct Plan {
 
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
 // cfg 5, 6: the 128x128 and 256x128 tiles of the bf16-split kernel (gemm_bf16x.hip), one 512-thread workgroup per CU
-// cfg 7: the 256x256 tile of the one-plane (bf16) plane kernel (gemm_planes.hip gemm_bf16_256_kernel)
-constexpr int NCFG = 8;
-constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256, 256};
-constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128, 256};
-constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 / 128 KB, VGPR budget)
+constexpr int NCFG = 7;
+constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256};
+constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128};
+constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
 
 bool use_bf16x(int M, int N, int precision) { return precision != GRAPPA_GEMM_F32_MFMA && M > 32 && N > 32; }
 
@@ -307,8 +306,8 @@ PlanOverride g_override;
 // costing a whole extra round.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
 struct CostModel {
     // MACs per cycle per CU sustained in the main loop, and the per-tile prologue + epilogue expressed in columns of K
-    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0, 460.0};      // (cfg 7 relative to cfg 6 in the one-plane mode)
-    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0, 160.0};
+    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0};
+    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0};
     double grid(int c, long wgs, int kps) const {
         const int conc = CFG_CONC[c];
         const double t = (double)CFG_BM[c] * CFG_BN[c] * (kps + k0[c]) / rate[c];
@@ -321,8 +320,7 @@ struct CostModel {
     static double splitk(int nsplit, double elems) { return 12000.0 + nsplit * elems / 200.0; }   // two launches + slab write / reduce
 };
 
-// planes: 0 = fp32 operands, 1 = plane operands (256 x 128 tile), 2 = one-plane bf16 operands (256 x 128 or 256 x 256)
-Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, int planes = 0) {
+Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool planes = false) {
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
@@ -339,8 +337,7 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, int pla
     for (int c = 0; c < NCFG; ++c) {
         if (g_override.cfg >= 0 && c != g_override.cfg && !planes) continue;
         if (bf16x != (c >= 5)) continue;
-        if (c == 7 && planes != 2) continue;
-        if (planes && c != 6 && c != 7) continue;        // the plane-format kernels have the 256 x 128 tile (and 256 x 256 for one plane)
+        if (planes && c != 6) continue;                  // the plane-format kernel has the 256 x 128 tile only
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
@@ -427,10 +424,8 @@ extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
     if (use_bf16x(M, N, GRAPPA_GEMM_F32_BF16X9)) {
         const size_t c = plan_workspace_floats(make_plan(M, N, K, true, true), M, N);
         if (c > a) a = c;
-        for (int pm = 1; pm <= 2; ++pm) {
-            const size_t e = plan_workspace_floats(make_plan(M, N, K, true, true, pm), M, N);
-            if (e > a) a = e;
-        }
+        const size_t e = plan_workspace_floats(make_plan(M, N, K, true, true, true), M, N);
+        if (e > a) a = e;
     }
     return a * sizeof(float);
 }
@@ -651,8 +646,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool bf16x = planes || use_bf16x(d->M, d->N, d->precision);
     // the native fp32 kernel (precision F32_MFMA, or M / N <= 32) keeps its register-lean fp32-only epilogue walk
     if (!bf16x && (d->Cp || d->C1p || d->resp || d->auxp || !d->C)) return GRAPPA_ERR_ARG;
-    const int plane_mode = !planes ? 0 : (d->a_planes && d->precision == GRAPPA_GEMM_BF16 ? 2 : 1);
-    Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, plane_mode);
+    Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
     if (need > 0 && (!ws || ws_bytes < need)) return GRAPPA_ERR_WORKSPACE;

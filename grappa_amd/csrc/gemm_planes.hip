@@ -590,225 +590,6 @@ int launch_wplanes(hipStream_t st, GemmParams& p) {
     return grappa_launch_status();
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// bf16 x bf16 product (one plane per operand: the bf16 storage configuration) on a 256 x 256 tile.  With one plane the 256 x 128 tile
-// moves 24 KB per slab for 8 MFMAs per wavefront: the LDS-DMA path (~46 GB/s per CU on this workload) feeds at
-// most ~1,000 TFLOP/s of it.  256 x 256 halves the bytes per MFMA.  8 wavefronts as 4 x 2, 64 x 128 per wavefront (8 accumulators =
-// 128 registers), slabs of 32 in a ring of FOUR 32 KB stages: the DMA runs three slabs ahead, one barrier per slab, the fragments
-// of the next 16-deep step are read under the MFMAs of the current one.  Both operands use the A-tile images of the kernel above.
-constexpr int W256_STAGE = 2 * A_PLANE;       // A 16 KB + B 16 KB
-constexpr int W256_NSTAGE = 4;
-
-struct LaneSrc256 { unsigned a0, a1, b0, b1; };
-
-template <bool KMAJOR>
-__device__ inline LaneSrc256 lane_sources256(const grappa_gemm_desc& d, int m0, int n0, int wave, int lane) {
-    LaneSrc256 s;
-    if (!KMAJOR) {
-        const int rin = lane >> 2, c = (lane & 3) ^ ((lane >> 4) & 3);
-        const int ra0 = min(m0 + wave * 16 + rin, d.M - 1), ra1 = min(m0 + (wave + 8) * 16 + rin, d.M - 1);
-        const int rb0 = min(n0 + wave * 16 + rin, d.N - 1), rb1 = min(n0 + (wave + 8) * 16 + rin, d.N - 1);
-        s.a0 = ((unsigned)ra0 * (unsigned)d.lda + 8u * c) * 2u;
-        s.a1 = ((unsigned)ra1 * (unsigned)d.lda + 8u * c) * 2u;
-        s.b0 = ((unsigned)rb0 * (unsigned)d.ldb + 8u * c) * 2u;
-        s.b1 = ((unsigned)rb1 * (unsigned)d.ldb + 8u * c) * 2u;
-    } else {
-        const int k0 = 2 * wave + (lane >> 5), k1 = 2 * (wave + 8) + (lane >> 5);
-        const int j0 = (lane & 31) ^ ((k0 & 3) << 2), j1 = (lane & 31) ^ ((k1 & 3) << 2);
-        s.a0 = ((unsigned)k0 * (unsigned)d.lda + (unsigned)min(m0 + 8 * j0, d.lda - 8)) * 2u;
-        s.a1 = ((unsigned)k1 * (unsigned)d.lda + (unsigned)min(m0 + 8 * j1, d.lda - 8)) * 2u;
-        s.b0 = ((unsigned)k0 * (unsigned)d.ldb + (unsigned)min(n0 + 8 * j0, d.ldb - 8)) * 2u;
-        s.b1 = ((unsigned)k1 * (unsigned)d.ldb + (unsigned)min(n0 + 8 * j1, d.ldb - 8)) * 2u;
-    }
-    return s;
-}
-
-template <bool KMAJOR>
-__device__ inline void issue_slab256(const char* __restrict__ A, const char* __restrict__ B, const LaneSrc256& s, char* __restrict__ stage, int wave,
-                                     int lane, int krem) {
-    if (KMAJOR && krem < PSLAB) {
-        const char* z = reinterpret_cast<const char*>(grappa_zero16);
-        const bool ok0 = 2 * wave + (lane >> 5) < krem, ok1 = 2 * (wave + 8) + (lane >> 5) < krem;
-        glds16(ok0 ? A + s.a0 : z, stage + wave * 1024);
-        glds16(ok1 ? A + s.a1 : z, stage + (wave + 8) * 1024);
-        glds16(ok0 ? B + s.b0 : z, stage + A_PLANE + wave * 1024);
-        glds16(ok1 ? B + s.b1 : z, stage + A_PLANE + (wave + 8) * 1024);
-        return;
-    }
-    glds16(A + s.a0, stage + wave * 1024);
-    glds16(A + s.a1, stage + (wave + 8) * 1024);
-    glds16(B + s.b0, stage + A_PLANE + wave * 1024);
-    glds16(B + s.b1, stage + A_PLANE + (wave + 8) * 1024);
-}
-
-struct Frags256 { bf16x8 a[2], b[4]; };
-
-struct ReadOff256 {
-    unsigned kk[2];                  // K-contiguous: offset inside a 32-row band for k-half 0 / 1
-    unsigned ta[2][2], tb[4][2];     // k-major: [sub tile][read 0 / 1] for k-half 0
-};
-
-template <bool KMAJOR>
-__device__ inline ReadOff256 read_offsets256(int wave, int lane) {
-    ReadOff256 r;
-    if (!KMAJOR) {
-        const int lr = lane & 31, lh = lane >> 5, swz = (lr >> 2) & 3;
-        r.kk[0] = lr * 64 + ((lh ^ swz) << 4);
-        r.kk[1] = lr * 64 + (((2 + lh) ^ swz) << 4);
-    } else {
-        const int g16 = lane >> 4, blk = (g16 & 1) * 16, lh = g16 >> 1, q = (lane & 15) >> 2, pp = lane & 3;
-        const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 128;
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const int k = 8 * lh + 4 * rd + q;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ma = wm0 + i * 32 + blk + 4 * pp;
-                r.ta[i][rd] = k * (PBM * 2) + ((((ma >> 3) ^ (q << 2))) << 4) + ((ma & 7) << 1);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nb = wn0 + j * 32 + blk + 4 * pp;
-                r.tb[j][rd] = k * (PBM * 2) + ((((nb >> 3) ^ (q << 2))) << 4) + ((nb & 7) << 1);
-            }
-        }
-    }
-    return r;
-}
-
-template <bool KMAJOR>
-__device__ inline void read_frags256(const char* __restrict__ stage, const ReadOff256& ro, int kh, int wm0, int wn0, Frags256& f) {
-    const char* a_s = stage;
-    const char* b_s = stage + A_PLANE;
-    if (!KMAJOR) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(a_s + (wm0 + i * 32) * 64 + ro.kk[kh]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(b_s + (wn0 + j * 32) * 64 + ro.kk[kh]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) f.a[i] = tr_pair(a_s + kh * 16 * (PBM * 2) + ro.ta[i][0], a_s + kh * 16 * (PBM * 2) + ro.ta[i][1]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f.b[j] = tr_pair(b_s + kh * 16 * (PBM * 2) + ro.tb[j][0], b_s + kh * 16 * (PBM * 2) + ro.tb[j][1]);
-    }
-}
-
-__device__ inline void mfma256(const Frags256& f, f32x16 (&acc)[2][4]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
-}
-
-template <bool KMAJOR>
-__global__ __launch_bounds__(PNT, 2) void gemm_bf16_256_kernel(GemmParams p) {
-    constexpr int BN256 = 256;
-    extern __shared__ char smem[];
-    const grappa_gemm_desc& d = p.d;
-    const TileCoord tc = map_workgroup(p);
-    const int split = tc.split, tile_local = tc.tile_local, tile_n = tc.tile_n;
-    const int m0 = tc.tile_m * PBM, n0 = tile_n * BN256;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 128;
-    const int kbeg = split * p.k_per_split;
-    const int kend = min(d.K, kbeg + p.k_per_split);
-    const int nslab = (kend - kbeg + PSLAB - 1) / PSLAB;
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const bool do_cs = KMAJOR && d.a_colsum != nullptr && tile_n == 0 && (wave & 1) == 0;
-    float cs[2] = {0.f, 0.f};
-    if (nslab > 0) {
-        const size_t a_step = KMAJOR ? (size_t)PSLAB * d.lda * 2 : (size_t)PSLAB * 2;
-        const size_t b_step = KMAJOR ? (size_t)PSLAB * d.ldb * 2 : (size_t)PSLAB * 2;
-        const char* A = reinterpret_cast<const char*>(d.A) + (size_t)kbeg / PSLAB * a_step;
-        const char* B = reinterpret_cast<const char*>(d.B) + (size_t)kbeg / PSLAB * b_step;
-        const LaneSrc256 src = lane_sources256<KMAJOR>(d, m0, n0, wave, lane);
-        const ReadOff256 ro = read_offsets256<KMAJOR>(wave, lane);
-        const int krem_last = (kend - kbeg) - (nslab - 1) * PSLAB;
-#define G256_ISSUE(T_) issue_slab256<KMAJOR>(A + (size_t)(T_) * a_step, B + (size_t)(T_) * b_step, src, smem + ((T_) & 3) * W256_STAGE, wave, lane, \
-                                             (T_) == nslab - 1 ? krem_last : PSLAB)
-        // prologue: three slabs in flight
-        G256_ISSUE(0);
-        if (nslab > 1) G256_ISSUE(1);
-        if (nslab > 2) G256_ISSUE(2);
-        Frags256 f0, f1;
-        for (int t = 0; t < nslab; ++t) {
-            // slab t has landed for this wavefront when at most the younger slabs' pieces are outstanding (4 per slab)
-            if (t + 2 < nslab) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (t + 1 < nslab) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();               // ... for every wavefront; and everyone is done with slab t-1 (its stage is reused now)
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 3 < nslab) G256_ISSUE(t + 3);
-            const char* cur = smem + (t & 3) * W256_STAGE;
-            read_frags256<KMAJOR>(cur, ro, 0, wm0, wn0, f0);
-            read_frags256<KMAJOR>(cur, ro, 1, wm0, wn0, f1);
-            mfma256(f0, acc);
-            mfma256(f1, acc);
-            if (do_cs) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) cs[i] += frag_sum(f0.a[i]) + frag_sum(f1.a[i]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef G256_ISSUE
-    }
-
-    if (do_cs) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float sum = cs[i] + __shfl_xor(cs[i], 32, 64);
-            const int m = m0 + wm0 + i * 32 + (lane & 31);
-            if (lane < 32 && m < d.M) {
-                if (p.nsplit > 1) p.cs_slab[(size_t)split * d.M + m] = sum;
-                else d.a_colsum[m] += sum;
-            }
-        }
-    }
-    __syncthreads();
-    float* wave_buf = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
-    const bool vec_io = p.vec_io != 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int n = n0 + wn0 + 64 * h + ((lane & 15) << 2);
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.bias && p.nsplit == 1) {
-            b4.x = n < d.N ? d.bias[n] : 0.f;
-            b4.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
-            b4.z = n + 2 < d.N ? d.bias[n + 2] : 0.f;
-            b4.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const f32x16 band[2] = {acc[i][2 * h], acc[i][2 * h + 1]};
-            epilogue_band<PBM, BN256, 2>(p, band, wave_buf, m0, n0, m0 + wm0 + 32 * i, n, lane, b4, split, tile_local, vec_io);
-        }
-    }
-}
-
-template <bool KMAJOR>
-int launch_bf16_256(hipStream_t st, GemmParams& p) {
-    constexpr size_t stages = (size_t)W256_NSTAGE * W256_STAGE, staging = (PNT / 64) * (size_t)EPI_WAVE_BYTES;
-    constexpr size_t smem = stages > staging ? stages : staging;
-    auto kern = gemm_bf16_256_kernel<KMAJOR>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return GRAPPA_ERR_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles_launch * p.nsplit), dim3(PNT), smem, st, p);
-    return grappa_launch_status();
-}
-
 template <int MODE, bool KMAJOR>
 int launch_planes(hipStream_t st, GemmParams& p) {
     constexpr size_t stages = 2 * (size_t)PPieces<MODE>::NP * (A_PLANE + B_PLANE), staging = (PNT / 64) * (size_t)EPI_WAVE_BYTES;
@@ -885,10 +666,6 @@ int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision) {
             case GRAPPA_GEMM_BF16: return launch_wplanes<PX1>(st, p);
             default: return GRAPPA_ERR_ARG;
         }
-    }
-    if (p.bn == 256) {                                   // the planner chose the 256 x 256 tile: one-plane (bf16) operands only
-        if (precision != GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
-        return p.d.a_kcontig ? launch_bf16_256<false>(st, p) : launch_bf16_256<true>(st, p);
     }
     switch (precision) {
         case GRAPPA_GEMM_F32_BF16X9: return launch_planes_layout<PX9>(st, p);
