@@ -10,10 +10,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hip.so")   # override: kernel A/B builds (tools/)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
 GEMM_GROUP_MAX = 16
-GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4}
+GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4, "f32_f16x3": 5}
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -30,7 +30,8 @@ class GemmDesc(C.Structure):
                 ("Cp", C.c_void_p), ("ldcp", C.c_int), ("cp_plane_stride", C.c_size_t),
                 ("resp", C.c_void_p), ("ldresp", C.c_int), ("resp_plane_stride", C.c_size_t),
                 ("auxp", C.c_void_p), ("ldauxp", C.c_int), ("auxp_plane_stride", C.c_size_t),
-                ("cp_nplanes", C.c_int), ("resp_nplanes", C.c_int), ("auxp_nplanes", C.c_int), ("C1p", C.c_void_p), ("ldc1p", C.c_int)]
+                ("cp_nplanes", C.c_int), ("resp_nplanes", C.c_int), ("auxp_nplanes", C.c_int), ("C1p", C.c_void_p), ("ldc1p", C.c_int),
+                ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("amax_bcast", C.c_int), ("out_amax", C.c_void_p)]
 
 
 class MMDesc(C.Structure):
@@ -62,6 +63,9 @@ SIGNATURES = {
     "grappa_abi_version": (_i, []),
     "grappa_build_arch": (C.c_char_p, []),
     "grappa_split_planes_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _sz, _i]),
+    "grappa_amax_f32_workspace_bytes": (_sz, [_i, _i]),
+    "grappa_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz]),
+    "grappa_amax_reduce": (_i, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _vp]),
     "grappa_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
     "grappa_gemm_f32_plan": (_i, [_i, _i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "grappa_gemm_f32_set_plan_override": (None, [_i, _i, _i]),
@@ -71,10 +75,13 @@ SIGNATURES = {
     "grappa_colsum_workspace_bytes": (_sz, [_i, _i]),
     "grappa_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz]),
     "grappa_act_dropout_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i]),
+    "grappa_act_dropout_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp]),
     "grappa_add_f32": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "grappa_layernorm_fwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "grappa_layernorm_fwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "grappa_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "grappa_layernorm_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
+    "grappa_layernorm_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "grappa_gat_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "grappa_gat_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "grappa_neighbor_mean_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i]),
@@ -83,6 +90,8 @@ SIGNATURES = {
     "grappa_tuple_gather_bwd_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i]),
     "grappa_seqattn_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "grappa_seqattn_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "grappa_seqattn_fwd_amax_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "grappa_seqattn_bwd_amax_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "grappa_perm_concat_fwd_f32": (_i, [_vp, _i, _i, _i, _i, c_int_p, _vp, _vp]),
     "grappa_perm_concat_bwd_f32": (_i, [_vp, _i, _i, _i, _i, c_int_p, _vp, _vp]),
     "grappa_param_out_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),

@@ -84,6 +84,19 @@ def _flat(t: torch.Tensor, name: str, dev, dtype=torch.float32) -> None:
 DEFAULT_GEMM_PRECISION = "f32_bf16x6"
 
 
+_AMAX_LOG = None      # tools/amax_passes.py sets a list here
+
+
+class Amax:
+    """largest magnitudes of a 2-d fp32 tensor as int32 tensors of fp32 bit patterns: per row (activations: written by the kernel
+    that produced the tensor, or by one pass of grappa_amax_f32), per column (weights), and of the whole tensor (`tmax`, one value:
+    max over the rows, for the weight-gradient products whose reduction runs over the rows)"""
+    __slots__ = ("row", "col", "tmax")
+
+    def __init__(self, row=None, col=None, tmax=None):
+        self.row, self.col, self.tmax = row, col, tmax
+
+
 class HipBackend:
     name = "hip"
 
@@ -113,6 +126,14 @@ class HipBackend:
         self.weight_planes = os.environ.get("GRAPPA_WEIGHT_PLANES", "0") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
         self._wepoch = 0
+        # precision "f32_f16x3": largest |element| per row / column of every operand (grappa_amax_f32).  Weights: cached until the
+        # optimiser step; activations: an `Amax` record travels with the tensor through ops.py (gemm returns it, the backward
+        # products receive it), anything missing is computed by one pass over the tensor
+        self._wamax = {}       # (data_ptr, rows, cols) -> (version key, weight kept alive, Amax)
+        # weight-gradient products reduce over the tokens, so each operand gets ONE scale (its largest magnitude): columns more than
+        # 2^16 below it lose relative precision gradually.  GRAPPA_WGRAD_COLUMN_MAXIMA=1 gives every column its own scale instead,
+        # at the price of one extra pass over both operands of every weight-gradient product (rigorous, ~15 % slower steps)
+        self.wgrad_column_maxima = os.environ.get("GRAPPA_WGRAD_COLUMN_MAXIMA", "0") not in ("0", "")
 
     def set_gemm_precision(self, name: str) -> None:
         if name not in _lib.GEMM_PRECISIONS:
@@ -149,6 +170,82 @@ class HipBackend:
                                               planes.stride(0), int(transposed)), "grappa_split_planes_f32")
         self._wplanes[key] = (ver, planes)
         return planes
+
+    # ------------------------------------------------------------------ row / column maxima (scales of the fp16-split products)
+    def _amax_launch(self, t: torch.Tensor, rows: bool, cols: bool):
+        R, Cc = t.shape
+        if _AMAX_LOG is not None:                  # tools: which tensors still need a pass of their own
+            import traceback
+            fr = [f for f in traceback.extract_stack(limit=8) if f.filename.endswith("ops.py")]
+            _AMAX_LOG.append((R, Cc, rows, cols, fr[-1].lineno if fr else 0))
+        dev = t.device
+        ld = _f32_2d(t, "amax operand", dev)
+        row = torch.empty(R, dtype=torch.int32, device=dev) if rows else None
+        col = torch.empty(Cc, dtype=torch.int32, device=dev) if cols else None
+        need = self.lib.grappa_amax_f32_workspace_bytes(R, Cc) if cols else 0
+        ws = self._workspace_amax(need, dev) if need else None
+        self._timed("amax", 0.0, 4.0 * R * Cc,
+                    lambda: _chk(self.lib.grappa_amax_f32(self._stream(), R, Cc, t.data_ptr(), ld, _ptr(row), _ptr(col), _ptr(ws),
+                                                          ws.numel() if ws is not None else 0), "grappa_amax_f32"))
+        return row, col
+
+    def _workspace_amax(self, nbytes: int, dev) -> torch.Tensor:
+        key = (dev, torch.cuda.current_stream().cuda_stream, "amax")      # not the products' workspace: a queued group may hold that
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    def amax(self, t: torch.Tensor, have: "Optional[Amax]" = None, rows: bool = False, cols: bool = False, tmax: bool = False) -> "Amax":
+        """`have` completed by the maxima asked for (one pass over t for missing row / column maxima; the whole-tensor maximum is
+        a reduction of the row maxima)"""
+        am = have if have is not None else Amax()
+        need_r, need_c = (rows or tmax) and am.row is None, cols and am.col is None
+        if need_r or need_c:
+            r, c = self._amax_launch(t, need_r, need_c)
+            am.row = r if need_r else am.row
+            am.col = c if need_c else am.col
+        if tmax and am.tmax is None:
+            self._tmax_of([am], t.device)
+        return am
+
+    def _tmax_of(self, records, dev) -> None:
+        """whole-tensor maxima of the records that lack one, from their row maxima: one launch per 32 records"""
+        todo = [r for r in records if r.tmax is None]
+        if not todo:
+            return
+        n = len(todo)
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        ptrs = (C.c_void_p * n)(*[r.row.data_ptr() for r in todo])
+        lens = (C.c_int * n)(*[r.row.numel() for r in todo])
+        self._timed("amax", 0.0, 4.0 * sum(r.row.numel() for r in todo),
+                    lambda: _chk(self.lib.grappa_amax_reduce(self._stream(), n, ptrs, lens, out.data_ptr()), "grappa_amax_reduce"))
+        for i, r in enumerate(todo):
+            r.tmax = out[i:i + 1]
+
+    def wants_amax(self, backward: bool = False) -> bool:
+        """do the dense products of this pass run on fp16 pieces, i.e. should producers write the row maxima of their outputs"""
+        prec = self.gemm_precision_bwd if (backward and self.gemm_precision_bwd is not None) else self.gemm_precision
+        return prec == _lib.GEMM_PRECISIONS["f32_f16x3"]
+
+    def _new_row_amax(self, t: torch.Tensor, backward: bool, want) -> "Optional[torch.Tensor]":
+        if want is False or t.dtype != torch.float32 or t.shape[0] == 0 or (want is None and not self.wants_amax(backward)):
+            return None
+        return torch.empty(t.shape[0], dtype=torch.int32, device=t.device)
+
+    def _amax_of_weight(self, w: torch.Tensor) -> "Amax":
+        """row and column maxima of a weight matrix, refreshed when the weight changed (as _planes_of_weight); the entry keeps the
+        weight alive, so its address cannot be handed to another tensor while the entry exists"""
+        R, Cc = w.shape
+        key = (w.data_ptr(), R, Cc, w.stride(0))
+        ver = (w._version, self._wepoch)
+        hit = self._wamax.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[2]
+        am = self.amax(w, None, rows=True, cols=True)
+        self._wamax[key] = (ver, w, am)
+        return am
 
     # ------------------------------------------------------------------ in-process kernel timing (bench.py roofline)
     def start_profile(self) -> None:
@@ -213,11 +310,14 @@ class HipBackend:
         return t.data_ptr() % 16 == 0 and ld % 8 == 0
 
     def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
-             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None) -> None:
+             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None, a_scales=None, b_scales=None, out_amax=False):
         """C = epilogue(A B^T) (include/grappa_hip.h).  Operands and epilogue tensors may be float32 or -- the bf16 storage
         configuration -- bfloat16: a bf16 A (and, for the wgrad layout, B) is read by the LDS-DMA plane kernels as a one-plane
         operand when the shape allows it, otherwise converted to fp32 first; out / out2 / res / aux are written / read in their own
-        element type by the shared epilogue."""
+        element type by the shared epilogue.
+        Precision "f32_f16x3": returns the `Amax` record of A (given as a_scales, completed as needed; in the forward layout with a
+        completed as needed); otherwise None.  out_amax=True: the kernel also writes the row maxima of the final output and the
+        return value becomes (record of A, record of the output) -- for an output that is the A operand of the next product."""
         dev = out.device
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
@@ -287,7 +387,7 @@ class HipBackend:
                 if dst is not None and dst is not src:
                     _chk(self.lib.grappa_convert_f32_to_bf16(self._stream(), M, N, src.data_ptr(), N, dst.data_ptr(), _f32_2d(dst, "out", dev, bf16)),
                          "grappa_convert_f32_to_bf16")
-            return
+            return (None, None) if out_amax else None
         # ---- outputs and epilogue tensors, each in its own element type
         def plane_ok(t, name):
             ld = _f32_2d(t, name, dev, bf16)
@@ -340,6 +440,27 @@ class HipBackend:
                 raise ValueError("gemm: a_colsum needs the row-contiguous A layout and length M")
             d.a_colsum = a_colsum.data_ptr()
         d.act, d.drop_p, d.drop_seed, d.accumulate = int(act), float(drop_p), int(drop_seed) & (2 ** 64 - 1), int(accumulate)
+        sa = so = None
+        if d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] and big and planes_a is None and planes_b is None:
+            # power-of-two scales of both operands from their largest magnitudes along the reduced dimension
+            if a_kcontig:
+                sa = self.amax(a, a_scales, rows=True)
+                wm = self._amax_of_weight(b)
+                am, bm = sa.row, (wm.row if b_kcontig else wm.col)
+                if am.numel() != M or bm.numel() != N:
+                    raise ValueError("gemm: operand maxima do not match the operands")
+            elif self.wgrad_column_maxima:
+                sa = self.amax(a, a_scales, cols=True)
+                am, bm = sa.col, self.amax(b, b_scales, cols=True).col
+            else:
+                # weight gradient: the reduction runs over the rows (tokens) of both operands -> one scale per operand
+                sa = self.amax(a, a_scales, tmax=True)
+                am, bm = sa.tmax, self.amax(b, b_scales, tmax=True).tmax
+                d.amax_bcast = 3
+            d.a_amax, d.b_amax = am.data_ptr(), bm.data_ptr()
+        if out_amax and final.dtype == torch.float32:
+            so = Amax(row=torch.empty(M, dtype=torch.int32, device=dev))
+            d.out_amax = so.row.data_ptr()
         need = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
         ws = self._workspace(need, dev) if need else None
         el = lambda t: 0 if t is None else t.element_size()      # noqa: E731
@@ -347,36 +468,47 @@ class HipBackend:
                                                          + M * N * el(final)),
                     lambda: _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0),
                                  "grappa_gemm_f32"))
+        return (sa, so) if out_amax else sa
 
     # ------------------------------------------------------------------ weight gradients, grouped
-    def gemm_wgrad(self, dz, x, dw, db=None) -> None:
+    def gemm_wgrad(self, dz, x, dw, db=None, dz_scales=None, x_scales=None):
         """dW += dz^T x (dz (tokens, N'), x (tokens, K'), dW (N', K')), db += column sums of dz.  fp32 products with enough rows and
         columns are queued and launched as ONE grouped grid when 16 are waiting or the backward pass ends (autograd's end-of-pass
         callback; `flush_wgrads()` is also called by the gradient reducer and the optimiser): results are those of `gemm` up to the
-        summation order of the K chunks."""
+        summation order of the K chunks.  Returns the `Amax` record of dz (precision "f32_f16x3") for the input-gradient product."""
         Np, Kp, T = dz.shape[1], x.shape[1], dz.shape[0]
         prec = self.gemm_precision if self.gemm_precision_bwd is None else self.gemm_precision_bwd
         ok = (self.defer_wgrads and dz.dtype == torch.float32 and x.dtype == torch.float32 and Np > 32 and Kp > 32 and T > 0
               and prec != _lib.GEMM_PRECISIONS["f32"] and torch.cuda.current_stream() == torch.cuda.default_stream())
         if not ok:
-            self.gemm(dz, x, dw, M=Np, N=Kp, K=T, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=db)
-            return
+            return self.gemm(dz, x, dw, M=Np, N=Kp, K=T, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=db,
+                             a_scales=dz_scales, b_scales=x_scales)
         dev = dw.device
         if tuple(dw.shape) != (Np, Kp) or x.shape[0] != T or (db is not None and db.numel() != Np):
             raise ValueError("gemm_wgrad: shapes")
         _f32_2d(dz, "dz", dev), _f32_2d(x, "x", dev), _f32_2d(dw, "dW", dev)
         if db is not None:
             _flat(db, "db", dev)
-        self._wq.append((dz, x, dw, db))
+        sdz = am = None
+        if prec == _lib.GEMM_PRECISIONS["f32_f16x3"]:
+            # row maxima now (they also serve the input-gradient product of dz); the whole-tensor maxima of the group in one launch at the flush
+            if self.wgrad_column_maxima:
+                sdz = self.amax(dz, dz_scales, rows=True, cols=True)
+                am = (sdz, self.amax(x, x_scales, cols=True))
+            else:
+                sdz = self.amax(dz, dz_scales, rows=True)
+                am = (sdz, self.amax(x, x_scales, rows=True))
+        self._wq.append((dz, x, dw, db, am))
         if not self._wq_callback:
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(self.flush_wgrads)      # runs when this backward pass ends
                 self._wq_callback = True
             except RuntimeError:                  # not inside a backward pass: nothing will call back
                 self.flush_wgrads()
-                return
+                return sdz
         if len(self._wq) >= _lib.GEMM_GROUP_MAX:
             self._launch_wgrad_group()
+        return sdz
 
     def flush_wgrads(self) -> None:
         self._wq_callback = False
@@ -390,7 +522,9 @@ class HipBackend:
         prec = self.gemm_precision if self.gemm_precision_bwd is None else self.gemm_precision_bwd
         arr = (_lib.GemmDesc * n)()
         flops = nbytes = 0.0
-        for d, (dz, x, dw, db) in zip(arr, items):
+        if not self.wgrad_column_maxima:
+            self._tmax_of([r for it in items if it[4] is not None for r in it[4]], dev)
+        for d, (dz, x, dw, db, am) in zip(arr, items):
             d.M, d.N, d.K = dz.shape[1], x.shape[1], dz.shape[0]
             d.a_kcontig, d.b_kcontig = 0, 0
             d.A, d.lda = dz.data_ptr(), dz.stride(0)
@@ -398,6 +532,11 @@ class HipBackend:
             d.C, d.ldc = dw.data_ptr(), dw.stride(0)
             d.a_colsum = None if db is None else db.data_ptr()
             d.accumulate, d.precision = 1, prec
+            if am is not None:
+                if self.wgrad_column_maxima:
+                    d.a_amax, d.b_amax = am[0].col.data_ptr(), am[1].col.data_ptr()
+                else:
+                    d.a_amax, d.b_amax, d.amax_bcast = am[0].tmax.data_ptr(), am[1].tmax.data_ptr(), 3
             flops += 2.0 * d.M * d.N * d.K
             nbytes += 4.0 * (d.M * d.K + d.N * d.K + d.M * d.N)
         need = self.lib.grappa_gemm_f32_grouped_workspace_bytes(arr, n)
@@ -417,15 +556,21 @@ class HipBackend:
         _chk(self.lib.grappa_colsum_f32(self._stream(), M, N, x.data_ptr(), ldx, out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()),
              "grappa_colsum_f32")
 
-    def act_dropout_bwd(self, dy, y, drop_p, drop_seed, dz) -> None:
+    def act_dropout_bwd(self, dy, y, drop_p, drop_seed, dz, amax=None):
+        """-> the `Amax` record (row maxima) of dz when the backward products run on fp16 pieces (amax=False: never), else None"""
         dev = dz.device
         M, N = dy.shape
         if tuple(dz.shape) != (M, N) or (y is not None and tuple(y.shape) != (M, N)):
             raise ValueError("act_dropout_bwd: shapes")
         dt = _same_dtype(dy, y, dz)
-        fn = getattr(self.lib, f"grappa_act_dropout_bwd_{_sfx(dz)}")
-        _chk(fn(self._stream(), M, N, dy.data_ptr(), _f32_2d(dy, "dy", dev, dt), _ptr(y), _f32_2d(y, "y", dev, dt) if y is not None else 0,
-                float(drop_p), int(drop_seed) & (2 ** 64 - 1), dz.data_ptr(), _f32_2d(dz, "dz", dev, dt)), "grappa_act_dropout_bwd")
+        row = self._new_row_amax(dz, True, amax)
+        args = (self._stream(), M, N, dy.data_ptr(), _f32_2d(dy, "dy", dev, dt), _ptr(y), _f32_2d(y, "y", dev, dt) if y is not None else 0,
+                float(drop_p), int(drop_seed) & (2 ** 64 - 1), dz.data_ptr(), _f32_2d(dz, "dz", dev, dt))
+        if row is not None:
+            _chk(self.lib.grappa_act_dropout_bwd_amax_f32(*args, row.data_ptr()), "grappa_act_dropout_bwd_amax_f32")
+            return Amax(row=row)
+        _chk(getattr(self.lib, f"grappa_act_dropout_bwd_{_sfx(dz)}")(*args), "grappa_act_dropout_bwd")
+        return None
 
     def add(self, x, z, y) -> None:
         dev = y.device
@@ -436,7 +581,7 @@ class HipBackend:
         _chk(self.lib.grappa_add_f32(self._stream(), x.numel(), x.data_ptr(), z.data_ptr(), y.data_ptr()), "grappa_add_f32")
 
     # ------------------------------------------------------------------ layer norm
-    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd) -> None:
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, amax=None):
         dev = y.device
         M, W = x.shape
         _flat(gamma, "gamma", dev), _flat(beta, "beta", dev)
@@ -447,11 +592,16 @@ class HipBackend:
             if mean.numel() != M or rstd.numel() != M:
                 raise ValueError("layernorm: stats length")
         dt = _same_dtype(x, y)
-        fn = getattr(self.lib, f"grappa_layernorm_fwd_{_sfx(x)}")
-        _chk(fn(self._stream(), M, W, x.data_ptr(), _f32_2d(x, "x", dev, dt), gamma.data_ptr(), beta.data_ptr(),
-                y.data_ptr(), _f32_2d(y, "y", dev, dt), _ptr(mean), _ptr(rstd)), "grappa_layernorm_fwd")
+        row = self._new_row_amax(y, False, amax)
+        args = (self._stream(), M, W, x.data_ptr(), _f32_2d(x, "x", dev, dt), gamma.data_ptr(), beta.data_ptr(),
+                y.data_ptr(), _f32_2d(y, "y", dev, dt), _ptr(mean), _ptr(rstd))
+        if row is not None:
+            _chk(self.lib.grappa_layernorm_fwd_amax_f32(*args, row.data_ptr()), "grappa_layernorm_fwd_amax_f32")
+            return Amax(row=row)
+        _chk(getattr(self.lib, f"grappa_layernorm_fwd_{_sfx(x)}")(*args), "grappa_layernorm_fwd")
+        return None
 
-    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True) -> None:
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True, amax=None):
         dev = dx.device
         M, W = x.shape
         for t, n, k in ((mean, "mean", M), (rstd, "rstd", M), (gamma, "gamma", W), (dgamma, "dgamma", W), (dbeta, "dbeta", W)):
@@ -462,10 +612,15 @@ class HipBackend:
             raise ValueError("layernorm_bwd: shapes")
         dt = _same_dtype(dy, x, dx)
         ws = self._workspace(self.lib.grappa_layernorm_bwd_workspace_bytes(M, W), dev)
-        fn = getattr(self.lib, f"grappa_layernorm_bwd_{_sfx(x)}")
-        _chk(fn(self._stream(), M, W, dy.data_ptr(), _f32_2d(dy, "dy", dev, dt), x.data_ptr(), _f32_2d(x, "x", dev, dt),
+        row = self._new_row_amax(dx, True, amax)
+        args = (self._stream(), M, W, dy.data_ptr(), _f32_2d(dy, "dy", dev, dt), x.data_ptr(), _f32_2d(x, "x", dev, dt),
                 mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _f32_2d(dx, "dx", dev, dt),
-                dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()), "grappa_layernorm_bwd")
+                dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel())
+        if row is not None:
+            _chk(self.lib.grappa_layernorm_bwd_amax_f32(*args, row.data_ptr()), "grappa_layernorm_bwd_amax_f32")
+            return Amax(row=row)
+        _chk(getattr(self.lib, f"grappa_layernorm_bwd_{_sfx(x)}")(*args), "grappa_layernorm_bwd")
+        return None
 
     # ------------------------------------------------------------------ graph
     def _csr_check(self, plan, N, dev):
@@ -559,25 +714,35 @@ class HipBackend:
                 _f32_2d(dx, "dx", dev, dt), da.data_ptr(), _f32_2d(da, "da", dev, dt), int(has_pe), int(accumulate)),
              "grappa_tuple_gather_bwd")
 
-    def seqattn_fwd(self, qkv, s, T, nheads, out) -> None:
+    def seqattn_fwd(self, qkv, s, T, nheads, out, amax=None):
         dev = out.device
         dt = _same_dtype(qkv, out)
         _flat(qkv, "qkv", dev, dt), _flat(out, "out", dev, dt)
         F = out.shape[1]
         if qkv.shape != (s * T, 3 * F) or out.shape[0] != s * T or F % nheads:
             raise ValueError("seqattn_fwd: shapes")
-        fn = getattr(self.lib, f"grappa_seqattn_fwd_{_sfx(out)}")
-        _chk(fn(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), out.data_ptr()), "grappa_seqattn_fwd")
+        row = self._new_row_amax(out, False, amax)
+        args = (self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), out.data_ptr())
+        if row is not None:
+            _chk(self.lib.grappa_seqattn_fwd_amax_f32(*args, row.data_ptr()), "grappa_seqattn_fwd_amax_f32")
+            return Amax(row=row)
+        _chk(getattr(self.lib, f"grappa_seqattn_fwd_{_sfx(out)}")(*args), "grappa_seqattn_fwd")
+        return None
 
-    def seqattn_bwd(self, qkv, dout, s, T, nheads, dqkv) -> None:
+    def seqattn_bwd(self, qkv, dout, s, T, nheads, dqkv, amax=None):
         dev = dqkv.device
         dt = _same_dtype(qkv, dout, dqkv)
         _flat(qkv, "qkv", dev, dt), _flat(dout, "dout", dev, dt), _flat(dqkv, "dqkv", dev, dt)
         F = dout.shape[1]
         if qkv.shape != (s * T, 3 * F) or dqkv.shape != qkv.shape or dout.shape[0] != s * T:
             raise ValueError("seqattn_bwd: shapes")
-        fn = getattr(self.lib, f"grappa_seqattn_bwd_{_sfx(dqkv)}")
-        _chk(fn(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr()), "grappa_seqattn_bwd")
+        row = self._new_row_amax(dqkv, True, amax)
+        args = (self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr())
+        if row is not None:
+            _chk(self.lib.grappa_seqattn_bwd_amax_f32(*args, row.data_ptr()), "grappa_seqattn_bwd_amax_f32")
+            return Amax(row=row)
+        _chk(getattr(self.lib, f"grappa_seqattn_bwd_{_sfx(dqkv)}")(*args), "grappa_seqattn_bwd")
+        return None
 
     def perm_concat_fwd(self, x, s, T, perms: Sequence[Sequence[int]], z) -> None:
         dev = z.device

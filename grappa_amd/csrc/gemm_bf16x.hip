@@ -5,6 +5,11 @@
 //   X9 : all 9 a_p*b_q -- every partial product is exact in fp32, so only the accumulation order differs from an fp32 FMA chain
 //   X6 : drops a1*b2, a2*b1, a2*b2 (each <= 2^-24 |a||b|): ~2 ulp of fp32 per product
 //   X3 : two pieces, a0*b0 + a0*b1 + a1*b0 (~2^-16 relative);  X1: plain bf16 operands (bf16 compute configs)
+//   H3 : TWO fp16 pieces (11 + 11 bits and a sign carry 24), hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16: fp32-grade at half
+//        the matrix instructions of X6.  fp16 has 5 exponent bits, so every row of A and of B is scaled by a power of two that
+//        puts its largest magnitude (a_amax / b_amax, one pass over the operand ahead of the product) into [2^14, 2^15); the
+//        accumulators are scaled back (v_ldexp_f32, exact) before the epilogue.  Small elements of a row become fp16 denormals
+//        (kept by the gfx950 matrix cores): absolute error <= 2^-39 of the row's maximum.
 //
 // What bounds this kernel is the LDS, not the matrix pipe: three pieces triple every fragment read and every store, so the
 // tile is shaped to minimise LDS bytes per MFMA.  256x128 macro tile, 8 wavefronts as 4 x 2, each a 64x64 block of four 32x32
@@ -22,6 +27,8 @@ using namespace grappa_gemm;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -29,11 +36,16 @@ constexpr int SK = 16;                  // k-slab per pipeline step (one 32x32x1
 constexpr int ROWB = 48;                // LDS row: 16 bf16 (32 B) + 16 B pad -> conflict-free ds_read_b128 per 16-lane group
 constexpr int AHEAD = 4;                // register sets: slab s+4 is loaded while slab s is multiplied
 
-enum Mode { X1 = 1, X3 = 3, X6 = 6, X9 = 9 };
+enum Mode { X1 = 1, X3 = 3, X6 = 6, X9 = 9, H3 = 103 };
 template <int MODE> struct Pieces {
-    static constexpr int NP = MODE == X1 ? 1 : (MODE == X3 ? 2 : 3);
-    static constexpr int NPROD = MODE;
+    static constexpr bool HALF = MODE == H3;
+    static constexpr int NP = MODE == X1 ? 1 : (MODE == X3 || MODE == H3 ? 2 : 3);
+    static constexpr int NPROD = MODE == H3 ? 3 : MODE;
 };
+
+// power of two that moves a row's largest magnitude (fp32 bit pattern) into [2^14, 2^15): exponent field E -> 2^(141 - E)
+// (zero / denormal rows: 2^141, still finite after scaling; Inf / NaN rows stay Inf / NaN)
+__device__ inline int amax_shift(unsigned bits) { return 141 - (int)((bits >> 23) & 0xffu); }
 
 struct Quad { float x[4]; };
 
@@ -79,8 +91,9 @@ __device__ inline float u2f(unsigned x) { return __uint_as_float(x); }
 // split 4 consecutive-k fp32 values into NP bf16 pieces (round to nearest even; the residual r - float(piece) is exact in
 // fp32) and store each piece's 4 values as one 8-byte LDS write.  krem = valid k of this slab counted from its first column
 // (MASK: a slab at the end of a K range, whose tail is zero-filled here).
-template <int NT, int NP, int ROWS, bool KCONT, bool MASK>
-__device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[ROWS * 4 / NT], int krem) {
+// HALF: the row's power-of-two scale first (shift[j], exact), then fp16 pieces hi = f16(r), lo = f16(r - hi).
+template <int NT, int NP, int ROWS, bool KCONT, bool MASK, bool HALF>
+__device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[ROWS * 4 / NT], int krem, const int (&shift)[ROWS * 4 / NT]) {
 #pragma unroll
     for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
@@ -91,6 +104,24 @@ __device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[RO
             for (int e = 0; e < 4; ++e) r[e] = kq + e < krem ? r[e] : 0.f;
         }
         char* dst = opbase + row * ROWB + kq * 2;
+        if (HALF) {
+            // (packed multiplies and v_fma_mix_f32 residuals -- 40 instead of 67 vector instructions per slab -- measured no faster:
+            // the vector unit is not what this kernel waits for; the plain form keeps the exact v_ldexp_f32 for any shift)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = __builtin_ldexpf(r[e], shift[j]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                f16x2 h01, h23;
+                h01[0] = (_Float16)r[0]; h01[1] = (_Float16)r[1];        // round to nearest even; |r| < 2^15 never overflows
+                h23[0] = (_Float16)r[2]; h23[1] = (_Float16)r[3];
+                *reinterpret_cast<uint2*>(dst + p * (ROWS * ROWB)) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                if (p + 1 < NP) {
+                    r[0] -= (float)h01[0]; r[1] -= (float)h01[1];
+                    r[2] -= (float)h23[0]; r[3] -= (float)h23[1];
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             bf16x2 h01, h23;
@@ -156,13 +187,19 @@ __device__ inline void mfma_range(const Frags<Pieces<MODE>::NP, TM, TN>& f, f32x
             const int pb = s - pa;
             if (pb < 0 || pb >= NP) continue;
             if (MODE == X6 && s > 2) continue;                  // X6 keeps pa + pb <= 2
-            if (MODE == X3 && s > 1) continue;                  // X3 keeps pa + pb <= 1
+            if ((MODE == X3 || MODE == H3) && s > 1) continue;  // X3 / H3 keep pa + pb <= 1
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     // B fragment first: the accumulator holds the transposed tile (4 consecutive n per lane, tile_epilogue_rows)
-                    if (idx >= LO && idx < HI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j][pb], f.a[i][pa], acc[i][j], 0, 0, 0);
+                    if (idx >= LO && idx < HI) {
+                        if (MODE == H3)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b[j][pb]), __builtin_bit_cast(f16x8, f.a[i][pa]),
+                                                                               acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j][pb], f.a[i][pa], acc[i][j], 0, 0, 0);
+                    }
                     ++idx;
                 }
         }
@@ -215,7 +252,7 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
                                      const KRange& kr, int s, int wm0, int wn0, int lr, int lh, Quad (&la)[BM * 4 / NT], Quad (&lb)[BN * 4 / NT],
                                      const Quad (&sa)[BM * 4 / NT], const Quad (&sb)[BN * 4 / NT],
                                      const Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fc, Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fn,
-                                     float& cs, bool do_cs) {
+                                     float& cs, bool do_cs, const int (&sha)[BM * 4 / NT], const int (&shb)[BN * 4 / NT]) {
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
     constexpr int STAGE = NP * (BM + BN) * ROWB;
     constexpr int NM = Pieces<MODE>::NPROD * TM * TN;
@@ -233,15 +270,15 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     mfma_range<MODE, TM, TN, 0, NFIRST>(fc, acc);
     if (do_store) {
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
-        store_quads<NT, NP, BM, AK, TAIL>(nxt, sa, krem);
-        store_quads<NT, NP, BN, BKC, TAIL>(nxt + NP * BM * ROWB, sb, krem);
+        store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF>(nxt, sa, krem, sha);
+        store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF>(nxt + NP * BM * ROWB, sb, krem, shb);
         if (!AK && do_cs) cs += TAIL ? quad_sum_masked<NT, BM, AK>(sa, krem) : quad_sum(sa);
     }
     if (!TAIL) {
         // issue order of this phase: one MFMA, then a slice of the split arithmetic and of the LDS stores, so that the matrix
         // pipe runs under the vector work instead of before it (left alone the compiler bunches all MFMAs after the barrier)
         constexpr int NQ = (BM + BN) * 4 / NT;
-        PhaseOrder<0, NFIRST, NQ * NP, NQ * (NP == 3 ? 26 : NP == 2 ? 16 : 6)>::emit();      // vector ops per quad as counted in the ISA (an over-estimate leaves the last MFMAs bare)
+        PhaseOrder<0, NFIRST, NQ * NP, NQ * (NP == 3 ? 26 : NP == 2 ? (Pieces<MODE>::HALF ? 20 : 16) : 6)>::emit();      // vector ops per quad as counted in the ISA (an over-estimate leaves the last MFMAs bare)
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
@@ -286,6 +323,19 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    int sha[NQA], shb[NQB];            // H3: power-of-two scale of the row each staged quad belongs to
+#pragma unroll
+    for (int j = 0; j < NQA; ++j) {
+        int row, kq;
+        quad_coords<NT, BM, AK>(j, row, kq);
+        sha[j] = Pieces<MODE>::HALF ? amax_shift(d.a_amax[(d.amax_bcast & 1) ? 0 : min(m0 + row, d.M - 1)]) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NQB; ++j) {
+        int row, kq;
+        quad_coords<NT, BN, BKC>(j, row, kq);
+        shb[j] = Pieces<MODE>::HALF ? amax_shift(d.b_amax[(d.amax_bcast & 2) ? 0 : min(n0 + row, d.N - 1)]) : 0;
+    }
     const bool do_cs = !AK && d.a_colsum != nullptr && tile_n == 0;
     float cs = 0.f;                    // sum over k of A(row, k) for the row this thread stages (the same row for all its quads)
     if (nsteps > 0) {
@@ -299,15 +349,15 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
         GRAPPA_LOAD(2, a2, b2);
         GRAPPA_LOAD(3, a3, b3);
 #undef GRAPPA_LOAD
-        store_quads<NT, NP, BM, AK, true>(smem, a0, kr.kend - kr.kbeg);
-        store_quads<NT, NP, BN, BKC, true>(smem + NP * BM * ROWB, b0, kr.kend - kr.kbeg);
+        store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF>(smem, a0, kr.kend - kr.kbeg, sha);
+        store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF>(smem + NP * BM * ROWB, b0, kr.kend - kr.kbeg, shb);
         if (!AK && do_cs) cs += quad_sum_masked<NT, BM, AK>(a0, kr.kend - kr.kbeg);
         __syncthreads();
         read_frags<NP, BM, BN, TM, TN>(smem, wm0, wn0, lr, lh, fe);
         int s = 0;
         // step s stores slab s+1 (register set (s+1) % 4) and loads slab s+4 into the set slab s occupied
 #define GRAPPA_STEP(TAIL, LA, LB, SA, SB, FC, FN) \
-    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, TAIL>(d, smem, acc, m0, n0, kr, s, wm0, wn0, lr, lh, LA, LB, SA, SB, FC, FN, cs, do_cs)
+    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, TAIL>(d, smem, acc, m0, n0, kr, s, wm0, wn0, lr, lh, LA, LB, SA, SB, FC, FN, cs, do_cs, sha, shb)
         // main loop: four steps per trip (the register sets rotate); never stores the last slab of the range and every load
         // it issues is for an existing slab
         for (; s + 7 < nsteps; s += 4) {
@@ -356,6 +406,21 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
                 else d.a_colsum[m] += sum;
             }
         }
+    }
+    if (Pieces<MODE>::HALF) {
+        // undo the row scales: accumulator element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, wn0 + 32 j + 8 (e / 4) + 4 lh + e % 4)
+        int ea[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ea[i] = amax_shift(d.a_amax[(d.amax_bcast & 1) ? 0 : min(m0 + wm0 + i * 32 + lr, d.M - 1)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn0 + j * 32 + (e >> 2) * 8 + lh * 4 + (e & 3);
+                const int eb = amax_shift(d.b_amax[(d.amax_bcast & 2) ? 0 : min(n, d.N - 1)]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j][e] = __builtin_ldexpf(acc[i][j][e], -(ea[i] + eb));
+            }
     }
     __syncthreads();                                         // the stages (and the column-sum scratch) are dead: reuse as staging
     tile_epilogue_rows<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES), m0, n0, wm0, wn0, lane, split, tile_local,
@@ -434,6 +499,7 @@ int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, con
         case GRAPPA_GEMM_F32_BF16X6: return launch_grouped_wgrad<X6>(st, d_ps, d_wg_begin, nprob, total_wgs);
         case GRAPPA_GEMM_BF16X3: return launch_grouped_wgrad<X3>(st, d_ps, d_wg_begin, nprob, total_wgs);
         case GRAPPA_GEMM_BF16: return launch_grouped_wgrad<X1>(st, d_ps, d_wg_begin, nprob, total_wgs);
+        case GRAPPA_GEMM_F32_F16X3: return launch_grouped_wgrad<H3>(st, d_ps, d_wg_begin, nprob, total_wgs);
         default: return GRAPPA_ERR_ARG;
     }
 }
@@ -445,6 +511,7 @@ int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool 
         case GRAPPA_GEMM_F32_BF16X6: return launch_tile<X6>(st, p, vec_kcontig);
         case GRAPPA_GEMM_BF16X3: return launch_tile<X3>(st, p, vec_kcontig);
         case GRAPPA_GEMM_BF16: return launch_tile<X1>(st, p, vec_kcontig);
+        case GRAPPA_GEMM_F32_F16X3: return launch_tile<H3>(st, p, vec_kcontig);
         default: return GRAPPA_ERR_ARG;
     }
 }

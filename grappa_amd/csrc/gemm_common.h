@@ -21,6 +21,11 @@ struct GemmParams {
     int ntiles_launch;
     int bm, bn;            // tile shape (for the reduce kernel)
     int vec_io;            // every epilogue tensor is 16-byte aligned with a leading dimension % 4 == 0 (float4 epilogue)
+    // d.out_amax: row maxima of OUT are first written per column segment (amax_seg columns wide: one wavefront's share of a tile
+    // row), amax_part[seg * M + m] -- plain stores, no atomics (device-scope atomics cost more than the whole pass they replace) --
+    // and combined by amax_combine_kernel after the product's launches
+    unsigned* amax_part;
+    int amax_seg;
 };
 
 // ---- plane format (include/grappa_hip.h): X = P0 + P1 + P2, three bf16 planes
@@ -71,7 +76,8 @@ __device__ inline void planes_store1(uint16_t* __restrict__ p, size_t stride, si
     }
 }
 
-__device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v) {
+// returns the value OUT(m, n) received
+__device__ inline float epilogue_store(const GemmParams& p, int m, int n, float v) {
     const grappa_gemm_desc& d = p.d;
     if (d.pre) v += d.pre[(size_t)m * d.ldpre + n];
     if (d.bias) v += d.bias[n];
@@ -95,7 +101,9 @@ __device__ inline void epilogue_store(const GemmParams& p, int m, int n, float v
         *o = v;
     }
     if (d.Cp) planes_store1(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v, d.cp_nplanes ? d.cp_nplanes : 3);
+    return v;
 }
+__device__ inline unsigned mag_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 
 
 // XCD-aware bijective remap of the linear workgroup id (blocks b and b+8 share an XCD): consecutive LOGICAL ids run on one XCD.
@@ -200,66 +208,75 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
         const int row = it * ROWS_PER_IT + rrow;
         const float4 v4 = *reinterpret_cast<const float4*>(wave_buf + row * EPI_LD + rc4);
         const int m = mband + row;
-        if (m >= d.M || n >= d.N) continue;
-        if (p.nsplit > 1) {                                  // raw partial sums, tile-local [BM][BN] slab (always aligned)
-            float* srow = p.slab + ((size_t)split * p.ntiles_launch + tile_local) * (BM * BN) + (size_t)(m - m0) * BN + (n - n0);
-            *reinterpret_cast<float4*>(srow) = v4;
-            continue;
-        }
-        if (!vec_io || n + 3 >= d.N) {
-            const float ve[4] = {v4.x, v4.y, v4.z, v4.w};
+        unsigned am = 0u;                                    // largest |OUT(m, n .. n+3)| of this lane (d.out_amax)
+        if (m < d.M && n < d.N) {
+            if (p.nsplit > 1) {                              // raw partial sums, tile-local [BM][BN] slab (always aligned)
+                float* srow = p.slab + ((size_t)split * p.ntiles_launch + tile_local) * (BM * BN) + (size_t)(m - m0) * BN + (n - n0);
+                *reinterpret_cast<float4*>(srow) = v4;
+            } else if (!vec_io || n + 3 >= d.N) {
+                const float ve[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (n + q < d.N) epilogue_store(p, m, n + q, ve[q]);
-            continue;
-        }
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        if (d.pre) {
-            const float4 t = *reinterpret_cast<const float4*>(d.pre + (size_t)m * d.ldpre + n);
-            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-        }
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        if (d.act == GRAPPA_ACT_ELU) {
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < d.N) am = max(am, mag_bits(epilogue_store(p, m, n + q, ve[q])));
+            } else {
+                float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                if (d.pre) {
+                    const float4 t = *reinterpret_cast<const float4*>(d.pre + (size_t)m * d.ldpre + n);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                }
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                if (d.act == GRAPPA_ACT_ELU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = grappa_elu(v[q]);
-        }
-        if (d.aux) {
-            const float4 t = *reinterpret_cast<const float4*>(d.aux + (size_t)m * d.ldaux + n);
-            v[0] *= grappa_elu_grad_from_out(t.x); v[1] *= grappa_elu_grad_from_out(t.y);
-            v[2] *= grappa_elu_grad_from_out(t.z); v[3] *= grappa_elu_grad_from_out(t.w);
-        } else if (d.auxp) {
-            float t[4];
-            planes_load4(d.auxp, d.auxp_plane_stride, (size_t)m * d.ldauxp + n, t, d.auxp_nplanes ? d.auxp_nplanes : 3);
+                    for (int q = 0; q < 4; ++q) v[q] = grappa_elu(v[q]);
+                }
+                if (d.aux) {
+                    const float4 t = *reinterpret_cast<const float4*>(d.aux + (size_t)m * d.ldaux + n);
+                    v[0] *= grappa_elu_grad_from_out(t.x); v[1] *= grappa_elu_grad_from_out(t.y);
+                    v[2] *= grappa_elu_grad_from_out(t.z); v[3] *= grappa_elu_grad_from_out(t.w);
+                } else if (d.auxp) {
+                    float t[4];
+                    planes_load4(d.auxp, d.auxp_plane_stride, (size_t)m * d.ldauxp + n, t, d.auxp_nplanes ? d.auxp_nplanes : 3);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] *= grappa_elu_grad_from_out(t[q]);
-        }
-        float* o = d.C ? d.C + (size_t)m * d.ldc + n : nullptr;
-        if (d.C2) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-            o = d.C2 + (size_t)m * d.ldc2 + n;
-        }
-        if (d.C1p) planes_store4(d.C1p, 0, (size_t)m * d.ldc1p + n, v, 1);
-        if (d.drop_p > 0.0f) {
-            const uint64_t idx = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
+                    for (int q = 0; q < 4; ++q) v[q] *= grappa_elu_grad_from_out(t[q]);
+                }
+                float* o = d.C ? d.C + (size_t)m * d.ldc + n : nullptr;
+                if (d.C2) {
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    o = d.C2 + (size_t)m * d.ldc2 + n;
+                }
+                if (d.C1p) planes_store4(d.C1p, 0, (size_t)m * d.ldc1p + n, v, 1);
+                if (d.drop_p > 0.0f) {
+                    const uint64_t idx = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = grappa_keep(d.drop_seed, idx + q, d.drop_p) ? v[q] * p.drop_scale : 0.0f;
-        }
-        if (d.res) {
-            const float4 t = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
-            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-        } else if (d.resp) {
-            float t[4];
-            planes_load4(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, t, d.resp_nplanes ? d.resp_nplanes : 3);
-            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-        }
-        if (o) {
-            if (d.accumulate) {
-                const float4 t = *reinterpret_cast<const float4*>(o);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    for (int q = 0; q < 4; ++q) v[q] = grappa_keep(d.drop_seed, idx + q, d.drop_p) ? v[q] * p.drop_scale : 0.0f;
+                }
+                if (d.res) {
+                    const float4 t = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                } else if (d.resp) {
+                    float t[4];
+                    planes_load4(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, t, d.resp_nplanes ? d.resp_nplanes : 3);
+                    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+                }
+                if (o) {
+                    if (d.accumulate) {
+                        const float4 t = *reinterpret_cast<const float4*>(o);
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    }
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                if (d.Cp) planes_store4(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v, d.cp_nplanes ? d.cp_nplanes : 3);
+                am = max(max(mag_bits(v[0]), mag_bits(v[1])), max(mag_bits(v[2]), mag_bits(v[3])));
             }
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        if (d.Cp) planes_store4(d.Cp, d.cp_plane_stride, (size_t)m * d.ldcp + n, v, d.cp_nplanes ? d.cp_nplanes : 3);
+        if (p.amax_part && p.nsplit == 1) {
+            // the 16 (TN == 2) or 8 lanes that hold one row segment combine; segment-major layout: the 4 / 8 rows of a trip are
+            // consecutive words, the 32 rows of the band one 128-byte line
+#pragma unroll
+            for (int o = (TN == 2 ? 8 : 4); o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+            const int nseg0 = n - rc4;                       // first column of this wavefront's segment
+            if ((lane & (TN == 2 ? 15 : 7)) == 0 && m < d.M && nseg0 < d.N) p.amax_part[(size_t)(nseg0 / p.amax_seg) * d.M + m] = am;
+        }
     }
 }
 
@@ -320,17 +337,24 @@ __device__ inline void splitk_reduce_body(const GemmParams& p, int nblocks, int 
         const int tl = (int)(i / tile_elems), rem = (int)(i - (size_t)tl * tile_elems);
         const int tile = p.tile_begin + tl;
         const int m = (tile / p.tiles_n) * p.bm + rem / p.bn, n = (tile % p.tiles_n) * p.bn + rem % p.bn;
-        if (m >= p.d.M || n >= p.d.N) continue;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned am = 0u;
+        if (m < p.d.M && n < p.d.N) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-        for (int s = 0; s < p.nsplit; ++s) {
-            const float4 t = *reinterpret_cast<const float4*>(p.slab + (size_t)s * split_stride + i);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        const float ve[4] = {v.x, v.y, v.z, v.w};
+            for (int s = 0; s < p.nsplit; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(p.slab + (size_t)s * split_stride + i);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const float ve[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (n + q < p.d.N) epilogue_store(p, m, n + q, ve[q]);
+            for (int q = 0; q < 4; ++q)
+                if (n + q < p.d.N) am = max(am, mag_bits(epilogue_store(p, m, n + q, ve[q])));
+        }
+        if (p.amax_part) {
+            // amax_seg / 4 adjacent lanes (8 or 16, aligned: bn and the block size are multiples of 64 columns) share one row segment
+            for (int o = p.amax_seg >> 3; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+            if ((threadIdx.x & ((p.amax_seg >> 2) - 1)) == 0 && m < p.d.M && n < p.d.N) p.amax_part[(size_t)(n / p.amax_seg) * p.d.M + m] = am;
+        }
     }
 }
 

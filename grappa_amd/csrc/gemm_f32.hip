@@ -21,6 +21,7 @@ using namespace grappa_gemm;
 
 int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool vec_kcontig);   // gemm_bf16x.hip
 int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision);                      // gemm_planes.hip
+int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* part, unsigned* out);   // amax.hip
 int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision);   // gemm_bf16x.hip
 
 namespace {
@@ -416,6 +417,10 @@ int dispatch(hipStream_t st, GemmParams& p, int cfg, bool vec) {
 
 }  // namespace
 
+// per-segment row maxima of OUT (d.out_amax): M x ceil(N / 32) words at most (32 columns = the narrowest wavefront share of a tile row),
+// placed behind the split-K slabs
+static size_t amax_part_bytes(int M, int N) { return (size_t)M * ((N + 31) / 32) * sizeof(unsigned); }
+
 extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     size_t a = plan_workspace_floats(make_plan(M, N, K, true), M, N);
@@ -427,12 +432,12 @@ extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
         const size_t e = plan_workspace_floats(make_plan(M, N, K, true, true, true), M, N);
         if (e > a) a = e;
     }
-    return a * sizeof(float);
+    return a * sizeof(float) + amax_part_bytes(M, N);
 }
 
 extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
     if (M <= 0 || N <= 0 || K <= 0 || !tile_m || !tile_n || !nsplit || !tail_tiles || !tail_nsplit) return GRAPPA_ERR_ARG;
-    if (precision < GRAPPA_GEMM_F32_MFMA || precision > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
+    if (precision < GRAPPA_GEMM_F32_MFMA || precision > GRAPPA_GEMM_F32_F16X3) return GRAPPA_ERR_ARG;
     Plan pl = make_plan(M, N, K, true, use_bf16x(M, N, precision));
     *tile_m = CFG_BM[pl.cfg];
     *tile_n = CFG_BN[pl.cfg];
@@ -480,9 +485,10 @@ struct GroupPlan {
 
 bool group_desc_ok(const grappa_gemm_desc& d, int precision) {
     if (d.a_kcontig || d.b_kcontig || d.a_planes || d.b_planes) return false;          // the wgrad layout, fp32 operands
-    if (!d.A || !d.B || !d.C || d.Cp || d.C1p || d.resp || d.auxp) return false;
+    if (!d.A || !d.B || !d.C || d.Cp || d.C1p || d.resp || d.auxp || d.out_amax) return false;
     if (d.M <= 32 || d.N <= 32 || d.K <= 0) return false;
     if (d.precision != precision || d.precision == GRAPPA_GEMM_F32_MFMA) return false;
+    if (d.precision == GRAPPA_GEMM_F32_F16X3 && (!d.a_amax || !d.b_amax)) return false;
     if (d.drop_p < 0.0f || d.drop_p >= 1.0f) return false;
     return true;
 }
@@ -577,6 +583,8 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
             p.tile_begin = 0;
             p.ntiles_launch = g.tiles[i];
             p.vec_io = al16(d.C, d.ldc) && al16(d.C2, d.ldc2) && al16(d.pre, d.ldpre) && al16(d.res, d.ldres) && al16(d.aux, d.ldaux);
+            p.amax_part = nullptr;
+            p.amax_seg = 64;
             ix.wg_begin[i + 1] = ix.wg_begin[i] + g.tiles[i] * g.nsplit[i];
             int blocks = 0;
             if (p.nsplit > 1) {
@@ -642,8 +650,10 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
     auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
     p.vec_io = al16(d->C, d->ldc) && al16(d->C2, d->ldc2) && al16(d->pre, d->ldpre) && al16(d->res, d->ldres) && al16(d->aux, d->ldaux);
-    if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_BF16) return GRAPPA_ERR_ARG;
+    if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_F32_F16X3) return GRAPPA_ERR_ARG;
     const bool bf16x = planes || use_bf16x(d->M, d->N, d->precision);
+    // fp16 pieces need the row maxima of both operands (fp32 operands only: the plane format is a bf16 split)
+    if (d->precision == GRAPPA_GEMM_F32_F16X3 && bf16x && (planes || !d->a_amax || !d->b_amax)) return GRAPPA_ERR_ARG;
     // the native fp32 kernel (precision F32_MFMA, or M / N <= 32) keeps its register-lean fp32-only epilogue walk
     if (!bf16x && (d->Cp || d->C1p || d->resp || d->auxp || !d->C)) return GRAPPA_ERR_ARG;
     Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes);
@@ -679,8 +689,23 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
         return rc;
     };
     int rc = GRAPPA_OK;
+    // row maxima of OUT: the row-epilogue kernels and the split-K reduction leave per-segment maxima behind the slabs (plain stores),
+    // one small launch combines them; the native fp32 kernel (tiny or non-default products) leaves them to one pass over its output
+    const bool amax_fused = d->out_amax && bf16x;
+    if (d->out_amax && !amax_fused && !d->C) return GRAPPA_ERR_ARG;
+    p.amax_part = nullptr;
+    p.amax_seg = p.bm == 256 ? 64 : 32;                     // 256 x 128 tile: wavefronts of 64 columns; 128 x 128: of 32
+    if (amax_fused) {
+        if (!ws || ws_bytes < need + amax_part_bytes(d->M, d->N)) return GRAPPA_ERR_WORKSPACE;
+        p.amax_part = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + need);
+    }
     if (pl.main_tiles > 0) rc = launch(0, pl.main_tiles, pl.nsplit, pl.k_per_split);
     if (rc == GRAPPA_OK && pl.tail_nsplit > 1 && pl.main_tiles < tiles)
         rc = launch(pl.main_tiles, tiles - pl.main_tiles, pl.tail_nsplit, pl.tail_k_per_split);
+    if (rc == GRAPPA_OK && amax_fused) rc = grappa_launch_amax_combine(st, d->M, (d->N + p.amax_seg - 1) / p.amax_seg, p.amax_part, d->out_amax);
+    if (rc == GRAPPA_OK && d->out_amax && !amax_fused) {
+        const float* o = d->C2 ? d->C2 : d->C;
+        rc = grappa_amax_f32(stream, d->M, d->N, o, d->C2 ? d->ldc2 : d->ldc, d->out_amax, nullptr, nullptr, 0);
+    }
     return rc;
 }

@@ -8,13 +8,24 @@ namespace {
 
 constexpr int LN_MAX_CHUNKS = 8;   // 8 float4 per lane * 64 lanes = 2048 floats
 
+// magnitudes as fp32 bit patterns with the sign cleared: their unsigned order is the order of the magnitudes (amax.hip)
+__device__ inline unsigned mag4(const float4& v) {
+    return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+               max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+}
+__device__ inline unsigned wave_umax(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
 // NCH = float4 chunks per lane (row width <= 256 * NCH): the row lives in registers, so the chunk count is a template parameter --
 // sized for the widest row (8 chunks) every width would carry ~130 live registers and run at 3 wavefronts per SIMD
 template <int NCH, bool STORE_STATS, typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const T* __restrict__ x, int ldx,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             T* __restrict__ y, int ldy, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out) {
+                                                            float* __restrict__ rstd_out, unsigned* __restrict__ y_amax) {
     const int lane = threadIdx.x & 63;
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -45,6 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
         T* yr = y + (size_t)row * ldy;
+        unsigned am = 0u;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
@@ -57,11 +69,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
                 o.z = (v[i].z - mean) * rstd * g.z + b.z;
                 o.w = (v[i].w - mean) * rstd * g.w + b.w;
                 st4(yr, c, o);
+                am = max(am, mag4(o));
             }
         }
         if (STORE_STATS && lane == 0) {
             mean_out[row] = mean;
             rstd_out[row] = rstd;
+        }
+        if (y_amax) {                                    // largest |y| of the row (fp32 bit pattern): scale of an F32_F16X3 product
+            am = wave_umax(am);
+            if (lane == 0) y_amax[row] = am;
         }
     }
 }
@@ -71,7 +88,8 @@ template <int NCH, typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const T* __restrict__ dy, int lddy,
                                                             const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                            T* __restrict__ dx, int lddx, float* __restrict__ part) {
+                                                            T* __restrict__ dx, int lddx, float* __restrict__ part,
+                                                            unsigned* __restrict__ dx_amax) {
     extern __shared__ float red[];   // [4 waves][2][W]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_global = blockIdx.x * 4 + wave;
@@ -104,6 +122,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
         }
         const float m1 = wave_sum(s1) / (float)W, m2 = wave_sum(s2) / (float)W;
         T* dxr = dx + (size_t)row * lddx;
+        unsigned am = 0u;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
@@ -114,7 +133,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
                 o.z = rs * (g[i].z - m1 - xh[i].z * m2);
                 o.w = rs * (g[i].w - m1 - xh[i].w * m2);
                 st4(dxr, c, o);
+                am = max(am, mag4(o));
             }
+        }
+        if (dx_amax) {
+            am = wave_umax(am);
+            if (lane == 0) dx_amax[row] = am;
         }
     }
     // block reduction of the per-wave partials (fixed order -> reproducible)
@@ -229,6 +253,44 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_vec_kernel(int M, int N, 
     }
 }
 
+// the same, one wavefront per row (as LayerNorm), so that the row's largest |dz| falls out of a wavefront reduction (dz_amax: the scale
+// of the F32_F16X3 products that read dz).  N <= 256 * NCH, 16-byte accesses.
+template <int NCH>
+__global__ __launch_bounds__(256) void act_dropout_bwd_rows_kernel(int M, int N, const float* __restrict__ dy, int lddy,
+                                                                   const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
+                                                                   float* __restrict__ dz, int lddz, unsigned* __restrict__ dz_amax) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nvec = N >> 2;
+    for (int row = wave_global; row < M; row += nwaves) {
+        unsigned am = 0u;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float4 v = ld4(dy + (size_t)row * lddy, c);
+                if (p > 0.f) {
+                    const uint64_t idx = (uint64_t)row * (uint64_t)N + (uint64_t)(c << 2);
+                    v.x = grappa_keep(seed, idx, p) ? v.x * scale : 0.f;
+                    v.y = grappa_keep(seed, idx + 1, p) ? v.y * scale : 0.f;
+                    v.z = grappa_keep(seed, idx + 2, p) ? v.z * scale : 0.f;
+                    v.w = grappa_keep(seed, idx + 3, p) ? v.w * scale : 0.f;
+                }
+                if (y) {
+                    const float4 t = ld4(y + (size_t)row * ldy, c);
+                    v.x *= grappa_elu_grad_from_out(t.x); v.y *= grappa_elu_grad_from_out(t.y);
+                    v.z *= grappa_elu_grad_from_out(t.z); v.w *= grappa_elu_grad_from_out(t.w);
+                }
+                st4(dz + (size_t)row * lddz, c, v);
+                am = max(am, mag4(v));
+            }
+        }
+        am = wave_umax(am);
+        if (lane == 0) dz_amax[row] = am;
+    }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(size_t n, const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i] + z[i];
 }
@@ -310,7 +372,7 @@ inline int colsum_blocks(int M) {
 namespace {
 template <typename T>
 int layernorm_fwd_impl(void* stream, int M, int W, const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, float* mean,
-                       float* rstd) {
+                       float* rstd, unsigned* y_amax = nullptr) {
     if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (ldy & 3)) return GRAPPA_ERR_ARG;
     if (M == 0) return GRAPPA_OK;
     if (!x || !gamma || !beta || !y) return GRAPPA_ERR_ARG;
@@ -322,9 +384,9 @@ int layernorm_fwd_impl(void* stream, int M, int W, const T* x, int ldx, const fl
     const int blocks = W <= 1024 ? ((M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4) : ln_blocks(M);
 #define GRAPPA_LN_FWD(NCH)                                                                                                              \
     if (mean && rstd)                                                                                                                   \
-        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, true, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd); \
+        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, true, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, false, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, false, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax)
     if (W <= 256) { GRAPPA_LN_FWD(1); }
     else if (W <= 512) { GRAPPA_LN_FWD(2); }
     else if (W <= 1024) { GRAPPA_LN_FWD(4); }
@@ -335,7 +397,8 @@ int layernorm_fwd_impl(void* stream, int M, int W, const T* x, int ldx, const fl
 
 template <typename T>
 int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const T* x, int ldx, const float* mean, const float* rstd,
-                       const float* gamma, T* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
+                       const float* gamma, T* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                       unsigned* dx_amax = nullptr) {
     if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return GRAPPA_ERR_ARG;
     if (M == 0) return GRAPPA_OK;
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return GRAPPA_ERR_ARG;
@@ -349,7 +412,7 @@ int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const 
     float* part = reinterpret_cast<float*>(ws);
     float* scratch = part + (size_t)blocks * 2 * W;
     const size_t smem = (size_t)4 * 2 * W * sizeof(float);
-#define GRAPPA_LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, T>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part)
+#define GRAPPA_LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, T>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax)
     if (W <= 256) GRAPPA_LN_BWD(1);
     else if (W <= 512) GRAPPA_LN_BWD(2);
     else if (W <= 1024) GRAPPA_LN_BWD(4);
@@ -413,6 +476,10 @@ extern "C" int grappa_convert_bf16_to_f32(void* stream, int M, int N, const uint
     return grappa_launch_status();
 }
 
+extern "C" int grappa_layernorm_fwd_amax_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
+                                             float* y, int ldy, float* mean, float* rstd, uint32_t* y_amax) {
+    return layernorm_fwd_impl<float>(stream, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax);
+}
 extern "C" size_t grappa_layernorm_bwd_workspace_bytes(int M, int W) {
     return ((size_t)ln_blocks(M) * 2 * W + (size_t)REDUCE_GROUPS * 2 * W) * sizeof(float);
 }
@@ -421,6 +488,11 @@ extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float*
                                         const float* mean, const float* rstd, const float* gamma, float* dx, int lddx,
                                         float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
     return layernorm_bwd_impl<float>(stream, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, accumulate, ws, ws_bytes);
+}
+extern "C" int grappa_layernorm_bwd_amax_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
+                                             const float* mean, const float* rstd, const float* gamma, float* dx, int lddx,
+                                             float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, uint32_t* dx_amax) {
+    return layernorm_bwd_impl<float>(stream, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, accumulate, ws, ws_bytes, dx_amax);
 }
 extern "C" int grappa_layernorm_bwd_bf16(void* stream, int M, int W, const uint16_t* dy, int lddy, const uint16_t* x, int ldx,
                                          const float* mean, const float* rstd, const float* gamma, uint16_t* dx, int lddx,
@@ -453,6 +525,29 @@ extern "C" int grappa_colsum_f32(void* stream, int M, int N, const float* x, int
 extern "C" int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
                                           float drop_p, uint64_t drop_seed, float* dz, int lddz) {
     return act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
+}
+extern "C" int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
+                                               float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax) {
+    if (!dz_amax) return act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
+    if (M < 0 || N < 0 || drop_p < 0.f || drop_p >= 1.f) return GRAPPA_ERR_ARG;
+    if (M == 0 || N == 0) return GRAPPA_OK;
+    if (!dy || !dz) return GRAPPA_ERR_ARG;
+    const bool rows = (N & 3) == 0 && N <= 2048 && (lddy & 3) == 0 && (lddz & 3) == 0 && (!y || (ldy & 3) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (!rows) {                                         // odd shapes: the plain kernel, then one pass over dz
+        const int rc = act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
+        return rc != GRAPPA_OK ? rc : grappa_amax_f32(stream, M, N, dz, lddz, dz_amax, nullptr, nullptr, 0);
+    }
+    const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = (M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4;
+#define GRAPPA_ADB(NCH) hipLaunchKernelGGL((act_dropout_bwd_rows_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz, dz_amax)
+    if (N <= 256) GRAPPA_ADB(1);
+    else if (N <= 512) GRAPPA_ADB(2);
+    else if (N <= 1024) GRAPPA_ADB(4);
+    else GRAPPA_ADB(8);
+#undef GRAPPA_ADB
+    return grappa_launch_status();
 }
 extern "C" int grappa_act_dropout_bwd_bf16(void* stream, int M, int N, const uint16_t* dy, int lddy, const uint16_t* y, int ldy,
                                            float drop_p, uint64_t drop_seed, uint16_t* dz, int lddz) {

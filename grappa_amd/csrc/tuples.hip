@@ -59,13 +59,29 @@ __global__ __launch_bounds__(256) void tuple_gather_bwd_kernel(int N, int W, con
 // ------------------------------------------------------------------------------------------------ attention
 __device__ inline float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
+// magnitudes as fp32 bit patterns with the sign cleared (amax.hip): the rows' largest |value| for a following F32_F16X3 product
+__device__ inline unsigned mag4(const float4& v) {
+    return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+               max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+}
+__device__ inline unsigned wave_umax(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+// row_amax (optional): largest |out| of each of the tuple's S token rows
 template <int S, typename TE>
-__global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, TE* __restrict__ out) {
+__global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, TE* __restrict__ out,
+                                                          unsigned* __restrict__ row_amax) {
     const int lane = threadIdx.x & 63;
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (t >= T) return;
     const int nvec = F >> 2, lph = dh >> 2;
     const float scale = 1.0f / sqrtf((float)dh);
+    unsigned am[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) am[i] = 0u;
     for (int c0 = 0; c0 < nvec; c0 += 64) {
         const int c = c0 + lane;
         const bool ok = c < nvec;
@@ -98,20 +114,33 @@ __global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, 
                 const float p = sc[j] * inv;
                 o.x += p * v[j].x; o.y += p * v[j].y; o.z += p * v[j].z; o.w += p * v[j].w;
             }
-            if (ok) st4(out + ((size_t)i * T + t) * F, c, o);
+            if (ok) {
+                st4(out + ((size_t)i * T + t) * F, c, o);
+                am[i] = max(am[i], mag4(o));
+            }
+        }
+    }
+    if (row_amax) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const unsigned m = wave_umax(am[i]);
+            if (lane == 0) row_amax[(size_t)i * T + t] = m;
         }
     }
 }
 
 template <int S, typename TE>
 __global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, const TE* __restrict__ dout,
-                                                          TE* __restrict__ dqkv) {
+                                                          TE* __restrict__ dqkv, unsigned* __restrict__ row_amax) {
     const int lane = threadIdx.x & 63;
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (t >= T) return;
     const int nvec = F >> 2, lph = dh >> 2;
     const float scale = 1.0f / sqrtf((float)dh);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned am[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) am[i] = 0u;
     for (int c0 = 0; c0 < nvec; c0 += 64) {
         const int c = c0 + lane;
         const bool ok = c < nvec;
@@ -162,7 +191,15 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, 
                 st4(row, c, dq[i]);
                 st4(row, nvec + c, dk[i]);
                 st4(row, 2 * nvec + c, dv[i]);
+                am[i] = max(am[i], max(mag4(dq[i]), max(mag4(dk[i]), mag4(dv[i]))));
             }
+        }
+    }
+    if (row_amax) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const unsigned m = wave_umax(am[i]);
+            if (lane == 0) row_amax[(size_t)i * T + t] = m;
         }
     }
 }
@@ -444,7 +481,7 @@ int tuple_gather_bwd_impl(void* stream, int N, int W, const int* inv_ptr, const 
 }
 
 template <typename TE>
-int seqattn_fwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* qkv, TE* out) {
+int seqattn_fwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* qkv, TE* out, unsigned* row_amax = nullptr) {
     if (s < 1 || s > 4 || T < 0 || nheads <= 0 || dh <= 0 || (dh & 3) || !pow2(dh / 4) || dh / 4 > 64 || nheads * dh > 1024) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
     if (!qkv || !out || !aligned_el<TE>(qkv) || !aligned_el<TE>(out)) return GRAPPA_ERR_ARG;
@@ -463,16 +500,16 @@ int seqattn_fwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* q
         }
     }
     switch (s) {
-        case 1: hipLaunchKernelGGL((seqattn_fwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-        case 2: hipLaunchKernelGGL((seqattn_fwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-        case 3: hipLaunchKernelGGL((seqattn_fwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-        default: hipLaunchKernelGGL((seqattn_fwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+        case 1: hipLaunchKernelGGL((seqattn_fwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
+        case 2: hipLaunchKernelGGL((seqattn_fwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
+        case 3: hipLaunchKernelGGL((seqattn_fwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
+        default: hipLaunchKernelGGL((seqattn_fwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
     }
     return grappa_launch_status();
 }
 
 template <typename TE>
-int seqattn_bwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* qkv, const TE* dout, TE* dqkv) {
+int seqattn_bwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* qkv, const TE* dout, TE* dqkv, unsigned* row_amax = nullptr) {
     if (s < 1 || s > 4 || T < 0 || nheads <= 0 || dh <= 0 || (dh & 3) || !pow2(dh / 4) || dh / 4 > 64 || nheads * dh > 1024) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
     if (!qkv || !dout || !dqkv || !aligned_el<TE>(qkv) || !aligned_el<TE>(dout) || !aligned_el<TE>(dqkv)) return GRAPPA_ERR_ARG;
@@ -492,10 +529,10 @@ int seqattn_bwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* q
         }
     }
     switch (s) {
-        case 1: hipLaunchKernelGGL((seqattn_bwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-        case 2: hipLaunchKernelGGL((seqattn_bwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-        case 3: hipLaunchKernelGGL((seqattn_bwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-        default: hipLaunchKernelGGL((seqattn_bwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+        case 1: hipLaunchKernelGGL((seqattn_bwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
+        case 2: hipLaunchKernelGGL((seqattn_bwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
+        case 3: hipLaunchKernelGGL((seqattn_bwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
+        default: hipLaunchKernelGGL((seqattn_bwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
     }
     return grappa_launch_status();
 }
@@ -519,6 +556,13 @@ extern "C" int grappa_tuple_gather_bwd_bf16(void* stream, int N, int W, const in
 }
 extern "C" int grappa_seqattn_fwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out) {
     return seqattn_fwd_impl<float>(stream, s, T, nheads, dh, qkv, out);
+}
+extern "C" int grappa_seqattn_fwd_amax_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out, uint32_t* out_amax) {
+    return seqattn_fwd_impl<float>(stream, s, T, nheads, dh, qkv, out, out_amax);
+}
+extern "C" int grappa_seqattn_bwd_amax_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv,
+                                           uint32_t* dqkv_amax) {
+    return seqattn_bwd_impl<float>(stream, s, T, nheads, dh, qkv, dout, dqkv, dqkv_amax);
 }
 extern "C" int grappa_seqattn_fwd_bf16(void* stream, int s, int T, int nheads, int dh, const uint16_t* qkv, uint16_t* out) {
     return seqattn_fwd_impl<grappa_bf16_t>(stream, s, T, nheads, dh, qkv, out);

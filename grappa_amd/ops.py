@@ -102,78 +102,83 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------
 # shared sub-sequences (plain functions on the backend; used inside the Functions)
-def _linear_bwd_params(be, dz, x, w, b):
-    """dW += dz^T x ; db += colsum(dz)."""
+def _linear_bwd_params(be, dz, x, w, b, xs=None, zs=None):
+    """dW += dz^T x ; db += colsum(dz).  xs / zs: the backend's records of the largest magnitudes of x (what the forward product
+    returned) and of dz (what the kernel that produced dz returned), or None; returns the record for dz, to be handed to the
+    input-gradient product that follows."""
     M, N = dz.shape
     K = x.shape[1]
     if M == 0:
-        return
+        return zs
     want_b = b is not None and b.requires_grad
     if w.requires_grad:
         # the bias gradient colsum(dz) is produced by the same kernel from the dz tiles it stages anyway; on the GPU the products of
         # one backward pass are queued and launched as a group (backend.gemm_wgrad)
         if hasattr(be, "gemm_wgrad"):
-            be.gemm_wgrad(dz, x, _pgrad(w), _pgrad(b) if want_b else None)
-        else:
-            be.gemm(dz, x, _pgrad(w), M=N, N=K, K=M, a_kcontig=False, b_kcontig=False, accumulate=True,
-                    a_colsum=_pgrad(b) if want_b else None)
-    elif want_b:
+            return be.gemm_wgrad(dz, x, _pgrad(w), _pgrad(b) if want_b else None, x_scales=xs, dz_scales=zs)
+        return be.gemm(dz, x, _pgrad(w), M=N, N=K, K=M, a_kcontig=False, b_kcontig=False, accumulate=True,
+                       a_colsum=_pgrad(b) if want_b else None, b_scales=xs, a_scales=zs)
+    if want_b:
         be.colsum(dz, _pgrad(b), accumulate=True)
+    return zs
 
 
 def _ln_fwd(be, x, w, b):
     M = x.shape[0]
     y = _new(x.shape, x)
     mean, rstd = _new((M,), x, F32), _new((M,), x, F32)
-    be.layernorm_fwd(x, w, b, y, mean, rstd)
-    return y, mean, rstd
+    sy = be.layernorm_fwd(x, w, b, y, mean, rstd)          # (HIP backend, fp16-split products: the row maxima of y; else None)
+    return y, mean, rstd, sy
 
 
 def _ln_bwd(be, dy, x, mean, rstd, w, b):
+    """-> (dx, the backend's record of dx's row maxima or None)"""
     dx = _new(x.shape, x)
     if x.shape[0] == 0:
-        return dx
+        return dx, None
     # a frozen affine pair still needs somewhere to put the reductions the kernel produces
     dw = _pgrad(w) if w.requires_grad else torch.zeros_like(w)
     db = _pgrad(b) if b.requires_grad else torch.zeros_like(b)
-    be.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, db, accumulate=True)
-    return dx
+    sdx = be.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, db, accumulate=True)
+    return dx, sdx
 
 
 def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip):
     """FeedForward: xn = LN(x); u = ELU(xn W1^T + b1); y = act2(u W2^T + b2); out = drop(y) (+ xn)."""
     M = x.shape[0]
-    xn, mean, rstd = _ln_fwd(be, x, norm_w, norm_b)
+    xn, mean, rstd, sxn = _ln_fwd(be, x, norm_w, norm_b)
     Hd, Nout = w1.shape[0], w2.shape[0]
     narrow = Nout <= 32                       # the output maps' last product (2 .. 12 columns): fp32 kernels, fp32 operands and result
     u = _new((M, Hd), x, F32 if narrow else None)
-    be.gemm(xn, w1, u, M=M, N=Hd, K=x.shape[1], bias=b1, act=ELU)
+    sxn, su = be.gemm(xn, w1, u, M=M, N=Hd, K=x.shape[1], bias=b1, act=ELU, a_scales=sxn, out_amax=True)      # u feeds the next product
     out = _new((M, Nout), x, F32 if narrow else None)
     res = xn if skip else None
     pre = None
     if act2:
         pre = _new((M, Nout), x)
-        be.gemm(u, w2, pre, M=M, N=Nout, K=Hd, bias=b2, act=ELU, drop_p=drop_p, drop_seed=seed, res=res, out2=out)
+        su = be.gemm(u, w2, pre, M=M, N=Nout, K=Hd, bias=b2, act=ELU, drop_p=drop_p, drop_seed=seed, res=res, out2=out, a_scales=su)
     else:
-        be.gemm(u, w2, out, M=M, N=Nout, K=Hd, bias=b2, drop_p=drop_p, drop_seed=seed, res=res)
-    return out, (x, mean, rstd, xn, u, pre)
+        su = be.gemm(u, w2, out, M=M, N=Nout, K=Hd, bias=b2, drop_p=drop_p, drop_seed=seed, res=res, a_scales=su)
+    return out, (x, mean, rstd, xn, u, pre, sxn, su)
 
 
-def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip):
-    x, mean, rstd, xn, u, pre = saved
+def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip, sdout=None):
+    """-> (dx, record of dx's row maxima or None); sdout: the record for dout when the kernel that produced it wrote one"""
+    x, mean, rstd, xn, u, pre, sxn, su = saved
     M = x.shape[0]
-    dout = _c(dout)
+    if not dout.is_contiguous():
+        dout, sdout = dout.contiguous(), None
     if act2 or drop_p > 0:
         dz2 = _new(dout.shape, dout)
-        be.act_dropout_bwd(dout, pre if act2 else None, drop_p, seed, dz2)
+        sz = be.act_dropout_bwd(dout, pre if act2 else None, drop_p, seed, dz2)
     else:
-        dz2 = dout
-    _linear_bwd_params(be, dz2, u, w2, b2)
+        dz2, sz = dout, sdout
+    sz = _linear_bwd_params(be, dz2, u, w2, b2, su, sz)
     dz1 = _new(u.shape, xn)                                        # (u is fp32 in front of a narrow output product, xn never)
-    be.gemm(dz2, w2, dz1, M=M, N=u.shape[1], K=dz2.shape[1], b_kcontig=False, aux=u)          # fused ELU'(u)
-    _linear_bwd_params(be, dz1, xn, w1, b1)
+    _, sz = be.gemm(dz2, w2, dz1, M=M, N=u.shape[1], K=dz2.shape[1], b_kcontig=False, aux=u, a_scales=sz, out_amax=True)   # fused ELU'(u)
+    sz = _linear_bwd_params(be, dz1, xn, w1, b1, sxn, sz)
     dxn = _new(xn.shape, xn)
-    be.gemm(dz1, w1, dxn, M=M, N=xn.shape[1], K=u.shape[1], b_kcontig=False, res=dout if skip else None)
+    be.gemm(dz1, w1, dxn, M=M, N=xn.shape[1], K=u.shape[1], b_kcontig=False, res=dout if skip else None, a_scales=sz)
     return _ln_bwd(be, dxn, x, mean, rstd, norm_w, norm_b)
 
 
@@ -191,9 +196,9 @@ class LinearFn(Function):
         pre = None
         if act and drop_p > 0:
             pre = _new((M, N), x, out_dtype)
-            be.gemm(x, w, pre, M=M, N=N, K=K, bias=b, act=act, drop_p=drop_p, drop_seed=seed, out2=y)
+            ctx.sx = be.gemm(x, w, pre, M=M, N=N, K=K, bias=b, act=act, drop_p=drop_p, drop_seed=seed, out2=y)
         else:
-            be.gemm(x, w, y, M=M, N=N, K=K, bias=b, act=act, drop_p=drop_p, drop_seed=seed)
+            ctx.sx = be.gemm(x, w, y, M=M, N=N, K=K, bias=b, act=act, drop_p=drop_p, drop_seed=seed)
         ctx.save_for_backward(x, w, b, pre if pre is not None else (y if act else None))
         ctx.cfg = (act, drop_p, seed)
         return y
@@ -206,14 +211,14 @@ class LinearFn(Function):
         dy = _c(dy)
         if act or drop_p > 0:
             dz = _new(dy.shape, dy)
-            be.act_dropout_bwd(dy, ysaved if act else None, drop_p, seed, dz)
+            sz = be.act_dropout_bwd(dy, ysaved if act else None, drop_p, seed, dz)
         else:
-            dz = dy
-        _linear_bwd_params(be, dz, x, w, b)
+            dz, sz = dy, None
+        sz = _linear_bwd_params(be, dz, x, w, b, ctx.sx, sz)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _new(x.shape, x)
-            be.gemm(dz, w, dx, M=x.shape[0], N=x.shape[1], K=w.shape[0], b_kcontig=False)
+            be.gemm(dz, w, dx, M=x.shape[0], N=x.shape[1], K=w.shape[0], b_kcontig=False, a_scales=sz)
         return dx, None, None, None, None, None, None
 
 
@@ -223,16 +228,16 @@ class AttBlockFn(Function):
         be = get_backend()
         h = _c(h)
         N, Fd = h.shape
-        h1, mean1, rstd1 = _ln_fwd(be, h, ln_w, ln_b)
+        h1, mean1, rstd1, sh1 = _ln_fwd(be, h, ln_w, ln_b)
         ft = _new((N, w_fc.shape[0]), h)
-        be.gemm(h1, w_fc, ft, M=N, N=w_fc.shape[0], K=Fd)
+        sh1 = be.gemm(h1, w_fc, ft, M=N, N=w_fc.shape[0], K=Fd, a_scales=sh1)
         m = _new(ft.shape, h)
         alpha = _new((plan.E, heads), h, F32)
         be.gat_fwd(plan, ft, heads, ft.shape[1] // heads, m, alpha)
         h3 = _new((N, Fd), h)
-        be.gemm(m, w_r, h3, M=N, N=Fd, K=m.shape[1], bias=b_r, drop_p=drop_p, drop_seed=seed1, res=h1)
+        sm = be.gemm(m, w_r, h3, M=N, N=Fd, K=m.shape[1], bias=b_r, drop_p=drop_p, drop_seed=seed1, res=h1)
         out, ff_saved = _ff_fwd(be, h3, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
-        ctx.plan, ctx.cfg = plan, (heads, drop_p, seed1, seed2)
+        ctx.plan, ctx.cfg, ctx.scales = plan, (heads, drop_p, seed1, seed2), (sh1, sm)
         ctx.ff_saved = ff_saved
         ctx.save_for_backward(h, mean1, rstd1, h1, ft, m, alpha, ln_w, ln_b, w_fc, w_r, b_r, ln2_w, ln2_b, w1, b1, w2, b2)
         return out
@@ -244,22 +249,23 @@ class AttBlockFn(Function):
         heads, drop_p, seed1, seed2 = ctx.cfg
         plan = ctx.plan
         N, Fd = h.shape
-        dh3 = _ff_bwd(be, ctx.ff_saved, dout, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
+        dh3, sz = _ff_bwd(be, ctx.ff_saved, dout, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
         ctx.ff_saved = None
         if drop_p > 0:
             dzr = _new(dh3.shape, dh3)
-            be.act_dropout_bwd(dh3, None, drop_p, seed1, dzr)
+            sz = be.act_dropout_bwd(dh3, None, drop_p, seed1, dzr)
         else:
             dzr = dh3
-        _linear_bwd_params(be, dzr, m, w_r, b_r)
+        sh1, sm = ctx.scales
+        sz = _linear_bwd_params(be, dzr, m, w_r, b_r, sm, sz)
         dm = _new(m.shape, m)
-        be.gemm(dzr, w_r, dm, M=N, N=m.shape[1], K=Fd, b_kcontig=False)
+        be.gemm(dzr, w_r, dm, M=N, N=m.shape[1], K=Fd, b_kcontig=False, a_scales=sz)
         dft = _new(ft.shape, ft)
         be.gat_bwd(plan, ft, m, alpha, dm, heads, ft.shape[1] // heads, dft)
-        _linear_bwd_params(be, dft, h1, w_fc, None)
+        sz = _linear_bwd_params(be, dft, h1, w_fc, None, sh1)
         dh1 = _new(h1.shape, h1)
-        be.gemm(dft, w_fc, dh1, M=N, N=Fd, K=ft.shape[1], b_kcontig=False, res=dh3)        # + residual branch
-        dh = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
+        be.gemm(dft, w_fc, dh1, M=N, N=Fd, K=ft.shape[1], b_kcontig=False, res=dh3, a_scales=sz)        # + residual branch
+        dh, _ = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
         return (dh,) + (None,) * 16
 
 
@@ -271,19 +277,19 @@ class ConvBlockFn(Function):
         be = get_backend()
         h = _c(h)
         N, Fd = h.shape
-        h1, mean1, rstd1 = _ln_fwd(be, h, ln_w, ln_b)
+        h1, mean1, rstd1, sh1 = _ln_fwd(be, h, ln_w, ln_b)
         mn = _new((N, Fd), h)
         be.neighbor_mean(plan, h1, mn, False)
         t = _new((N, Fd), h)
-        be.gemm(mn, w_neigh, t, M=N, N=Fd, K=Fd)
+        smn = be.gemm(mn, w_neigh, t, M=N, N=Fd, K=Fd)
         y1 = _new((N, Fd), h)          # ELU output before dropout
         h3 = _new((N, Fd), h)
-        be.gemm(h1, w_self, y1, M=N, N=Fd, K=Fd, bias=bias, pre=t, act=ELU, drop_p=drop_p, drop_seed=seed1, res=h1, out2=h3)
-        h4, mean2, rstd2 = _ln_fwd(be, h3, ln2_w, ln2_b)
+        sh1 = be.gemm(h1, w_self, y1, M=N, N=Fd, K=Fd, bias=bias, pre=t, act=ELU, drop_p=drop_p, drop_seed=seed1, res=h1, out2=h3, a_scales=sh1)
+        h4, mean2, rstd2, sh4 = _ln_fwd(be, h3, ln2_w, ln2_b)
         y2 = _new((N, Fd), h)
         out = _new((N, Fd), h)
-        be.gemm(h4, w, y2, M=N, N=Fd, K=Fd, bias=b, act=ELU, drop_p=drop_p, drop_seed=seed2, res=h4, out2=out)
-        ctx.plan, ctx.cfg = plan, (drop_p, seed1, seed2)
+        sh4 = be.gemm(h4, w, y2, M=N, N=Fd, K=Fd, bias=b, act=ELU, drop_p=drop_p, drop_seed=seed2, res=h4, out2=out, a_scales=sh4)
+        ctx.plan, ctx.cfg, ctx.scales = plan, (drop_p, seed1, seed2), (smn, sh1, sh4)
         ctx.save_for_backward(h, mean1, rstd1, h1, mn, y1, h3, mean2, rstd2, h4, y2, ln_w, ln_b, w_self, w_neigh, bias, ln2_w, ln2_b, w, b)
         return out
 
@@ -296,21 +302,22 @@ class ConvBlockFn(Function):
         N, Fd = h.shape
         dout = _c(dout)
         dz2 = _new(dout.shape, dout)
-        be.act_dropout_bwd(dout, y2, drop_p, seed2, dz2)
-        _linear_bwd_params(be, dz2, h4, w, b)
+        sz = be.act_dropout_bwd(dout, y2, drop_p, seed2, dz2)
+        smn, sh1, sh4 = ctx.scales
+        sz = _linear_bwd_params(be, dz2, h4, w, b, sh4, sz)
         dh4 = _new(h4.shape, h4)
-        be.gemm(dz2, w, dh4, M=N, N=Fd, K=Fd, b_kcontig=False, res=dout)
-        dh3 = _ln_bwd(be, dh4, h3, mean2, rstd2, ln2_w, ln2_b)
+        be.gemm(dz2, w, dh4, M=N, N=Fd, K=Fd, b_kcontig=False, res=dout, a_scales=sz)
+        dh3, _ = _ln_bwd(be, dh4, h3, mean2, rstd2, ln2_w, ln2_b)
         dz1 = _new(dh3.shape, dh3)
-        be.act_dropout_bwd(dh3, y1, drop_p, seed1, dz1)
-        _linear_bwd_params(be, dz1, h1, w_self, bias)
-        _linear_bwd_params(be, dz1, mn, w_neigh, None)
+        sz = be.act_dropout_bwd(dh3, y1, drop_p, seed1, dz1)
+        sz = _linear_bwd_params(be, dz1, h1, w_self, bias, sh1, sz)
+        sz = _linear_bwd_params(be, dz1, mn, w_neigh, None, smn, sz)
         dmn = _new(mn.shape, mn)
-        be.gemm(dz1, w_neigh, dmn, M=N, N=Fd, K=Fd, b_kcontig=False)
+        be.gemm(dz1, w_neigh, dmn, M=N, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)
         dh1 = _new(h1.shape, h1)
         be.neighbor_mean(plan, dmn, dh1, True)                         # transpose of the mean aggregation
-        be.gemm(dz1, w_self, dh1, M=N, N=Fd, K=Fd, b_kcontig=False, res=dh3, accumulate=True)
-        dh = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
+        be.gemm(dz1, w_self, dh1, M=N, N=Fd, K=Fd, b_kcontig=False, res=dh3, accumulate=True, a_scales=sz)
+        dh, _ = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
         return (dh,) + (None,) * 13
 
 
@@ -326,7 +333,7 @@ class ProjGatherFn(Function):
         Fd = Wp + (1 if pe is not None else 0)
         T = idx32.shape[0]
         a = _zeros((N, Fd), h, out_dtype)
-        be.gemm(h, w, a[:, :Wp], M=N, N=Wp, K=R, bias=b, act=ELU)
+        ctx.sh = be.gemm(h, w, a[:, :Wp], M=N, N=Wp, K=R, bias=b, act=ELU)
         x = _new((s * T, Fd), a)
         if T:
             be.tuple_gather_fwd(a, idx32, s, pe, x)
@@ -346,10 +353,10 @@ class ProjGatherFn(Function):
         da = _new(a.shape, a)
         be.tuple_gather_bwd(inv_ptr, inv_rows, dx, da, has_pe, False)
         dz = _new((N, Wp), a)
-        be.act_dropout_bwd(da[:, :Wp], a[:, :Wp], 0.0, 0, dz)
-        _linear_bwd_params(be, dz, h, w, b)
+        sz = be.act_dropout_bwd(da[:, :Wp], a[:, :Wp], 0.0, 0, dz)
+        sz = _linear_bwd_params(be, dz, h, w, b, ctx.sh, sz)
         dh = _new(h.shape, h)
-        be.gemm(dz, w, dh, M=N, N=R, K=Wp, b_kcontig=False)
+        be.gemm(dz, w, dh, M=N, N=R, K=Wp, b_kcontig=False, a_scales=sz)
         return (dh,) + (None,) * 8
 
 
@@ -361,16 +368,15 @@ class TransformerLayerFn(Function):
         be = get_backend()
         x = _c(x)
         M, Fd = x.shape
-        x1, mean1, rstd1 = _ln_fwd(be, x, n1_w, n1_b)
+        x1, mean1, rstd1, sx1 = _ln_fwd(be, x, n1_w, n1_b)
         qkv = _new((M, 3 * Fd), x)
-        be.gemm(x1, w_in, qkv, M=M, N=3 * Fd, K=Fd, bias=b_in)
+        sx1 = be.gemm(x1, w_in, qkv, M=M, N=3 * Fd, K=Fd, bias=b_in, a_scales=sx1)
         att = _new((M, Fd), x)
-        if T:
-            be.seqattn_fwd(qkv, s, T, nheads, att)
+        satt = be.seqattn_fwd(qkv, s, T, nheads, att) if T else None
         x2 = _new((M, Fd), x)
-        be.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x1)
+        satt = be.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x1, a_scales=satt)
         out, ff_saved = _ff_fwd(be, x2, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
-        ctx.cfg = (s, T, nheads, drop_p, seed1, seed2)
+        ctx.cfg, ctx.scales = (s, T, nheads, drop_p, seed1, seed2), (sx1, satt)
         ctx.ff_saved = ff_saved
         ctx.save_for_backward(x, mean1, rstd1, x1, qkv, att, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)
         return out
@@ -383,22 +389,23 @@ class TransformerLayerFn(Function):
         M, Fd = x.shape
         if M == 0:
             return (torch.zeros_like(x),) + (None,) * 18
-        dx2 = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
         ctx.ff_saved = None
         if drop_p > 0:
             dzo = _new(dx2.shape, dx2)
-            be.act_dropout_bwd(dx2, None, drop_p, seed1, dzo)
+            sz = be.act_dropout_bwd(dx2, None, drop_p, seed1, dzo)
         else:
             dzo = dx2
-        _linear_bwd_params(be, dzo, att, w_o, b_o)
+        sx1, satt = ctx.scales
+        sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)
         datt = _new(att.shape, att)
-        be.gemm(dzo, w_o, datt, M=M, N=Fd, K=Fd, b_kcontig=False)
+        be.gemm(dzo, w_o, datt, M=M, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)
         dqkv = _new(qkv.shape, qkv)
-        be.seqattn_bwd(qkv, datt, s, T, nheads, dqkv)
-        _linear_bwd_params(be, dqkv, x1, w_in, b_in)
+        sz = be.seqattn_bwd(qkv, datt, s, T, nheads, dqkv)
+        sz = _linear_bwd_params(be, dqkv, x1, w_in, b_in, sx1, sz)
         dx1 = _new(x1.shape, x1)
-        be.gemm(dqkv, w_in, dx1, M=M, N=Fd, K=3 * Fd, b_kcontig=False, res=dx2)
-        dx = _ln_bwd(be, dx1, x, mean1, rstd1, n1_w, n1_b)
+        be.gemm(dqkv, w_in, dx1, M=M, N=Fd, K=3 * Fd, b_kcontig=False, res=dx2, a_scales=sz)
+        dx, _ = _ln_bwd(be, dx1, x, mean1, rstd1, n1_w, n1_b)
         return (dx,) + (None,) * 18
 
 
@@ -434,11 +441,11 @@ class SymmetriserFn(Function):
         nret = 5 + 6 * n_layers
         if T == 0:
             return (torch.zeros(xshape, dtype=xdtype, device=dout.device),) + (None,) * (nret - 1)
-        g = _c(dout)
+        g, sg = _c(dout), None
         for i in reversed(range(n_layers)):
             nw, nb, w1, b1, w2, b2 = ctx.layers[i]
             skip = (i != 0) and (i != n_layers - 1)
-            g = _ff_bwd(be, ctx.saved_layers[i], g, nw, nb, w1, b1, w2, b2, False, 0.0, 0, skip)
+            g, sg = _ff_bwd(be, ctx.saved_layers[i], g, nw, nb, w1, b1, w2, b2, False, 0.0, 0, skip, sg)
         ctx.saved_layers = None
         dx = torch.empty(xshape, dtype=xdtype, device=dout.device)
         be.perm_concat_bwd(g, s, T, perms, dx)

@@ -27,7 +27,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 3
+#define GRAPPA_ABI_VERSION 4
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -63,12 +63,19 @@ const char* grappa_build_arch(void);
  *   F32_BF16X6  the 6 largest partial products (drops terms <= 2^-24 |a||b|): fp32-grade, ~2 ulp per product
  *   BF16X3      2 pieces / 3 products (~2^-16 relative);  BF16: operands rounded to bf16 (the "bf16" trainer precision of
  *               the reference's configs, experiment/trainrun.py / Lightning `precision`)
+ *   F32_F16X3   (ABI 4) each fp32 operand, scaled by a power of two per row of the product so that its largest magnitude lands in
+ *               [2^14, 2^15), is split into 2 fp16 pieces (11 + 11 significant bits and a sign: a - hi - lo <= 2^-24 |a|); the 3
+ *               products hi*hi + hi*lo + lo*hi run on the fp16 matrix cores (every product exact in fp32), the dropped lo*lo is
+ *               <= 2^-24 |a||b|: fp32-grade like F32_BF16X6 at half the matrix instructions.  Needs a_amax / b_amax (below): the
+ *               largest |element| of every row of the product's A (M values) and B (N values), from grappa_amax_f32.  Elements
+ *               more than 2^16 below their row's maximum lose relative (never absolute: <= 2^-39 of the maximum) precision.
  * Shapes with M <= 32 or N <= 32 always take the native fp32 path. */
 #define GRAPPA_GEMM_F32_MFMA 0
 #define GRAPPA_GEMM_F32_BF16X9 1
 #define GRAPPA_GEMM_F32_BF16X6 2
 #define GRAPPA_GEMM_BF16X3 3
 #define GRAPPA_GEMM_BF16 4
+#define GRAPPA_GEMM_F32_F16X3 5
 
 typedef struct grappa_gemm_desc {
     int M, N, K;
@@ -105,7 +112,26 @@ typedef struct grappa_gemm_desc {
      * configuration: activations are kept in bf16 in HBM, precision GRAPPA_GEMM_BF16 reads plane 0 of both operands) */
     int cp_nplanes, resp_nplanes, auxp_nplanes;                   /* (Cp / C1p / resp / auxp are not available with F32_MFMA or M, N <= 32) */
     uint16_t* C1p; int ldc1p;                                     /* bf16 copy of the value C receives when C2 is used (before dropout / residual) */
+    /* ---- ABI 4, precision F32_F16X3 only: bit patterns of max_k |A(m, k)| (M values) and max_k |B(n, k)| (N values); fp32 operands.
+     * amax_bcast bit 0 / bit 1: a_amax / b_amax is ONE value for all rows (an upper bound of the whole operand; the weight-gradient
+     * product, whose reduction runs over the tokens, takes max over the token maxima: elements more than 2^16 below the tensor's
+     * largest lose relative precision gradually, absolute error <= 2^-39 of that largest) */
+    const uint32_t* a_amax; const uint32_t* b_amax; int amax_bcast;
+    /* any precision, optional: receives max_n |OUT(m, n)| (M values, fp32 bit patterns) of the final output, for a following
+     * F32_F16X3 product that reads OUT as its A operand */
+    uint32_t* out_amax;
 } grappa_gemm_desc;
+
+/* Largest magnitudes of an fp32 matrix x[R][C] (leading dimension ldx), as fp32 bit patterns: row_amax[r] = max_c |x[r][c]|,
+ * col_amax[c] = max_r |x[r][c]| (either may be NULL), one pass over x.  A product's operand uses the array ALONG which it is
+ * not reduced: forward x[tok][in] -> row_amax, W[out][in] -> row_amax; dgrad dY[tok][out] -> row_amax, W -> col_amax;
+ * wgrad dY -> col_amax, x -> col_amax.  NaN counts as larger than everything (the product is then NaN / Inf as in fp32).
+ * ws: grappa_amax_f32_workspace_bytes(R, C) bytes (partial column maxima), needed only with col_amax. */
+size_t grappa_amax_f32_workspace_bytes(int R, int C);
+int grappa_amax_f32(void* stream, int R, int C, const float* x, int ldx, uint32_t* row_amax, uint32_t* col_amax, void* ws, size_t ws_bytes);
+/* out[b] = max_i in[b][i], i < n[b], for `count` arrays in one launch per 32 (bit patterns of magnitudes: unsigned order): whole-tensor
+ * maxima from row maxima.  `in` and `n` are HOST arrays (of device pointers / lengths). */
+int grappa_amax_reduce(void* stream, int count, const uint32_t* const* in, const int* n, uint32_t* out);
 
 /* fp32 X[R][C] -> plane format: planes[p][r][c] (transpose == 0) or planes[p][c][r] (transpose != 0), p = 0..2, leading
  * dimension ldp, `plane_stride` elements between planes.  Only the R x C (C x R) block is written: padding the GEMM relies on
@@ -142,6 +168,11 @@ int grappa_colsum_f32(void* stream, int M, int N, const float* x, int ldx, float
  * act+dropout epilogue).  y == NULL: no activation.  dz may alias dy. */
 int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
                                float drop_p, uint64_t drop_seed, float* dz, int lddz);
+/* ABI 4, *_amax_f32 variants of the producers of dense-product operands: the same kernel also writes the largest magnitude of every
+ * row of its output (M fp32 bit patterns, as grappa_amax_f32's row_amax) -- the scales of a following F32_F16X3 product, without a
+ * pass of their own.  A NULL array gives the plain kernel. */
+int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
+                                    float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax);
 
 /* y = x + z elementwise (used to merge gradient branches); y may alias x */
 int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float* y);
@@ -152,12 +183,18 @@ int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float
  * network_utils.py:38,:98. */
 int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
                              float* y, int ldy, float* mean, float* rstd);
+int grappa_layernorm_fwd_amax_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
+                                  float* y, int ldy, float* mean, float* rstd, uint32_t* y_amax);
 size_t grappa_layernorm_bwd_workspace_bytes(int M, int W);
 /* dx may alias dy.  dgamma/dbeta: accumulate != 0 adds to the existing values. */
 int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
                              const float* mean, const float* rstd, const float* gamma,
                              float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
                              void* ws, size_t ws_bytes);
+int grappa_layernorm_bwd_amax_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
+                                  const float* mean, const float* rstd, const float* gamma,
+                                  float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                                  void* ws, size_t ws_bytes, uint32_t* dx_amax);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph attention message passing (DGL DotGatConv, graph_attention.py:249/:283 -> DGL u_dot_v +
@@ -201,6 +238,10 @@ int grappa_tuple_gather_bwd_f32(void* stream, int N, int W, const int* inv_ptr, 
  * dh % 4 == 0, dh/4 a power of two, F = nheads*dh <= 1024. */
 int grappa_seqattn_fwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out);
 int grappa_seqattn_bwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv);
+/* ABI 4: the same kernels, also writing the largest magnitude of every row of out (s*T values) / of dqkv (s*T values) */
+int grappa_seqattn_fwd_amax_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out, uint32_t* out_amax);
+int grappa_seqattn_bwd_amax_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv,
+                                uint32_t* dqkv_amax);
 
 /* Symmetriser input (perm_equiv_transformer.py:248-261): z[p*T+t, j*F+f] = x[perm[p*s+j]*T+t, f].
  * bwd: dx[i*T+t, f] = sum_p dz[p*T+t, inv_p(i)*F+f].  h_perm is a HOST array (P*s ints). */

@@ -49,7 +49,7 @@ class RefBackend:
 
     # ------------------------------------------------------------------ dense
     def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
-             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None):
+             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None, a_scales=None, b_scales=None, out_amax=False):
         A = a if a_kcontig else a.t()
         Bm = b if b_kcontig else b.t()
         assert tuple(A.shape) == (M, K) and tuple(Bm.shape) == (N, K) and tuple(out.shape) == (M, N)
@@ -77,6 +77,7 @@ class RefBackend:
         if accumulate:
             v = v + target
         target.copy_(v)
+        return (None, None) if out_amax else None      # (the HIP backend's fp16-split products hand back operand maxima here)
 
     def colsum(self, x, out, accumulate=False):
         s = x.sum(0)

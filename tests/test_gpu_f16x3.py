@@ -1,0 +1,220 @@
+"""GPU (-m gpu): the fp16-split arithmetic of the dense products (precision "f32_f16x3", include/grappa_hip.h): the maxima kernels and
+every producer that writes row maxima against torch (bit-exact: a maximum is order-free), the products on operands whose rows /
+columns span many orders of magnitude against float64, and whole train steps against the default arithmetic and the oracle."""
+import math
+
+import pytest
+import torch
+
+import golden_utils as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from grappa_amd.backend import HipBackend
+    return HipBackend()
+
+
+def bits(t):
+    """magnitudes as the int32 bit patterns the kernels write"""
+    return t.detach().abs().float().contiguous().view(torch.int32)
+
+
+def row_bits(t):
+    return bits(t).amax(dim=1) if t.shape[1] else torch.zeros(t.shape[0], dtype=torch.int32, device=t.device)
+
+
+@pytest.mark.parametrize("R,C,ld", [(1000, 512, 512), (83, 85, 88), (4097, 1536, 1536), (17, 2048, 2048), (300, 2500, 2500), (5, 4, 4), (700, 511, 511)])
+def test_amax_rows_and_columns(hip, R, C, ld):
+    g = torch.Generator().manual_seed(R + C)
+    full = torch.randn(R, ld, generator=g) * torch.exp(torch.randn(R, ld, generator=g) * 3)
+    full[R // 2, C // 3] = -1e30
+    x = full.cuda()[:, :C]
+    am = hip.amax(x, None, rows=True, cols=True, tmax=True)
+    torch.cuda.synchronize()
+    assert torch.equal(am.row, bits(x).amax(dim=1))
+    assert torch.equal(am.col, bits(x).amax(dim=0))
+    assert int(am.tmax) == int(bits(x).max())
+    rows_only = hip.amax(x, None, rows=True)
+    assert torch.equal(rows_only.row, am.row) and rows_only.col is None
+
+
+def test_amax_orders_nan_above_everything(hip):
+    x = torch.randn(64, 256, device="cuda")
+    x[3, 7] = float("nan")
+    x[5, 9] = float("inf")
+    am = hip.amax(x, None, rows=True, cols=True)
+    torch.cuda.synchronize()
+    r = am.row.cpu()
+    assert r[3] > 0x7f800000 and r[5] == 0x7f800000 and int(am.col[7]) > 0x7f800000
+
+
+@pytest.mark.parametrize("M,W", [(1000, 512), (333, 256), (70, 1536), (40, 2048), (9, 64)])
+def test_producers_write_row_maxima(hip, M, W):
+    """LayerNorm forward / backward, activation-dropout backward: the row maxima they write are those of their outputs"""
+    g = torch.Generator().manual_seed(M + W)
+    x = (torch.randn(M, W, generator=g) * 3 + 1).cuda()
+    gamma, beta = torch.randn(W, generator=g).cuda(), torch.randn(W, generator=g).cuda()
+    y, mean, rstd = torch.empty_like(x), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    am = hip.layernorm_fwd(x, gamma, beta, y, mean, rstd, amax=True)
+    dy = (torch.randn(M, W, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 4)).cuda()
+    dx, dg, db = torch.empty_like(x), torch.zeros(W, device="cuda"), torch.zeros(W, device="cuda")
+    am_b = hip.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dg, db, amax=True)
+    dz = torch.empty_like(x)
+    am_z = hip.act_dropout_bwd(dy, y, 0.3, 1234, dz, amax=True)
+    dz2 = torch.empty_like(x)
+    hip.act_dropout_bwd(dy, y, 0.3, 1234, dz2, amax=False)
+    torch.cuda.synchronize()
+    assert am is not None and am_b is not None and am_z is not None, "the producers must hand back maxima when asked"
+    assert torch.equal(am.row, row_bits(y))
+    assert torch.equal(am_b.row, row_bits(dx))
+    assert torch.equal(am_z.row, row_bits(dz))
+    assert torch.equal(dz, dz2), "the row-wise kernel and the flat kernel compute the same dz"
+
+
+def test_act_dropout_bwd_row_maxima_odd_shape(hip):
+    dy = torch.randn(50, 85, device="cuda")
+    dz = torch.empty_like(dy)
+    am = hip.act_dropout_bwd(dy, None, 0.0, 0, dz, amax=True)
+    torch.cuda.synchronize()
+    assert torch.equal(am.row, row_bits(dz)) and torch.equal(dz, dy)
+
+
+@pytest.mark.parametrize("s,T,heads", [(4, 500, 8), (3, 77, 8), (2, 1000, 4)])
+def test_seqattn_row_maxima(hip, s, T, heads):
+    F = 512
+    g = torch.Generator().manual_seed(s * T)
+    qkv = torch.randn(s * T, 3 * F, generator=g).cuda()
+    out, out2 = torch.empty(s * T, F, device="cuda"), torch.empty(s * T, F, device="cuda")
+    am = hip.seqattn_fwd(qkv, s, T, heads, out, amax=True)
+    hip.seqattn_fwd(qkv, s, T, heads, out2, amax=False)
+    dout = torch.randn(s * T, F, generator=g).cuda()
+    dqkv, dqkv2 = torch.empty_like(qkv), torch.empty_like(qkv)
+    am_b = hip.seqattn_bwd(qkv, dout, s, T, heads, dqkv, amax=True)
+    hip.seqattn_bwd(qkv, dout, s, T, heads, dqkv2, amax=False)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(dqkv, dqkv2)
+    assert torch.equal(am.row, row_bits(out)) and torch.equal(am_b.row, row_bits(dqkv))
+
+
+@pytest.mark.parametrize("precision", ["f32_f16x3", "f32_bf16x6", "f32"])
+@pytest.mark.parametrize("M,N,K,ak,bk,kw", [(1000, 512, 512, 1, 1, "plain"), (8300, 1536, 512, 1, 1, "epi"), (83328 // 8, 512, 512, 1, 0, "aux"),
+                                            (700, 320, 1536, 1, 0, "plain"), (257, 511, 256, 1, 1, "epi"), (40, 512, 300, 1, 1, "plain"),
+                                            (20, 16, 64, 1, 1, "plain"), (2600, 512, 4096, 1, 1, "plain")])
+def test_gemm_writes_output_row_maxima(hip, M, N, K, ak, bk, kw, precision):
+    """out_amax: row maxima of the FINAL output (after bias / ELU / dropout / residual), from the row epilogue, the split-K reduction
+    (tail launches) and -- native kernel -- the pass that follows it"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn((N, K) if bk else (K, N), generator=g) / math.sqrt(K)).cuda()
+    out = torch.empty(M, N, device="cuda")
+    extra = {}
+    if kw == "epi":
+        extra = dict(bias=torch.randn(N, generator=g).cuda(), act=1, drop_p=0.25, drop_seed=77, res=torch.randn(M, N, generator=g).cuda())
+    elif kw == "aux":
+        extra = dict(aux=torch.randn(M, N, generator=g).cuda())
+    _, so = hip.gemm(A, B, out, M=M, N=N, K=K, a_kcontig=True, b_kcontig=bool(bk), precision=precision, out_amax=True, **extra)
+    torch.cuda.synchronize()
+    assert so is not None and torch.equal(so.row, row_bits(out)), f"{precision} {M}x{N}x{K}"
+
+
+def _rowrel(out, exact):
+    return ((out.double().cpu() - exact).abs().amax(dim=1) / exact.abs().amax(dim=1).clamp_min(1e-300)).max().item()
+
+
+def test_products_on_rows_of_very_different_scales(hip):
+    """forward / dgrad layouts scale every row on its own: rows 60 orders of magnitude apart, zero rows and rows whose largest element
+    is an fp32 denormal all come out as accurately as from the native fp32 matrix instruction"""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 600, 256, 512
+    A = torch.randn(M, K, generator=g) * torch.pow(10.0, torch.empty(M, 1).uniform_(-30, 30, generator=g))
+    A[::7] = 0.0
+    B = torch.randn(N, K, generator=g) * torch.pow(10.0, torch.empty(N, 1).uniform_(-6, 6, generator=g))
+    exact = A.double() @ B.double().t()
+    errs = {}
+    for p in ("f32", "f32_f16x3"):
+        out = torch.empty(M, N, device="cuda")
+        hip.gemm(A.cuda(), B.cuda(), out, M=M, N=N, K=K, precision=p)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        errs[p] = _rowrel(out, exact)
+    assert errs["f32_f16x3"] <= 2.0 * errs["f32"] + 5e-7, errs
+
+
+def test_small_elements_under_a_large_one_keep_their_bits(hip):
+    """elements 2^-18 below their row's maximum live in the LOW fp16 piece as fp16 denormals: the matrix cores must not flush them
+    (flushed: ~2^-12 relative error of this result; kept: fp32-grade)"""
+    M, N, K = 256, 256, 512
+    g = torch.Generator().manual_seed(9)
+    A = (1.0 + torch.rand(M, K, generator=g)) * 2.0 ** -18
+    A[:, 0] = 1.0
+    B = torch.randn(N, K, generator=g)
+    B[:, 0] = 0.0
+    exact = A.double() @ B.double().t()
+    out = torch.empty(M, N, device="cuda")
+    hip.gemm(A.cuda(), B.cuda(), out, M=M, N=N, K=K, precision="f32_f16x3")
+    torch.cuda.synchronize()
+    assert _rowrel(out, exact) < 2e-6
+
+
+def test_weight_gradient_with_columns_of_very_different_scales(hip):
+    """the weight-gradient product scales each operand by ONE power of two (the reduction runs over its rows): columns up to 2^16 below
+    the tensor's largest element keep full precision, smaller ones lose it gradually (documented bound: absolute error per element
+    <= 2^-39 of the tensor's largest); checked column by column against float64"""
+    g = torch.Generator().manual_seed(21)
+    T, Np, Kp = 6000, 512, 512
+    colscale = torch.pow(2.0, -torch.arange(Np, dtype=torch.float32) * (24.0 / Np))      # columns from 1 down to 2^-24
+    dz = torch.randn(T, Np, generator=g) * colscale
+    x = torch.randn(T, Kp, generator=g)
+    exact = dz.double().t() @ x.double()
+    dw = torch.zeros(Np, Kp, device="cuda")
+    hip.gemm(dz.cuda(), x.cuda(), dw, M=Np, N=Kp, K=T, a_kcontig=False, b_kcontig=False, accumulate=True, precision="f32_f16x3")
+    torch.cuda.synchronize()
+    err_rows = (dw.double().cpu() - exact).abs().amax(dim=1) / exact.abs().amax(dim=1)         # one row of dW per column of dz
+    full = colscale >= 2.0 ** -15
+    assert err_rows[full].max() < 2e-6, err_rows[full].max()
+    # below: at most 2^-39 of the largest element per term, sqrt(T) terms -> relative to the column's own scale
+    bound = 2e-6 + (2.0 ** -39) * math.sqrt(T) * 4 / colscale.double()
+    assert (err_rows <= bound).all(), (err_rows / bound).max()
+
+
+def _train_step(precision, wl="C1-dipeptide-b8"):
+    import bench
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import WORKLOADS, build_batch_from_pool, workload_molecule_ids
+    be = get_backend()
+    old = be.gemm_precision_name
+    be.set_gemm_precision(precision)
+    try:
+        dev = torch.device("cuda:0")
+        model = model_from_config(get_default_model_config())
+        bench.keyed_init(model)
+        model = model.to(dev).train()
+        ops.manual_seed(99)
+        ids = workload_molecule_ids(wl)[:8]
+        gph = build_batch_from_pool(ids, n_confs=WORKLOADS[wl][3], seed=0).to(dev)
+        loss = MolwiseLoss(**bench.LOSS_KW)(Energy()(model(gph)))
+        loss.backward()
+        be.flush_wgrads()
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+    finally:
+        be.set_gemm_precision(old)
+
+
+def test_train_step_matches_default_arithmetic():
+    """one train step (dropout on, same seeds) in f32_f16x3 and in the default f32_bf16x6: loss and every parameter gradient agree
+    to fp32 rounding (the gate of SURVEY 8(d) is 1e-4; measured here ~1e-6)"""
+    l6, g6 = _train_step("f32_bf16x6")
+    l3, g3 = _train_step("f32_f16x3")
+    assert abs(l3 - l6) <= 2e-6 * abs(l6), (l3, l6)
+    worst = 0.0
+    for n in g6:
+        scale = g6[n].abs().max().item()
+        if scale == 0:
+            continue
+        worst = max(worst, (g3[n] - g6[n]).abs().max().item() / scale)
+    assert worst < 2e-5, worst

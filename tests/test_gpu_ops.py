@@ -102,14 +102,14 @@ def test_gemm_epilogues(hip, ref, precision):
 
 
 # tolerance of each arithmetic mode of the GEMM (include/grappa_hip.h GRAPPA_GEMM_*) against a float64 product, relative to max|C|
-GEMM_MODE_TOL = {"f32": 1e-5, "f32_bf16x9": 1e-5, "f32_bf16x6": 1e-5, "bf16x3": 1e-4, "bf16": 2e-2}
+GEMM_MODE_TOL = {"f32": 1e-5, "f32_bf16x9": 1e-5, "f32_bf16x6": 1e-5, "f32_f16x3": 1e-5, "bf16x3": 1e-4, "bf16": 2e-2}
 
 
 @pytest.mark.parametrize("precision", list(GEMM_MODE_TOL))
 @pytest.mark.parametrize("M,N,K,ak,bk", GEMM_CASES + [(8300, 1536, 512, 1, 1), (8300, 512, 2048, 1, 0), (33, 33, 31, 1, 1), (640, 640, 64, 0, 0)])
 def test_gemm_precision_modes(hip, M, N, K, ak, bk, precision):
-    """bf16-split emulation of the fp32 product: the x9 / x6 modes must be as close to the exact (float64) product as the native
-    fp32 matrix instruction is; operands with a wide dynamic range (1e-3 .. 1e3 scales per row) exercise the low-order pieces."""
+    """bf16-split (x9 / x6) and fp16-split (f16x3) emulation of the fp32 product: they must be as close to the exact (float64) product
+    as the native fp32 matrix instruction is; operands with a wide dynamic range (1e-3 .. 1e3 scales per row) exercise the low-order pieces."""
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + 1)
     A = torch.randn((M, K) if ak else (K, M), generator=g)
     B = torch.randn((N, K) if bk else (K, N), generator=g)
@@ -126,7 +126,7 @@ def test_gemm_precision_modes(hip, M, N, K, ak, bk, precision):
     except OSError:
         pass
     assert math.isfinite(err) and err < GEMM_MODE_TOL[precision], f"{precision} {M}x{N}x{K}: {err:.3e}"
-    if precision in ("f32_bf16x9", "f32_bf16x6"):
+    if precision in ("f32_bf16x9", "f32_bf16x6", "f32_f16x3"):
         # fp32-grade claim: no further from the exact product than the native fp32 matrix instruction on the same inputs
         # (both carry ~sqrt(K) * 2^-24 of accumulation-order noise; 2x + 5e-7 absorbs the difference in summation order)
         hip.gemm(A.cuda(), B.cuda(), out_h, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), precision="f32")
