@@ -158,10 +158,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=1024, help="molecules per forward/backward pass of a rank (larger shards are accumulated over chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the C3 and C4-on-one-GPU timings that follow the headline measurement")
-    ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_bf16x6)")
+    ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_f16x3)")
     ap.add_argument("--act-dtype", default="f32", choices=["f32", "bf16"], help="bf16: the bf16 STORAGE configuration for the main job (profiling / "
                     "BASELINE configs[2] runs; the line's dtype then reads bf16 -- never the default)")
-    ap.add_argument("--alt-precision", default="f32", help="also time K steps with this GEMM arithmetic (reported beside the default); '' to skip")
+    ap.add_argument("--alt-precision", default="f32,f32_bf16x6", help="also time K steps with these GEMM arithmetics (comma separated; reported beside the default); '' to skip")
     ap.add_argument("--bwd-precision", default="", help="also time K steps with the backward-pass products in this arithmetic (reported beside the default, never as `value`); '' to skip")
     ap.add_argument("--cpu-sample", type=int, default=32, help="molecules in the CPU baseline sample")
     ap.add_argument("--cpu-limit", type=float, default=150.0, help="wall-clock limit of the CPU baseline children, seconds")
@@ -292,7 +292,8 @@ def main():
     log(f"timed region done: {1e3 * dt / args.steps:.1f} ms/step; instrumented pass")
 
     GEMM_PEAK_NOTE = ("achieved = algorithmic 2MNK FLOPs / HIP-event time of the calls; peak = bf16 dense MFMA peak (16 x 157.3 TFLOP/s, "
-                      "MI355X_MICROARCH.md) / partial products issued per fp32 product")
+                      "MI355X_MICROARCH.md; the fp16 one is the same) / partial products issued per fp32 product; the time of the operands' "
+                      "maxima passes (f32_f16x3) is charged to the products")
 
     def instrument(j, steps):
         """instrumented repetition of a job's steps: HIP events around every GEMM / GAT launch on the launch stream (one stream:
@@ -354,12 +355,12 @@ def main():
         return {"value": job.global_batch * args.steps / d, "ms_per_step": 1e3 * d / args.steps}
 
     # the same K steps with the dense products on the native fp32 matrix instruction, for reference next to the default
-    alt = None
-    if args.alt_precision and args.alt_precision != be.gemm_precision_name:
+    alt = {}
+    for name in [a for a in args.alt_precision.split(",") if a and a != be.gemm_precision_name]:
         default_precision = be.gemm_precision_name
-        alt = alt_run(lambda: be.set_gemm_precision(args.alt_precision), lambda: be.set_gemm_precision(default_precision))
-        alt["gemm_precision"] = args.alt_precision
-        log(f"alt precision {args.alt_precision}: {alt['ms_per_step']:.1f} ms/step")
+        alt[name] = alt_run(lambda: be.set_gemm_precision(name), lambda: be.set_gemm_precision(default_precision))
+        alt[name]["gemm_precision"] = name
+        log(f"alt precision {name}: {alt[name]['ms_per_step']:.1f} ms/step")
     bwd = None
     if args.bwd_precision:
         bwd = alt_run(lambda: be.set_gemm_precision_bwd(args.bwd_precision), lambda: be.set_gemm_precision_bwd(None))
@@ -371,12 +372,15 @@ def main():
     # opt-in kernel (GRAPPA_WEIGHT_PLANES): the same steps with the weights read from their pre-split bf16 planes by LDS-DMA
     wpl = None
     if world == 1 and not args.no_extras and not be.weight_planes and args.act_dtype == "f32":
+        default_precision = be.gemm_precision_name
+        be.set_gemm_precision("f32_bf16x6")            # the plane format is a bf16 split: it rides on the bf16x6 arithmetic
         be.weight_planes = True
         d_w, _ = job.timed(args.steps, 1)
         be.weight_planes = False
-        wpl = {"value": job.global_batch * args.steps / d_w, "ms_per_step": 1e3 * d_w / args.steps,
-               "note": "GRAPPA_WEIGHT_PLANES=1: forward / dgrad products read the weight from bf16 planes split once per optimiser step "
-                       "(csrc/gemm_planes.hip gemm_wplanes_kernel); results equal the default to rounding; not the default"}
+        be.set_gemm_precision(default_precision)
+        wpl = {"value": job.global_batch * args.steps / d_w, "ms_per_step": 1e3 * d_w / args.steps, "gemm_precision": "f32_bf16x6",
+               "note": "GRAPPA_WEIGHT_PLANES=1 with GRAPPA_GEMM_PRECISION=f32_bf16x6: forward / dgrad products read the weight from bf16 planes "
+                       "split once per optimiser step (csrc/gemm_planes.hip gemm_wplanes_kernel); results equal f32_bf16x6 to rounding; not the default"}
         log(f"weight planes: {wpl['ms_per_step']:.1f} ms/step")
 
     # N = 1: the other single-GPU configurations, timed right after the headline measurement: C3 in the headline arithmetic, C3 in the
@@ -439,11 +443,13 @@ def main():
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16" if args.act_dtype == "bf16" else "f32", "data": "synthetic",
             "config": cfg,
             "gemm_arithmetic": {"default": be.gemm_precision_name,
-                                "note": "inputs, outputs, accumulation and every non-GEMM kernel are fp32; f32_bf16x6 splits each fp32 operand "
-                                        "exactly into 3 bf16 pieces and sums the 6 largest partial products on the bf16 matrix cores "
-                                        "(error vs a float64 product <= that of the native fp32 MFMA: tests/test_gpu_ops.py::"
-                                        "test_gemm_precision_modes; end-to-end parity: tests/test_gpu_e2e.py, tests/test_gpu_configs.py)",
-                                "native_f32_mfma": alt, "backward_reduced": bwd, "weight_planes": wpl},
+                                "note": "inputs, outputs, accumulation and every non-GEMM kernel are fp32; f32_f16x3 scales every row of an "
+                                        "fp32 operand by a power of two (largest magnitude -> [2^14, 2^15)), splits it into 2 fp16 pieces "
+                                        "(24 significant bits) and sums the 3 largest partial products on the fp16 matrix cores; f32_bf16x6 "
+                                        "(the previous default) = 3 bf16 pieces, 6 products.  Error vs a float64 product <= that of the native "
+                                        "fp32 MFMA for both (tests/test_gpu_ops.py::test_gemm_precision_modes, tests/test_gpu_f16x3.py); "
+                                        "end-to-end parity: tests/test_gpu_e2e.py, tests/test_gpu_configs.py",
+                                "native_f32_mfma": alt.get("f32"), "f32_bf16x6": alt.get("f32_bf16x6"), "backward_reduced": bwd, "weight_planes": wpl},
             "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": ms_instr, "final_loss": final_loss,
         }
         out.update(extras)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "grappa_split_planes_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _sz, _i]),
     "grappa_amax_f32_workspace_bytes": (_sz, [_i, _i]),
     "grappa_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz]),
+    "grappa_amax_f32_batched": (_i, [_vp, _i, _vp]),
     "grappa_amax_reduce": (_i, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _vp]),
     "grappa_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
     "grappa_gemm_f32_plan": (_i, [_i, _i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),

@@ -81,7 +81,7 @@ def _flat(t: torch.Tensor, name: str, dev, dtype=torch.float32) -> None:
         raise ValueError(f"{name}: expected a contiguous {dtype} tensor on {dev}")
 
 
-DEFAULT_GEMM_PRECISION = "f32_bf16x6"
+DEFAULT_GEMM_PRECISION = "f32_f16x3"
 
 
 _AMAX_LOG = None      # tools/amax_passes.py sets a list here
@@ -105,9 +105,10 @@ class HipBackend:
             raise RuntimeError("grappa_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self._ws = {}
-        # arithmetic of the dense products (include/grappa_hip.h GRAPPA_GEMM_*): "f32_bf16x6" = fp32 operands split into three
-        # bf16 pieces on the bf16 matrix cores with fp32 accumulation -- at least as close to the exact product as the native
-        # fp32 MFMA (tests/test_gpu_ops.py::test_gemm_precision_modes) at ~1.7x its speed; "f32" = native fp32 MFMA
+        # arithmetic of the dense products (include/grappa_hip.h GRAPPA_GEMM_*): "f32_f16x3" = fp32 operands, every row scaled by a
+        # power of two, split into two fp16 pieces (3 partial products on the fp16 matrix cores, fp32 accumulation); "f32_bf16x6" =
+        # three bf16 pieces, 6 products (the default until round 2).  Both are at least as close to the exact product as the native
+        # fp32 MFMA (tests/test_gpu_ops.py::test_gemm_precision_modes) at ~2.3x / ~1.7x its speed; "f32" = native fp32 MFMA
         self.set_gemm_precision(os.environ.get("GRAPPA_GEMM_PRECISION", DEFAULT_GEMM_PRECISION))
         # optional, OFF by default: a separate arithmetic for the products of the BACKWARD pass (dgrad / wgrad layouts), e.g.
         # "bf16x3" (two bf16 pieces per operand, 2^-16 per product).  The forward pass -- parameters, energies, forces, loss -- is
@@ -129,7 +130,8 @@ class HipBackend:
         # precision "f32_f16x3": largest |element| per row / column of every operand (grappa_amax_f32).  Weights: cached until the
         # optimiser step; activations: an `Amax` record travels with the tensor through ops.py (gemm returns it, the backward
         # products receive it), anything missing is computed by one pass over the tensor
-        self._wamax = {}       # (data_ptr, rows, cols) -> (version key, weight kept alive, Amax)
+        self._wamax = {}       # (data_ptr, rows, cols, ld) -> [version key, weight kept alive, Amax, epoch of last use, batchable]
+        self._wtable = None    # (device table of grappa_amax_item, count) of the batchable entries
         # weight-gradient products reduce over the tokens, so each operand gets ONE scale (its largest magnitude): columns more than
         # 2^16 below it lose relative precision gradually.  GRAPPA_WGRAD_COLUMN_MAXIMA=1 gives every column its own scale instead,
         # at the price of one extra pass over both operands of every weight-gradient product (rigorous, ~15 % slower steps)
@@ -235,17 +237,48 @@ class HipBackend:
         return torch.empty(t.shape[0], dtype=torch.int32, device=t.device)
 
     def _amax_of_weight(self, w: torch.Tensor) -> "Amax":
-        """row and column maxima of a weight matrix, refreshed when the weight changed (as _planes_of_weight); the entry keeps the
-        weight alive, so its address cannot be handed to another tensor while the entry exists"""
+        """row and column maxima of a weight matrix, refreshed when the weight changed (as _planes_of_weight).  Entries keep their
+        weight alive, so its address cannot be handed to another tensor while the entry exists.  After an optimiser step the first
+        stale weight refreshes EVERY registered weight in one launch (grappa_amax_f32_batched: one workgroup per weight)."""
         R, Cc = w.shape
         key = (w.data_ptr(), R, Cc, w.stride(0))
         ver = (w._version, self._wepoch)
         hit = self._wamax.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[2]
-        am = self.amax(w, None, rows=True, cols=True)
-        self._wamax[key] = (ver, w, am)
+        if hit is not None:
+            hit[3] = self._wepoch
+            if hit[0] == ver:
+                return hit[2]
+            if hit[4]:                                     # registered for the batched refresh
+                self._refresh_weight_amax()
+                if hit[0] == ver:
+                    return hit[2]
+        am = self.amax(w, None, rows=True, cols=True)      # a new weight, or one the batched kernel cannot take: a pass of its own
+        batchable = Cc % 4 == 0 and Cc <= 2048 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0 and w.stride(1) == 1
+        self._wamax[key] = [ver, w, am, self._wepoch, batchable]
+        self._wtable = None
         return am
+
+    def _refresh_weight_amax(self) -> None:
+        import numpy as np
+        # weights not used since the step before last leave the table (dead models of a test session, frozen heads, ...)
+        for k in [k for k, e in self._wamax.items() if e[3] < self._wepoch - 1]:
+            del self._wamax[k]
+            self._wtable = None
+        live = [e for e in self._wamax.values() if e[4]]
+        if not live:
+            return
+        if self._wtable is None:
+            dt = np.dtype([("x", "<u8"), ("R", "<i4"), ("C", "<i4"), ("ld", "<i4"), ("pad", "<i4"), ("row", "<u8"), ("col", "<u8")])
+            tab = np.zeros(len(live), dtype=dt)
+            for i, e in enumerate(live):
+                w, am = e[1], e[2]
+                tab[i] = (w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), 0, am.row.data_ptr(), am.col.data_ptr())
+            self._wtable = (torch.from_numpy(tab.view(np.uint8).copy()).to(live[0][1].device), len(live))
+        tab, n = self._wtable
+        self._timed("amax", 0.0, 4.0 * sum(e[1].numel() for e in live),
+                    lambda: _chk(self.lib.grappa_amax_f32_batched(self._stream(), n, tab.data_ptr()), "grappa_amax_f32_batched"))
+        for e in live:
+            e[0] = (e[1]._version, self._wepoch)
 
     # ------------------------------------------------------------------ in-process kernel timing (bench.py roofline)
     def start_profile(self) -> None:
@@ -326,7 +359,7 @@ class HipBackend:
         if tuple(a.shape) != (ar, ac) or tuple(b.shape) != (br, bc) or tuple(out.shape) != (M, N):
             raise ValueError(f"gemm: shapes A{tuple(a.shape)} B{tuple(b.shape)} C{tuple(out.shape)} do not match M={M} N={N} K={K}")
         if M == 0 or N == 0:
-            return
+            return (None, None) if out_amax else None
         if K == 0:
             raise ValueError("gemm: K == 0")
         if precision is not None:
@@ -351,7 +384,8 @@ class HipBackend:
                 else:
                     a = self.to_f32(a)
             if planes_a is None and (self.weight_planes and b.requires_grad and big and K % 32 == 0 and a_colsum is None
-                                     and d.precision != _lib.GEMM_PRECISIONS["f32"] and a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0):
+                                     and d.precision not in (_lib.GEMM_PRECISIONS["f32"], _lib.GEMM_PRECISIONS["f32_f16x3"])
+                                     and a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0):
                 planes_b = self._planes_of_weight(b, transposed=not b_kcontig)      # fp32 activations x pre-split weight planes
         else:
             if b_kcontig:

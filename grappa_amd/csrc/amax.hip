@@ -144,6 +144,47 @@ __global__ __launch_bounds__(256) void amax_combine_kernel(int M, int nseg, cons
     out[m] = v;
 }
 
+// one workgroup per matrix (weights: at most a few MB each); column maxima meet in LDS (ds_max_u32)
+__global__ __launch_bounds__(1024) void amax_batched_kernel(const grappa_amax_item* __restrict__ descs) {
+    __shared__ unsigned colmax[2048];
+    const grappa_amax_item d = descs[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < 2048; c += 1024) colmax[c] = 0u;
+    __syncthreads();
+    uint4 cm[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) cm[ch] = make_uint4(0u, 0u, 0u, 0u);
+    for (int r = wave; r < d.R; r += 16) {
+        const unsigned* row = reinterpret_cast<const unsigned*>(d.x) + (size_t)r * d.ld;
+        unsigned rm = 0u;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const int c = ch * 256 + lane * 4;
+            if (c < d.C) {
+                const uint4 t = *reinterpret_cast<const uint4*>(row + c);
+                const uint4 v = make_uint4(t.x & 0x7fffffffu, t.y & 0x7fffffffu, t.z & 0x7fffffffu, t.w & 0x7fffffffu);
+                rm = max(rm, umax4(v));
+                cm[ch] = make_uint4(max(cm[ch].x, v.x), max(cm[ch].y, v.y), max(cm[ch].z, v.z), max(cm[ch].w, v.w));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rm = max(rm, (unsigned)__shfl_xor((int)rm, o, 64));
+        if (lane == 0) d.row_amax[r] = rm;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        const int c = ch * 256 + lane * 4;
+        if (c < d.C) {
+            atomicMax(&colmax[c], cm[ch].x);
+            atomicMax(&colmax[c + 1], cm[ch].y);
+            atomicMax(&colmax[c + 2], cm[ch].z);
+            atomicMax(&colmax[c + 3], cm[ch].w);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.C; c += 1024) d.col_amax[c] = colmax[c];
+}
+
 int amax_blocks(int R) {
     const int per = (AMAX_THREADS / 64) * AMAX_ROWS_IN_FLIGHT;
     const int b = (R + per - 1) / per;
@@ -216,5 +257,12 @@ extern "C" int grappa_amax_reduce(void* stream, int count, const uint32_t* const
 // called by grappa_gemm_f32 (gemm_f32.hip) after a product that wrote per-segment row maxima
 int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* part, unsigned* out) {
     hipLaunchKernelGGL(amax_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, nseg, part, out);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_amax_f32_batched(void* stream, int count, const grappa_amax_item* descs) {
+    if (count < 0 || (count > 0 && !descs)) return GRAPPA_ERR_ARG;
+    if (count == 0) return GRAPPA_OK;
+    hipLaunchKernelGGL(amax_batched_kernel, dim3(count), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), descs);
     return grappa_launch_status();
 }

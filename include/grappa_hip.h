@@ -129,6 +129,14 @@ typedef struct grappa_gemm_desc {
  * ws: grappa_amax_f32_workspace_bytes(R, C) bytes (partial column maxima), needed only with col_amax. */
 size_t grappa_amax_f32_workspace_bytes(int R, int C);
 int grappa_amax_f32(void* stream, int R, int C, const float* x, int ldx, uint32_t* row_amax, uint32_t* col_amax, void* ws, size_t ws_bytes);
+/* Row and column maxima of many small matrices in ONE launch (the weights of a model, refreshed once per optimiser step): matrix i is
+ * handled by workgroup i.  `descs` is a DEVICE array; every matrix needs C % 4 == 0, C <= 2048, ld % 4 == 0 and a 16-byte aligned base
+ * (the caller checks: the library cannot read the table). */
+typedef struct grappa_amax_item {
+    const float* x; int R, C, ld, pad_;
+    uint32_t* row_amax; uint32_t* col_amax;
+} grappa_amax_item;
+int grappa_amax_f32_batched(void* stream, int count, const grappa_amax_item* descs);
 /* out[b] = max_i in[b][i], i < n[b], for `count` arrays in one launch per 32 (bit patterns of magnitudes: unsigned order): whole-tensor
  * maxima from row maxima.  `in` and `n` are HOST arrays (of device pointers / lengths). */
 int grappa_amax_reduce(void* stream, int count, const uint32_t* const* in, const int* n, uint32_t* out);

@@ -218,3 +218,33 @@ def test_train_step_matches_default_arithmetic():
             continue
         worst = max(worst, (g3[n] - g6[n]).abs().max().item() / scale)
     assert worst < 2e-5, worst
+
+
+def test_weight_maxima_follow_the_optimiser(hip):
+    """weights: maxima cached per optimiser step; the step after, one batched launch refreshes every registered weight"""
+    ws = [torch.randn(r, c, device="cuda").requires_grad_() for r, c in ((512, 512), (1536, 512), (256, 2048), (300, 85), (512, 2052))]
+    x = {w.shape[1]: torch.randn(100, w.shape[1], device="cuda") for w in ws}
+
+    def run():
+        outs = []
+        for w in ws:
+            o = torch.empty(100, w.shape[0], device="cuda")
+            hip.gemm(x[w.shape[1]], w, o, M=100, N=w.shape[0], K=w.shape[1], precision="f32_f16x3")
+            outs.append(o)
+        torch.cuda.synchronize()
+        return outs
+
+    run()
+    for w in ws:
+        am = hip._amax_of_weight(w)
+        assert torch.equal(am.row, bits(w).amax(dim=1)) and torch.equal(am.col, bits(w).amax(dim=0))
+    with torch.no_grad():
+        for i, w in enumerate(ws):
+            w.view(-1)[::7] *= 1000.0 * (i + 1)             # the "optimiser": rewrites the weights ...
+    hip.invalidate_weight_planes()                          # ... and says so (FusedAdam.step does)
+    outs = run()
+    for w, o in zip(ws, outs):
+        am = hip._amax_of_weight(w)
+        assert torch.equal(am.row, bits(w).amax(dim=1)) and torch.equal(am.col, bits(w).amax(dim=0))
+        exact = x[w.shape[1]].double().cpu() @ w.detach().double().cpu().t()
+        assert torch.isfinite(o).all() and _rowrel(o, exact) < 2e-6

@@ -57,7 +57,9 @@ def test_train_steps_with_weight_planes_match_the_default():
     from grappa_amd.optim import FlatParams, FusedAdam
     be = get_backend()
     res = []
+    default_precision = be.gemm_precision_name
     try:
+        be.set_gemm_precision("f32_bf16x6")                     # the plane format is a bf16 split: it rides on this arithmetic
         for use in (False, True):
             be.weight_planes = use
             model = model_from_config(get_default_model_config())
@@ -78,6 +80,7 @@ def test_train_steps_with_weight_planes_match_the_default():
             res.append(out)
     finally:
         be.weight_planes = False
+        be.set_gemm_precision(default_precision)
     # per product the two kernels are bit-identical (test_plane_gemms_against_float64); inside the model the planner may pick
     # another tile / split-K plan for the plane kernel (256 x 128 only), i.e. another summation order: fp32 rounding noise
     for (l0, g0, k0), (l1, g1, k1) in zip(*res):
