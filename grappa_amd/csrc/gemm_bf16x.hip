@@ -25,6 +25,15 @@
 
 using namespace grappa_gemm;
 
+// timing experiments only (tools/gemm_f16x3_check.py --build-variants): GB_KNOCK = 1 no MFMAs, 2 no split arithmetic (raw halves
+// stored), 3 no global loads in the steady state, 4 no LDS traffic in the steady state, 5 no barrier in the steady state, 6 no epilogue
+#ifndef GB_KNOCK
+#define GB_KNOCK 0
+#endif
+#ifndef GB_STAGGER
+#define GB_STAGGER 0
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -107,6 +116,12 @@ __device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[RO
         if (HALF) {
             // (packed multiplies and v_fma_mix_f32 residuals -- 40 instead of 67 vector instructions per slab -- measured no faster:
             // the vector unit is not what this kernel waits for; the plain form keeps the exact v_ldexp_f32 for any shift)
+            if (GB_KNOCK == 2) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    *reinterpret_cast<uint2*>(dst + p * (ROWS * ROWB)) = make_uint2(__float_as_uint(r[p]) & 0x3bff3bffu, __float_as_uint(r[p + 2]) & 0x3bff3bffu);
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] = __builtin_ldexpf(r[e], shift[j]);
 #pragma unroll
@@ -193,7 +208,7 @@ __device__ inline void mfma_range(const Frags<Pieces<MODE>::NP, TM, TN>& f, f32x
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     // B fragment first: the accumulator holds the transposed tile (4 consecutive n per lane, tile_epilogue_rows)
-                    if (idx >= LO && idx < HI) {
+                    if (GB_KNOCK != 1 && idx >= LO && idx < HI) {
                         if (MODE == H3)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b[j][pb]), __builtin_bit_cast(f16x8, f.a[i][pa]),
                                                                                acc[i][j], 0, 0, 0);
@@ -261,14 +276,14 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     constexpr int NFIRST = NM >= 12 ? NM * 2 / 3 : NM / 2;
     const bool do_store = !TAIL || s + 1 < kr.nsteps;
     const bool do_load = !TAIL || s + AHEAD < kr.nsteps;
-    if (do_load) {
+    if (do_load && !(GB_KNOCK == 3 && !TAIL)) {
         load_quads<NT, BM, AK, VEC>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
         load_quads<NT, BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
     }
     __builtin_amdgcn_sched_barrier(0);
     char* nxt = smem + ((s + 1) & 1) * STAGE;
     mfma_range<MODE, TM, TN, 0, NFIRST>(fc, acc);
-    if (do_store) {
+    if (do_store && !(GB_KNOCK == 4 && !TAIL)) {
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
         store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF>(nxt, sa, krem, sha);
         store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF>(nxt + NP * BM * ROWB, sb, krem, shb);
@@ -281,9 +296,10 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
         PhaseOrder<0, NFIRST, NQ * NP, NQ * (NP == 3 ? 26 : NP == 2 ? (Pieces<MODE>::HALF ? 20 : 16) : 6)>::emit();      // vector ops per quad as counted in the ISA (an over-estimate leaves the last MFMAs bare)
     }
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    if (!(GB_KNOCK == 5 && !TAIL)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (do_store) read_frags<NP, BM, BN, TM, TN>(nxt, wm0, wn0, lr, lh, fn);
+    if (do_store && !(GB_KNOCK == 4 && !TAIL)) read_frags<NP, BM, BN, TM, TN>(nxt, wm0, wn0, lr, lh, fn);
+    if (GB_KNOCK == 4 && !TAIL) fn = fc;
     mfma_range<MODE, TM, TN, NFIRST, NM>(fc, acc);
     if (!TAIL) {
         // the next slab's fragment reads ride between these MFMAs instead of all eight wavefronts bursting them at the LDS
@@ -303,6 +319,10 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
     static_assert((NT / 64 / WN) * 64 == BM, "wavefront grid must cover the tile");
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
+    if (GB_STAGGER > 0 && wgid < 256) {                      // experiment: the first workgroup of a CU starts late by 0 .. 3 units
+        const int ph = (wgid >> 3) & 3;
+        for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(GB_STAGGER);
+    }
     const TileCoord tc = map_logical(p, nwg, wgid);
     const int split = tc.split, tile_local = tc.tile_local, tile_n = tc.tile_n;
     const int m0 = tc.tile_m * BM, n0 = tile_n * BN;
@@ -407,7 +427,7 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
             }
         }
     }
-    if (Pieces<MODE>::HALF) {
+    if (Pieces<MODE>::HALF && GB_KNOCK != 8) {
         // undo the row scales: accumulator element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, wn0 + 32 j + 8 (e / 4) + 4 lh + e % 4)
         int ea[TM];
 #pragma unroll
@@ -423,6 +443,17 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
             }
     }
     __syncthreads();                                         // the stages (and the column-sum scratch) are dead: reuse as staging
+    if (GB_KNOCK == 6) {
+        float t = 0.f;                                       // keep every accumulator alive
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        if (t == 123.456f) p.d.C[0] = t;
+        return;
+    }
     tile_epilogue_rows<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES), m0, n0, wm0, wn0, lane, split, tile_local,
                                        p.vec_io != 0);
 }

@@ -5,6 +5,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef GB_KNOCK
+#define GB_KNOCK 0            // timing experiments (gemm_bf16x.hip): 7 = the row epilogue issues no global stores
+#endif
 namespace grappa_gemm {
 
 constexpr int GEMM_BK = 32;
@@ -26,6 +29,9 @@ struct GemmParams {
     // and combined by amax_combine_kernel after the product's launches
     unsigned* amax_part;
     int amax_seg;
+    // straight-line row epilogue for the common fp32 cases (host-chosen, epilogue_band_fast): 0 = the general walk; 1 = bias;
+    // 2 = bias + ELU; 3 = bias + dropout + residual; 4 = ELU' from the saved output (aux), optional residual
+    int epi_class;
 };
 
 // ---- plane format (include/grappa_hip.h): X = P0 + P1 + P2, three bf16 planes
@@ -104,6 +110,24 @@ __device__ inline float epilogue_store(const GemmParams& p, int m, int n, float 
     return v;
 }
 __device__ inline unsigned mag_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+// max over aligned groups of G = 16 or 8 lanes, valid in every lane, on the DPP data path (a __shfl_xor is an LDS crossbar round trip:
+// four dependent ones per row made the row maxima cost more than the pass they replace)
+template <int G>
+__device__ inline unsigned group_umax(unsigned v) {
+#define GRAPPA_DPP_MAX(CTRL) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true))
+    if (G == 16) {
+        GRAPPA_DPP_MAX(0x128);      // row_ror:8
+        GRAPPA_DPP_MAX(0x124);      // row_ror:4
+        GRAPPA_DPP_MAX(0x122);      // row_ror:2
+        GRAPPA_DPP_MAX(0x121);      // row_ror:1
+    } else {
+        GRAPPA_DPP_MAX(0x141);      // row_half_mirror: lane i <-> 7 - i
+        GRAPPA_DPP_MAX(0xB1);       // quad_perm [1, 0, 3, 2]
+        GRAPPA_DPP_MAX(0x4E);       // quad_perm [2, 3, 0, 1]
+    }
+#undef GRAPPA_DPP_MAX
+    return v;
+}
 
 
 // XCD-aware bijective remap of the linear workgroup id (blocks b and b+8 share an XCD): consecutive LOGICAL ids run on one XCD.
@@ -189,9 +213,79 @@ __device__ inline void tile_epilogue(const GemmParams& p, const f32x16 (&acc)[TM
 constexpr int EPI_LD = 68;                          // floats per staged row (64 + 4 pad: conflict-free 16-byte writes)
 constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;     // private staging region per wavefront
 
+// The common cases of the row epilogue as straight-line code.  The general walk below decides ~30 uniform branches per trip (which
+// tensors exist, their element types, ...): at K = 512 that walk was a quarter of the kernel (knock-outs: profiles/r2z_gemm_f16x3_*).
+// Here the case is a template parameter, every LDS read and every load of res / aux is issued before the first use, and a lane works
+// on whole float4s only (host: N % 4 == 0, all tensors 16-byte aligned, fp32, one output tensor, no pre-activation addend).
+//   CLS 1: v + bias            2: elu(v + bias)            3: drop(v + bias) + res (drop_p may be 0, res may be NULL)
+//   CLS 4: v * elu'(aux) (+ res)
+template <int TN, int CLS>
+__device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f32x16 (&acc_i)[TN], float* __restrict__ wave_buf, int mband, int n, int lane,
+                                          const float4& b4) {
+    const grappa_gemm_desc& d = p.d;
+    const int lr = lane & 31, lh = lane >> 5;
+    constexpr int ROWS_PER_IT = TN == 2 ? 4 : 8;
+    constexpr int NIT = 32 / ROWS_PER_IT;
+    const int rrow = TN == 2 ? (lane >> 4) : (lane >> 3), rc4 = TN == 2 ? ((lane & 15) << 2) : ((lane & 7) << 2);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(wave_buf + lr * EPI_LD + j * 32 + 8 * g + 4 * lh) =
+                make_float4(acc_i[j][4 * g], acc_i[j][4 * g + 1], acc_i[j][4 * g + 2], acc_i[j][4 * g + 3]);
+    const bool col_ok = n < d.N;
+    const int mfirst = mband + rrow;
+    const float* side = CLS == 3 ? d.res : (CLS == 4 ? d.aux : nullptr);
+    const int ldside = CLS == 3 ? d.ldres : d.ldaux;
+    constexpr int HB = NIT / 2;                              // two batches of trips: loads of a batch in flight together
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 v[HB], t[HB], r4[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const int it = h * HB + k, m = mfirst + it * ROWS_PER_IT;
+            v[k] = *reinterpret_cast<const float4*>(wave_buf + (it * ROWS_PER_IT + rrow) * EPI_LD + rc4);
+            t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            r4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((CLS == 3 || CLS == 4) && side && col_ok && m < d.M) t[k] = *reinterpret_cast<const float4*>(side + (size_t)m * ldside + n);
+            if (CLS == 4 && d.res && col_ok && m < d.M) r4[k] = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
+        }
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const int it = h * HB + k, m = mfirst + it * ROWS_PER_IT;
+            float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            if (CLS != 4) { x[0] += b4.x; x[1] += b4.y; x[2] += b4.z; x[3] += b4.w; }
+            if (CLS == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = grappa_elu(x[q]);
+            }
+            if (CLS == 3) {
+                if (d.drop_p > 0.0f) {
+                    const uint64_t idx = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = grappa_keep(d.drop_seed, idx + q, d.drop_p) ? x[q] * p.drop_scale : 0.0f;
+                }
+                x[0] += t[k].x; x[1] += t[k].y; x[2] += t[k].z; x[3] += t[k].w;
+            }
+            if (CLS == 4) {
+                x[0] = x[0] * grappa_elu_grad_from_out(t[k].x) + r4[k].x; x[1] = x[1] * grappa_elu_grad_from_out(t[k].y) + r4[k].y;
+                x[2] = x[2] * grappa_elu_grad_from_out(t[k].z) + r4[k].z; x[3] = x[3] * grappa_elu_grad_from_out(t[k].w) + r4[k].w;
+            }
+            const bool ok = col_ok && m < d.M;
+            if (ok) *reinterpret_cast<float4*>(d.C + (size_t)m * d.ldc + n) = make_float4(x[0], x[1], x[2], x[3]);
+            if (p.amax_part) {
+                unsigned am = ok ? max(max(mag_bits(x[0]), mag_bits(x[1])), max(mag_bits(x[2]), mag_bits(x[3]))) : 0u;
+                am = group_umax<TN == 2 ? 16 : 8>(am);
+                const int nseg0 = n - rc4;
+                if ((lane & (TN == 2 ? 15 : 7)) == 0 && m < d.M && nseg0 < d.N) p.amax_part[(size_t)(nseg0 / p.amax_seg) * d.M + m] = am;
+            }
+        }
+    }
+}
+
 // one 32-row band (accumulator row i of the wavefront's TM x TN grid)
 template <int BM, int BN, int TN>
-__device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[TN], float* __restrict__ wave_buf, int m0, int n0, int mband,
+__device__ __forceinline__ void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[TN], float* __restrict__ wave_buf, int m0, int n0, int mband,
                                      int n, int lane, const float4& b4, int split, int tile_local, bool vec_io) {
     const grappa_gemm_desc& d = p.d;
     const int lr = lane & 31, lh = lane >> 5;
@@ -258,7 +352,7 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
                     planes_load4(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, t, d.resp_nplanes ? d.resp_nplanes : 3);
                     v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
                 }
-                if (o) {
+                if (o && !(GB_KNOCK == 7 && v[0] != 123.456f)) {
                     if (d.accumulate) {
                         const float4 t = *reinterpret_cast<const float4*>(o);
                         v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
@@ -272,8 +366,7 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
         if (p.amax_part && p.nsplit == 1) {
             // the 16 (TN == 2) or 8 lanes that hold one row segment combine; segment-major layout: the 4 / 8 rows of a trip are
             // consecutive words, the 32 rows of the band one 128-byte line
-#pragma unroll
-            for (int o = (TN == 2 ? 8 : 4); o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+            am = group_umax<TN == 2 ? 16 : 8>(am);
             const int nseg0 = n - rc4;                       // first column of this wavefront's segment
             if ((lane & (TN == 2 ? 15 : 7)) == 0 && m < d.M && nseg0 < d.N) p.amax_part[(size_t)(nseg0 / p.amax_seg) * d.M + m] = am;
         }
@@ -281,7 +374,7 @@ __device__ inline void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[
 }
 
 template <int BM, int BN, int TM, int TN>
-__device__ inline void tile_epilogue_rows(const GemmParams& p, const f32x16 (&acc)[TM][TN], float* __restrict__ wave_buf, int m0, int n0,
+__device__ __forceinline__ void tile_epilogue_rows(const GemmParams& p, const f32x16 (&acc)[TM][TN], float* __restrict__ wave_buf, int m0, int n0,
                                           int wm0, int wn0, int lane, int split, int tile_local, bool vec_io) {
     static_assert(TN * 32 <= 64 && TM == 2, "staging row holds 64 floats; two bands per wavefront");
     const grappa_gemm_desc& d = p.d;
@@ -292,6 +385,16 @@ __device__ inline void tile_epilogue_rows(const GemmParams& p, const f32x16 (&ac
         b4.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
         b4.z = n + 2 < d.N ? d.bias[n + 2] : 0.f;
         b4.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
+    }
+    if (p.epi_class != 0 && p.nsplit == 1) {
+        const int mb = m0 + wm0;
+        switch (p.epi_class) {
+            case 1: epilogue_band_fast<TN, 1>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, 1>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break;
+            case 2: epilogue_band_fast<TN, 2>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, 2>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break;
+            case 3: epilogue_band_fast<TN, 3>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, 3>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break;
+            default: epilogue_band_fast<TN, 4>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, 4>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break;
+        }
+        return;
     }
     epilogue_band<BM, BN, TN>(p, acc[0], wave_buf, m0, n0, m0 + wm0, n, lane, b4, split, tile_local, vec_io);
     epilogue_band<BM, BN, TN>(p, acc[1], wave_buf, m0, n0, m0 + wm0 + 32, n, lane, b4, split, tile_local, vec_io);

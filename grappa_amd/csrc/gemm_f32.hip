@@ -585,6 +585,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
             p.vec_io = al16(d.C, d.ldc) && al16(d.C2, d.ldc2) && al16(d.pre, d.ldpre) && al16(d.res, d.ldres) && al16(d.aux, d.ldaux);
             p.amax_part = nullptr;
             p.amax_seg = 64;
+            p.epi_class = 0;
             ix.wg_begin[i + 1] = ix.wg_begin[i] + g.tiles[i] * g.nsplit[i];
             int blocks = 0;
             if (p.nsplit > 1) {
@@ -695,6 +696,13 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     if (d->out_amax && !amax_fused && !d->C) return GRAPPA_ERR_ARG;
     p.amax_part = nullptr;
     p.amax_seg = p.bm == 256 ? 64 : 32;                     // 256 x 128 tile: wavefronts of 64 columns; 128 x 128: of 32
+    // the straight-line row epilogues (gemm_common.h epilogue_band_fast): one fp32 output, whole float4s, no pre-activation addend
+    p.epi_class = 0;
+    if (bf16x && p.vec_io && (d->N & 3) == 0 && d->C && !d->C2 && !d->Cp && !d->C1p && !d->resp && !d->auxp && !d->pre && !d->accumulate) {
+        if (d->aux) p.epi_class = (!d->bias && d->act == GRAPPA_ACT_NONE && d->drop_p == 0.0f) ? 4 : 0;
+        else if (d->act == GRAPPA_ACT_ELU) p.epi_class = (d->drop_p == 0.0f && !d->res) ? 2 : 0;
+        else p.epi_class = (d->drop_p > 0.0f || d->res) ? 3 : 1;
+    }
     if (amax_fused) {
         if (!ws || ws_bytes < need + amax_part_bytes(d->M, d->N)) return GRAPPA_ERR_WORKSPACE;
         p.amax_part = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + need);

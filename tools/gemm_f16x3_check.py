@@ -123,7 +123,30 @@ def bench(be):
     print("  sum: " + "  ".join(f"{m} {tot[m]:.3f} ms" for m in MODES) + f"  maxima {tot_amax:.3f} ms")
 
 
+def build_variants():
+    """libraries with the timing knock-outs of csrc/gemm_bf16x.hip (GB_KNOCK); run each with GRAPPA_HIP_LIB=<so> ... --bench-only"""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    csrc = os.path.join(root, "grappa_amd", "csrc")
+    outdir = os.path.join(root, "build", "variants")
+    os.makedirs(outdir, exist_ok=True)
+    objs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".o") and f != "gemm_bf16x.o"]
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    for k, name in ((1, "nomfma"), (2, "nosplit"), (3, "noglobal"), (4, "nolds"), (5, "nobarrier"), (6, "noepi"), (7, "nostore"), (8, "nodescale"), (-40, "stagger40"), (-80, "stagger80"),
+                    (-120, "stagger120")):
+        if only and name not in only[0]:
+            continue
+        o, so = os.path.join(outdir, f"gemm_bf16x_{name}.o"), os.path.join(outdir, f"libgrappa_hip_bx_{name}.so")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-DGB_KNOCK={k}" if k > 0 else f"-DGB_STAGGER={-k}", "-c",
+                        os.path.join(csrc, "gemm_bf16x.hip"), "-o", o], check=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, o, *objs], check=True)
+        print(so)
+
+
 def main():
+    if "--build-variants" in sys.argv:
+        build_variants()
+        return
     be = HipBackend()
     if "--bench-only" not in sys.argv:
         accuracy(be)
