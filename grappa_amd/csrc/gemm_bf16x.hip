@@ -60,11 +60,16 @@ struct Quad { float x[4]; };
 
 // slab element (row, kq..kq+3) owned by this thread for quad slot j of an operand with ROWS rows.
 // K-contiguous source: 4 lanes cover the 64 bytes of one row; k-major source: 64 lanes cover 64 consecutive rows of one k.
-template <int NT, int ROWS, bool KCONT>
+// KMV (k-major source read with 16-byte loads ALONG ITS ROWS): the quad is (rows row..row+3, ONE k = kq); 64 lanes cover 1 KB of one k.
+template <int NT, int ROWS, bool KCONT, bool KMV = false>
 __device__ inline void quad_coords(int j, int& row, int& kq) {
     if (KCONT) {
         row = (threadIdx.x >> 2) + (NT / 4) * j;
         kq = (threadIdx.x & 3) << 2;
+    } else if (KMV) {
+        const int f = threadIdx.x + j * NT;
+        row = (f % (ROWS / 4)) << 2;
+        kq = f / (ROWS / 4);
     } else {
         const int f = threadIdx.x + j * NT;
         row = f & (ROWS - 1);
@@ -72,16 +77,26 @@ __device__ inline void quad_coords(int j, int& row, int& kq) {
     }
 }
 
+// bytes of one piece of an operand in an LDS stage: [row][16 k + pad] (ROWB per row), or -- KMV -- [k][row] (transposing reads)
+template <int ROWS, bool KMV> struct PieceBytes { static constexpr int value = KMV ? SK * ROWS * 2 : ROWS * ROWB; };
+
 // Loads never wait for their data: out-of-range rows and k are only CLAMPED here (the addresses stay inside the operand);
 // the k tail is zeroed when the slab is split and stored (store_quads<MASK>), AHEAD - 1 steps later.
-template <int NT, int ROWS, bool KCONT, bool VEC>
+template <int NT, int ROWS, bool KCONT, bool VEC, bool KMV = false>
 __device__ inline void load_quads(const float* __restrict__ src, int ld, int row0, int k0, int R, int Kend, Quad (&q)[ROWS * 4 / NT]) {
 #pragma unroll
     for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
-        quad_coords<NT, ROWS, KCONT>(j, row, kq);
-        const int gr = min(row0 + row, R - 1);          // out-of-range rows are clamped: their results are never stored
+        quad_coords<NT, ROWS, KCONT, KMV>(j, row, kq);
         const int gk = k0 + kq;
+        if (!KCONT && KMV) {
+            // four consecutive rows of one k: the (16-byte padded, host-checked) source row covers round_up(R, 4)
+            const int gr = min(row0 + row, ((R + 3) & ~3) - 4);
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(gk < Kend ? gk : 0) * ld + gr);
+            q[j].x[0] = v.x; q[j].x[1] = v.y; q[j].x[2] = v.z; q[j].x[3] = v.w;
+            continue;
+        }
+        const int gr = min(row0 + row, R - 1);          // out-of-range rows are clamped: their results are never stored
         if (KCONT && VEC) {
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)gr * ld + (gk < Kend ? gk : 0));   // K % 4 == 0 here
             q[j].x[0] = v.x; q[j].x[1] = v.y; q[j].x[2] = v.z; q[j].x[3] = v.w;
@@ -101,35 +116,38 @@ __device__ inline float u2f(unsigned x) { return __uint_as_float(x); }
 // fp32) and store each piece's 4 values as one 8-byte LDS write.  krem = valid k of this slab counted from its first column
 // (MASK: a slab at the end of a K range, whose tail is zero-filled here).
 // HALF: the row's power-of-two scale first (shift[j], exact), then fp16 pieces hi = f16(r), lo = f16(r - hi).
-template <int NT, int NP, int ROWS, bool KCONT, bool MASK, bool HALF>
-__device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[ROWS * 4 / NT], int krem, const int (&shift)[ROWS * 4 / NT]) {
+template <int NT, int NP, int ROWS, bool KCONT, bool MASK, bool HALF, bool KMV = false>
+__device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[ROWS * 4 / NT], int krem, const int (&shift)[ROWS * 4 / NT][KMV ? 4 : 1]) {
+    constexpr int PIECE = PieceBytes<ROWS, KMV>::value;
 #pragma unroll
     for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
-        quad_coords<NT, ROWS, KCONT>(j, row, kq);
+        quad_coords<NT, ROWS, KCONT, KMV>(j, row, kq);
         float r[4] = {q[j].x[0], q[j].x[1], q[j].x[2], q[j].x[3]};
         if (MASK) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = kq + e < krem ? r[e] : 0.f;
+            for (int e = 0; e < 4; ++e) r[e] = (KMV ? kq : kq + e) < krem ? r[e] : 0.f;
         }
-        char* dst = opbase + row * ROWB + kq * 2;
+        // KMV: [k][row] with the 16-byte chunk (8 rows) swizzled by the k-row, chunk ^ ((k & 3) << 2): the transposing fragment reads
+        // (read_frags) then meet no bank conflicts; otherwise [row][k] with a padded row
+        char* dst = KMV ? opbase + kq * (ROWS * 2) + ((((row >> 3) ^ ((kq & 3) << 2))) << 4) + ((row & 7) << 1) : opbase + row * ROWB + kq * 2;
         if (HALF) {
             // (packed multiplies and v_fma_mix_f32 residuals -- 40 instead of 67 vector instructions per slab -- measured no faster:
             // the vector unit is not what this kernel waits for; the plain form keeps the exact v_ldexp_f32 for any shift)
             if (GB_KNOCK == 2) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    *reinterpret_cast<uint2*>(dst + p * (ROWS * ROWB)) = make_uint2(__float_as_uint(r[p]) & 0x3bff3bffu, __float_as_uint(r[p + 2]) & 0x3bff3bffu);
+                    *reinterpret_cast<uint2*>(dst + p * PIECE) = make_uint2(__float_as_uint(r[p]) & 0x3bff3bffu, __float_as_uint(r[p + 2]) & 0x3bff3bffu);
                 continue;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = __builtin_ldexpf(r[e], shift[j]);
+            for (int e = 0; e < 4; ++e) r[e] = __builtin_ldexpf(r[e], shift[j][KMV ? e : 0]);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 f16x2 h01, h23;
                 h01[0] = (_Float16)r[0]; h01[1] = (_Float16)r[1];        // round to nearest even; |r| < 2^15 never overflows
                 h23[0] = (_Float16)r[2]; h23[1] = (_Float16)r[3];
-                *reinterpret_cast<uint2*>(dst + p * (ROWS * ROWB)) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                *reinterpret_cast<uint2*>(dst + p * PIECE) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
                 if (p + 1 < NP) {
                     r[0] -= (float)h01[0]; r[1] -= (float)h01[1];
                     r[2] -= (float)h23[0]; r[3] -= (float)h23[1];
@@ -143,7 +161,7 @@ __device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[RO
             h01[0] = (__bf16)r[0]; h01[1] = (__bf16)r[1];
             h23[0] = (__bf16)r[2]; h23[1] = (__bf16)r[3];
             const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
-            *reinterpret_cast<uint2*>(dst + p * (ROWS * ROWB)) = make_uint2(u01, u23);
+            *reinterpret_cast<uint2*>(dst + p * PIECE) = make_uint2(u01, u23);
             if (p + 1 < NP) {                       // float(bf16) is the 16 bits moved to the top half of the word
                 r[0] -= u2f(u01 << 16); r[1] -= u2f(u01 & 0xffff0000u);
                 r[2] -= u2f(u23 << 16); r[3] -= u2f(u23 & 0xffff0000u);
@@ -152,40 +170,62 @@ __device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[RO
     }
 }
 
-template <int NQ>
-__device__ inline float quad_sum(const Quad (&q)[NQ]) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) s += (q[j].x[0] + q[j].x[1]) + (q[j].x[2] + q[j].x[3]);
-    return s;
-}
-
-template <int NT, int ROWS, bool KCONT>
-__device__ inline float quad_sum_masked(const Quad (&q)[ROWS * 4 / NT], int krem) {
-    float s = 0.f;
+// bias gradient: sum over k of A(row, k) for the rows a thread stages.  Row-contiguous A, dword loads: one row per thread (cs[0]);
+// KMV: four consecutive rows per thread (cs[0..3])
+template <int NT, int ROWS, bool KMV, bool MASK>
+__device__ inline void quad_rowsum(const Quad (&q)[ROWS * 4 / NT], int krem, float (&cs)[4]) {
 #pragma unroll
     for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
-        quad_coords<NT, ROWS, KCONT>(j, row, kq);
+        quad_coords<NT, ROWS, false, KMV>(j, row, kq);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s += kq + e < krem ? q[j].x[e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+            const float v = (!MASK || (KMV ? kq : kq + e) < krem) ? q[j].x[e] : 0.f;
+            cs[KMV ? e : 0] += v;
+        }
     }
-    return s;
 }
 
 template <int NP, int TM, int TN> struct Frags { bf16x8 a[TM][NP], b[TN][NP]; };
 
-// MFMA operand fragments of one staged slab ((TM + TN) * NP ds_read_b128)
-template <int NP, int BM, int BN, int TM, int TN>
-__device__ inline void read_frags(const char* __restrict__ stage, int wm0, int wn0, int lr, int lh, Frags<NP, TM, TN>& f) {
-    const char* a_s = stage + lh * 16;
-    const char* b_s = a_s + NP * BM * ROWB;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// KMV operands lie [k][row] in the stage; ds_read_tr16_b64 transposes on the way out: a 16-lane group reads a block of 4 k-rows x 16
+// rows -- lane 4q + p supplies &(k-row q, rows 4p .. 4p + 3) and receives row (lane & 15) of the four k-rows.  An MFMA operand lane
+// (lr, lh) wants row lr, k = 8 lh + 0..7: two reads (k-rows 8 lh + 4 rd + q, rd = 0, 1)
+template <int ROWS>
+__device__ inline unsigned tr_offset(int row0, int lane, int rd) {
+    const int g16 = lane >> 4, blk = (g16 & 1) * 16, lh = g16 >> 1, q = (lane & 15) >> 2, pp = lane & 3;
+    const int k = 8 * lh + 4 * rd + q, m = row0 + blk + 4 * pp;
+    return (unsigned)(k * (ROWS * 2) + ((((m >> 3) ^ (q << 2))) << 4) + ((m & 7) << 1));
+}
+__device__ inline bf16x8 tr_pair(const char* p0, const char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// MFMA operand fragments of one staged slab ((TM + TN) * NP ds_read_b128, or two transposing 8-byte reads each for KMV operands)
+template <int NP, int BM, int BN, int TM, int TN, bool AKMV, bool BKMV>
+__device__ inline void read_frags(const char* __restrict__ stage, int wm0, int wn0, int lane, Frags<NP, TM, TN>& f) {
+    const int lr = lane & 31, lh = lane >> 5;
+    constexpr int PA = PieceBytes<BM, AKMV>::value, PB = PieceBytes<BN, BKMV>::value;
+    const char* a_s = stage;
+    const char* b_s = stage + NP * PA;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) f.a[i][p] = *reinterpret_cast<const bf16x8*>(a_s + p * (BM * ROWB) + (wm0 + i * 32 + lr) * ROWB);
+        for (int i = 0; i < TM; ++i) {
+            if (AKMV) f.a[i][p] = tr_pair(a_s + p * PA + tr_offset<BM>(wm0 + i * 32, lane, 0), a_s + p * PA + tr_offset<BM>(wm0 + i * 32, lane, 1));
+            else f.a[i][p] = *reinterpret_cast<const bf16x8*>(a_s + p * PA + (wm0 + i * 32 + lr) * ROWB + lh * 16);
+        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) f.b[j][p] = *reinterpret_cast<const bf16x8*>(b_s + p * (BN * ROWB) + (wn0 + j * 32 + lr) * ROWB);
+        for (int j = 0; j < TN; ++j) {
+            if (BKMV) f.b[j][p] = tr_pair(b_s + p * PB + tr_offset<BN>(wn0 + j * 32, lane, 0), b_s + p * PB + tr_offset<BN>(wn0 + j * 32, lane, 1));
+            else f.b[j][p] = *reinterpret_cast<const bf16x8*>(b_s + p * PB + (wn0 + j * 32 + lr) * ROWB + lh * 16);
+        }
     }
 }
 
@@ -262,14 +302,17 @@ struct KRange {
 //   (registers S) into the other stage | barrier | fragment reads of slab s+1 -> fn, one per MFMA of the last third
 // TAIL = one of the last steps of the K range: loads / stores happen only while slabs remain and the stored slab is masked to
 // the valid k; main-loop steps do both unconditionally.
-template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool TAIL>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV, bool TAIL>
 __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict__ smem, f32x16 (&acc)[2][BN / WN / 32], int m0, int n0,
-                                     const KRange& kr, int s, int wm0, int wn0, int lr, int lh, Quad (&la)[BM * 4 / NT], Quad (&lb)[BN * 4 / NT],
+                                     const KRange& kr, int s, int wm0, int wn0, int lane, Quad (&la)[BM * 4 / NT], Quad (&lb)[BN * 4 / NT],
                                      const Quad (&sa)[BM * 4 / NT], const Quad (&sb)[BN * 4 / NT],
                                      const Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fc, Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fn,
-                                     float& cs, bool do_cs, const int (&sha)[BM * 4 / NT], const int (&shb)[BN * 4 / NT]) {
+                                     float (&cs)[4], bool do_cs, const int (&sha)[BM * 4 / NT][(!AK && KMV) ? 4 : 1],
+                                     const int (&shb)[BN * 4 / NT][(!BKC && KMV) ? 4 : 1]) {
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
-    constexpr int STAGE = NP * (BM + BN) * ROWB;
+    constexpr bool AV = !AK && KMV, BV = !BKC && KMV;          // row-contiguous operands read by 16-byte loads along their rows
+    constexpr int PA = PieceBytes<BM, AV>::value, PB = PieceBytes<BN, BV>::value;
+    constexpr int STAGE = NP * (PA + PB);
     constexpr int NM = Pieces<MODE>::NPROD * TM * TN;
     // MFMAs issued before the barrier (they carry the split + LDS stores of the next slab); the rest cover its fragment reads.
     // Two thirds / one third measured 1 % faster than halves (the vector work is spread thinner), three quarters no better
@@ -277,17 +320,17 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     const bool do_store = !TAIL || s + 1 < kr.nsteps;
     const bool do_load = !TAIL || s + AHEAD < kr.nsteps;
     if (do_load && !(GB_KNOCK == 3 && !TAIL)) {
-        load_quads<NT, BM, AK, VEC>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
-        load_quads<NT, BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
+        load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
+        load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
     }
     __builtin_amdgcn_sched_barrier(0);
     char* nxt = smem + ((s + 1) & 1) * STAGE;
     mfma_range<MODE, TM, TN, 0, NFIRST>(fc, acc);
     if (do_store && !(GB_KNOCK == 4 && !TAIL)) {
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
-        store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF>(nxt, sa, krem, sha);
-        store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF>(nxt + NP * BM * ROWB, sb, krem, shb);
-        if (!AK && do_cs) cs += TAIL ? quad_sum_masked<NT, BM, AK>(sa, krem) : quad_sum(sa);
+        store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF, AV>(nxt, sa, krem, sha);
+        store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF, BV>(nxt + NP * PA, sb, krem, shb);
+        if (!AK && do_cs) quad_rowsum<NT, BM, AV, TAIL>(sa, krem, cs);
     }
     if (!TAIL) {
         // issue order of this phase: one MFMA, then a slice of the split arithmetic and of the LDS stores, so that the matrix
@@ -298,24 +341,26 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     __builtin_amdgcn_sched_barrier(0);
     if (!(GB_KNOCK == 5 && !TAIL)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (do_store && !(GB_KNOCK == 4 && !TAIL)) read_frags<NP, BM, BN, TM, TN>(nxt, wm0, wn0, lr, lh, fn);
+    if (do_store && !(GB_KNOCK == 4 && !TAIL)) read_frags<NP, BM, BN, TM, TN, AV, BV>(nxt, wm0, wn0, lane, fn);
     if (GB_KNOCK == 4 && !TAIL) fn = fc;
     mfma_range<MODE, TM, TN, NFIRST, NM>(fc, acc);
     if (!TAIL) {
         // the next slab's fragment reads ride between these MFMAs instead of all eight wavefronts bursting them at the LDS
         // right after the barrier (an MFMA issues only once its wavefront's reads are queued): +1.7 % on the workload's shapes
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        ReadOrder<0, NM - NFIRST, (TM + TN) * NP>::emit();
+        ReadOrder<0, NM - NFIRST, (TM + TN) * NP + (AV ? TM * NP : 0) + (BV ? TN * NP : 0)>::emit();
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // one workgroup's tile; (nwg, wgid) = size of the problem's workgroup grid and this workgroup's place in it (a launch of its own:
 // gridDim / blockIdx; a grouped launch: the problem's share of the grid)
-template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
 __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, int wgid) {
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
     constexpr int NQA = BM * 4 / NT, NQB = BN * 4 / NT;
+    constexpr bool AV = !AK && KMV, BV = !BKC && KMV;
+    constexpr int PA = PieceBytes<BM, AV>::value;
     static_assert((NT / 64 / WN) * 64 == BM, "wavefront grid must cover the tile");
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
@@ -343,41 +388,45 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    int sha[NQA], shb[NQB];            // H3: power-of-two scale of the row each staged quad belongs to
+    int sha[NQA][AV ? 4 : 1], shb[NQB][BV ? 4 : 1];            // H3: power-of-two scale of the row(s) each staged quad belongs to
 #pragma unroll
     for (int j = 0; j < NQA; ++j) {
         int row, kq;
-        quad_coords<NT, BM, AK>(j, row, kq);
-        sha[j] = Pieces<MODE>::HALF ? amax_shift(d.a_amax[(d.amax_bcast & 1) ? 0 : min(m0 + row, d.M - 1)]) : 0;
+        quad_coords<NT, BM, AK, AV>(j, row, kq);
+#pragma unroll
+        for (int e = 0; e < (AV ? 4 : 1); ++e)
+            sha[j][e] = Pieces<MODE>::HALF ? amax_shift(d.a_amax[(d.amax_bcast & 1) ? 0 : min(m0 + row + e, d.M - 1)]) : 0;
     }
 #pragma unroll
     for (int j = 0; j < NQB; ++j) {
         int row, kq;
-        quad_coords<NT, BN, BKC>(j, row, kq);
-        shb[j] = Pieces<MODE>::HALF ? amax_shift(d.b_amax[(d.amax_bcast & 2) ? 0 : min(n0 + row, d.N - 1)]) : 0;
+        quad_coords<NT, BN, BKC, BV>(j, row, kq);
+#pragma unroll
+        for (int e = 0; e < (BV ? 4 : 1); ++e)
+            shb[j][e] = Pieces<MODE>::HALF ? amax_shift(d.b_amax[(d.amax_bcast & 2) ? 0 : min(n0 + row + e, d.N - 1)]) : 0;
     }
     const bool do_cs = !AK && d.a_colsum != nullptr && tile_n == 0;
-    float cs = 0.f;                    // sum over k of A(row, k) for the row this thread stages (the same row for all its quads)
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};      // sums over k of A(row, k) for the row (KMV: the four rows) this thread stages -- the same for all its quads
     if (nsteps > 0) {
         Quad a0[NQA], b0[NQB], a1[NQA], b1[NQB], a2[NQA], b2[NQB], a3[NQA], b3[NQB];
         Frags<NP, TM, TN> fe, fo;      // fragments of even / odd slabs
 #define GRAPPA_LOAD(S, QA, QB)                                                                      \
-    load_quads<NT, BM, AK, VEC>(d.A, d.lda, m0, kr.k_of((S) < nsteps ? (S) : 0), d.M, kr.kend, QA); \
-    load_quads<NT, BN, BKC, VEC>(d.B, d.ldb, n0, kr.k_of((S) < nsteps ? (S) : 0), d.N, kr.kend, QB)
+    load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of((S) < nsteps ? (S) : 0), d.M, kr.kend, QA); \
+    load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of((S) < nsteps ? (S) : 0), d.N, kr.kend, QB)
         GRAPPA_LOAD(0, a0, b0);
         GRAPPA_LOAD(1, a1, b1);
         GRAPPA_LOAD(2, a2, b2);
         GRAPPA_LOAD(3, a3, b3);
 #undef GRAPPA_LOAD
-        store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF>(smem, a0, kr.kend - kr.kbeg, sha);
-        store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF>(smem + NP * BM * ROWB, b0, kr.kend - kr.kbeg, shb);
-        if (!AK && do_cs) cs += quad_sum_masked<NT, BM, AK>(a0, kr.kend - kr.kbeg);
+        store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF, AV>(smem, a0, kr.kend - kr.kbeg, sha);
+        store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF, BV>(smem + NP * PA, b0, kr.kend - kr.kbeg, shb);
+        if (!AK && do_cs) quad_rowsum<NT, BM, AV, true>(a0, kr.kend - kr.kbeg, cs);
         __syncthreads();
-        read_frags<NP, BM, BN, TM, TN>(smem, wm0, wn0, lr, lh, fe);
+        read_frags<NP, BM, BN, TM, TN, AV, BV>(smem, wm0, wn0, lane, fe);
         int s = 0;
         // step s stores slab s+1 (register set (s+1) % 4) and loads slab s+4 into the set slab s occupied
 #define GRAPPA_STEP(TAIL, LA, LB, SA, SB, FC, FN) \
-    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, TAIL>(d, smem, acc, m0, n0, kr, s, wm0, wn0, lr, lh, LA, LB, SA, SB, FC, FN, cs, do_cs, sha, shb)
+    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, TAIL>(d, smem, acc, m0, n0, kr, s, wm0, wn0, lane, LA, LB, SA, SB, FC, FN, cs, do_cs, sha, shb)
         // main loop: four steps per trip (the register sets rotate); never stores the last slab of the range and every load
         // it issues is for an existing slab
         for (; s + 7 < nsteps; s += 4) {
@@ -414,12 +463,19 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
     if (!AK && do_cs) {
         __syncthreads();                                     // every wavefront is past its last fragment read
         float* red = reinterpret_cast<float*>(smem);
-        red[threadIdx.x] = cs;
-        __syncthreads();
-        if (threadIdx.x < BM) {                              // threads t, t + BM, ... staged row t
-            float sum = 0.f;
+        if (AV) {
+            // thread t staged rows 4 (t % 64) .. + 3 (k = t / 64 and t / 64 + 8): red[t / 64][row]
 #pragma unroll
-            for (int t = 0; t < NT / BM; ++t) sum += red[threadIdx.x + t * BM];
+            for (int e = 0; e < 4; ++e) red[(threadIdx.x / (BM / 4)) * BM + ((threadIdx.x % (BM / 4)) << 2) + e] = cs[e];
+        } else {
+            red[threadIdx.x] = cs[0];                        // threads t, t + BM, ... staged row t
+        }
+        __syncthreads();
+        if (threadIdx.x < BM) {
+            float sum = 0.f;
+            constexpr int NG = AV ? NT / (BM / 4) : NT / BM;
+#pragma unroll
+            for (int t = 0; t < NG; ++t) sum += red[threadIdx.x + t * BM];
             const int m = m0 + threadIdx.x;
             if (m < d.M) {
                 if (p.nsplit > 1) p.cs_slab[(size_t)split * d.M + m] = sum;
@@ -458,28 +514,29 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
                                        p.vec_io != 0);
 }
 
-template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16x_kernel(GemmParams p) {
-    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC>(p, gridDim.x, blockIdx.x);
+    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV>(p, gridDim.x, blockIdx.x);
 }
 
 // Grouped launch: ONE grid over several independent products (the weight gradients of a backward pass, deferred and launched
 // together).  A wgrad alone has 8 .. 24 tiles and must cut its K (= tokens) 10 .. 32 ways to fill 256 CUs, i.e. write and re-read
 // 10 .. 32 partial tiles per output tile; sixteen of them together fill the chip with 3 .. 11 cuts each.  Problem descriptors and
 // the prefix of workgroups per problem live in device memory (copied ahead of the launch on the same stream).
-template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16x_grouped_kernel(const GemmParams* __restrict__ ps, const int* __restrict__ wg_begin, int nprob) {
     const int wg = blockIdx.x;
     int g = 0;
     while (g + 1 < nprob && wg >= wg_begin[g + 1]) ++g;
-    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC>(ps[g], wg_begin[g + 1] - wg_begin[g], wg - wg_begin[g]);
+    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV>(ps[g], wg_begin[g + 1] - wg_begin[g], wg - wg_begin[g]);
 }
 
-template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
 int launch_mode(hipStream_t st, GemmParams& p) {
-    constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (BM + BN) * ROWB, staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
+    constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (PieceBytes<BM, !AK && KMV>::value + PieceBytes<BN, !BKC && KMV>::value);
+    constexpr size_t staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
     constexpr size_t smem = stages > staging ? stages : staging;
-    auto kern = gemm_bf16x_kernel<NT, MODE, BM, BN, WN, AK, BKC, VEC>;
+    auto kern = gemm_bf16x_kernel<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -490,12 +547,14 @@ int launch_mode(hipStream_t st, GemmParams& p) {
     return grappa_launch_status();
 }
 
+// vec: every operand can be read with 16-byte loads (K-contiguous: along k; row-contiguous: along its rows, which then lie [k][row] in
+// the LDS and reach the MFMA through transposing reads)
 template <int NT, int MODE, int BM, int BN, int WN>
 int launch_layout(hipStream_t st, GemmParams& p, bool vec) {
     const grappa_gemm_desc& d = p.d;
-    if (d.a_kcontig && d.b_kcontig) return vec ? launch_mode<NT, MODE, BM, BN, WN, true, true, true>(st, p) : launch_mode<NT, MODE, BM, BN, WN, true, true, false>(st, p);
-    if (d.a_kcontig) return vec ? launch_mode<NT, MODE, BM, BN, WN, true, false, true>(st, p) : launch_mode<NT, MODE, BM, BN, WN, true, false, false>(st, p);
-    return launch_mode<NT, MODE, BM, BN, WN, false, false, false>(st, p);     // row-contiguous operands never use the float4 path
+    if (d.a_kcontig && d.b_kcontig) return vec ? launch_mode<NT, MODE, BM, BN, WN, true, true, true, false>(st, p) : launch_mode<NT, MODE, BM, BN, WN, true, true, false, false>(st, p);
+    if (d.a_kcontig) return vec ? launch_mode<NT, MODE, BM, BN, WN, true, false, true, true>(st, p) : launch_mode<NT, MODE, BM, BN, WN, true, false, false, false>(st, p);
+    return vec ? launch_mode<NT, MODE, BM, BN, WN, false, false, false, true>(st, p) : launch_mode<NT, MODE, BM, BN, WN, false, false, false, false>(st, p);
 }
 
 template <int MODE>
@@ -505,12 +564,13 @@ int launch_tile(hipStream_t st, GemmParams& p, bool vec) {
     return GRAPPA_ERR_ARG;
 }
 
-template <int MODE>
+template <int MODE, bool KMV>
 int launch_grouped_wgrad(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs) {
     constexpr int NT = 512, BM = 256, BN = 128;
-    constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (BM + BN) * ROWB, staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
+    constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (PieceBytes<BM, KMV>::value + PieceBytes<BN, KMV>::value);
+    constexpr size_t staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
     constexpr size_t smem = stages > staging ? stages : staging;
-    auto kern = gemm_bf16x_grouped_kernel<NT, MODE, BM, BN, 2, false, false, false>;
+    auto kern = gemm_bf16x_grouped_kernel<NT, MODE, BM, BN, 2, false, false, false, KMV>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -524,15 +584,17 @@ int launch_grouped_wgrad(hipStream_t st, const GemmParams* d_ps, const int* d_wg
 }  // namespace
 
 // grouped weight-gradient products (layout a_kcontig = b_kcontig = 0, tile 256 x 128): called by grappa_gemm_f32_grouped
-int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision) {
+int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision, bool vec) {
+#define GRAPPA_GROUPED(MODE) (vec ? launch_grouped_wgrad<MODE, true>(st, d_ps, d_wg_begin, nprob, total_wgs) : launch_grouped_wgrad<MODE, false>(st, d_ps, d_wg_begin, nprob, total_wgs))
     switch (precision) {
-        case GRAPPA_GEMM_F32_BF16X9: return launch_grouped_wgrad<X9>(st, d_ps, d_wg_begin, nprob, total_wgs);
-        case GRAPPA_GEMM_F32_BF16X6: return launch_grouped_wgrad<X6>(st, d_ps, d_wg_begin, nprob, total_wgs);
-        case GRAPPA_GEMM_BF16X3: return launch_grouped_wgrad<X3>(st, d_ps, d_wg_begin, nprob, total_wgs);
-        case GRAPPA_GEMM_BF16: return launch_grouped_wgrad<X1>(st, d_ps, d_wg_begin, nprob, total_wgs);
-        case GRAPPA_GEMM_F32_F16X3: return launch_grouped_wgrad<H3>(st, d_ps, d_wg_begin, nprob, total_wgs);
+        case GRAPPA_GEMM_F32_BF16X9: return GRAPPA_GROUPED(X9);
+        case GRAPPA_GEMM_F32_BF16X6: return GRAPPA_GROUPED(X6);
+        case GRAPPA_GEMM_BF16X3: return GRAPPA_GROUPED(X3);
+        case GRAPPA_GEMM_BF16: return GRAPPA_GROUPED(X1);
+        case GRAPPA_GEMM_F32_F16X3: return GRAPPA_GROUPED(H3);
         default: return GRAPPA_ERR_ARG;
     }
+#undef GRAPPA_GROUPED
 }
 
 // called by grappa_gemm_f32 (gemm_f32.hip) for precision != GRAPPA_GEMM_F32_MFMA; (p.bm, p.bn) is 256x128 or 128x128

@@ -22,7 +22,7 @@ using namespace grappa_gemm;
 int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool vec_kcontig);   // gemm_bf16x.hip
 int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision);                      // gemm_planes.hip
 int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* part, unsigned* out);   // amax.hip
-int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision);   // gemm_bf16x.hip
+int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision, bool vec);   // gemm_bf16x.hip
 
 namespace {
 
@@ -563,6 +563,13 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
     ix.wg_begin[0] = ix.blk_begin[0] = 0;
     auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
     int total_blocks = 0;
+    // 16-byte loads along the rows of both operands of every product: aligned bases, leading dimensions % 4 == 0 covering round_up(rows, 4)
+    bool vec = true;
+    for (int i = 0; i < n; ++i) {
+        const grappa_gemm_desc& d = descs[i];
+        vec = vec && (reinterpret_cast<uintptr_t>(d.A) & 15) == 0 && (d.lda & 3) == 0 && ((d.M + 3) & ~3) <= d.lda &&
+              (reinterpret_cast<uintptr_t>(d.B) & 15) == 0 && (d.ldb & 3) == 0 && ((d.N + 3) & ~3) <= d.ldb;
+    }
     for (int i0 = 0; i0 < n; i0 += 8) {
         const int cnt = n - i0 < 8 ? n - i0 : 8;
         for (int j = 0; j < cnt; ++j) {
@@ -599,7 +606,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
     }
     hipLaunchKernelGGL(group_index_kernel, dim3(1), dim3(64), 0, st, ix, n, d_wg, d_blk);
     if (grappa_launch_status() != GRAPPA_OK) return GRAPPA_ERR_LAUNCH;
-    int rc = grappa_launch_gemm_bf16x_grouped(st, d_ps, d_wg, n, g.total_wgs, precision);
+    int rc = grappa_launch_gemm_bf16x_grouped(st, d_ps, d_wg, n, g.total_wgs, precision, vec);
     if (rc != GRAPPA_OK) return rc;
     if (total_blocks > 0) {
         hipLaunchKernelGGL(gemm_splitk_reduce_grouped_kernel, dim3(total_blocks), dim3(REDUCE_THREADS), 0, st, d_ps, d_blk, n);

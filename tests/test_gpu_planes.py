@@ -84,7 +84,7 @@ def test_train_steps_with_weight_planes_match_the_default():
     # per product the two kernels are bit-identical (test_plane_gemms_against_float64); inside the model the planner may pick
     # another tile / split-K plan for the plane kernel (256 x 128 only), i.e. another summation order: fp32 rounding noise
     for (l0, g0, k0), (l1, g1, k1) in zip(*res):
-        assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
+        assert abs(float(l0) - float(l1)) <= 5e-6 * abs(float(l0))         # a few tens of fp32 ulps of a sum over ~1e5 terms
         assert float((k0 - k1).abs().max()) <= 2e-5 * float(k0.abs().max())
         assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
     assert not torch.equal(res[0][0][0], res[0][1][0])          # the two steps differ (the weights moved)
