@@ -551,6 +551,18 @@ class HipBackend:
 
     def _launch_wgrad_group(self) -> None:
         items, self._wq = self._wq, []
+        # one grid per load style: products whose operands allow 16-byte loads along their rows (aligned, leading dimension % 4 == 0
+        # and covering round_up(columns, 4)) run the faster kernel together; an odd one (513-wide tuple features) would drag its whole
+        # group onto the dword-load kernel
+        def vec(t):
+            return t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and (t.shape[1] + 3) // 4 * 4 <= t.stride(0)
+        fast = [it for it in items if vec(it[0]) and vec(it[1])]
+        slow = [it for it in items if not (vec(it[0]) and vec(it[1]))]
+        for part in (fast, slow):
+            if part:
+                self._launch_wgrad_items(part)
+
+    def _launch_wgrad_items(self, items) -> None:
         n = len(items)
         dev = items[0][2].device
         prec = self.gemm_precision if self.gemm_precision_bwd is None else self.gemm_precision_bwd
