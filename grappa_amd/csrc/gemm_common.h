@@ -29,8 +29,9 @@ struct GemmParams {
     // and combined by amax_combine_kernel after the product's launches
     unsigned* amax_part;
     int amax_seg;
-    // straight-line row epilogue for the common fp32 cases (host-chosen, epilogue_band_fast): 0 = the general walk; 1 = bias;
-    // 2 = bias + ELU; 3 = bias + dropout + residual; 4 = ELU' from the saved output (aux), optional residual
+    // straight-line row epilogue for the common cases (host-chosen, epilogue_band_fast): 0 = the general walk; 1 = bias;
+    // 2 = bias + ELU; 3 = bias + dropout + residual; 4 = ELU' from the saved output (aux), optional residual; + 8: the same with
+    // bf16 output / residual / aux (the bf16 storage configuration)
     int epi_class;
 };
 
@@ -219,10 +220,11 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;     // private staging region pe
 // on whole float4s only (host: N % 4 == 0, all tensors 16-byte aligned, fp32, one output tensor, no pre-activation addend).
 //   CLS 1: v + bias            2: elu(v + bias)            3: drop(v + bias) + res (drop_p may be 0, res may be NULL)
 //   CLS 4: v * elu'(aux) (+ res)
-template <int TN, int CLS>
+template <int TN, int CLS, typename T, int HB>
 __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f32x16 (&acc_i)[TN], float* __restrict__ wave_buf, int mband, int n, int lane,
-                                          const float4& b4) {
+                                                   const float4& b4) {
     const grappa_gemm_desc& d = p.d;
+    constexpr bool BF = sizeof(T) == 2;                      // the bf16 storage configuration: one-plane (= plain bf16) output / res / aux
     const int lr = lane & 31, lh = lane >> 5;
     constexpr int ROWS_PER_IT = TN == 2 ? 4 : 8;
     constexpr int NIT = 32 / ROWS_PER_IT;
@@ -235,11 +237,16 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
                 make_float4(acc_i[j][4 * g], acc_i[j][4 * g + 1], acc_i[j][4 * g + 2], acc_i[j][4 * g + 3]);
     const bool col_ok = n < d.N;
     const int mfirst = mband + rrow;
-    const float* side = CLS == 3 ? d.res : (CLS == 4 ? d.aux : nullptr);
-    const int ldside = CLS == 3 ? d.ldres : d.ldaux;
-    constexpr int HB = NIT / 2;                              // two batches of trips: loads of a batch in flight together
+    T* out = BF ? reinterpret_cast<T*>(d.Cp) : reinterpret_cast<T*>(d.C);
+    const int ldo = BF ? d.ldcp : d.ldc;
+    const T* resq = BF ? reinterpret_cast<const T*>(d.resp) : reinterpret_cast<const T*>(d.res);
+    const int ldr = BF ? d.ldresp : d.ldres;
+    const T* side = CLS == 3 ? resq : (CLS == 4 ? (BF ? reinterpret_cast<const T*>(d.auxp) : reinterpret_cast<const T*>(d.aux)) : nullptr);
+    const int ldside = CLS == 3 ? ldr : (BF ? d.ldauxp : d.ldaux);
+    // HB trips per batch: the LDS reads and the loads of a batch are in flight together (4: 48 registers; the one-plane kernel, which
+    // lives on 128 registers for two workgroups per CU, takes 2)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NIT / HB; ++h) {
         float4 v[HB], t[HB], r4[HB];
 #pragma unroll
         for (int k = 0; k < HB; ++k) {
@@ -247,8 +254,8 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
             v[k] = *reinterpret_cast<const float4*>(wave_buf + (it * ROWS_PER_IT + rrow) * EPI_LD + rc4);
             t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             r4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((CLS == 3 || CLS == 4) && side && col_ok && m < d.M) t[k] = *reinterpret_cast<const float4*>(side + (size_t)m * ldside + n);
-            if (CLS == 4 && d.res && col_ok && m < d.M) r4[k] = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
+            if ((CLS == 3 || CLS == 4) && side && col_ok && m < d.M) t[k] = ld4(side + (size_t)m * ldside + n, 0);
+            if (CLS == 4 && resq && col_ok && m < d.M) r4[k] = ld4(resq + (size_t)m * ldr + n, 0);
         }
 #pragma unroll
         for (int k = 0; k < HB; ++k) {
@@ -272,8 +279,8 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
                 x[2] = x[2] * grappa_elu_grad_from_out(t[k].z) + r4[k].z; x[3] = x[3] * grappa_elu_grad_from_out(t[k].w) + r4[k].w;
             }
             const bool ok = col_ok && m < d.M;
-            if (ok) *reinterpret_cast<float4*>(d.C + (size_t)m * d.ldc + n) = make_float4(x[0], x[1], x[2], x[3]);
-            if (p.amax_part) {
+            if (ok) st4(out + (size_t)m * ldo + n, 0, make_float4(x[0], x[1], x[2], x[3]));
+            if (!BF && p.amax_part) {
                 unsigned am = ok ? max(max(mag_bits(x[0]), mag_bits(x[1])), max(mag_bits(x[2]), mag_bits(x[3]))) : 0u;
                 am = group_umax<TN == 2 ? 16 : 8>(am);
                 const int nseg0 = n - rc4;
@@ -373,7 +380,7 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, const f32x16 
     }
 }
 
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, int EPI_BATCH = 4>
 __device__ __forceinline__ void tile_epilogue_rows(const GemmParams& p, const f32x16 (&acc)[TM][TN], float* __restrict__ wave_buf, int m0, int n0,
                                           int wm0, int wn0, int lane, int split, int tile_local, bool vec_io) {
     static_assert(TN * 32 <= 64 && TM == 2, "staging row holds 64 floats; two bands per wavefront");
@@ -386,16 +393,24 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmParams& p, const f3
         b4.z = n + 2 < d.N ? d.bias[n + 2] : 0.f;
         b4.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
     }
+#ifndef GRAPPA_NO_FAST_EPI
     if (p.epi_class != 0 && p.nsplit == 1) {
         const int mb = m0 + wm0;
+#define GRAPPA_FAST(CLS, T) epilogue_band_fast<TN, CLS, T, EPI_BATCH>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, CLS, T, EPI_BATCH>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break
         switch (p.epi_class) {
-            case 1: epilogue_band_fast<TN, 1>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, 1>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break;
-            case 2: epilogue_band_fast<TN, 2>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, 2>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break;
-            case 3: epilogue_band_fast<TN, 3>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, 3>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break;
-            default: epilogue_band_fast<TN, 4>(p, acc[0], wave_buf, mb, n, lane, b4); epilogue_band_fast<TN, 4>(p, acc[1], wave_buf, mb + 32, n, lane, b4); break;
+            case 1: GRAPPA_FAST(1, float);
+            case 2: GRAPPA_FAST(2, float);
+            case 3: GRAPPA_FAST(3, float);
+            case 4: GRAPPA_FAST(4, float);
+            case 9: GRAPPA_FAST(1, grappa_bf16_t);
+            case 10: GRAPPA_FAST(2, grappa_bf16_t);
+            case 11: GRAPPA_FAST(3, grappa_bf16_t);
+            default: GRAPPA_FAST(4, grappa_bf16_t);
         }
+#undef GRAPPA_FAST
         return;
     }
+#endif
     epilogue_band<BM, BN, TN>(p, acc[0], wave_buf, m0, n0, m0 + wm0, n, lane, b4, split, tile_local, vec_io);
     epilogue_band<BM, BN, TN>(p, acc[1], wave_buf, m0, n0, m0 + wm0 + 32, n, lane, b4, split, tile_local, vec_io);
 }

@@ -705,10 +705,19 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     p.amax_seg = p.bm == 256 ? 64 : 32;                     // 256 x 128 tile: wavefronts of 64 columns; 128 x 128: of 32
     // the straight-line row epilogues (gemm_common.h epilogue_band_fast): one fp32 output, whole float4s, no pre-activation addend
     p.epi_class = 0;
-    if (bf16x && p.vec_io && (d->N & 3) == 0 && d->C && !d->C2 && !d->Cp && !d->C1p && !d->resp && !d->auxp && !d->pre && !d->accumulate) {
-        if (d->aux) p.epi_class = (!d->bias && d->act == GRAPPA_ACT_NONE && d->drop_p == 0.0f) ? 4 : 0;
-        else if (d->act == GRAPPA_ACT_ELU) p.epi_class = (d->drop_p == 0.0f && !d->res) ? 2 : 0;
-        else p.epi_class = (d->drop_p > 0.0f || d->res) ? 3 : 1;
+    if (bf16x && (d->N & 3) == 0 && !d->C2 && !d->C1p && !d->pre && !d->accumulate) {
+        const bool f32_only = p.vec_io && d->C && !d->Cp && !d->resp && !d->auxp;
+        const bool bf16_only = d->Cp && !d->C && !d->res && !d->aux && d->cp_nplanes == 1 && (!d->resp || d->resp_nplanes == 1) &&
+                               (!d->auxp || d->auxp_nplanes == 1);
+        static const int fast_mask = getenv("GRAPPA_EPI_FAST") ? atoi(getenv("GRAPPA_EPI_FAST")) : 3;      // tuning only: bit 0 fp32, bit 1 bf16 classes
+        if ((f32_only && (fast_mask & 1)) || (bf16_only && (fast_mask & 2))) {
+            const bool has_aux = d->aux || d->auxp, has_res = d->res || d->resp;
+            int cls;
+            if (has_aux) cls = (!d->bias && d->act == GRAPPA_ACT_NONE && d->drop_p == 0.0f) ? 4 : 0;
+            else if (d->act == GRAPPA_ACT_ELU) cls = (d->drop_p == 0.0f && !has_res) ? 2 : 0;
+            else cls = (d->drop_p > 0.0f || has_res) ? 3 : 1;
+            p.epi_class = cls == 0 ? 0 : cls + (bf16_only ? 8 : 0);
+        }
     }
     if (amax_fused) {
         if (!ws || ws_bytes < need + amax_part_bytes(d->M, d->N)) return GRAPPA_ERR_WORKSPACE;

@@ -24,6 +24,9 @@
 // starts into it; three quarters into the slab every wavefront waits for ITS pieces of slab t+1 (counted vmcnt: slab t+2 stays in
 // flight), barrier X2, and the first fragments of slab t+1 are read under the remaining MFMAs.  A slab's DMA is in flight for
 // ~1.5 slab times with both LDS stages owned by the DMA engine: the registers are the third buffer.
+// the straight-line epilogue classes (gemm_common.h) cost this file's one-plane kernel 30 registers, i.e. its second workgroup per CU
+// (115 -> 145 VGPRs: the bf16 storage configuration's step went 86 -> 91 ms with them, 99 ms with the registers but without the classes)
+#define GRAPPA_NO_FAST_EPI
 #include "gemm_common.h"
 
 using namespace grappa_gemm;
