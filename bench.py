@@ -427,8 +427,12 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel_source_hash") == kernel_source_hash():
-                    roof["traffic"] = tj["families"]["gemm_f32"]["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch; same kernel sources)"
+                    # per product call, like `achieved`: the bytes of every kernel the products launch (main, grouped, split-K reduce,
+                    # row-maxima passes) per step, over the product calls per step
+                    roof["traffic"] = tj["families"]["dense_products"]["hbm_bytes_per_step"] / max(roof["launches_per_step"], 1.0)
+                    roof["traffic_source"] = ("profiles/pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                              "gfx950 corrections of MI355X_MICROARCH.md; HBM bytes of all kernels of the dense products per "
+                                              "step / product calls per step; same kernel sources)")
                 else:
                     roof["traffic_source"] = "profiles/pmc_traffic_c2.json was measured on other kernel sources: not reported"
             except Exception:

@@ -17,7 +17,11 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FAMILIES = {"gemm_f32": r"gemm_f32_kernel|gemm_bf16x_kernel", "gemm_bf16x": r"gemm_bf16x_kernel", "gemm_splitk_reduce": r"gemm_splitk_reduce_kernel", "gat_fwd": r"gat_fwd_kernel",
+# "dense_products": every kernel a dense product launches (main, grouped, split-K reduction, row-maxima passes and combines): bench.py
+# divides its bytes PER STEP by the product calls per step, the unit of roofline.achieved / algorithmic_bytes_per_launch
+FAMILIES = {"dense_products": r"gemm_f32_kernel|gemm_bf16x_kernel|gemm_bf16x_grouped_kernel|gemm_planes_kernel|gemm_wplanes_kernel|gemm_splitk_reduce|amax_|group_upload|group_index",
+            "adam": r"adam_kernel",
+            "gemm_f32": r"gemm_f32_kernel|gemm_bf16x_kernel", "gemm_bf16x": r"gemm_bf16x_kernel", "gemm_splitk_reduce": r"gemm_splitk_reduce_kernel", "gat_fwd": r"gat_fwd_kernel",
             "gat_bwd": r"gat_bwd_kernel|gat_delta_kernel", "layernorm": r"layernorm_", "seqattn": r"seqattn_"}
 
 
@@ -42,13 +46,16 @@ def main():
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1",
            "kernel_source_hash": kernel_source_hash(),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "families": {}}
+    steps = fc["adam"]                      # one optimiser step per train step
+    out["steps"] = steps
     for fam in FAMILIES:
-        if fc[fam] == 0:
+        if fc[fam] == 0 or fam == "adam":
             continue
         n = fc[fam]
         fetch_b, write_b = 2.0 * ft[fam] * 1024.0, wt[fam] * 1024.0 * (n / max(wc[fam], 1))
         out["families"][fam] = {"launches": n, "fetch_bytes_per_launch": fetch_b / n, "write_bytes_per_launch": write_b / n,
-                                "hbm_bytes_per_launch": (fetch_b + write_b) / n}
+                                "hbm_bytes_per_launch": (fetch_b + write_b) / n,
+                                "hbm_bytes_per_step": (fetch_b + write_b) / max(steps, 1)}
     print(json.dumps(out, indent=1))
 
 
