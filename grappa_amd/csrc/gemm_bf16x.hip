@@ -488,14 +488,25 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
         int ea[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) ea[i] = amax_shift(d.a_amax[(d.amax_bcast & 1) ? 0 : min(m0 + wm0 + i * 32 + lr, d.M - 1)]);
+        const bool b_rows = (d.amax_bcast & 2) == 0 && (reinterpret_cast<uintptr_t>(d.b_amax) & 15) == 0;
+        const int eb_all = (d.amax_bcast & 2) ? amax_shift(d.b_amax[0]) : 0;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = n0 + wn0 + j * 32 + (e >> 2) * 8 + lh * 4 + (e & 3);
-                const int eb = amax_shift(d.b_amax[(d.amax_bcast & 2) ? 0 : min(n, d.N - 1)]);
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn0 + j * 32 + g * 8 + lh * 4;                 // four consecutive columns, n % 4 == 0
+                int eb[4];
+                if (b_rows && n + 3 < d.N) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(d.b_amax + n);
+                    eb[0] = amax_shift(u.x); eb[1] = amax_shift(u.y); eb[2] = amax_shift(u.z); eb[3] = amax_shift(u.w);
+                } else {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j][e] = __builtin_ldexpf(acc[i][j][e], -(ea[i] + eb));
+                    for (int q = 0; q < 4; ++q) eb[q] = (d.amax_bcast & 2) ? eb_all : amax_shift(d.b_amax[min(n + q, d.N - 1)]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j][4 * g + q] = __builtin_ldexpf(acc[i][j][4 * g + q], -(ea[i] + eb[q]));
             }
     }
     __syncthreads();                                         // the stages (and the column-sum scratch) are dead: reuse as staging
