@@ -1,5 +1,5 @@
 // Largest magnitude of every row and every column of an fp32 matrix, one pass: the power-of-two scales of the F32_F16X3 products
-// (gemm_bf16x.hip, mode H3).  Magnitudes travel as fp32 bit patterns with the sign cleared: unsigned integer order is then the
+// (gemm_bf16x_impl.h, mode H3).  Magnitudes travel as fp32 bit patterns with the sign cleared: unsigned integer order is then the
 // order of the magnitudes (NaN above Inf above every finite value), so the whole reduction is integer max -- exact, order-free.
 // HBM-bound: R * C * 4 bytes read once; a wavefront walks rows (64 lanes x 16 B = 256 columns per load), four rows in flight.
 #include "common.h"

@@ -6,7 +6,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef GB_KNOCK
-#define GB_KNOCK 0            // timing experiments (gemm_bf16x.hip): 7 = the row epilogue issues no global stores
+#define GB_KNOCK 0            // timing experiments (gemm_bf16x_impl.h): 7 = the row epilogue issues no global stores
 #endif
 namespace grappa_gemm {
 

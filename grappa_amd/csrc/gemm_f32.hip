@@ -288,7 +288,7 @@ struct Plan {
 };
 
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
-// cfg 5, 6: the 128x128 and 256x128 tiles of the bf16-split kernel (gemm_bf16x.hip), one 512-thread workgroup per CU
+// cfg 5, 6: the 128x128 and 256x128 tiles of the bf16-split kernel (gemm_bf16x_impl.h), one 512-thread workgroup per CU
 constexpr int NCFG = 7;
 constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256};
 constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128};

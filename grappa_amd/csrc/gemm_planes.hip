@@ -11,7 +11,7 @@
 // transposing ds_read_b64_tr_b16 (k-major operands: the weight-gradient layout), and the wavefront issues the 6 partial
 // products a0b0, a0b1, a1b0, a1b1, a0b2, a2b0 (smallest first) as v_mfma_f32_32x32x16_bf16 into fp32 accumulators.
 //
-// Tile 256 x 128, 512 threads = 8 wavefronts as 4 x 2, 64 x 64 per wavefront (transposed accumulators as in gemm_bf16x.hip, same
+// Tile 256 x 128, 512 threads = 8 wavefronts as 4 x 2, 64 x 64 per wavefront (transposed accumulators as in gemm_bf16x_impl.h, same
 // float4 row epilogue).  K advances in slabs of 32: one stage = 3 planes x (256 + 128) rows x 64 B = 72 KB, two stages.
 // LDS image of a stage (linear per plane, which LDS-DMA requires: destination = wave-uniform base + 16 * lane):
 //   K-contiguous operand: [row][4 chunks of 16 B]; the chunk a lane fetches is XOR-ed with (row >> 2) & 3 on the SOURCE side and

@@ -124,22 +124,26 @@ def bench(be):
 
 
 def build_variants():
-    """libraries with the timing knock-outs of csrc/gemm_bf16x.hip (GB_KNOCK); run each with GRAPPA_HIP_LIB=<so> ... --bench-only"""
+    """libraries with the timing knock-outs of csrc/gemm_bf16x_impl.h (GB_KNOCK); run each with GRAPPA_HIP_LIB=<so> ... --bench-only"""
     import subprocess
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     csrc = os.path.join(root, "grappa_amd", "csrc")
     outdir = os.path.join(root, "build", "variants")
     os.makedirs(outdir, exist_ok=True)
-    objs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".o") and f != "gemm_bf16x.o"]
+    mode_units = ("gemm_bf16x_h3", "gemm_bf16x_x6")           # the two arithmetics the tool times (one translation unit each)
+    objs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".o") and f[:-2] not in mode_units]
     only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
-    for k, name in ((1, "nomfma"), (2, "nosplit"), (3, "noglobal"), (4, "nolds"), (5, "nobarrier"), (6, "noepi"), (7, "nostore"), (8, "nodescale"), (-40, "stagger40"), (-80, "stagger80"),
-                    (-120, "stagger120")):
+    for k, name in ((1, "nomfma"), (2, "nosplit"), (3, "noglobal"), (4, "nolds"), (5, "nobarrier"), (6, "noepi"), (7, "nostore"), (8, "nodescale")):
         if only and name not in only[0]:
             continue
-        o, so = os.path.join(outdir, f"gemm_bf16x_{name}.o"), os.path.join(outdir, f"libgrappa_hip_bx_{name}.so")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-DGB_KNOCK={k}" if k > 0 else f"-DGB_STAGGER={-k}", "-c",
-                        os.path.join(csrc, "gemm_bf16x.hip"), "-o", o], check=True)
-        subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, o, *objs], check=True)
+        so = os.path.join(outdir, f"libgrappa_hip_bx_{name}.so")
+        built = []
+        for unit in mode_units:
+            o = os.path.join(outdir, f"{unit}_{name}.o")
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-DGB_KNOCK={k}", "-c",
+                            os.path.join(csrc, unit + ".hip"), "-o", o], check=True)
+            built.append(o)
+        subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, *built, *objs], check=True)
         print(so)
 
 
