@@ -248,3 +248,40 @@ def test_weight_maxima_follow_the_optimiser(hip):
         assert torch.equal(am.row, bits(w).amax(dim=1)) and torch.equal(am.col, bits(w).amax(dim=0))
         exact = x[w.shape[1]].double().cpu() @ w.detach().double().cpu().t()
         assert torch.isfinite(o).all() and _rowrel(o, exact) < 2e-6
+
+
+def test_weight_gradient_column_maxima_option(hip):
+    """GRAPPA_WGRAD_COLUMN_MAXIMA (backend.wgrad_column_maxima): every column of both operands of a weight-gradient product gets
+    its own scale -- the columns 2^-24 below the tensor's largest element come out as accurately as the large ones; single products
+    and the grouped launch"""
+    g = torch.Generator().manual_seed(22)
+    T, Np, Kp = 6000, 512, 512
+    colscale = torch.pow(2.0, -torch.arange(Np, dtype=torch.float32) * (24.0 / Np))
+    dz = (torch.randn(T, Np, generator=g) * colscale).cuda()
+    x = torch.randn(T, Kp, generator=g).cuda()
+    exact = dz.double().cpu().t() @ x.double().cpu()
+    old_cols, old_prec = hip.wgrad_column_maxima, hip.gemm_precision_name
+    try:
+        hip.wgrad_column_maxima = True
+        hip.set_gemm_precision("f32_f16x3")
+        dw = torch.zeros(Np, Kp, device="cuda")
+        hip.gemm(dz, x, dw, M=Np, N=Kp, K=T, a_kcontig=False, b_kcontig=False, accumulate=True)
+        dw2, db2 = torch.zeros(Np, Kp, device="cuda"), torch.zeros(Np, device="cuda")
+        hip.gemm_wgrad(dz, x, dw2, db2)            # outside a backward pass: queued and flushed at once as a group of one
+        hip.flush_wgrads()
+        torch.cuda.synchronize()
+    finally:
+        hip.wgrad_column_maxima = old_cols
+        hip.set_gemm_precision(old_prec)
+    for out in (dw, dw2):
+        err_rows = (out.double().cpu() - exact).abs().amax(dim=1) / exact.abs().amax(dim=1)
+        assert err_rows.max() < 2e-6, err_rows.max()
+    assert torch.allclose(db2.cpu(), dz.sum(0).cpu(), rtol=1e-5, atol=1e-6)
+
+
+def test_gemm_rejects_maxima_of_the_wrong_length(hip):
+    from grappa_amd.backend import Amax
+    A, B = torch.randn(300, 256, device="cuda"), torch.randn(128, 256, device="cuda")
+    out = torch.empty(300, 128, device="cuda")
+    with pytest.raises(ValueError):
+        hip.gemm(A, B, out, M=300, N=128, K=256, precision="f32_f16x3", a_scales=Amax(row=torch.zeros(17, dtype=torch.int32, device="cuda")))
