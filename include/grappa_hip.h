@@ -117,15 +117,17 @@ typedef struct grappa_gemm_desc {
      * product, whose reduction runs over the tokens, takes max over the token maxima: elements more than 2^16 below the tensor's
      * largest lose relative precision gradually, absolute error <= 2^-39 of that largest) */
     const uint32_t* a_amax; const uint32_t* b_amax; int amax_bcast;
-    /* any precision, optional: receives max_n |OUT(m, n)| (M values, fp32 bit patterns) of the final output, for a following
-     * F32_F16X3 product that reads OUT as its A operand */
+    /* any precision, optional: receives max_n |OUT(m, n)| (M values, fp32 bit patterns) of the final fp32 output, for a following
+     * F32_F16X3 product that reads OUT as its A operand.  The row epilogue leaves per-segment maxima in the workspace (behind the
+     * split-K slabs: grappa_gemm_f32_workspace_bytes includes them) and one small launch combines them; not with the grouped entry */
     uint32_t* out_amax;
 } grappa_gemm_desc;
 
 /* Largest magnitudes of an fp32 matrix x[R][C] (leading dimension ldx), as fp32 bit patterns: row_amax[r] = max_c |x[r][c]|,
  * col_amax[c] = max_r |x[r][c]| (either may be NULL), one pass over x.  A product's operand uses the array ALONG which it is
  * not reduced: forward x[tok][in] -> row_amax, W[out][in] -> row_amax; dgrad dY[tok][out] -> row_amax, W -> col_amax;
- * wgrad dY -> col_amax, x -> col_amax.  NaN counts as larger than everything (the product is then NaN / Inf as in fp32).
+ * wgrad dY -> col_amax, x -> col_amax (or, with amax_bcast, the single maximum of each: grappa_amax_reduce over the row maxima).
+ * NaN counts as larger than everything (the product is then NaN / Inf as in fp32).
  * ws: grappa_amax_f32_workspace_bytes(R, C) bytes (partial column maxima), needed only with col_amax. */
 size_t grappa_amax_f32_workspace_bytes(int R, int C);
 int grappa_amax_f32(void* stream, int R, int C, const float* x, int ldx, uint32_t* row_amax, uint32_t* col_amax, void* ws, size_t ws_bytes);
