@@ -25,7 +25,10 @@ def run(defer):
     be.defer_wgrads = defer
     for dz, x, dw, db in probs:
         if defer:
-            be._wq.append((dz, x, dw, db))
+            am = None
+            if be.wants_amax(True):          # the fp16-split arithmetic: row maxima of both operands ride along (as gemm_wgrad queues them)
+                am = (be.amax(dz, None, rows=True), be.amax(x, None, rows=True))
+            be._wq.append((dz, x, dw, db, am))
         else:
             be.gemm_wgrad(dz, x, dw, db)
     if defer:
