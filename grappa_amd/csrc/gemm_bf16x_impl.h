@@ -44,7 +44,10 @@ namespace {
 
 constexpr int SK = 16;                  // k-slab per pipeline step (one 32x32x16 MFMA deep)
 constexpr int ROWB = 48;                // LDS row: 16 bf16 (32 B) + 16 B pad -> conflict-free ds_read_b128 per 16-lane group
-constexpr int AHEAD = 4;                // register sets: slab s+4 is loaded while slab s is multiplied
+#ifndef GB_AHEAD
+#define GB_AHEAD 4
+#endif
+constexpr int AHEAD = GB_AHEAD;         // register sets (even): slab s+AHEAD is loaded while slab s is multiplied
 
 enum Mode { X1 = 1, X3 = 3, X6 = 6, X9 = 9, H3 = 103 };
 template <int MODE> struct Pieces {
@@ -409,54 +412,34 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
     const bool do_cs = !AK && d.a_colsum != nullptr && tile_n == 0;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};      // sums over k of A(row, k) for the row (KMV: the four rows) this thread stages -- the same for all its quads
     if (nsteps > 0) {
-        Quad a0[NQA], b0[NQB], a1[NQA], b1[NQB], a2[NQA], b2[NQB], a3[NQA], b3[NQB];
-        Frags<NP, TM, TN> fe, fo;      // fragments of even / odd slabs
-#define GRAPPA_LOAD(S, QA, QB)                                                                      \
-    load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of((S) < nsteps ? (S) : 0), d.M, kr.kend, QA); \
-    load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of((S) < nsteps ? (S) : 0), d.N, kr.kend, QB)
-        GRAPPA_LOAD(0, a0, b0);
-        GRAPPA_LOAD(1, a1, b1);
-        GRAPPA_LOAD(2, a2, b2);
-        GRAPPA_LOAD(3, a3, b3);
-#undef GRAPPA_LOAD
-        store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF, AV>(smem, a0, kr.kend - kr.kbeg, sha);
-        store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF, BV>(smem + NP * PA, b0, kr.kend - kr.kbeg, shb);
-        if (!AK && do_cs) quad_rowsum<NT, BM, AV, true>(a0, kr.kend - kr.kbeg, cs);
-        __syncthreads();
-        read_frags<NP, BM, BN, TM, TN, AV, BV>(smem, wm0, wn0, lane, fe);
-        int s = 0;
-        // step s stores slab s+1 (register set (s+1) % 4) and loads slab s+4 into the set slab s occupied
-#define GRAPPA_STEP(TAIL, LA, LB, SA, SB, FC, FN) \
-    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, TAIL>(d, smem, acc, m0, n0, kr, s, wm0, wn0, lane, LA, LB, SA, SB, FC, FN, cs, do_cs, sha, shb)
-        // main loop: four steps per trip (the register sets rotate); never stores the last slab of the range and every load
-        // it issues is for an existing slab
-        for (; s + 7 < nsteps; s += 4) {
-            GRAPPA_STEP(false, a0, b0, a1, b1, fe, fo);
-            ++s;
-            GRAPPA_STEP(false, a1, b1, a2, b2, fo, fe);
-            ++s;
-            GRAPPA_STEP(false, a2, b2, a3, b3, fe, fo);
-            ++s;
-            GRAPPA_STEP(false, a3, b3, a0, b0, fo, fe);
-            s -= 3;
+        static_assert(AHEAD % 2 == 0, "the fragment sets alternate with the slabs");
+        Quad qa[AHEAD][NQA], qb[AHEAD][NQB];      // register sets: slab t lives in set t % AHEAD from its load to its split
+        Frags<NP, TM, TN> fr[2];                  // fragments of even / odd slabs
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
+            load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
         }
-        for (; s < nsteps; s += 4) {                  // the last (up to 7) steps
-            GRAPPA_STEP(true, a0, b0, a1, b1, fe, fo);
-            if (s + 1 < nsteps) {
-                ++s;
-                GRAPPA_STEP(true, a1, b1, a2, b2, fo, fe);
-                --s;
-            }
-            if (s + 2 < nsteps) {
-                s += 2;
-                GRAPPA_STEP(true, a2, b2, a3, b3, fe, fo);
-                s -= 2;
-            }
-            if (s + 3 < nsteps) {
-                s += 3;
-                GRAPPA_STEP(true, a3, b3, a0, b0, fo, fe);
-                s -= 3;
-            }
+        store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF, AV>(smem, qa[0], kr.kend - kr.kbeg, sha);
+        store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF, BV>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, shb);
+        if (!AK && do_cs) quad_rowsum<NT, BM, AV, true>(qa[0], kr.kend - kr.kbeg, cs);
+        __syncthreads();
+        read_frags<NP, BM, BN, TM, TN, AV, BV>(smem, wm0, wn0, lane, fr[0]);
+        int s = 0;
+        // step s stores slab s+1 (register set (s+1) % AHEAD) and loads slab s+AHEAD into the set slab s occupied
+#define GRAPPA_STEP(TAIL, U) \
+    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, TAIL>(d, smem, acc, m0, n0, kr, s + (U), wm0, wn0, lane, qa[U], qb[U], qa[((U) + 1) % AHEAD], \
+                                                                 qb[((U) + 1) % AHEAD], fr[(U) & 1], fr[((U) + 1) & 1], cs, do_cs, sha, shb)
+        // main loop: AHEAD steps per trip (the register sets rotate); never stores the last slab of the range and every load
+        // it issues is for an existing slab
+        for (; s + 2 * AHEAD - 1 < nsteps; s += AHEAD) {
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) { GRAPPA_STEP(false, u); }
+        }
+        for (; s < nsteps; s += AHEAD) {              // the last (up to 2 AHEAD - 1) steps
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u)
+                if (s + u < nsteps) { GRAPPA_STEP(true, u); }
         }
 #undef GRAPPA_STEP
     }
