@@ -180,7 +180,7 @@ def test_weight_gradient_with_columns_of_very_different_scales(hip):
     assert (err_rows <= bound).all(), (err_rows / bound).max()
 
 
-def _train_step(precision, wl="C1-dipeptide-b8"):
+def _train_step(precision, wl="C1-dipeptide-b8", n=8):
     import bench
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.backend import get_backend
@@ -194,7 +194,7 @@ def _train_step(precision, wl="C1-dipeptide-b8"):
         bench.keyed_init(model)
         model = model.to(dev).train()
         ops.manual_seed(99)
-        ids = workload_molecule_ids(wl)[:8]
+        ids = workload_molecule_ids(wl)[:n]
         gph = build_batch_from_pool(ids, n_confs=WORKLOADS[wl][3], seed=0).to(dev)
         loss = MolwiseLoss(**bench.LOSS_KW)(Energy()(model(gph)))
         loss.backward()
@@ -205,11 +205,13 @@ def _train_step(precision, wl="C1-dipeptide-b8"):
         be.set_gemm_precision(old)
 
 
-def test_train_step_matches_default_arithmetic():
-    """one train step (dropout on, same seeds) in f32_f16x3 and in the default f32_bf16x6: loss and every parameter gradient agree
-    to fp32 rounding (the gate of SURVEY 8(d) is 1e-4; measured here ~1e-6)"""
-    l6, g6 = _train_step("f32_bf16x6")
-    l3, g3 = _train_step("f32_f16x3")
+@pytest.mark.parametrize("wl,n", [("C1-dipeptide-b8", 8), ("C2-pubchem-b256", 256)])
+def test_train_step_matches_default_arithmetic(wl, n):
+    """one train step (dropout on, same seeds) in f32_f16x3 (the default) and in f32_bf16x6 (the default it replaced): loss and every
+    parameter gradient agree to fp32 rounding (the gate of SURVEY 8(d) is 1e-4; measured here ~1e-6) -- at C1's size and on the
+    full 256-molecule batch of the headline workload"""
+    l6, g6 = _train_step("f32_bf16x6", wl, n)
+    l3, g3 = _train_step("f32_f16x3", wl, n)
     assert abs(l3 - l6) <= 2e-6 * abs(l6), (l3, l6)
     worst = 0.0
     for n in g6:
