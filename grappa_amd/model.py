@@ -9,8 +9,8 @@ torch.nn.Linear / LayerNorm / MultiheadAttention instances are used as parameter
 initialisation as the reference); their forward() is never called.  All arithmetic goes through
 grappa_amd.ops (block-level autograd nodes -> C ABI).
 
-Restrictions (raise at construction): layer_norm=True, self_interaction=True,
-learnable_statistics=False -- the only values the reference's shipped configurations use.
+Restriction (raises at construction): learnable_statistics=False -- the only value the reference's shipped configurations use.
+layer_norm=False / self_interaction=False drop the same sub-modules the reference drops (same state-dict keys).
 """
 from __future__ import annotations
 
@@ -48,43 +48,64 @@ class _SageParams(nn.Module):
         nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
 
 
+def _wb(norm):
+    """(weight, bias) of an optional LayerNorm"""
+    return (None, None) if norm is None else (norm.weight, norm.bias)
+
+
 class ResidualAttentionBlock(nn.Module):
-    def __init__(self, in_feats, num_heads, dropout):
+    """reference models/graph_attention.py:226-310; the same sub-modules exist under the same names for the same options
+    (layer_norm=False: no layer_norm / interaction_norm; self_interaction=False: no self_interaction, no interaction_norm)"""
+
+    def __init__(self, in_feats, num_heads, dropout, layer_norm=True, self_interaction=True):
         super().__init__()
         assert in_feats % num_heads == 0
         self.num_heads, self.p = num_heads, float(dropout)
         self.graph_module = _GraphFC(in_feats, in_feats // num_heads, num_heads)
-        self.layer_norm = nn.LayerNorm(in_feats)
+        if layer_norm:
+            self.layer_norm = nn.LayerNorm(in_feats)
         self.head_reducer = nn.Linear(in_feats, in_feats)
-        self.interaction_norm = nn.LayerNorm(in_feats)
-        self.self_interaction = nn.Sequential(nn.Linear(in_feats, 4 * in_feats), nn.ELU(), nn.Linear(4 * in_feats, in_feats), nn.ELU())
+        if self_interaction:
+            if layer_norm:
+                self.interaction_norm = nn.LayerNorm(in_feats)
+            self.self_interaction = nn.Sequential(nn.Linear(in_feats, 4 * in_feats), nn.ELU(), nn.Linear(4 * in_feats, in_feats), nn.ELU())
+        else:
+            self.self_interaction = None
 
     def forward(self, plan, h):
         p = self.p if self.training else 0.0
         s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
         si = self.self_interaction
-        return ops.AttBlockFn.apply(h, plan, self.num_heads, p, s1, s2, self.layer_norm.weight, self.layer_norm.bias,
+        si_params = (None,) * 4 if si is None else (si[0].weight, si[0].bias, si[2].weight, si[2].bias)
+        return ops.AttBlockFn.apply(h, plan, self.num_heads, p, s1, s2, *_wb(getattr(self, "layer_norm", None)),
                                     self.graph_module.fc.weight, self.head_reducer.weight, self.head_reducer.bias,
-                                    self.interaction_norm.weight, self.interaction_norm.bias, si[0].weight, si[0].bias,
-                                    si[2].weight, si[2].bias)
+                                    *_wb(getattr(self, "interaction_norm", None)), *si_params)
 
 
 class ResidualConvBlock(nn.Module):
-    def __init__(self, in_feats, dropout):
+    """reference models/graph_attention.py:343-415"""
+
+    def __init__(self, in_feats, dropout, layer_norm=True, self_interaction=True):
         super().__init__()
         self.p = float(dropout)
         self.graph_module = _SageParams(in_feats, in_feats)
-        self.layer_norm = nn.LayerNorm(in_feats)
-        self.self_interaction = nn.Sequential(nn.Linear(in_feats, in_feats), nn.ELU())
-        self.interaction_norm = nn.LayerNorm(in_feats)
+        if layer_norm:
+            self.layer_norm = nn.LayerNorm(in_feats)
+        if self_interaction:
+            self.self_interaction = nn.Sequential(nn.Linear(in_feats, in_feats), nn.ELU())
+            if layer_norm:
+                self.interaction_norm = nn.LayerNorm(in_feats)
+        else:
+            self.self_interaction = None
 
     def forward(self, plan, h):
         p = self.p if self.training else 0.0
         s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
         gm = self.graph_module
-        return ops.ConvBlockFn.apply(h, plan, p, s1, s2, self.layer_norm.weight, self.layer_norm.bias, gm.fc_self.weight,
-                                     gm.fc_neigh.weight, gm.bias, self.interaction_norm.weight, self.interaction_norm.bias,
-                                     self.self_interaction[0].weight, self.self_interaction[0].bias)
+        si = self.self_interaction
+        si_params = (None, None) if si is None else (si[0].weight, si[0].bias)
+        return ops.ConvBlockFn.apply(h, plan, p, s1, s2, *_wb(getattr(self, "layer_norm", None)), gm.fc_self.weight,
+                                     gm.fc_neigh.weight, gm.bias, *_wb(getattr(self, "interaction_norm", None)), *si_params)
 
 
 class GrappaGNN(nn.Module):
@@ -92,7 +113,7 @@ class GrappaGNN(nn.Module):
 
     def __init__(self, out_feats=512, in_feats=None, node_feats=None, n_conv=3, n_att=3, n_heads=8,
                  in_feat_name=("atomic_number", "ring_encoding", "partial_charge"), in_feat_dims={}, conv_dropout=0.,
-                 attention_dropout=0., final_dropout=0., initial_dropout=0., charge_encoding=True):
+                 attention_dropout=0., final_dropout=0., initial_dropout=0., layer_norm=True, self_interaction=True, charge_encoding=True):
         super().__init__()
         if not isinstance(in_feat_name, (list, tuple)):
             in_feat_name = [in_feat_name]
@@ -109,8 +130,9 @@ class GrappaGNN(nn.Module):
         self.pre_dense = nn.Sequential(nn.Linear(self.in_feats, node_feats), nn.ELU())
         self.no_convs = (n_conv + n_att) == 0
         if not self.no_convs:
-            self.conv_blocks = nn.ModuleList([ResidualConvBlock(node_feats, conv_dropout) for _ in range(n_conv)])
-            self.att_blocks = nn.ModuleList([ResidualAttentionBlock(node_feats, n_heads, attention_dropout) for _ in range(n_att)])
+            self.conv_blocks = nn.ModuleList([ResidualConvBlock(node_feats, conv_dropout, layer_norm, self_interaction) for _ in range(n_conv)])
+            self.att_blocks = nn.ModuleList([ResidualAttentionBlock(node_feats, n_heads, attention_dropout, layer_norm, self_interaction)
+                                             for _ in range(n_att)])
         self.post_dense = nn.Sequential(nn.Linear(node_feats, out_feats))
         if not self.no_convs:
             self.blocks = self.conv_blocks + self.att_blocks       # same aliasing as the reference (state-dict keys twice)
@@ -148,35 +170,37 @@ class GrappaGNN(nn.Module):
 class FeedForwardLayer(nn.Module):
     """parameter holder: linear1, linear2, norm1 (reference models/network_utils.py:5-54)"""
 
-    def __init__(self, in_feats, hidden_feats, out_feats):
+    def __init__(self, in_feats, hidden_feats, out_feats, layer_norm=True):
         super().__init__()
         self.linear1 = nn.Linear(in_feats, hidden_feats)
         self.linear2 = nn.Linear(hidden_feats, out_feats)
-        self.norm1 = nn.LayerNorm(in_feats)
+        if layer_norm:
+            self.norm1 = nn.LayerNorm(in_feats)
 
     def params(self):
-        return (self.norm1.weight, self.norm1.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+        return (*_wb(getattr(self, "norm1", None)), self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
 
 
 class DottedAttWithMLP(nn.Module):
-    def __init__(self, n_feats, num_heads, hidden_feats, dropout):
+    def __init__(self, n_feats, num_heads, hidden_feats, dropout, layer_norm=True):
         super().__init__()
         assert n_feats % num_heads == 0, f"Number of features ({n_feats}) must be divisible by the number of heads ({num_heads})."
         self.num_heads, self.p = num_heads, float(dropout)
-        self.norm1 = nn.LayerNorm(n_feats)
+        if layer_norm:
+            self.norm1 = nn.LayerNorm(n_feats)
         self.attn = nn.MultiheadAttention(n_feats, num_heads, dropout=0)
-        self.ff = FeedForwardLayer(n_feats, hidden_feats, n_feats)
+        self.ff = FeedForwardLayer(n_feats, hidden_feats, n_feats, layer_norm)
 
     def forward(self, x, s, T):
         p = self.p if self.training else 0.0
         s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
-        return ops.TransformerLayerFn.apply(x, s, T, self.num_heads, p, s1, s2, self.norm1.weight, self.norm1.bias,
+        return ops.TransformerLayerFn.apply(x, s, T, self.num_heads, p, s1, s2, *_wb(getattr(self, "norm1", None)),
                                             self.attn.in_proj_weight, self.attn.in_proj_bias, self.attn.out_proj.weight,
                                             self.attn.out_proj.bias, *self.ff.params())
 
 
 class GrappaTransformer(nn.Module):
-    def __init__(self, n_feats, n_heads, hidden_feats, n_layers, positional_encoding: Optional[torch.Tensor], dropout):
+    def __init__(self, n_feats, n_heads, hidden_feats, n_layers, positional_encoding: Optional[torch.Tensor], dropout, layer_norm=True):
         super().__init__()
         if positional_encoding is not None:
             self.register_buffer("positional_encoding", positional_encoding.float())
@@ -186,11 +210,11 @@ class GrappaTransformer(nn.Module):
         if n_feats % n_heads:
             raise ValueError(f"The number of input features cannot be divided by the number of heads: {n_feats} / {n_heads}")
         self.n_feats = n_feats
-        self.transformer = nn.Sequential(*[DottedAttWithMLP(n_feats, n_heads, hidden_feats, dropout) for _ in range(n_layers)])
+        self.transformer = nn.Sequential(*[DottedAttWithMLP(n_feats, n_heads, hidden_feats, dropout, layer_norm) for _ in range(n_layers)])
 
 
 class Symmetriser(nn.Module):
-    def __init__(self, in_feats, out_feats, permutations: torch.Tensor, hidden_feats, n_layers):
+    def __init__(self, in_feats, out_feats, permutations: torch.Tensor, hidden_feats, n_layers, layer_norm=True):
         super().__init__()
         assert n_layers >= 1, "n_layers must be >= 1"
         P, s = permutations.shape
@@ -198,24 +222,24 @@ class Symmetriser(nn.Module):
         self.register_buffer("permutation_prefactors", torch.ones(P, dtype=torch.float32).view(P, 1, 1))
         self.register_buffer("permutations", permutations.int())
         self.n_seq, self.out_feats = s, out_feats
-        layers = [FeedForwardLayer(in_feats * s, hidden_feats, hidden_feats if n_layers > 1 else out_feats)]
+        layers = [FeedForwardLayer(in_feats * s, hidden_feats, hidden_feats if n_layers > 1 else out_feats, layer_norm)]
         for i in range(1, n_layers):
-            layers.append(FeedForwardLayer(hidden_feats, hidden_feats, out_feats if i == n_layers - 1 else hidden_feats))
+            layers.append(FeedForwardLayer(hidden_feats, hidden_feats, out_feats if i == n_layers - 1 else hidden_feats, layer_norm))
         self.mlp = nn.Sequential(*layers)
         self._perm_list = [tuple(int(v) for v in p) for p in permutations.tolist()]
 
 
 class SymmetrisedTransformer(nn.Module):
     def __init__(self, n_feats, n_heads, hidden_feats, n_layers, out_feats, permutations, dropout, symmetriser_layers,
-                 symmetriser_hidden_feats, positional_encoding):
+                 symmetriser_hidden_feats, positional_encoding, layer_norm=True):
         super().__init__()
         if n_layers > 0:
-            self.grappa_transformer = GrappaTransformer(n_feats, n_heads, hidden_feats, n_layers, positional_encoding, dropout)
+            self.grappa_transformer = GrappaTransformer(n_feats, n_heads, hidden_feats, n_layers, positional_encoding, dropout, layer_norm)
             width = self.grappa_transformer.n_feats
         else:
             self.grappa_transformer = None
             width = n_feats
-        self.symmetriser = Symmetriser(width, out_feats, permutations, symmetriser_hidden_feats, symmetriser_layers)
+        self.symmetriser = Symmetriser(width, out_feats, permutations, symmetriser_hidden_feats, symmetriser_layers, layer_norm)
 
     def forward(self, x, s, T):
         """x: (s*T, F) token table (row = pos*T + t) -> (P*T, out_feats), one row per permuted copy."""
@@ -286,14 +310,14 @@ class _WriterBase(nn.Module):
 class WriteBondParameters(_WriterBase):
     level, s, kind = "n2", 2, 0
 
-    def __init__(self, rep_feats, between_feats, suffix, stats, n_att, n_heads, dense_layers, dropout, symmetriser_feats, gate):
+    def __init__(self, rep_feats, between_feats, suffix, stats, n_att, n_heads, dense_layers, dropout, symmetriser_feats, gate, layer_norm=True):
         super().__init__()
         eps = 1e-6
         self.suffix, self.gate = suffix, gate
         self.rep_projector = RepProjector(2, rep_feats, between_feats)
         self.bond_model = SymmetrisedTransformer(between_feats, n_heads, between_feats, n_att, 2 + int(gate),
                                                  torch.tensor([[0, 1], [1, 0]], dtype=torch.int32), dropout, dense_layers,
-                                                 symmetriser_feats, None)
+                                                 symmetriser_feats, None, layer_norm)
         self.to_k = ToPositive(stats["mean"]["n2_k"].item(), stats["std"]["n2_k"].item() + eps)
         self.to_eq = ToPositive(stats["mean"]["n2_eq"].item(), stats["std"]["n2_eq"].item() + eps)
 
@@ -317,7 +341,7 @@ class WriteAngleParameters(_WriterBase):
     level, s, kind = "n3", 3, 1
 
     def __init__(self, rep_feats, between_feats, suffix, stats, n_att, n_heads, dense_layers, dropout, symmetriser_feats,
-                 positional_encoding, gate):
+                 positional_encoding, gate, layer_norm=True):
         super().__init__()
         eps = 1e-6
         self.suffix, self.gate = suffix, gate
@@ -325,7 +349,7 @@ class WriteAngleParameters(_WriterBase):
         self.rep_projector = RepProjector(3, rep_feats, proj)
         self.angle_model = SymmetrisedTransformer(proj, n_heads, between_feats, n_att, 2 + int(gate),
                                                   torch.tensor([[0, 1, 2], [2, 1, 0]], dtype=torch.int32), dropout, dense_layers,
-                                                  symmetriser_feats, _pos_enc(3, positional_encoding))
+                                                  symmetriser_feats, _pos_enc(3, positional_encoding), layer_norm)
         self.to_k = ToPositive(stats["mean"]["n3_k"].item(), stats["std"]["n3_k"].item() + eps)
         self.to_eq = ToRange(math.pi, stats["std"]["n3_eq"].item() + eps)
 
@@ -351,7 +375,7 @@ class WriteTorsionParameters(_WriterBase):
     s, kind = 4, 2
 
     def __init__(self, rep_feats, between_feats, suffix, n_periodicity, improper, n_att, n_heads, dense_layers, dropout,
-                 symmetriser_feats, stats, positional_encoding, gated, wrong_symmetry, cutoff):
+                 symmetriser_feats, stats, positional_encoding, gated, wrong_symmetry, cutoff, layer_norm=True):
         super().__init__()
         eps = 1e-1 if gated else 1e-2
         self.gated, self.improper, self.suffix, self.cutoff_value = gated, improper, suffix, float(cutoff)
@@ -381,7 +405,7 @@ class WriteTorsionParameters(_WriterBase):
         self._P = len(perms)
         n_out = 2 * n_periodicity if gated else n_periodicity
         self.torsion_model = SymmetrisedTransformer(proj, n_heads, between_feats, n_att, n_out, torch.tensor(perms, dtype=torch.int32),
-                                                    dropout, dense_layers, symmetriser_feats, pe)
+                                                    dropout, dense_layers, symmetriser_feats, pe, layer_norm)
 
     def _model(self):
         return self.torsion_model
@@ -408,18 +432,20 @@ class WriteParameters(nn.Module):
         rep, drop, pos = cfg["graph_node_features"], cfg["parameter_dropout"], cfg["positional_encoding"]
         gate = cfg["harmonic_gate"]
         self.bond_writer = WriteBondParameters(rep, cfg["bond_transformer_width"], suffix, stats, cfg["bond_transformer_depth"],
-                                               cfg["bond_n_heads"], cfg["bond_symmetriser_depth"], drop, cfg["bond_symmetriser_width"], gate)
+                                               cfg["bond_n_heads"], cfg["bond_symmetriser_depth"], drop, cfg["bond_symmetriser_width"], gate,
+                                               layer_norm=cfg.get("layer_norm", True))
         self.angle_writer = WriteAngleParameters(rep, cfg["angle_transformer_width"], suffix, stats, cfg["angle_transformer_depth"],
                                                  cfg["angle_n_heads"], cfg["angle_symmetriser_depth"], drop,
-                                                 cfg["angle_symmetriser_width"], pos, gate)
+                                                 cfg["angle_symmetriser_width"], pos, gate, layer_norm=cfg.get("layer_norm", True))
         self.proper_writer = WriteTorsionParameters(rep, cfg["proper_transformer_width"], suffix, cfg["n_periodicity_proper"], False,
                                                     cfg["proper_transformer_depth"], cfg["proper_n_heads"], cfg["proper_symmetriser_depth"],
                                                     drop, cfg["proper_symmetriser_width"], stats, pos, cfg["gated_torsion"], False,
-                                                    cfg["torsion_cutoff"])
+                                                    cfg["torsion_cutoff"], layer_norm=cfg.get("layer_norm", True))
         self.improper_writer = WriteTorsionParameters(rep, cfg["improper_transformer_width"], suffix, cfg["n_periodicity_improper"], True,
                                                       cfg["improper_transformer_depth"], cfg["improper_n_heads"],
                                                       cfg["improper_symmetriser_depth"], drop, cfg["improper_symmetriser_width"], stats, pos,
-                                                      cfg["gated_torsion"], cfg["wrong_symmetry"], cfg["torsion_cutoff"])
+                                                      cfg["gated_torsion"], cfg["wrong_symmetry"], cfg["torsion_cutoff"],
+                                                      layer_norm=cfg.get("layer_norm", True))
 
         # The four writers read the same atom embedding and write disjoint tuple levels: on the GPU each CAN run on its own HIP stream
         # (largest first), so that the tail rounds and launch gaps of one head's kernels are filled by another head's; autograd
@@ -479,9 +505,8 @@ class GrappaModel(nn.Module):
                  wrong_symmetry=False, positional_encoding=True, layer_norm=True, self_interaction=True, learnable_statistics: bool = False,
                  param_statistics: dict = None, torsion_cutoff=1.e-4, harmonic_gate: bool = False):
         super().__init__()
-        if not (layer_norm and self_interaction) or learnable_statistics:
-            raise NotImplementedError("grappa_amd implements layer_norm=True, self_interaction=True, learnable_statistics=False "
-                                      "(the values of every configuration the reference ships)")
+        if learnable_statistics:
+            raise NotImplementedError("grappa_amd implements learnable_statistics=False (the value of every configuration the reference ships)")
         if param_statistics is None:
             param_statistics = get_default_statistics()
         cfg = dict(locals())
@@ -491,7 +516,8 @@ class GrappaModel(nn.Module):
         self.gnn = GrappaGNN(out_feats=graph_node_features, in_feats=in_feats, node_feats=gnn_width, n_conv=gnn_convolutions,
                              n_att=gnn_attentional_layers, n_heads=gnn_attention_heads, in_feat_name=in_feat_name,
                              in_feat_dims=in_feat_dims, conv_dropout=gnn_dropout_conv, attention_dropout=gnn_dropout_attention,
-                             final_dropout=gnn_dropout_final, initial_dropout=gnn_dropout_initial)
+                             final_dropout=gnn_dropout_final, initial_dropout=gnn_dropout_initial, layer_norm=layer_norm,
+                             self_interaction=self_interaction)
         self.parameter_writer = WriteParameters(cfg, param_statistics)
         self.field_of_view = gnn_attentional_layers + gnn_convolutions + 3
         self.on_heads_backward_done = None      # optional callback (dist.BucketedGradReducer): overlap of the gradient all-reduce

@@ -124,6 +124,8 @@ def _linear_bwd_params(be, dz, x, w, b, xs=None, zs=None):
 
 
 def _ln_fwd(be, x, w, b):
+    if w is None:                                   # layer_norm=False: the block works on its input as it is
+        return x, None, None, None
     M = x.shape[0]
     y = _new(x.shape, x)
     mean, rstd = _new((M,), x, F32), _new((M,), x, F32)
@@ -133,6 +135,8 @@ def _ln_fwd(be, x, w, b):
 
 def _ln_bwd(be, dy, x, mean, rstd, w, b):
     """-> (dx, the backend's record of dx's row maxima or None)"""
+    if w is None:                                   # layer_norm=False
+        return dy, None
     dx = _new(x.shape, x)
     if x.shape[0] == 0:
         return dx, None
@@ -236,7 +240,10 @@ class AttBlockFn(Function):
         be.gat_fwd(plan, ft, heads, ft.shape[1] // heads, m, alpha)
         h3 = _new((N, Fd), h)
         sm = be.gemm(m, w_r, h3, M=N, N=Fd, K=m.shape[1], bias=b_r, drop_p=drop_p, drop_seed=seed1, res=h1)
-        out, ff_saved = _ff_fwd(be, h3, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
+        if w1 is None:                              # self_interaction=False: attention + head reducer + skip only
+            out, ff_saved = h3, None
+        else:
+            out, ff_saved = _ff_fwd(be, h3, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
         ctx.plan, ctx.cfg, ctx.scales = plan, (heads, drop_p, seed1, seed2), (sh1, sm)
         ctx.ff_saved = ff_saved
         ctx.save_for_backward(h, mean1, rstd1, h1, ft, m, alpha, ln_w, ln_b, w_fc, w_r, b_r, ln2_w, ln2_b, w1, b1, w2, b2)
@@ -249,7 +256,10 @@ class AttBlockFn(Function):
         heads, drop_p, seed1, seed2 = ctx.cfg
         plan = ctx.plan
         N, Fd = h.shape
-        dh3, sz = _ff_bwd(be, ctx.ff_saved, dout, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
+        if ctx.ff_saved is None:
+            dh3, sz = _c(dout), None
+        else:
+            dh3, sz = _ff_bwd(be, ctx.ff_saved, dout, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
         ctx.ff_saved = None
         if drop_p > 0:
             dzr = _new(dh3.shape, dh3)
@@ -285,10 +295,14 @@ class ConvBlockFn(Function):
         y1 = _new((N, Fd), h)          # ELU output before dropout
         h3 = _new((N, Fd), h)
         sh1 = be.gemm(h1, w_self, y1, M=N, N=Fd, K=Fd, bias=bias, pre=t, act=ELU, drop_p=drop_p, drop_seed=seed1, res=h1, out2=h3, a_scales=sh1)
-        h4, mean2, rstd2, sh4 = _ln_fwd(be, h3, ln2_w, ln2_b)
-        y2 = _new((N, Fd), h)
-        out = _new((N, Fd), h)
-        sh4 = be.gemm(h4, w, y2, M=N, N=Fd, K=Fd, bias=b, act=ELU, drop_p=drop_p, drop_seed=seed2, res=h4, out2=out, a_scales=sh4)
+        if w is None:                               # self_interaction=False: the block ends behind the SAGE step
+            h4 = mean2 = rstd2 = y2 = sh4 = None
+            out = h3
+        else:
+            h4, mean2, rstd2, sh4 = _ln_fwd(be, h3, ln2_w, ln2_b)
+            y2 = _new((N, Fd), h)
+            out = _new((N, Fd), h)
+            sh4 = be.gemm(h4, w, y2, M=N, N=Fd, K=Fd, bias=b, act=ELU, drop_p=drop_p, drop_seed=seed2, res=h4, out2=out, a_scales=sh4)
         ctx.plan, ctx.cfg, ctx.scales = plan, (drop_p, seed1, seed2), (smn, sh1, sh4)
         ctx.save_for_backward(h, mean1, rstd1, h1, mn, y1, h3, mean2, rstd2, h4, y2, ln_w, ln_b, w_self, w_neigh, bias, ln2_w, ln2_b, w, b)
         return out
@@ -301,13 +315,16 @@ class ConvBlockFn(Function):
         plan = ctx.plan
         N, Fd = h.shape
         dout = _c(dout)
-        dz2 = _new(dout.shape, dout)
-        sz = be.act_dropout_bwd(dout, y2, drop_p, seed2, dz2)
         smn, sh1, sh4 = ctx.scales
-        sz = _linear_bwd_params(be, dz2, h4, w, b, sh4, sz)
-        dh4 = _new(h4.shape, h4)
-        be.gemm(dz2, w, dh4, M=N, N=Fd, K=Fd, b_kcontig=False, res=dout, a_scales=sz)
-        dh3, _ = _ln_bwd(be, dh4, h3, mean2, rstd2, ln2_w, ln2_b)
+        if w is None:
+            dh3 = dout
+        else:
+            dz2 = _new(dout.shape, dout)
+            sz = be.act_dropout_bwd(dout, y2, drop_p, seed2, dz2)
+            sz = _linear_bwd_params(be, dz2, h4, w, b, sh4, sz)
+            dh4 = _new(h4.shape, h4)
+            be.gemm(dz2, w, dh4, M=N, N=Fd, K=Fd, b_kcontig=False, res=dout, a_scales=sz)
+            dh3, _ = _ln_bwd(be, dh4, h3, mean2, rstd2, ln2_w, ln2_b)
         dz1 = _new(dh3.shape, dh3)
         sz = be.act_dropout_bwd(dh3, y1, drop_p, seed1, dz1)
         sz = _linear_bwd_params(be, dz1, h1, w_self, bias, sh1, sz)

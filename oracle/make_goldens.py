@@ -446,8 +446,24 @@ def make_predict_golden():
     print("wrote ref_predict.npz; raise conditions ->", raised)
 
 
+def make_options_golden():
+    """the reference with its optional sub-modules switched off (layer_norm=False, self_interaction=False; models/grappa.py:51,
+    graph_attention.py:255-310, :366-412, network_utils.py:36-48, :98-114): 1 SAGE + 1 attention block, ungated torsions"""
+    mols = build_inputs(pick_small(4, 10, 30, start=40), n_confs=5, seed=23, charge_model="amber99")
+    lk = dict(gradient_weight=0.5, energy_weight=1.0, param_weight=0.0)
+    for name, opts in (("ref_small_nonorm.npz", dict(layer_norm=False)), ("ref_small_nosi.npz", dict(self_interaction=False))):
+        cfg = small_config(n_conv=1, gated=False, n_att=1)
+        cfg.update(opts)
+        out, sd, g = run_reference(cfg, mols, 5, loss_kwargs=lk, with_param_refs=False)
+        extra = {"is_dummy": to_np(g.nodes["g"].data["is_dummy"]),
+                 "loss_kwargs_keys": np.array(list(lk.keys())), "loss_kwargs_vals": np.array(list(lk.values()))}
+        save(name, cfg, mols, out, sd, extra)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+    if len(sys.argv) > 1 and sys.argv[1] == "options":
+        make_options_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "eval":
         make_eval_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "tuples":
         make_tuple_golden()
@@ -458,3 +474,4 @@ if __name__ == "__main__":
         make_eval_golden()
         make_tuple_golden()
         make_predict_golden()
+        make_options_golden()

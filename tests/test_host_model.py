@@ -28,7 +28,8 @@ def _run(fx_name, n_confs, refs):
     return fx, g, loss, model
 
 
-@pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False)])
+@pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False),
+                                                 ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False)])     # last two: layer_norm=False / self_interaction=False
 def test_product_host_path_matches_reference(ref_backend, name, n_confs, refs):
     fx, g, loss, model = _run(name, n_confs, refs)
     out = gu.outputs_of(fx)
@@ -56,12 +57,13 @@ def test_product_host_path_matches_reference(ref_backend, name, n_confs, refs):
 
 
 def test_state_dict_keys_match_reference():
-    fx = gu.load("ref_small_att.npz")
-    sd_ref = gu.state_dict_of(fx)
-    sd = GrappaModel(**gu.config_of(fx)).state_dict()
-    assert list(sd.keys()) == list(sd_ref.keys())
-    for k in sd:
-        assert tuple(sd[k].shape) == tuple(sd_ref[k].shape) and sd[k].dtype == sd_ref[k].dtype, k
+    for name in ("ref_small_att.npz", "ref_small_nonorm.npz", "ref_small_nosi.npz"):       # incl. the optional sub-modules switched off
+        fx = gu.load(name)
+        sd_ref = gu.state_dict_of(fx)
+        sd = GrappaModel(**gu.config_of(fx)).state_dict()
+        assert list(sd.keys()) == list(sd_ref.keys()), name
+        for k in sd:
+            assert tuple(sd[k].shape) == tuple(sd_ref[k].shape) and sd[k].dtype == sd_ref[k].dtype, k
     prod = grappa_amd.model_from_config(grappa_amd.get_default_model_config())
     assert sum(p.numel() for p in prod.parameters()) == 40803347
     assert len(prod.state_dict()) == 410
