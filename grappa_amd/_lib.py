@@ -97,6 +97,8 @@ SIGNATURES = {
     "grappa_perm_concat_bwd_f32": (_i, [_vp, _i, _i, _i, _i, c_int_p, _vp, _vp]),
     "grappa_param_out_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),
     "grappa_param_out_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp]),
+    "grappa_param_out_stats_workspace_bytes": (_sz, [_i]),
+    "grappa_param_out_bwd_stats_f32": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz]),
     "grappa_mm_energy_fwd_f32": (_i, [_vp, C.POINTER(MMDesc), _vp, _vp, C.POINTER(VP4), C.POINTER(VP4)]),
     "grappa_mm_gradient_fwd_f32": (_i, [_vp, C.POINTER(MMDesc), _vp]),
     "grappa_mm_bwd_f32": (_i, [_vp, C.POINTER(MMDesc), _vp, _vp, C.POINTER(VP4), C.POINTER(VP4)]),

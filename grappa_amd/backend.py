@@ -833,6 +833,17 @@ class HipBackend:
         _chk(self.lib.grappa_param_out_bwd_f32(self._stream(), kind, T, P, n_per, int(gated), float(cutoff), o.data_ptr(), o.shape[1],
                                                consts.data_ptr(), _ptr(dk), _ptr(deq), d_o.data_ptr()), "grappa_param_out_bwd_f32")
 
+    def param_out_bwd_stats(self, kind, o, T, P, n_per, gated, cutoff, consts, dk, deq, d_consts) -> None:
+        """dL/d(statistics of the output map) (learnable_statistics=True)"""
+        dev = d_consts.device
+        _flat(o, "o", dev), _flat(consts, "consts", dev), _flat(d_consts, "d_consts", dev)
+        if o.shape[0] != P * T or d_consts.numel() != consts.numel():
+            raise ValueError("param_out_bwd_stats: shapes")
+        ws = self._workspace(self.lib.grappa_param_out_stats_workspace_bytes(T), dev)
+        _chk(self.lib.grappa_param_out_bwd_stats_f32(self._stream(), kind, T, P, n_per, int(gated), float(cutoff), _ptr(o), o.shape[1] if o.dim() == 2 else 0,
+                                                     consts.data_ptr(), _ptr(dk), _ptr(deq), d_consts.data_ptr(), ws.data_ptr(), ws.numel()),
+             "grappa_param_out_bwd_stats_f32")
+
     # ------------------------------------------------------------------ MM energy
     def _mm_desc(self, plan, xyz, ks, eqs, n_per, offset_torsion):
         from .constants import TUPLE_LEVELS

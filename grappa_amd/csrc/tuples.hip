@@ -445,6 +445,75 @@ __global__ __launch_bounds__(256) void param_out_bwd_kernel(int kind, int T, int
     }
 }
 
+// learnable_statistics=True (reference models/final_layer.py:21-44, :64-88, interaction_parameters.py:463-470): gradient of the
+// loss with respect to the statistics `cst` of an output map.  Per block: every thread's terms, summed in a fixed tree; the per-block
+// partials part[block][16] are added by one wavefront afterwards (param_out_stats_final_kernel): reproducible.
+//   bond    cst = [mos_eq, std_eq, min_eq, mos_k, std_k, min_k]   eq = std (elu(mos + c - 1) + 1) + min
+//   angle   cst = [std_over_max, max, 0, mos_k, std_k, min_k]     eq = max sigmoid(std_over_max c)
+//   torsion cst = [k_std[n_per], k_mean[n_per]]                   k = c k_std + k_mean  |  gated: c sigmoid(g) k_std
+constexpr int STATS_MAX = 16;
+__global__ __launch_bounds__(256) void param_out_stats_kernel(int kind, int T, int P, int n_per, int gated, float cutoff, const float* __restrict__ o,
+                                                              int ldo, const float* __restrict__ cst, const float* __restrict__ dk,
+                                                              const float* __restrict__ deq, float* __restrict__ part) {
+    __shared__ float red[4][STATS_MAX];
+    float acc[STATS_MAX];
+#pragma unroll
+    for (int i = 0; i < STATS_MAX; ++i) acc[i] = 0.f;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
+        if (kind == GRAPPA_OUT_TORSION) {
+            for (int n = 0; n < n_per; ++n) {
+                float c = 0.f, g = 0.f;
+                for (int p = 0; p < P; ++p) {
+                    const float* row = o + ((size_t)p * T + t) * ldo;
+                    c += row[n];
+                    if (gated) g += row[n_per + n];
+                }
+                const float sg = gated ? grappa_sigmoid(g) : 0.f;
+                const float v = gated ? c * sg * cst[n] : c * cst[n] + cst[n_per + n];
+                float up = dk ? dk[(size_t)t * n_per + n] : 0.f;
+                if (cutoff > 0.f && !(fabsf(v) > cutoff)) up = 0.f;
+                acc[n] += gated ? up * c * sg : up * c;
+                if (!gated) acc[n_per + n] += up;
+            }
+            continue;
+        }
+        float c0 = 0.f, c1 = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float* row = o + ((size_t)p * T + t) * ldo;
+            c0 += row[0];
+            c1 += row[1];
+        }
+        const float ueq = deq ? deq[t] : 0.f, uk = dk ? dk[t] : 0.f;
+        if (kind == GRAPPA_OUT_BOND) {
+            acc[0] += ueq * to_positive_grad(c0, cst[0], cst[1]);
+            acc[1] += ueq * (grappa_elu(cst[0] + c0 - 1.0f) + 1.0f);
+            acc[2] += ueq;
+        } else {
+            const float sg = grappa_sigmoid(cst[0] * c0);
+            acc[0] += ueq * cst[1] * sg * (1.0f - sg) * c0;
+            acc[1] += ueq * sg;
+        }
+        acc[3] += uk * to_positive_grad(c1, cst[3], cst[4]);
+        acc[4] += uk * (grappa_elu(cst[3] + c1 - 1.0f) + 1.0f);
+        acc[5] += uk;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < STATS_MAX; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < STATS_MAX) part[(size_t)blockIdx.x * STATS_MAX + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void param_out_stats_final_kernel(int nblocks, int ncst, const float* __restrict__ part, float* __restrict__ d_cst) {
+    const int i = threadIdx.x;
+    if (i >= ncst) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * STATS_MAX + i];
+    d_cst[i] = s;
+}
+
 inline int wave_grid(long nwaves, int cap = 8192) {
     long b = (nwaves + 3) / 4;
     if (b < 1) b = 1;
@@ -640,6 +709,25 @@ extern "C" int grappa_param_out_fwd_f32(void* stream, int kind, int T, int P, in
     return grappa_launch_status();
 }
 
+extern "C" size_t grappa_param_out_stats_workspace_bytes(int T) {
+    const int blocks = (T + 255) / 256 > 256 ? 256 : (T + 255) / 256;
+    return (size_t)(blocks < 1 ? 1 : blocks) * STATS_MAX * sizeof(float);
+}
+extern "C" int grappa_param_out_bwd_stats_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff, const float* o, int ldo,
+                                              const float* consts, const float* dk, const float* deq, float* d_consts, void* ws, size_t ws_bytes) {
+    const int ncst = kind == GRAPPA_OUT_TORSION ? 2 * n_per : 6;
+    if (kind < 0 || kind > 2 || T < 0 || P < 1 || ncst > STATS_MAX || (kind == GRAPPA_OUT_TORSION && n_per < 1)) return GRAPPA_ERR_ARG;
+    if (!d_consts) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (T == 0) return hipMemsetAsync(d_consts, 0, ncst * sizeof(float), st) == hipSuccess ? GRAPPA_OK : GRAPPA_ERR_LAUNCH;
+    if (!o || !consts) return GRAPPA_ERR_ARG;
+    const int blocks = (T + 255) / 256 > 256 ? 256 : (T + 255) / 256;
+    if (!ws || ws_bytes < (size_t)blocks * STATS_MAX * sizeof(float)) return GRAPPA_ERR_WORKSPACE;
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(param_out_stats_kernel, dim3(blocks), dim3(256), 0, st, kind, T, P, n_per, gated, cutoff, o, ldo, consts, dk, deq, part);
+    hipLaunchKernelGGL(param_out_stats_final_kernel, dim3(1), dim3(64), 0, st, blocks, ncst, part, d_consts);
+    return grappa_launch_status();
+}
 extern "C" int grappa_param_out_bwd_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff, const float* o, int ldo,
                                         const float* consts, const float* dk, const float* deq, float* d_o) {
     if (T < 0 || P < 1 || kind < 0 || kind > 2) return GRAPPA_ERR_ARG;

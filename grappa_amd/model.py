@@ -9,8 +9,8 @@ torch.nn.Linear / LayerNorm / MultiheadAttention instances are used as parameter
 initialisation as the reference); their forward() is never called.  All arithmetic goes through
 grappa_amd.ops (block-level autograd nodes -> C ABI).
 
-Restriction (raises at construction): learnable_statistics=False -- the only value the reference's shipped configurations use.
-layer_norm=False / self_interaction=False drop the same sub-modules the reference drops (same state-dict keys).
+Constructor options as in the reference (models/grappa.py:51): layer_norm=False / self_interaction=False drop the same sub-modules the
+reference drops, learnable_statistics=True turns the same statistics into parameters (same state-dict keys either way).
 """
 from __future__ import annotations
 
@@ -259,17 +259,28 @@ class RepProjector(nn.Module):
 
 
 class ToPositive(nn.Module):
-    def __init__(self, mean, std, min_=0.):
+    """parameter holder (reference models/final_layer.py:11-51): learnable_statistics turns mean_over_std and std into parameters"""
+
+    def __init__(self, mean, std, min_=0., learnable_statistics=False):
         super().__init__()
-        self.register_buffer("mean_over_std", torch.tensor(float(mean / std)))
-        self.register_buffer("std", torch.tensor(float(std)))
+        if learnable_statistics:
+            self.mean_over_std = nn.Parameter(torch.tensor(float(mean / std)).float())
+            self.std = nn.Parameter(torch.tensor(float(std)).float())
+        else:
+            self.register_buffer("mean_over_std", torch.tensor(float(mean / std)))
+            self.register_buffer("std", torch.tensor(float(std)))
         self.register_buffer("min_", torch.tensor(float(min_)))
 
 
 class ToRange(nn.Module):
-    def __init__(self, max_, std):
+    """reference models/final_layer.py:53-96: learnable_statistics turns std_over_max into a parameter"""
+
+    def __init__(self, max_, std, learnable_statistics=False):
         super().__init__()
-        self.register_buffer("std_over_max", torch.tensor(float(std / max_)).float())
+        if learnable_statistics:
+            self.std_over_max = nn.Parameter(torch.tensor(float(std / max_)).float())
+        else:
+            self.register_buffer("std_over_max", torch.tensor(float(std / max_)).float())
         self.register_buffer("max", torch.tensor(float(max_)).float())
 
 
@@ -310,7 +321,7 @@ class _WriterBase(nn.Module):
 class WriteBondParameters(_WriterBase):
     level, s, kind = "n2", 2, 0
 
-    def __init__(self, rep_feats, between_feats, suffix, stats, n_att, n_heads, dense_layers, dropout, symmetriser_feats, gate, layer_norm=True):
+    def __init__(self, rep_feats, between_feats, suffix, stats, n_att, n_heads, dense_layers, dropout, symmetriser_feats, gate, layer_norm=True, learnable_statistics=False):
         super().__init__()
         eps = 1e-6
         self.suffix, self.gate = suffix, gate
@@ -318,8 +329,8 @@ class WriteBondParameters(_WriterBase):
         self.bond_model = SymmetrisedTransformer(between_feats, n_heads, between_feats, n_att, 2 + int(gate),
                                                  torch.tensor([[0, 1], [1, 0]], dtype=torch.int32), dropout, dense_layers,
                                                  symmetriser_feats, None, layer_norm)
-        self.to_k = ToPositive(stats["mean"]["n2_k"].item(), stats["std"]["n2_k"].item() + eps)
-        self.to_eq = ToPositive(stats["mean"]["n2_eq"].item(), stats["std"]["n2_eq"].item() + eps)
+        self.to_k = ToPositive(stats["mean"]["n2_k"].item(), stats["std"]["n2_k"].item() + eps, 0., learnable_statistics)
+        self.to_eq = ToPositive(stats["mean"]["n2_eq"].item(), stats["std"]["n2_eq"].item() + eps, 0., learnable_statistics)
 
     def _model(self):
         return self.bond_model
@@ -341,7 +352,7 @@ class WriteAngleParameters(_WriterBase):
     level, s, kind = "n3", 3, 1
 
     def __init__(self, rep_feats, between_feats, suffix, stats, n_att, n_heads, dense_layers, dropout, symmetriser_feats,
-                 positional_encoding, gate, layer_norm=True):
+                 positional_encoding, gate, layer_norm=True, learnable_statistics=False):
         super().__init__()
         eps = 1e-6
         self.suffix, self.gate = suffix, gate
@@ -350,8 +361,8 @@ class WriteAngleParameters(_WriterBase):
         self.angle_model = SymmetrisedTransformer(proj, n_heads, between_feats, n_att, 2 + int(gate),
                                                   torch.tensor([[0, 1, 2], [2, 1, 0]], dtype=torch.int32), dropout, dense_layers,
                                                   symmetriser_feats, _pos_enc(3, positional_encoding), layer_norm)
-        self.to_k = ToPositive(stats["mean"]["n3_k"].item(), stats["std"]["n3_k"].item() + eps)
-        self.to_eq = ToRange(math.pi, stats["std"]["n3_eq"].item() + eps)
+        self.to_k = ToPositive(stats["mean"]["n3_k"].item(), stats["std"]["n3_k"].item() + eps, 0., learnable_statistics)
+        self.to_eq = ToRange(math.pi, stats["std"]["n3_eq"].item() + eps, learnable_statistics)
 
     def _model(self):
         return self.angle_model
@@ -375,7 +386,7 @@ class WriteTorsionParameters(_WriterBase):
     s, kind = 4, 2
 
     def __init__(self, rep_feats, between_feats, suffix, n_periodicity, improper, n_att, n_heads, dense_layers, dropout,
-                 symmetriser_feats, stats, positional_encoding, gated, wrong_symmetry, cutoff, layer_norm=True):
+                 symmetriser_feats, stats, positional_encoding, gated, wrong_symmetry, cutoff, layer_norm=True, learnable_statistics=False):
         super().__init__()
         eps = 1e-1 if gated else 1e-2
         self.gated, self.improper, self.suffix, self.cutoff_value = gated, improper, suffix, float(cutoff)
@@ -390,8 +401,12 @@ class WriteTorsionParameters(_WriterBase):
             km, ks = stats["mean"]["n4_improper_k"], stats["std"]["n4_improper_k"] + eps
             if len(km) < n_periodicity or len(ks) < n_periodicity:
                 raise ValueError(f"n_periodicity is {n_periodicity} but the param_statistics contains {len(km)} values for the improper torsion parameters.")
-        self.register_buffer("k_mean", km[:n_periodicity].clone().float().unsqueeze(0))
-        self.register_buffer("k_std", ks[:n_periodicity].clone().float().unsqueeze(0))
+        if learnable_statistics:                    # reference interaction_parameters.py:465-470
+            self.k_mean = nn.Parameter(km[:n_periodicity].clone().float().unsqueeze(0))
+            self.k_std = nn.Parameter(ks[:n_periodicity].clone().float().unsqueeze(0))
+        else:
+            self.register_buffer("k_mean", km[:n_periodicity].clone().float().unsqueeze(0))
+            self.register_buffer("k_std", ks[:n_periodicity].clone().float().unsqueeze(0))
         proj = between_feats - 1 if positional_encoding else between_feats
         self.rep_projector = RepProjector(4, rep_feats, proj, improper=improper)
         pe = _pos_enc(4, positional_encoding)
@@ -433,19 +448,19 @@ class WriteParameters(nn.Module):
         gate = cfg["harmonic_gate"]
         self.bond_writer = WriteBondParameters(rep, cfg["bond_transformer_width"], suffix, stats, cfg["bond_transformer_depth"],
                                                cfg["bond_n_heads"], cfg["bond_symmetriser_depth"], drop, cfg["bond_symmetriser_width"], gate,
-                                               layer_norm=cfg.get("layer_norm", True))
+                                               layer_norm=cfg.get("layer_norm", True), learnable_statistics=cfg.get("learnable_statistics", False))
         self.angle_writer = WriteAngleParameters(rep, cfg["angle_transformer_width"], suffix, stats, cfg["angle_transformer_depth"],
                                                  cfg["angle_n_heads"], cfg["angle_symmetriser_depth"], drop,
-                                                 cfg["angle_symmetriser_width"], pos, gate, layer_norm=cfg.get("layer_norm", True))
+                                                 cfg["angle_symmetriser_width"], pos, gate, layer_norm=cfg.get("layer_norm", True), learnable_statistics=cfg.get("learnable_statistics", False))
         self.proper_writer = WriteTorsionParameters(rep, cfg["proper_transformer_width"], suffix, cfg["n_periodicity_proper"], False,
                                                     cfg["proper_transformer_depth"], cfg["proper_n_heads"], cfg["proper_symmetriser_depth"],
                                                     drop, cfg["proper_symmetriser_width"], stats, pos, cfg["gated_torsion"], False,
-                                                    cfg["torsion_cutoff"], layer_norm=cfg.get("layer_norm", True))
+                                                    cfg["torsion_cutoff"], layer_norm=cfg.get("layer_norm", True), learnable_statistics=cfg.get("learnable_statistics", False))
         self.improper_writer = WriteTorsionParameters(rep, cfg["improper_transformer_width"], suffix, cfg["n_periodicity_improper"], True,
                                                       cfg["improper_transformer_depth"], cfg["improper_n_heads"],
                                                       cfg["improper_symmetriser_depth"], drop, cfg["improper_symmetriser_width"], stats, pos,
                                                       cfg["gated_torsion"], cfg["wrong_symmetry"], cfg["torsion_cutoff"],
-                                                      layer_norm=cfg.get("layer_norm", True))
+                                                      layer_norm=cfg.get("layer_norm", True), learnable_statistics=cfg.get("learnable_statistics", False))
 
         # The four writers read the same atom embedding and write disjoint tuple levels: on the GPU each CAN run on its own HIP stream
         # (largest first), so that the tail rounds and launch gaps of one head's kernels are filled by another head's; autograd
@@ -505,8 +520,6 @@ class GrappaModel(nn.Module):
                  wrong_symmetry=False, positional_encoding=True, layer_norm=True, self_interaction=True, learnable_statistics: bool = False,
                  param_statistics: dict = None, torsion_cutoff=1.e-4, harmonic_gate: bool = False):
         super().__init__()
-        if learnable_statistics:
-            raise NotImplementedError("grappa_amd implements learnable_statistics=False (the value of every configuration the reference ships)")
         if param_statistics is None:
             param_statistics = get_default_statistics()
         cfg = dict(locals())

@@ -495,10 +495,16 @@ class ParamOutFn(Function):
         o, consts = ctx.saved_tensors
         kind, T, P, n_per, gated, cutoff = ctx.cfg
         d_o = _new(o.shape, o)
+        dk = _c(dk) if dk is not None else None
+        deq = _c(deq) if deq is not None else None
         if T:
-            be.param_out_bwd(kind, o, T, P, n_per, gated, cutoff, consts, _c(dk) if dk is not None else None,
-                             _c(deq) if deq is not None else None, d_o)
-        return (d_o,) + (None,) * 7
+            be.param_out_bwd(kind, o, T, P, n_per, gated, cutoff, consts, dk, deq, d_o)
+        d_consts = None
+        if ctx.needs_input_grad[7]:                 # learnable_statistics=True: the statistics are parameters
+            d_consts = torch.zeros_like(consts)
+            if T:
+                be.param_out_bwd_stats(kind, o, T, P, n_per, gated, cutoff, consts, dk, deq, d_consts)
+        return (d_o,) + (None,) * 6 + (d_consts,)
 
 
 class MMEnergyFn(Function):

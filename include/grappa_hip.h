@@ -275,6 +275,12 @@ int grappa_param_out_fwd_f32(void* stream, int kind, int T, int P, int n_per, in
 int grappa_param_out_bwd_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff,
                              const float* o, int ldo, const float* consts, const float* dk, const float* deq,
                              float* d_o);
+/* ABI 4, learnable_statistics=True (reference models/final_layer.py:21-44, :64-88; interaction_parameters.py:463-470): d_consts[i] =
+ * dL/d consts[i] of the same map (6 values for bonds / angles, 2 * n_per for torsions; entries of constants that are buffers in the
+ * reference -- min_, max -- are computed but meaningless).  Fixed-order two-stage sum: reproducible. */
+size_t grappa_param_out_stats_workspace_bytes(int T);
+int grappa_param_out_bwd_stats_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff, const float* o, int ldo,
+                                   const float* consts, const float* dk, const float* deq, float* d_consts, void* ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * Molecular-mechanics energy / force and its backward (models/internal_coordinates.py:15-125,:150-210;

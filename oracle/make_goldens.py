@@ -448,10 +448,12 @@ def make_predict_golden():
 
 def make_options_golden():
     """the reference with its optional sub-modules switched off (layer_norm=False, self_interaction=False; models/grappa.py:51,
-    graph_attention.py:255-310, :366-412, network_utils.py:36-48, :98-114): 1 SAGE + 1 attention block, ungated torsions"""
+    graph_attention.py:255-310, :366-412, network_utils.py:36-48, :98-114) and with learnable statistics (final_layer.py:21-44, :64-88,
+    interaction_parameters.py:463-470): 1 SAGE + 1 attention block, ungated torsions"""
     mols = build_inputs(pick_small(4, 10, 30, start=40), n_confs=5, seed=23, charge_model="amber99")
     lk = dict(gradient_weight=0.5, energy_weight=1.0, param_weight=0.0)
-    for name, opts in (("ref_small_nonorm.npz", dict(layer_norm=False)), ("ref_small_nosi.npz", dict(self_interaction=False))):
+    for name, opts in (("ref_small_nonorm.npz", dict(layer_norm=False)), ("ref_small_nosi.npz", dict(self_interaction=False)),
+                       ("ref_small_learnstats.npz", dict(learnable_statistics=True))):
         cfg = small_config(n_conv=1, gated=False, n_att=1)
         cfg.update(opts)
         out, sd, g = run_reference(cfg, mols, 5, loss_kwargs=lk, with_param_refs=False)

@@ -253,6 +253,29 @@ class RefBackend:
             eq.copy_(consts[1] * torch.sigmoid(consts[0] * c[:, 0]))
         k.copy_(self._to_pos(c[:, 1], consts[3], consts[4], consts[5]))
 
+    def param_out_bwd_stats(self, kind, o, T, P, n_per, gated, cutoff, consts, dk, deq, d_consts):
+        """dL/d consts of the output map by autograd through the restated forward (reference models/final_layer.py)"""
+        with torch.enable_grad():
+            return self._param_out_bwd_stats(kind, o, T, P, n_per, gated, cutoff, consts, dk, deq, d_consts)
+
+    def _param_out_bwd_stats(self, kind, o, T, P, n_per, gated, cutoff, consts, dk, deq, d_consts):
+        cst = consts.detach().clone().requires_grad_(True)
+        c = o.detach().view(P, T, -1).sum(0)
+        if kind == 2:
+            if gated:
+                v = c[:, :n_per] * torch.sigmoid(c[:, n_per:2 * n_per]) * cst[:n_per]
+            else:
+                v = c[:, :n_per] * cst[:n_per] + cst[n_per:2 * n_per]
+            if cutoff > 0:
+                v = torch.where(v.abs() > cutoff, v, torch.zeros_like(v))
+            loss = (v * dk.view(T, n_per)).sum() if dk is not None else v.sum() * 0
+        else:
+            eq = self._to_pos(c[:, 0], cst[0], cst[1], cst[2]) if kind == 0 else cst[1] * torch.sigmoid(cst[0] * c[:, 0])
+            k = self._to_pos(c[:, 1], cst[3], cst[4], cst[5])
+            loss = (eq * deq).sum() if deq is not None else eq.sum() * 0
+            loss = loss + ((k * dk).sum() if dk is not None else 0)
+        d_consts.copy_(torch.autograd.grad(loss, cst, allow_unused=True)[0])
+
     def param_out_bwd(self, kind, o, T, P, n_per, gated, cutoff, consts, dk, deq, d_o):
         if T == 0:
             return

@@ -34,7 +34,8 @@ def _check_graph(g, out, loss):
 
 
 @pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False),
-                                                 ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False)])     # last two: layer_norm=False / self_interaction=False
+                                                 ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False),
+                                                 ("ref_small_learnstats.npz", 5, False)])     # last three: layer_norm=False / self_interaction=False / learnable_statistics=True
 def test_small_configs_against_reference_goldens(name, n_confs, refs):
     from grappa_amd import Energy, GrappaModel, MolwiseLoss
     _assert_loaded()

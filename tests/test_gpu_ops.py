@@ -343,6 +343,11 @@ def test_param_out(hip, ref, kind, nout, n_per, gated):
     ref.param_out_bwd(kind, o, T, P, n_per, gated, 1e-4, consts, dk, deq, d_r)
     hip.param_out_bwd(kind, o.cuda(), T, P, n_per, gated, 1e-4, consts.cuda(), dk.cuda(), None if deq is None else deq.cuda(), d_h)
     _cmp(d_h, d_r, 2e-5, "param_out_bwd")
+    # learnable_statistics=True: the gradient of the map's own constants (sums over all T tuples)
+    c_r, c_h = torch.zeros_like(consts), torch.full_like(consts, 7.0).cuda()
+    ref.param_out_bwd_stats(kind, o, T, P, n_per, gated, 1e-4, consts, dk, deq, c_r)
+    hip.param_out_bwd_stats(kind, o.cuda(), T, P, n_per, gated, 1e-4, consts.cuda(), dk.cuda(), None if deq is None else deq.cuda(), c_h)
+    _cmp(c_h, c_r, 2e-5, "param_out_bwd_stats", floor_frac=0.05)
 
 
 @pytest.mark.parametrize("n_confs,offset", [(5, False), (32, False), (40, True), (1, False), (300, False)])

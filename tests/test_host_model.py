@@ -29,7 +29,8 @@ def _run(fx_name, n_confs, refs):
 
 
 @pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False),
-                                                 ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False)])     # last two: layer_norm=False / self_interaction=False
+                                                 ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False),
+                                                 ("ref_small_learnstats.npz", 5, False)])     # last three: layer_norm=False / self_interaction=False / learnable_statistics=True
 def test_product_host_path_matches_reference(ref_backend, name, n_confs, refs):
     fx, g, loss, model = _run(name, n_confs, refs)
     out = gu.outputs_of(fx)
@@ -57,7 +58,7 @@ def test_product_host_path_matches_reference(ref_backend, name, n_confs, refs):
 
 
 def test_state_dict_keys_match_reference():
-    for name in ("ref_small_att.npz", "ref_small_nonorm.npz", "ref_small_nosi.npz"):       # incl. the optional sub-modules switched off
+    for name in ("ref_small_att.npz", "ref_small_nonorm.npz", "ref_small_nosi.npz", "ref_small_learnstats.npz"):       # incl. the constructor options
         fx = gu.load(name)
         sd_ref = gu.state_dict_of(fx)
         sd = GrappaModel(**gu.config_of(fx)).state_dict()

@@ -34,10 +34,11 @@ def _loss(model, ids, seed, global_b=None):
     return lf(Energy()(model(g)))
 
 
-def test_train_mode_gradient_matches_finite_differences(ref_backend):
+@pytest.mark.parametrize("learn", [False, True])
+def test_train_mode_gradient_matches_finite_differences(ref_backend, learn):
     from grappa_amd import GrappaModel
     torch.manual_seed(0)
-    model = GrappaModel(**TINY).double().float()
+    model = GrappaModel(**TINY, learnable_statistics=learn).double().float()
     model.train()
     ids = [10, 11, 12]
     loss = _loss(model, ids, 7)
@@ -59,12 +60,13 @@ def test_train_mode_gradient_matches_finite_differences(ref_backend):
     assert abs(fd - gd) / max(abs(fd), abs(gd)) < 3e-2, (fd, gd)
 
 
-def test_flat_params_and_fused_adam_track_torch_adam(ref_backend):
+@pytest.mark.parametrize("learn", [False, True])       # learnable statistics: 0-dim parameters in the flat buffer
+def test_flat_params_and_fused_adam_track_torch_adam(ref_backend, learn):
     from grappa_amd import GrappaModel
     from grappa_amd.optim import FlatParams, FusedAdam
     torch.manual_seed(0)
-    model = GrappaModel(**TINY).eval()
-    twin = GrappaModel(**TINY).eval()
+    model = GrappaModel(**TINY, learnable_statistics=learn).eval()
+    twin = GrappaModel(**TINY, learnable_statistics=learn).eval()
     twin.load_state_dict(model.state_dict())
     flat = FlatParams(model)
     assert all(p.data_ptr() >= flat.data.data_ptr() for p in flat.params)
