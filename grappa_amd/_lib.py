@@ -70,6 +70,7 @@ SIGNATURES = {
     "grappa_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
     "grappa_gemm_f32_plan": (_i, [_i, _i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "grappa_gemm_f32_set_plan_override": (None, [_i, _i, _i]),
+    "grappa_gemm_f32_set_splitk_reduce_launch": (None, [_i]),
     "grappa_gemm_f32": (_i, [_vp, C.POINTER(GemmDesc), _vp, _sz]),
     "grappa_gemm_f32_grouped_workspace_bytes": (_sz, [C.POINTER(GemmDesc), _i]),
     "grappa_gemm_f32_grouped": (_i, [_vp, C.POINTER(GemmDesc), _i, _vp, _sz]),

@@ -507,6 +507,7 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
     }
     tile_epilogue_rows<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES), m0, n0, wm0, wn0, lane, split, tile_local,
                                        p.vec_io != 0);
+    if (p.nsplit > 1 && p.tickets) splitk_finish_tile<NT>(p, tile_local, reinterpret_cast<volatile int*>(smem));
 }
 
 template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>

@@ -33,6 +33,10 @@ struct GemmParams {
     // 2 = bias + ELU; 3 = bias + dropout + residual; 4 = ELU' from the saved output (aux), optional residual; + 8: the same with
     // bf16 output / residual / aux (the bf16 storage configuration)
     int epi_class;
+    // split-K finished inside the product's own launch: tickets[tile_local] counts the workgroups of a tile that have written their
+    // slab; the last one to arrive sums the slabs in the fixed order s = 0, 1, ... (the same bits whichever workgroup that is) and
+    // runs the epilogue.  nullptr: the host launches gemm_splitk_reduce_kernel instead (native fp32 and plane kernels)
+    int* tickets;
 };
 
 // ---- plane format (include/grappa_hip.h): X = P0 + P1 + P2, three bf16 planes
@@ -430,50 +434,76 @@ static __global__ __launch_bounds__(REDUCE_THREADS) void gemm_splitk_reduce_grou
     splitk_reduce_body(ps[g], blk_begin[g + 1] - blk_begin[g], b - blk_begin[g]);
 }
 
+// sums of one quad (four consecutive columns of a tile row, flat index i into the launch's [ntiles_launch][bm * bn] slab) over the
+// splits in the fixed order s = 0, 1, ..., epilogue, row-segment maximum
+__device__ __forceinline__ void splitk_reduce_quad(const GemmParams& p, size_t split_stride, int tile_elems, size_t i) {
+    const int tl = (int)(i / tile_elems), rem = (int)(i - (size_t)tl * tile_elems);
+    const int tile = p.tile_begin + tl;
+    const int m = (tile / p.tiles_n) * p.bm + rem / p.bn, n = (tile % p.tiles_n) * p.bn + rem % p.bn;
+    unsigned am = 0u;
+    if (m < p.d.M && n < p.d.N) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int s = 0; s < p.nsplit; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(p.slab + (size_t)s * split_stride + i);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (n + q < p.d.N) am = max(am, mag_bits(epilogue_store(p, m, n + q, ve[q])));
+    }
+    if (p.amax_part) {
+        // amax_seg / 4 adjacent lanes (8 or 16, aligned: bn and the block size are multiples of 64 columns) share one row segment
+        for (int o = p.amax_seg >> 3; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+        if ((threadIdx.x & ((p.amax_seg >> 2) - 1)) == 0 && m < p.d.M && n < p.d.N) p.amax_part[(size_t)(n / p.amax_seg) * p.d.M + m] = am;
+    }
+}
+
+// column-sum partials of the rows of launch tile tl (written by the tile_n == 0 workgroups)
+__device__ __forceinline__ void splitk_reduce_colsum(const GemmParams& p, int tl, int nthreads) {
+    const int tile = p.tile_begin + tl;
+    if (tile % p.tiles_n != 0) return;
+    const int m0 = (tile / p.tiles_n) * p.bm;
+    for (int mi = threadIdx.x; mi < p.bm; mi += nthreads) {
+        const int m = m0 + mi;
+        if (m >= p.d.M) continue;
+        float v = 0.0f;
+        for (int s = 0; s < p.nsplit; ++s) v += p.cs_slab[(size_t)s * p.d.M + m];
+        p.d.a_colsum[m] += v;
+    }
+}
+
 __device__ inline void splitk_reduce_body(const GemmParams& p, int nblocks, int block) {
     const int tile_elems = p.bm * p.bn;
     const size_t total = (size_t)p.ntiles_launch * tile_elems;
-    const size_t split_stride = total;
-    if (p.d.a_colsum && block == 0) {
-        // column-sum partials were written by the tile_n == 0 workgroups of this launch
-        for (int tl = 0; tl < p.ntiles_launch; ++tl) {
-            const int tile = p.tile_begin + tl;
-            if (tile % p.tiles_n != 0) continue;
-            const int m0 = (tile / p.tiles_n) * p.bm;
-            for (int mi = threadIdx.x; mi < p.bm; mi += REDUCE_THREADS) {
-                const int m = m0 + mi;
-                if (m >= p.d.M) continue;
-                float v = 0.0f;
-                for (int s = 0; s < p.nsplit; ++s) v += p.cs_slab[(size_t)s * p.d.M + m];
-                p.d.a_colsum[m] += v;
-            }
-        }
-    }
+    if (p.d.a_colsum && block == 0)
+        for (int tl = 0; tl < p.ntiles_launch; ++tl) splitk_reduce_colsum(p, tl, REDUCE_THREADS);
     // four consecutive columns of one tile row per thread (tiles are 16-byte aligned and bn % 4 == 0): 16-byte slab loads, several
     // in flight (the sum keeps its fixed order s = 0, 1, ...: reproducible)
-    for (size_t i = ((size_t)block * REDUCE_THREADS + threadIdx.x) * 4; i < total; i += (size_t)nblocks * REDUCE_THREADS * 4) {
-        const int tl = (int)(i / tile_elems), rem = (int)(i - (size_t)tl * tile_elems);
-        const int tile = p.tile_begin + tl;
-        const int m = (tile / p.tiles_n) * p.bm + rem / p.bn, n = (tile % p.tiles_n) * p.bn + rem % p.bn;
-        unsigned am = 0u;
-        if (m < p.d.M && n < p.d.N) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-            for (int s = 0; s < p.nsplit; ++s) {
-                const float4 t = *reinterpret_cast<const float4*>(p.slab + (size_t)s * split_stride + i);
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            const float ve[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (n + q < p.d.N) am = max(am, mag_bits(epilogue_store(p, m, n + q, ve[q])));
-        }
-        if (p.amax_part) {
-            // amax_seg / 4 adjacent lanes (8 or 16, aligned: bn and the block size are multiples of 64 columns) share one row segment
-            for (int o = p.amax_seg >> 3; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
-            if ((threadIdx.x & ((p.amax_seg >> 2) - 1)) == 0 && m < p.d.M && n < p.d.N) p.amax_part[(size_t)(n / p.amax_seg) * p.d.M + m] = am;
-        }
-    }
+    for (size_t i = ((size_t)block * REDUCE_THREADS + threadIdx.x) * 4; i < total; i += (size_t)nblocks * REDUCE_THREADS * 4)
+        splitk_reduce_quad(p, total, tile_elems, i);
+}
+
+// Split-K finished by the product's own launch (p.tickets): called by every workgroup after its slab (and column-sum partial) is
+// written.  Release (fence) -> ticket -> the last arrival acquires (fence) and reduces the tile.  No workgroup waits for another:
+// the grid drains whatever the order of arrival.  s_last: one word of LDS no wavefront uses any more.
+template <int NT>
+#ifndef SK_EXP
+#define SK_EXP 0          // timing experiments (tools/splitk_ab.sh): 1 = no fences (results not guaranteed), 2 = fences + ticket only (no sum: wrong results)
+#endif
+__device__ __forceinline__ void splitk_finish_tile(const GemmParams& p, int tile_local, volatile int* s_last) {
+    if (SK_EXP != 1) __threadfence();
+    __syncthreads();                                         // every wavefront's slab stores are fenced (and the LDS word is free)
+    if (threadIdx.x == 0) *s_last = atomicAdd(p.tickets + tile_local, 1) == p.nsplit - 1;
+    __syncthreads();
+    if (!*s_last || SK_EXP == 2) return;
+    if (SK_EXP != 1) __threadfence();
+    const int tile_elems = p.bm * p.bn;
+    const size_t total = (size_t)p.ntiles_launch * tile_elems;
+    if (p.d.a_colsum) splitk_reduce_colsum(p, tile_local, NT);
+    const size_t base = (size_t)tile_local * tile_elems;
+    for (int i = threadIdx.x * 4; i < tile_elems; i += NT * 4) splitk_reduce_quad(p, total, tile_elems, base + i);
 }
 
 

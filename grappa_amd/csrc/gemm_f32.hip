@@ -294,6 +294,15 @@ constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256};
 constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128};
 constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
 
+// split-K summed by a launch of gemm_splitk_reduce_kernel behind the product (default) or inside the product's own launch by the last
+// workgroup of each tile (GRAPPA_SPLITK_IN_KERNEL=1 / grappa_gemm_f32_set_splitk_reduce_launch(0)).  Same bits; the second is the
+// slower one on this chip (profiles/r2_splitk_in_kernel_rejected.txt): one workgroup sums nsplit x 128 KB behind an L2-invalidating
+// acquire while the rest of the chip idles at the end of the launch, the reduction kernel spreads the same reads over 256 CUs
+int g_splitk_launch = -1;
+bool splitk_in_kernel() {
+    static const bool env_in_kernel = getenv("GRAPPA_SPLITK_IN_KERNEL") && atoi(getenv("GRAPPA_SPLITK_IN_KERNEL")) != 0;
+    return g_splitk_launch < 0 ? env_in_kernel : g_splitk_launch == 0;
+}
 bool use_bf16x(int M, int N, int precision) { return precision != GRAPPA_GEMM_F32_MFMA && M > 32 && N > 32; }
 
 // tuning / tests only (grappa_gemm_f32_set_plan_override): force the tile configuration, split-K factor and tail use
@@ -389,9 +398,10 @@ size_t plan_workspace_floats(const Plan& pl, int M, int N) {
     const long tiles = (long)((M + CFG_BM[pl.cfg] - 1) / CFG_BM[pl.cfg]) * ((N + CFG_BN[pl.cfg] - 1) / CFG_BN[pl.cfg]);
     const size_t te = (size_t)CFG_BM[pl.cfg] * CFG_BN[pl.cfg];
     size_t need = 0;
-    if (pl.nsplit > 1) need = (size_t)pl.nsplit * tiles * te + (size_t)pl.nsplit * M;
+    // slabs, column-sum partials, one ticket (int) per tile of the launch
+    if (pl.nsplit > 1) need = (size_t)pl.nsplit * tiles * te + (size_t)pl.nsplit * M + tiles;
     if (pl.tail_nsplit > 1) {
-        const size_t t = (size_t)pl.tail_nsplit * (tiles - pl.main_tiles) * te + (size_t)pl.tail_nsplit * M;
+        const size_t t = (size_t)pl.tail_nsplit * (tiles - pl.main_tiles) * te + (size_t)pl.tail_nsplit * M + (tiles - pl.main_tiles);
         if (t > need) need = t;
     }
     return need;
@@ -448,6 +458,8 @@ extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* til
     return GRAPPA_OK;
 }
 
+extern "C" void grappa_gemm_f32_set_splitk_reduce_launch(int on) { g_splitk_launch = on < 0 ? -1 : (on != 0); }
+
 extern "C" void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail) {
     g_override.cfg = cfg;
     g_override.nsplit = nsplit;
@@ -468,11 +480,12 @@ __global__ void group_upload_kernel(GroupUpload u, int n, GemmParams* dst) {
     for (int i = threadIdx.x; i < n * words; i += blockDim.x)
         reinterpret_cast<unsigned*>(dst)[i] = reinterpret_cast<const unsigned*>(u.p)[i];
 }
-__global__ void group_index_kernel(GroupIndex ix, int n, int* dst_wg, int* dst_blk) {
+__global__ void group_index_kernel(GroupIndex ix, int n, int* dst_wg, int* dst_blk, int* tickets, int ntickets) {
     for (int i = threadIdx.x; i <= n; i += blockDim.x) {
         dst_wg[i] = ix.wg_begin[i];
         dst_blk[i] = ix.blk_begin[i];
     }
+    for (int i = threadIdx.x; i < ntickets; i += blockDim.x) tickets[i] = 0;      // split-K tickets of the launch that follows
 }
 
 struct GroupPlan {
@@ -480,7 +493,8 @@ struct GroupPlan {
     int nsplit[GROUP_MAX], tiles[GROUP_MAX];
     int total_wgs;
     size_t slab_floats[GROUP_MAX], cs_floats[GROUP_MAX];
-    size_t header_bytes, total_bytes;
+    size_t header_bytes, ticket_offset, total_bytes;      // tickets: one int per tile of every split problem, behind all slabs
+    int total_tickets;
 };
 
 bool group_desc_ok(const grappa_gemm_desc& d, int precision) {
@@ -536,7 +550,10 @@ GroupPlan plan_group(const grappa_gemm_desc* descs, int n) {
         off += g.slab_floats[i] + g.cs_floats[i];
     }
     g.header_bytes = ((size_t)n * sizeof(GemmParams) + 2 * (GROUP_MAX + 1) * sizeof(int) + 255) / 256 * 256;
-    g.total_bytes = g.header_bytes + off * sizeof(float);
+    g.ticket_offset = g.header_bytes + off * sizeof(float);
+    g.total_tickets = 0;
+    for (int i = 0; i < n; ++i) g.total_tickets += g.nsplit[i] > 1 ? g.tiles[i] : 0;
+    g.total_bytes = g.ticket_offset + (size_t)g.total_tickets * sizeof(int);
     return g;
 }
 }  // namespace
@@ -561,6 +578,9 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
     GroupIndex ix;
     GroupUpload up;
     ix.wg_begin[0] = ix.blk_begin[0] = 0;
+    const bool in_kernel = splitk_in_kernel();
+    int* tickets = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + g.ticket_offset);
+    int* next_ticket = tickets;
     auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
     int total_blocks = 0;
     // 16-byte loads along the rows of both operands of every product: aligned bases, leading dimensions % 4 == 0 covering round_up(rows, 4)
@@ -582,6 +602,11 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
             p.slab = p.nsplit > 1 ? slab : nullptr;
             p.cs_slab = p.nsplit > 1 ? slab + g.slab_floats[i] : nullptr;
             slab += g.slab_floats[i] + g.cs_floats[i];
+            p.tickets = nullptr;
+            if (p.nsplit > 1 && in_kernel) {
+                p.tickets = next_ticket;
+                next_ticket += g.tiles[i];
+            }
             p.drop_scale = d.drop_p > 0.0f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
             p.bm = 256;
             p.bn = 128;
@@ -595,7 +620,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
             p.epi_class = 0;
             ix.wg_begin[i + 1] = ix.wg_begin[i] + g.tiles[i] * g.nsplit[i];
             int blocks = 0;
-            if (p.nsplit > 1) {
+            if (p.nsplit > 1 && !in_kernel) {
                 blocks = (int)(((size_t)g.tiles[i] * 256 * 128 / 4 + REDUCE_THREADS - 1) / REDUCE_THREADS);
                 if (blocks > 1024) blocks = 1024;
             }
@@ -604,7 +629,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
         }
         hipLaunchKernelGGL(group_upload_kernel, dim3(1), dim3(256), 0, st, up, cnt, d_ps + i0);
     }
-    hipLaunchKernelGGL(group_index_kernel, dim3(1), dim3(64), 0, st, ix, n, d_wg, d_blk);
+    hipLaunchKernelGGL(group_index_kernel, dim3(1), dim3(256), 0, st, ix, n, d_wg, d_blk, tickets, in_kernel ? g.total_tickets : 0);
     if (grappa_launch_status() != GRAPPA_OK) return GRAPPA_ERR_LAUNCH;
     int rc = grappa_launch_gemm_bf16x_grouped(st, d_ps, d_wg, n, g.total_wgs, precision, vec);
     if (rc != GRAPPA_OK) return rc;
@@ -682,9 +707,14 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
         p.k_per_split = kps;
         p.slab = nullptr;
         p.cs_slab = nullptr;
+        p.tickets = nullptr;
         if (nsplit > 1) {
             p.slab = reinterpret_cast<float*>(ws);
             p.cs_slab = p.slab + (size_t)nsplit * ntiles * te;
+            if (bf16x && !planes && splitk_in_kernel()) {                // the last workgroup of a tile reduces it (gemm_common.h splitk_finish_tile)
+                p.tickets = reinterpret_cast<int*>(p.cs_slab + (size_t)nsplit * d->M);
+                if (hipMemsetAsync(p.tickets, 0, (size_t)ntiles * sizeof(int), st) != hipSuccess) return GRAPPA_ERR_LAUNCH;
+            }
         }
         int rc;
         if (planes) rc = grappa_launch_gemm_planes(st, p, d->precision);
@@ -693,7 +723,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
         else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
         else rc = dispatch<false, false>(st, p, pl.cfg, vec);
         if (rc != GRAPPA_OK) return rc;
-        if (nsplit > 1) rc = launch_splitk_reduce(st, p);
+        if (nsplit > 1 && !p.tickets) rc = launch_splitk_reduce(st, p);
         return rc;
     };
     int rc = GRAPPA_OK;

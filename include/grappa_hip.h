@@ -157,6 +157,12 @@ int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* t
 /* tuning and tests only, not thread safe: force the tile configuration index (0..6, -1 = model's choice), the split-K factor
  * (0 = model's choice) and the tail launch (1 on, 0 off, -1 = model's choice) of every following plan */
 void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail);
+/* tuning and tests only, not thread safe: where a split-K product of the fp32-operand split kernels sums its K slices.  1 (default):
+ * a launch of the reduction kernel behind the product; 0: inside the product's own launch -- the last workgroup of a tile to
+ * arrive (a ticket per tile in the workspace) adds the slabs in the fixed order 0, 1, ... and runs the epilogue.  Same bits either
+ * way; 0 measured 25 % slower per C2 step on MI355X.  -1 = back to the default (environment
+ * GRAPPA_SPLITK_IN_KERNEL=1 selects 0) */
+void grappa_gemm_f32_set_splitk_reduce_launch(int on);
 int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes);
 
 /* Grouped weight gradients: n <= GRAPPA_GEMM_GROUP_MAX independent products in the wgrad layout (a_kcontig = b_kcontig = 0, fp32

@@ -10,6 +10,8 @@
 import os
 import sys
 
+import ctypes
+
 import pytest
 import torch
 
@@ -121,6 +123,51 @@ def test_grouped_weight_gradients_match_single_launches():
         rb = dz.double().sum(0) - 1.0
         assert float((b1.double() - rb).abs().max()) < 2e-6 * float(rb.abs().max())
         assert float((b0 - b1).abs().max()) < 2e-6 * float(rb.abs().max())
+
+
+def test_split_k_finished_inside_the_launch_equals_the_reduction_launch_bit_for_bit():
+    """split-K products (single launches: a forward product with a tail, weight gradients with a fused bias gradient, row maxima of
+    the output; and a grouped launch) summed by the last workgroup of each tile inside the product's launch: the same bits as the
+    reduction kernel behind the launch (both add the slabs in the order 0, 1, ...), and the same bits run after run"""
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: torch.randn(s, generator=gen, device="cuda")      # noqa: E731
+    x, w, bias, res = rnd(50000, 512), rnd(512, 512) * 0.05, rnd(512), rnd(50000, 512)      # 196 x 4 tiles: 768 + a tail of 16, K cut 4 ways
+    wg = [(rnd(T, Np), rnd(T, Kp)) for T, Np, Kp in [(17158, 512, 512), (44325, 1536, 512), (30000, 512, 2048), (5000, 256, 300)]]
+    tm, tn, ns, tail_tiles, tail_ns = (ctypes.c_int() for _ in range(5))
+    be.lib.grappa_gemm_f32_plan(50000, 512, 512, 5, ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(ns), ctypes.byref(tail_tiles), ctypes.byref(tail_ns))
+    assert ns.value > 1 or tail_ns.value > 1, "the forward shape of this test must use split-K"
+
+    def run():
+        outs = []
+        y = torch.empty(50000, 512, device="cuda")
+        sy = be.gemm(x, w, y, M=50000, N=512, K=512, bias=bias, act=1, res=res, out_amax=True)
+        outs += [y, sy[1].row]
+        old = be.defer_wgrads
+        try:
+            for defer in (False, True):
+                be.defer_wgrads = defer
+                for dz, xx in wg:
+                    dw, db = torch.full((dz.shape[1], xx.shape[1]), 0.5, device="cuda"), torch.full((dz.shape[1],), -1.0, device="cuda")
+                    be.gemm_wgrad(dz, xx, dw, db)
+                    outs += [dw, db]
+                be.flush_wgrads()
+        finally:
+            be.defer_wgrads = old
+        torch.cuda.synchronize()
+        return outs
+
+    try:
+        be.lib.grappa_gemm_f32_set_splitk_reduce_launch(1)
+        want = run()
+        be.lib.grappa_gemm_f32_set_splitk_reduce_launch(0)
+        got = [run() for _ in range(3)]
+    finally:
+        be.lib.grappa_gemm_f32_set_splitk_reduce_launch(-1)
+    for r in got:
+        for a, b in zip(want, r):
+            assert torch.equal(a, b)
 
 
 def test_train_step_with_and_without_grouped_weight_gradients():
