@@ -1,7 +1,9 @@
 """GPU clock under a loop of the default dense product (and, for comparison, under the LayerNorm kernel): the matrix-core peak in
 MI355X_MICROARCH.md is quoted at 2.4 GHz; what the chip holds under this load scales the real ceiling (DVFS give-back).
     python tools/clock_probe.py > gpurun_out/clock_probe.txt
-The probing side is a child `rocm-smi --showclocks` (never touches the GPU context of this process)."""
+The probing side is a child `rocm-smi --showclocks --showpower --showmaxpower` (never touches the GPU context of this process).
+With GRAPPA_HIP_LIB=build/variants/libgrappa_hip_bx_<knock-out>.so (tools/gemm_f16x3_check.py --build-variants): clock and socket
+power under the kernel with one of its parts removed."""
 import os
 import subprocess
 import sys
@@ -17,8 +19,8 @@ from grappa_amd.backend import HipBackend  # noqa: E402
 def sample(tag, stop, out):
     while not stop.is_set():
         try:
-            r = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
-            lines = [ln.strip() for ln in r.splitlines() if "sclk" in ln or "mclk" in ln or "fclk" in ln]
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+            lines = [ln.strip() for ln in r.splitlines() if "sclk" in ln or "Power" in ln or "power" in ln]
             out.append((tag, time.time(), " | ".join(lines)))
         except Exception as e:  # noqa: BLE001
             out.append((tag, time.time(), f"rocm-smi failed: {e}"))
@@ -51,7 +53,8 @@ def main():
     out = []
     time.sleep(1.0)
     run("idle", lambda: None, 1.5, out)
-    for prec in ("f32_f16x3", "f32_bf16x6", "f32"):
+    precs = ("f32_f16x3",) if os.environ.get("GRAPPA_HIP_LIB") else ("f32_f16x3", "f32_bf16x6", "f32")      # a knock-out build: its one arithmetic
+    for prec in precs:
         rate = run(prec, lambda: be.gemm(A, B, C, M=M, N=N, K=K, precision=prec), 4.0, out)
         print(f"{prec}: {1e3 / rate:.3f} ms per product ({2.0 * M * N * K * rate / 1e12:.1f} TFLOP/s)")
     rate = run("layernorm", lambda: be.layernorm_fwd(A, g, b, Y, mean, rstd, amax=False), 3.0, out)
