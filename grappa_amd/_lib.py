@@ -34,6 +34,11 @@ class GemmDesc(C.Structure):
                 ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("amax_bcast", C.c_int), ("out_amax", C.c_void_p)]
 
 
+class ColsumItem(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("nrows", C.c_int), ("n", C.c_int), ("out", C.c_void_p), ("out2", C.c_void_p),
+                ("n_first", C.c_int), ("accumulate", C.c_int)]
+
+
 class MMDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("C", C.c_int), ("B", C.c_int), ("xyz", C.c_void_p), ("T", C.c_int * 4),
                 ("idx", C.c_void_p * 4), ("k", C.c_void_p * 4), ("eq", C.c_void_p * 4), ("mol_ptr", C.c_void_p * 4),
@@ -82,6 +87,8 @@ SIGNATURES = {
     "grappa_layernorm_fwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "grappa_layernorm_fwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "grappa_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "grappa_layernorm_bwd_partial_rows": (_i, [_i]),
+    "grappa_colsum_partials_batched": (_i, [_vp, C.POINTER(ColsumItem), _i]),
     "grappa_layernorm_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
     "grappa_layernorm_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "grappa_gat_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -123,6 +123,8 @@ class HipBackend:
         # cut its K (= tokens) 10 - 32 ways to fill the chip and pays for that many partial tiles per output tile
         self.defer_wgrads = os.environ.get("GRAPPA_DEFER_WGRADS", "1") not in ("0", "")
         self._wq = []                  # (dz, x, dW, db) kept alive until the flush
+        self.defer_ln = os.environ.get("GRAPPA_DEFER_LN_REDUCTIONS", "1") not in ("0", "")      # tuning: 0 = reduce every LayerNorm's parameter gradients at once
+        self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta)
         self._wq_callback = False
         self.weight_planes = os.environ.get("GRAPPA_WEIGHT_PLANES", "0") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
@@ -533,21 +535,34 @@ class HipBackend:
                 sdz = self.amax(dz, dz_scales, rows=True)
                 am = (sdz, self.amax(x, x_scales, rows=True))
         self._wq.append((dz, x, dw, db, am))
-        if not self._wq_callback:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(self.flush_wgrads)      # runs when this backward pass ends
-                self._wq_callback = True
-            except RuntimeError:                  # not inside a backward pass: nothing will call back
-                self.flush_wgrads()
-                return sdz
+        if not self._queue_flush():               # not inside a backward pass: nothing will call back
+            self.flush_wgrads()
+            return sdz
         if len(self._wq) >= _lib.GEMM_GROUP_MAX:
             self._launch_wgrad_group()
         return sdz
 
+    def _queue_flush(self) -> bool:
+        """ask autograd to call flush_wgrads when the running backward pass ends; False outside a backward pass"""
+        if not self._wq_callback:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush_wgrads)
+                self._wq_callback = True
+            except RuntimeError:
+                return False
+        return True
+
     def flush_wgrads(self) -> None:
+        """launch what a backward pass has queued: the grouped weight gradients and the LayerNorm parameter-gradient reductions"""
         self._wq_callback = False
         if self._wq:
             self._launch_wgrad_group()
+        if self._lnq:
+            items, self._lnq = self._lnq, []
+            arr = (_lib.ColsumItem * len(items))()
+            for d, (ws, nrows, W, pg, pb, _g, _b) in zip(arr, items):
+                d.part, d.nrows, d.n, d.out, d.out2, d.n_first, d.accumulate = ws.data_ptr(), nrows, 2 * W, pg, pb, W, 1
+            _chk(self.lib.grappa_colsum_partials_batched(self._stream(), arr, len(items)), "grappa_colsum_partials_batched")
 
     def _launch_wgrad_group(self) -> None:
         items, self._wq = self._wq, []
@@ -657,11 +672,18 @@ class HipBackend:
         if tuple(dy.shape) != (M, W) or tuple(dx.shape) != (M, W):
             raise ValueError("layernorm_bwd: shapes")
         dt = _same_dtype(dy, x, dx)
-        ws = self._workspace(self.lib.grappa_layernorm_bwd_workspace_bytes(M, W), dev)
+        # inside a backward pass the parameter gradients wait: the kernel leaves its per-block partial sums in a buffer of their own and
+        # ONE launch reduces those of all LayerNorms when the pass ends (flush_wgrads) instead of two small launches per LayerNorm
+        defer = (accumulate and self.defer_wgrads and self.defer_ln and M > 0 and torch.cuda.current_stream() == torch.cuda.default_stream()
+                 and all(q[3] != dgamma.data_ptr() for q in self._lnq) and self._queue_flush())
+        need = self.lib.grappa_layernorm_bwd_workspace_bytes(M, W)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev) if defer else self._workspace(need, dev)
         row = self._new_row_amax(dx, True, amax)
         args = (self._stream(), M, W, dy.data_ptr(), _f32_2d(dy, "dy", dev, dt), x.data_ptr(), _f32_2d(x, "x", dev, dt),
                 mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _f32_2d(dx, "dx", dev, dt),
-                dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel())
+                dgamma.data_ptr(), dbeta.data_ptr(), 2 if defer else int(accumulate), ws.data_ptr(), ws.numel())
+        if defer:
+            self._lnq.append((ws, self.lib.grappa_layernorm_bwd_partial_rows(M), W, dgamma.data_ptr(), dbeta.data_ptr(), dgamma, dbeta))
         if row is not None:
             _chk(self.lib.grappa_layernorm_bwd_amax_f32(*args, row.data_ptr()), "grappa_layernorm_bwd_amax_f32")
             return Amax(row=row)

@@ -200,6 +200,43 @@ inline void reduce_rows(hipStream_t st, int nrows, int stride, int n, const floa
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, groups, n, n, scratch, out, 0, accumulate, groups, out2, n_first);
 }
 
+// Column sums of many partial sets in one launch (the deferred LayerNorm parameter gradients of a backward pass): a block of 1024
+// threads = 64 columns x 16 row groups of one item; group g adds rows g, g + 16, ... (four loads in flight), the groups are combined
+// through the LDS in the order 0 .. 15: a fixed order, the same bits every run.
+constexpr int COLSUM_BATCH_MAX = 64;
+struct ColsumBatch {
+    grappa_colsum_item it[COLSUM_BATCH_MAX];
+    int blk_begin[COLSUM_BATCH_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(1024) void colsum_batched_kernel(ColsumBatch b) {
+    __shared__ float red[16][64];
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.blk_begin[i + 1]) ++i;
+    const grappa_colsum_item& it = b.it[i];
+    const int j = ((int)blockIdx.x - b.blk_begin[i]) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < it.n) {
+        int r = g;
+        for (; r + 48 < it.nrows; r += 64) {
+            s0 += it.part[(size_t)r * it.n + j];
+            s1 += it.part[(size_t)(r + 16) * it.n + j];
+            s2 += it.part[(size_t)(r + 32) * it.n + j];
+            s3 += it.part[(size_t)(r + 48) * it.n + j];
+        }
+        for (; r < it.nrows; r += 16) s0 += it.part[(size_t)r * it.n + j];
+    }
+    red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && j < it.n) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
+        float* o = (it.out2 && j >= it.n_first) ? it.out2 + (j - it.n_first) : it.out + j;
+        *o = it.accumulate ? *o + s : s;
+    }
+}
+
 // column sums: block = 256 threads = 64 columns x 4 row-lanes... simple: each block owns a row stripe,
 // threads stride over columns; partials[block][N]
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const float* __restrict__ x, int ldx, int rows_per_block,
@@ -401,7 +438,7 @@ int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const 
                        unsigned* dx_amax = nullptr) {
     if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return GRAPPA_ERR_ARG;
     if (M == 0) return GRAPPA_OK;
-    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return GRAPPA_ERR_ARG;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || (accumulate != 2 && (!dgamma || !dbeta))) return GRAPPA_ERR_ARG;
     const uintptr_t amask = sizeof(T) == 4 ? 15 : 7;
     if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & amask) || (reinterpret_cast<uintptr_t>(gamma) & 15))
         return GRAPPA_ERR_ARG;
@@ -420,6 +457,7 @@ int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const 
 #undef GRAPPA_LN_BWD
     int rc = grappa_launch_status();
     if (rc) return rc;
+    if (accumulate == 2) return GRAPPA_OK;                  // deferred: the caller reduces the partials (grappa_colsum_partials_batched)
     reduce_rows(st, blocks, 2 * W, 2 * W, part, dgamma, accumulate, scratch, dbeta, W);     // dgamma | dbeta in one pass (two launches, not four)
     return grappa_launch_status();
 }
@@ -482,6 +520,28 @@ extern "C" int grappa_layernorm_fwd_amax_f32(void* stream, int M, int W, const f
 }
 extern "C" size_t grappa_layernorm_bwd_workspace_bytes(int M, int W) {
     return ((size_t)ln_blocks(M) * 2 * W + (size_t)REDUCE_GROUPS * 2 * W) * sizeof(float);
+}
+
+extern "C" int grappa_layernorm_bwd_partial_rows(int M) { return M > 0 ? ln_blocks(M) : 0; }
+
+extern "C" int grappa_colsum_partials_batched(void* stream, const grappa_colsum_item* items, int count) {
+    if (count < 0 || (count > 0 && !items)) return GRAPPA_ERR_ARG;
+    for (int i = 0; i < count; ++i) {
+        const grappa_colsum_item& it = items[i];
+        if (it.nrows < 0 || it.n <= 0 || !it.out || (it.nrows > 0 && !it.part) || (it.out2 && (it.n_first <= 0 || it.n_first >= it.n))) return GRAPPA_ERR_ARG;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int i0 = 0; i0 < count; i0 += COLSUM_BATCH_MAX) {
+        ColsumBatch b;
+        b.count = count - i0 < COLSUM_BATCH_MAX ? count - i0 : COLSUM_BATCH_MAX;
+        b.blk_begin[0] = 0;
+        for (int i = 0; i < b.count; ++i) {
+            b.it[i] = items[i0 + i];
+            b.blk_begin[i + 1] = b.blk_begin[i] + (b.it[i].n + 63) / 64;
+        }
+        hipLaunchKernelGGL(colsum_batched_kernel, dim3(b.blk_begin[b.count]), dim3(1024), 0, st, b);
+    }
+    return grappa_launch_status();
 }
 
 extern "C" int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,

@@ -202,7 +202,22 @@ int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float* x, int ldx
 int grappa_layernorm_fwd_amax_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
                                   float* y, int ldy, float* mean, float* rstd, uint32_t* y_amax);
 size_t grappa_layernorm_bwd_workspace_bytes(int M, int W);
-/* dx may alias dy.  dgamma/dbeta: accumulate != 0 adds to the existing values. */
+/* dx may alias dy.  dgamma/dbeta: accumulate = 1 adds to the existing values, 0 overwrites.  accumulate = 2 defers them: the
+ * kernel leaves its per-block partial sums at the start of `ws` -- grappa_layernorm_bwd_partial_rows(M) rows of 2 W floats,
+ * [dgamma | dbeta] -- and writes neither vector; the caller keeps that `ws` alive and later hands the partials of many LayerNorms to
+ * ONE launch of grappa_colsum_partials_batched (a backward pass has ~50 LayerNorms: 100 small reduction launches otherwise). */
+int grappa_layernorm_bwd_partial_rows(int M);
+typedef struct {
+    const float* part;   /* nrows x n, row-major, contiguous */
+    int nrows, n;
+    float* out;          /* columns [0, n_first) (all n when out2 is NULL) */
+    float* out2;         /* columns [n_first, n), or NULL */
+    int n_first;
+    int accumulate;      /* != 0: add to the existing values */
+} grappa_colsum_item;
+/* out (+)= column sums of each item's partial rows, summed in a fixed order (the same bits every run); `items` is a HOST array, any
+ * count; two items of one call must not share an output */
+int grappa_colsum_partials_batched(void* stream, const grappa_colsum_item* items, int count);
 int grappa_layernorm_bwd_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
                              const float* mean, const float* rstd, const float* gamma,
                              float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,

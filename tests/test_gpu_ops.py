@@ -238,6 +238,57 @@ def test_layernorm(hip, ref, M, W):
     _cmp(dx_h, dx_r, 2e-5, "layernorm_bwd dx"), _cmp(dg_h, dg_r, 2e-5, "dgamma"), _cmp(db_h, db_r, 2e-5, "dbeta")
 
 
+def test_layernorm_parameter_gradients_deferred_to_one_batched_reduction(hip, ref):
+    """accumulate = 2: the kernel leaves its per-block partial sums in the caller's buffer; grappa_colsum_partials_batched reduces those
+    of several LayerNorms in ONE launch (what the backend does with a backward pass's ~50 LayerNorms): the gradients match the
+    oracle and the immediate reduction, and are the same bits run after run"""
+    import ctypes
+    from grappa_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for M, W in [(5000, 512), (83, 256), (20011, 2048), (3, 512), (9000, 1024)]:
+        x = (torch.randn(M, W, generator=g) * 2 + 0.5).cuda()
+        gamma, dy = (1 + 0.1 * torch.randn(W, generator=g)).cuda(), torch.randn(M, W, generator=g).cuda()
+        y, mean, rstd = torch.empty(M, W, device="cuda"), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+        hip.layernorm_fwd(x, gamma, torch.zeros(W, device="cuda"), y, mean, rstd)
+        cases.append((M, W, x, gamma, dy, mean, rstd))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def deferred():
+        outs, keep = [], []
+        arr = (_lib.ColsumItem * len(cases))()
+        for d, (M, W, x, gamma, dy, mean, rstd) in zip(arr, cases):
+            dx, dg, db = torch.empty(M, W, device="cuda"), torch.ones(W, device="cuda"), torch.full((W,), 2.0, device="cuda")
+            ws = torch.empty(hip.lib.grappa_layernorm_bwd_workspace_bytes(M, W), dtype=torch.uint8, device="cuda")
+            rc = hip.lib.grappa_layernorm_bwd_f32(stream, M, W, dy.data_ptr(), W, x.data_ptr(), W, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                                  dx.data_ptr(), W, None, None, 2, ws.data_ptr(), ws.numel())
+            assert rc == 0
+            d.part, d.nrows, d.n, d.out, d.out2, d.n_first, d.accumulate = ws.data_ptr(), hip.lib.grappa_layernorm_bwd_partial_rows(M), 2 * W, dg.data_ptr(), db.data_ptr(), W, 1
+            outs.append((dx, dg, db))
+            keep.append(ws)
+        assert hip.lib.grappa_colsum_partials_batched(stream, arr, len(cases)) == 0
+        torch.cuda.synchronize()
+        return outs
+
+    first, second = deferred(), deferred()
+    for (M, W, x, gamma, dy, mean, rstd), (dx, dg, db), (dx2, dg2, db2) in zip(cases, first, second):
+        assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dx, dx2)
+        dx_i, dg_i, db_i = torch.empty(M, W, device="cuda"), torch.ones(W, device="cuda"), torch.full((W,), 2.0, device="cuda")
+        hip.layernorm_bwd(dy, x, mean, rstd, gamma, dx_i, dg_i, db_i, True)           # outside a backward pass: reduced at once
+        assert torch.equal(dx, dx_i)
+        dx_r, dg_r, db_r = torch.empty(M, W), torch.ones(W), torch.full((W,), 2.0)
+        ref.layernorm_bwd(dy.cpu(), x.cpu(), mean.cpu(), rstd.cpu(), gamma.cpu(), dx_r, dg_r, db_r, True)
+        _cmp(dg, dg_r, 2e-5, f"deferred dgamma {M}x{W}"), _cmp(db, db_r, 2e-5, f"deferred dbeta {M}x{W}")
+        _cmp(dg_i, dg_r, 2e-5, "dgamma"), _cmp(db_i, db_r, 2e-5, "dbeta")
+    # argument checks: an item without an output, a second destination without a split column
+    bad = (_lib.ColsumItem * 1)()
+    bad[0].part, bad[0].nrows, bad[0].n, bad[0].out = first[0][1].data_ptr(), 1, 4, None
+    assert hip.lib.grappa_colsum_partials_batched(stream, bad, 1) != 0
+    bad[0].out, bad[0].out2, bad[0].n_first = first[0][1].data_ptr(), first[0][2].data_ptr(), 0
+    assert hip.lib.grappa_colsum_partials_batched(stream, bad, 1) != 0
+    assert hip.lib.grappa_colsum_partials_batched(stream, None, 0) == 0
+
+
 @pytest.mark.parametrize("H,D", [(16, 32), (4, 16), (8, 64)])
 def test_gat_fwd_bwd(hip, ref, H, D):
     g_cpu, g_gpu = _graph()
