@@ -118,6 +118,39 @@ class BatchPlan:
         self.device = dev
 
 
+def _plan_position_tables(self, lvl: str):
+    cache = self.__dict__.setdefault("_pos_tables", {})
+    if lvl not in cache:
+        cache[lvl] = _position_tables(self, lvl)
+    return cache[lvl]
+
+
+BatchPlan.position_tables = _plan_position_tables
+
+
+def _position_tables(plan: "BatchPlan", lvl: str):
+    """index tables of the (atom, position) formulation of a writer's first layer (ops.ProjFirstLayerFn), built on the plan's device
+    from idx32 and cached: table row pos*N + n holds atom n at position pos.
+      idx_id (N, s): idx_id[n, pos] = n                       -- "gather" that lays the table out from the atom rows
+      invid_ptr / invid_rows: atom n <- table rows pos*N + n   -- its inverse
+      idx_tab (T, s): idx_tab[t, pos] = pos*N + idx[t, pos]    -- tokens from table rows
+      invtab_ptr / invtab_rows: table row <- token rows pos*T + t (ascending) -- its inverse"""
+    s, N, T = LEVEL_ARITY[lvl], plan.N, plan.T[lvl]
+    dev = plan.idx32[lvl].device
+    i32 = dict(dtype=torch.int32, device=dev)
+    pos = torch.arange(s, **i32)
+    idx_id = torch.arange(N, **i32).view(N, 1).expand(N, s).contiguous()
+    invid_ptr = (torch.arange(N + 1, **i32) * s).contiguous()
+    invid_rows = (pos.view(1, s) * N + torch.arange(N, **i32).view(N, 1)).reshape(-1).contiguous()
+    idx_tab = (plan.idx32[lvl] + pos.view(1, s) * N).contiguous()
+    key = idx_tab.t().reshape(-1).long()                           # token row r = pos*T + t -> its table row
+    invtab_rows = torch.argsort(key, stable=True).to(torch.int32).contiguous()
+    counts = torch.bincount(key, minlength=s * N)
+    invtab_ptr = torch.zeros(s * N + 1, **i32)
+    invtab_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return idx_id, invid_ptr, invid_rows, idx_tab, invtab_ptr, invtab_rows
+
+
 def _cum(counts: np.ndarray) -> np.ndarray:
     out = np.zeros(len(counts) + 1, dtype=np.int32)
     out[1:] = np.cumsum(counts)

@@ -241,10 +241,13 @@ class SymmetrisedTransformer(nn.Module):
             width = n_feats
         self.symmetriser = Symmetriser(width, out_feats, permutations, symmetriser_hidden_feats, symmetriser_layers, layer_norm)
 
-    def forward(self, x, s, T):
-        """x: (s*T, F) token table (row = pos*T + t) -> (P*T, out_feats), one row per permuted copy."""
+    def forward(self, x, s, T, first_layer_done=False):
+        """x: (s*T, F) token table (row = pos*T + t) -> (P*T, out_feats), one row per permuted copy.  first_layer_done: x is already
+        the output of the first transformer layer (ops.ProjFirstLayerFn)."""
         if self.grappa_transformer is not None:
-            for layer in self.grappa_transformer.transformer:
+            for li, layer in enumerate(self.grappa_transformer.transformer):
+                if li == 0 and first_layer_done:
+                    continue
                 x = layer(x, s, T)
         sym = self.symmetriser
         flat = [t for ff in sym.mlp for t in ff.params()]
@@ -305,17 +308,31 @@ class _WriterBase(nn.Module):
     def _consts(self) -> torch.Tensor:
         raise NotImplementedError
 
-    def _tokens(self, g):
+    def _symmetrised(self, g):
+        """atom embeddings -> tokens -> transformer -> symmetriser: (o (P*T, out_feats), T)"""
         plan = g.plan()
         lvl = self.level
         h = g.nodes["n1"].data["h"]
         model = self._model()
+        T, N = plan.T[lvl], plan.N
         pe = None
-        if model.grappa_transformer is not None and model.grappa_transformer.positional_encoding is not None:
-            pe = model.grappa_transformer.positional_encoding.reshape(-1).contiguous()
+        layers = []
+        if model.grappa_transformer is not None:
+            layers = list(model.grappa_transformer.transformer)
+            if model.grappa_transformer.positional_encoding is not None:
+                pe = model.grappa_transformer.positional_encoding.reshape(-1).contiguous()
         lin = self.rep_projector.mlp[0]
+        # far fewer (atom, position) pairs than tokens (propers, angles): the first layer's LayerNorm and QKV product run on those
+        if ops.FIRST_LAYER_ON_ATOM_ROWS and layers and T > 0 and 4 * N <= 3 * T:
+            l0 = layers[0]
+            p = l0.p if l0.training else 0.0
+            s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+            x = ops.ProjFirstLayerFn.apply(h, lin.weight, lin.bias, plan.position_tables(lvl), self.s, T, pe, ops.act_dtype(), l0.num_heads, p, s1, s2,
+                                           *_wb(getattr(l0, "norm1", None)), l0.attn.in_proj_weight, l0.attn.in_proj_bias,
+                                           l0.attn.out_proj.weight, l0.attn.out_proj.bias, *l0.ff.params())
+            return model(x, self.s, T, first_layer_done=True), T
         x = ops.ProjGatherFn.apply(h, lin.weight, lin.bias, plan.idx32[lvl], plan.inv_ptr[lvl], plan.inv_rows[lvl], self.s, pe, ops.act_dtype())
-        return x, plan.T[lvl]
+        return model(x, self.s, T), T
 
 
 class WriteBondParameters(_WriterBase):
@@ -340,8 +357,7 @@ class WriteBondParameters(_WriterBase):
                             self.to_k.min_]).float().contiguous()
 
     def forward(self, g):
-        x, T = self._tokens(g)
-        o = self.bond_model(x, 2, T)
+        o, T = self._symmetrised(g)
         k, eq = ops.ParamOutFn.apply(o, 0, T, 2, 0, False, 0.0, self._consts())
         g.nodes["n2"].data["eq" + self.suffix] = eq
         g.nodes["n2"].data["k" + self.suffix] = k           # harmonic_gate has no effect on the outputs (reference quirk Q3)
@@ -374,8 +390,7 @@ class WriteAngleParameters(_WriterBase):
     def forward(self, g):
         if "n3" not in g.ntypes:
             return g
-        x, T = self._tokens(g)
-        o = self.angle_model(x, 3, T)
+        o, T = self._symmetrised(g)
         k, eq = ops.ParamOutFn.apply(o, 1, T, 2, 0, False, 0.0, self._consts())
         g.nodes["n3"].data["eq" + self.suffix] = eq
         g.nodes["n3"].data["k" + self.suffix] = k
@@ -432,8 +447,7 @@ class WriteTorsionParameters(_WriterBase):
         lvl = self.level
         if lvl not in g.ntypes:
             return g
-        x, T = self._tokens(g)
-        o = self.torsion_model(x, 4, T)
+        o, T = self._symmetrised(g)
         k = ops.ParamOutFn.apply(o, 2, T, self._P, self._n_per, self.gated, self.cutoff_value, self._consts())
         g.nodes[lvl].data["k" + self.suffix] = k
         return g

@@ -33,6 +33,11 @@ ELU = 1
 _SEED = {"base": 0x5DEECE66D, "counter": 0}
 
 
+# the first transformer layer of a writer on (atom, position) rows instead of tokens where those are far fewer (ProjFirstLayerFn);
+# GRAPPA_FIRST_LAYER_ROWS=0: always the token formulation (ProjGatherFn + TransformerLayerFn)
+FIRST_LAYER_ON_ATOM_ROWS = os.environ.get("GRAPPA_FIRST_LAYER_ROWS", "1") not in ("0", "")
+
+
 def manual_seed(seed: int) -> None:
     """seed of the counter-based dropout masks (independent of torch's generators)."""
     _SEED["base"] = int(seed) & (2 ** 63 - 1)
@@ -424,6 +429,88 @@ class TransformerLayerFn(Function):
         be.gemm(dqkv, w_in, dx1, M=M, N=Fd, K=3 * Fd, b_kcontig=False, res=dx2, a_scales=sz)
         dx, _ = _ln_bwd(be, dx1, x, mean1, rstd1, n1_w, n1_b)
         return (dx,) + (None,) * 18
+
+
+class ProjFirstLayerFn(Function):
+    """ProjGatherFn followed by the first TransformerLayerFn, with that layer's LayerNorm and QKV product done once per
+    (atom, position) row instead of once per token: a token x[pos*T + t] = [a[idx[t, pos]], pe[pos]] depends on its tuple only through
+    (idx[t, pos], pos), and so do LN(x) and LN(x) W_in^T + b_in -- s*N table rows instead of s*T tokens (propers: 32,932 instead of
+    83,328 on the C2 batch).  The normed rows and their q, k, v are gathered to the tokens behind the product; backward sums the
+    token gradients into the table rows first (inverse incidence of the table) and runs the dgrad / wgrad products and the
+    LayerNorm backward on the table.  Same arithmetic per row as the two functions it replaces (reference
+    models/interaction_parameters.py:155-180, perm_equiv_transformer.py:127-151, network_utils.py:112-133).
+    tabs = batch.BatchPlan.position_tables(level)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, tabs, s, T, pe, out_dtype, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2):
+        be = get_backend()
+        idx_id, invid_ptr, invid_rows, idx_tab, invtab_ptr, invtab_rows = tabs
+        h = _c(h)
+        N, R = h.shape
+        Wp = w.shape[0]
+        Fd = Wp + (1 if pe is not None else 0)
+        a = _zeros((N, Fd), h, out_dtype)
+        sh = be.gemm(h, w, a[:, :Wp], M=N, N=Wp, K=R, bias=b, act=ELU)
+        tab = _new((s * N, Fd), a)
+        be.tuple_gather_fwd(a, idx_id, s, pe, tab)                 # tab[pos*N + n] = [a[n], pe[pos]]
+        x1_tab, mean1, rstd1, sx1 = _ln_fwd(be, tab, n1_w, n1_b)
+        qkv_tab = _new((s * N, 3 * Fd), tab)
+        sx1 = be.gemm(x1_tab, w_in, qkv_tab, M=s * N, N=3 * Fd, K=Fd, bias=b_in, a_scales=sx1)
+        M = s * T
+        x1, qkv = _new((M, Fd), tab), _new((M, 3 * Fd), tab)
+        be.tuple_gather_fwd(x1_tab, idx_tab, s, None, x1)          # x1[pos*T + t] = x1_tab[pos*N + idx[t, pos]]
+        be.tuple_gather_fwd(qkv_tab, idx_tab, s, None, qkv)
+        del qkv_tab
+        att = _new((M, Fd), tab)
+        satt = be.seqattn_fwd(qkv, s, T, nheads, att)
+        x2 = _new((M, Fd), tab)
+        satt = be.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x1, a_scales=satt)
+        del x1
+        out, ff_saved = _ff_fwd(be, x2, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        ctx.cfg, ctx.scales = (s, T, N, Wp, pe is not None, nheads, drop_p, seed1, seed2), (sh, sx1, satt)
+        ctx.ff_saved = ff_saved
+        ctx.save_for_backward(h, a, tab, mean1, rstd1, x1_tab, qkv, att, invid_ptr, invid_rows, invtab_ptr, invtab_rows,
+                              w, b, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        be = get_backend()
+        (h, a, tab, mean1, rstd1, x1_tab, qkv, att, invid_ptr, invid_rows, invtab_ptr, invtab_rows,
+         w, b, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2) = ctx.saved_tensors
+        s, T, N, Wp, has_pe, nheads, drop_p, seed1, seed2 = ctx.cfg
+        sh, sx1, satt = ctx.scales
+        M, Fd = att.shape
+        R = h.shape[1]
+        dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        ctx.ff_saved = None
+        if drop_p > 0:
+            dzo = _new(dx2.shape, dx2)
+            sz = be.act_dropout_bwd(dx2, None, drop_p, seed1, dzo)
+        else:
+            dzo = dx2
+        sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)
+        datt = _new(att.shape, att)
+        be.gemm(dzo, w_o, datt, M=M, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)
+        dqkv = _new(qkv.shape, qkv)
+        be.seqattn_bwd(qkv, datt, s, T, nheads, dqkv)                      # (its rows are summed into the table before any product reads them)
+        # token gradients -> table rows (pos*N + n): the q, k, v gradients and the skip branch of x1
+        dqkv_tab, dres_tab = _new((s * N, 3 * Fd), qkv), _new((s * N, Fd), qkv)
+        be.tuple_gather_bwd(invtab_ptr, invtab_rows, dqkv, dqkv_tab, False, False)
+        be.tuple_gather_bwd(invtab_ptr, invtab_rows, dx2, dres_tab, False, False)
+        del dqkv
+        sz = _linear_bwd_params(be, dqkv_tab, x1_tab, w_in, b_in, sx1, None)
+        dx1_tab = _new(x1_tab.shape, x1_tab)
+        be.gemm(dqkv_tab, w_in, dx1_tab, M=s * N, N=Fd, K=3 * Fd, b_kcontig=False, res=dres_tab, a_scales=sz)
+        dtab, _ = _ln_bwd(be, dx1_tab, tab, mean1, rstd1, n1_w, n1_b)
+        da = _new(a.shape, a)
+        be.tuple_gather_bwd(invid_ptr, invid_rows, dtab, da, has_pe, False)      # sum over the positions of an atom
+        dz = _new((N, Wp), a)
+        sz = be.act_dropout_bwd(da[:, :Wp], a[:, :Wp], 0.0, 0, dz)
+        sz = _linear_bwd_params(be, dz, h, w, b, sh, sz)
+        dh = _new(h.shape, h)
+        be.gemm(dz, w, dh, M=N, N=R, K=Wp, b_kcontig=False, a_scales=sz)
+        return (dh,) + (None,) * 23
 
 
 class SymmetriserFn(Function):

@@ -218,6 +218,49 @@ def test_properties_at_c2_size():
     assert not torch.allclose(ka, g.nodes["n2"].data["k"])
 
 
+def test_first_layer_on_atom_position_rows_equals_the_token_formulation():
+    """ops.ProjFirstLayerFn (LayerNorm + QKV product of a writer's first layer once per (atom, position) row, gathered to the tokens
+    behind the product) against ProjGatherFn + TransformerLayerFn on the tokens: same parameters, loss and parameter gradients up to
+    fp32 summation order (the token gradients are summed into table rows before the products instead of inside them), train mode
+    with the same dropout masks"""
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.datasets import build_batch_from_pool
+    from grappa_amd.optim import FlatParams
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").train()
+    flat = FlatParams(model)
+    g0 = build_batch_from_pool(list(range(300, 364)), n_confs=8, seed=5).to("cuda")
+    plan = g0.plan()
+    assert 4 * plan.N <= 3 * plan.T["n4"] and 4 * plan.N <= 3 * plan.T["n3"] and 4 * plan.N > 3 * plan.T["n2"]      # propers + angles take the new path
+    res = []
+    old = ops.FIRST_LAYER_ON_ATOM_ROWS
+    try:
+        for rows in (False, True):
+            ops.FIRST_LAYER_ON_ATOM_ROWS = rows
+            ops.manual_seed(21)
+            flat.zero_grad()
+            g = Energy()(model(build_batch_from_pool(list(range(300, 364)), n_confs=8, seed=5).to("cuda")))
+            loss = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)(g)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), flat.grad.clone(), {lvl: g.nodes[lvl].data["k"].detach().clone() for lvl in ("n2", "n3", "n4", "n4_improper")}))
+    finally:
+        ops.FIRST_LAYER_ON_ATOM_ROWS = old
+    (l0, g0_, k0), (l1, g1_, k1) = res
+    assert abs(float(l0) - float(l1)) <= 1e-5 * abs(float(l0))
+    for lvl in k0:
+        assert float((k0[lvl] - k1[lvl]).abs().max()) <= 2e-5 * float(k0[lvl].abs().max()), lvl
+    assert torch.equal(k0["n2"], k1["n2"]) and torch.equal(k0["n4_improper"], k1["n4_improper"])      # untouched writers: the same bits
+    names = {id(p): k for k, p in model.named_parameters()}
+    for p in flat.params:                           # per tensor, against that tensor's own scale
+        lo, hi = flat._offsets[id(p)]
+        a, b = g0_[lo:hi], g1_[lo:hi]
+        scale = float(a.abs().max())
+        if scale > 0:
+            assert float((a - b).abs().max()) <= 1e-4 * scale, names[id(p)]
+
+
 def test_c3_batch_1024_bf16_arithmetic():
     """BASELINE.json configs[2]: 1024 molecules drawn from the whole Espaloma pool (~39 k atoms, ~0.75 M tokens), 32 conformations,
     production model, dense products in bf16 arithmetic on the matrix cores (fp32 accumulate; LayerNorm / softmax / energy in
