@@ -294,7 +294,8 @@ def main():
 
     GEMM_PEAK_NOTE = ("achieved = algorithmic 2MNK FLOPs / HIP-event time of the calls; peak = bf16 dense MFMA peak (16 x 157.3 TFLOP/s, "
                       "MI355X_MICROARCH.md; the fp16 one is the same) / partial products issued per fp32 product; the time of the operands' "
-                      "maxima passes (f32_f16x3) is charged to the products")
+                      "maxima passes (f32_f16x3) is charged to the products; FLOPs are those of the products as launched (the first layer of the proper "
+                      "and angle writers runs on (atom, position) rows: ~5 % fewer than SURVEY 8(d)'s per-token count)")
 
     def instrument(j, steps):
         """instrumented repetition of a job's steps: HIP events around every GEMM / GAT launch on the launch stream (one stream:
