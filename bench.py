@@ -294,8 +294,9 @@ def main():
 
     GEMM_PEAK_NOTE = ("achieved = algorithmic 2MNK FLOPs / HIP-event time of the calls; peak = bf16 dense MFMA peak (16 x 157.3 TFLOP/s, "
                       "MI355X_MICROARCH.md; the fp16 one is the same) / partial products issued per fp32 product; the time of the operands' "
-                      "maxima passes (f32_f16x3) is charged to the products; FLOPs are those of the products as launched (the first layer of the proper "
-                      "and angle writers runs on (atom, position) rows: ~5 % fewer than SURVEY 8(d)'s per-token count)")
+                      "maxima passes (f32_f16x3) is charged to the products; algorithmic FLOPs = SURVEY 8(d)'s per-token count (`tflop_per_step`); the first "
+                      "layer of the proper and angle writers runs its LayerNorm + QKV product on (atom, position) rows, so ~5 % of them are never "
+                      "launched (`tflop_per_step_launched`, `achieved_launched_flops_only` = the rate over the launched FLOPs alone)")
 
     def instrument(j, steps):
         """instrumented repetition of a job's steps: HIP events around every GEMM / GAT launch on the launch stream (one stream:
@@ -321,6 +322,10 @@ def main():
         n_amax, ms_amax = prof.get("amax", (0, 0.0, 0.0, 0.0))[:2]
         ms_products = ms
         ms += ms_amax
+        # algorithmic FLOPs = SURVEY 8(d)'s per-token count: those of the products launched plus those the (atom, position)-row
+        # formulation of the first writer layer did not have to launch (ops.ProjFirstLayerFn); both rates are reported
+        fl_launched = fl
+        fl += prof.get("gemm_saved", (0, 0.0, 0.0, 0.0))[2]
         achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
         kname, nprod = GEMM_KERNELS[be.gemm_precision_name]
         if ops.act_dtype() is not None:
@@ -333,7 +338,8 @@ def main():
                 "gemm_precision": be.gemm_precision_name,
                 "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": by / max(n, 1),
                 "launches_per_step": n / steps, "avg_launch_us": 1e3 * ms / max(n, 1), "gflop_per_launch": fl / max(n, 1) / 1e9,
-                "kernel_ms_per_step": ms / steps, "note": GEMM_PEAK_NOTE}
+                "kernel_ms_per_step": ms / steps, "tflop_per_step": fl / steps / 1e12, "tflop_per_step_launched": fl_launched / steps / 1e12,
+                "achieved_launched_flops_only": (fl_launched / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0, "note": GEMM_PEAK_NOTE}
         if n_amax:
             roof.update({"maxima_pass_ms_per_step": ms_amax / steps, "maxima_pass_launches_per_step": n_amax / steps,
                          "products_only_ms_per_step": ms_products / steps,

@@ -293,9 +293,15 @@ class HipBackend:
         out = {}
         for name, fl, by, e0, e1 in self._prof or []:
             n, ms, f, b = out.get(name, (0, 0.0, 0.0, 0.0))
-            out[name] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
+            out[name] = (n + 1, ms + (e0.elapsed_time(e1) if e0 is not None else 0.0), f + fl, b + by)
         self._prof = None
         return out
+
+    def credit(self, name, flops) -> None:
+        """profiling only: algorithmic work (SURVEY 8(d) counts per token) that a formulation did not have to launch -- e.g. the first
+        writer layer's products on (atom, position) rows instead of tokens -- recorded under its own family, without time"""
+        if self._prof is not None:
+            self._prof.append((name, float(flops), 0.0, None, None))
 
     def _timed(self, name, flops, nbytes, launch) -> None:
         if self._prof is None:

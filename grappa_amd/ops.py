@@ -457,6 +457,8 @@ class ProjFirstLayerFn(Function):
         qkv_tab = _new((s * N, 3 * Fd), tab)
         sx1 = be.gemm(x1_tab, w_in, qkv_tab, M=s * N, N=3 * Fd, K=Fd, bias=b_in, a_scales=sx1)
         M = s * T
+        if hasattr(be, "credit"):                 # profiling: the per-token count of this product (and of its two backward products below)
+            be.credit("gemm_saved", 2.0 * (M - s * N) * 3 * Fd * Fd)
         x1, qkv = _new((M, Fd), tab), _new((M, 3 * Fd), tab)
         be.tuple_gather_fwd(x1_tab, idx_tab, s, None, x1)          # x1[pos*T + t] = x1_tab[pos*N + idx[t, pos]]
         be.tuple_gather_fwd(qkv_tab, idx_tab, s, None, qkv)
@@ -500,6 +502,8 @@ class ProjFirstLayerFn(Function):
         be.tuple_gather_bwd(invtab_ptr, invtab_rows, dx2, dres_tab, False, False)
         del dqkv
         sz = _linear_bwd_params(be, dqkv_tab, x1_tab, w_in, b_in, sx1, None)
+        if hasattr(be, "credit"):
+            be.credit("gemm_saved", 2.0 * 2.0 * (M - s * N) * 3 * Fd * Fd)
         dx1_tab = _new(x1_tab.shape, x1_tab)
         be.gemm(dqkv_tab, w_in, dx1_tab, M=s * N, N=Fd, K=3 * Fd, b_kcontig=False, res=dres_tab, a_scales=sz)
         dtab, _ = _ln_bwd(be, dx1_tab, tab, mean1, rstd1, n1_w, n1_b)
