@@ -1,0 +1,67 @@
+"""Soak of the opt-in GRAPPA_HEAD_STREAMS=4 (writer heads on four HIP streams) against the one-stream default: every step is run twice from
+the same state and seed -- one stream, then four -- and loss and the whole flat gradient are compared bit for bit; the one-stream
+gradients then drive an optimiser step so that the operands keep changing.  (Deferred / grouped launches are switched off for both
+runs: they exist on the caller's stream only and change the summation order.)
+
+    python tools/head_streams_soak.py [steps] > gpurun_out/head_streams_soak.txt
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (keyed_init, LOSS_KW)
+from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops  # noqa: E402
+from grappa_amd.backend import get_backend  # noqa: E402
+from grappa_amd.datasets import build_workload  # noqa: E402
+from grappa_amd.optim import FlatParams, FusedAdam  # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    be = get_backend()
+    be.defer_wgrads = False
+    model = model_from_config(get_default_model_config())
+    bench.keyed_init(model)
+    model = model.to("cuda").train()
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=1.5e-5, max_grad_norm=10.0)
+    g = build_workload("C2-pubchem-b256", seed=0).to("cuda")
+    loss_fn = MolwiseLoss(**bench.LOSS_KW)
+    energy = Energy()
+
+    def run(streams, seed):
+        model.parameter_writer.head_streams = streams
+        ops.manual_seed(seed)
+        flat.zero_grad()
+        for lvl in ("n2", "n3", "n4", "n4_improper"):
+            for k in ("k", "eq"):
+                g.nodes[lvl].data.pop(k, None)
+        loss = loss_fn(energy(model(g)))
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), flat.grad.clone()
+
+    bad = 0
+    t0 = time.time()
+    for i in range(steps):
+        l1, g1 = run(1, 1000 + i)
+        l4, g4 = run(4, 1000 + i)
+        same = torch.equal(l1, l4) and torch.equal(g1, g4)
+        if not same:
+            bad += 1
+            d = (g1 - g4).abs()
+            print(f"step {i}: DEVIATION loss {float(l1)} vs {float(l4)}; gradient entries differing {int((d > 0).sum())}, max |diff| {float(d.max()):.3e} "
+                  f"of max |g| {float(g1.abs().max()):.3e}", flush=True)
+        flat.grad.copy_(g1)
+        model.parameter_writer.head_streams = 1
+        opt.step()
+        if i % 25 == 0:
+            print(f"step {i}: loss {float(l1):.4f} deviations so far {bad} ({time.time() - t0:.0f} s)", flush=True)
+    print(f"{steps} steps: {bad} deviating")
+
+
+if __name__ == "__main__":
+    main()
