@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--strong-global-batch", type=int, default=0, help="strong scaling of this many molecules of the workload's molecule range (default at N > 1: 4096 of C4)")
     ap.add_argument("--chunk", type=int, default=1024, help="molecules per forward/backward pass of a rank (larger shards are accumulated over chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--head-streams-extra", action="store_true", help="N = 1: also time K steps with the writer heads on four HIP streams (opt-in mode, reported beside, never as `value`)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the C3 and C4-on-one-GPU timings that follow the headline measurement")
     ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_f16x3)")
     ap.add_argument("--act-dtype", default="f32", choices=["f32", "bf16"], help="bf16: the bf16 STORAGE configuration for the main job (profiling / "
@@ -391,6 +392,22 @@ def main():
                        "split once per optimiser step (csrc/gemm_planes.hip gemm_wplanes_kernel); results equal f32_bf16x6 to rounding; not the default"}
         log(f"weight planes: {wpl['ms_per_step']:.1f} ms/step")
 
+    # opt-in configuration (never `value`): the four writer heads on four HIP streams
+    heads4 = None
+    if world == 1 and args.head_streams_extra and args.act_dtype == "f32" and model.parameter_writer.head_streams == 1:
+        import warnings
+        model.parameter_writer.head_streams = 4
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            d_h, _ = job.timed(args.steps, 2)
+        model.parameter_writer.head_streams = 1
+        heads4 = {"value": job.global_batch * args.steps / d_h, "ms_per_step": 1e3 * d_h / args.steps,
+                  "note": "GRAPPA_HEAD_STREAMS=4, opt-in and NOT the headline configuration: bond / angle / proper / improper writers on four HIP "
+                          "streams.  Bit-identical to one stream over a 5,000-step soak (tools/head_streams_soak.py) and in tests/test_gpu_e2e.py, "
+                          "but a since-removed kernel deviated under the same concurrency in round 1 for a reason never found "
+                          "(DESIGN.md section 6), so the default keeps compute on one queue"}
+        log(f"writer heads on 4 streams (opt-in): {heads4['ms_per_step']:.1f} ms/step")
+
     # N = 1: the other single-GPU configurations, timed right after the headline measurement: C3 in the headline arithmetic, C3 in the
     # bf16 STORAGE configuration BASELINE configs[2] names (never `value`), and the 4096-molecule batch of C4 on one GPU
     extras = {}
@@ -463,6 +480,7 @@ def main():
                                         "end-to-end parity: tests/test_gpu_e2e.py, tests/test_gpu_configs.py",
                                 "native_f32_mfma": alt.get("f32"), "f32_bf16x6": alt.get("f32_bf16x6"), "backward_reduced": bwd, "weight_planes": wpl},
             "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": ms_instr, "final_loss": final_loss,
+            "writer_heads_on_4_streams": heads4,
         }
         out.update(extras)
         out["cpu_baseline"] = cpu_base

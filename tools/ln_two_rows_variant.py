@@ -1,0 +1,124 @@
+"""Builds build/variants/libgrappa_hip_tworow.so: the shipped library with ONE kernel changed -- LayerNorm forward takes two rows per
+wavefront and trip (rows <= 512 wide), the round-1 kernel that returned deviating rows when this library's GEMMs ran on other queues
+("Multi-queue deviation").  Test material for tools/stream_order_probe.py only; nothing ships from here.
+
+    python tools/ln_two_rows_variant.py [gemm knock-out name ...]     # also links one library per named GEMM knock-out (GB_KNOCK)
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+CSRC = os.path.join(ROOT, "grappa_amd", "csrc")
+OUT = os.path.join(ROOT, "build", "variants")
+HIPCC = ["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+
+MARK = "    // one row per wavefront and trip."
+TWO_ROWS = r'''
+    if constexpr (NCH <= 2) {
+        // two rows per trip: the second row's loads and shuffle reductions fill the latency of the first's
+        for (int row0 = wave_global; row0 < M; row0 += 2 * nwaves) {
+            const int row1 = row0 + nwaves;
+            const bool two = row1 < M;
+            const T* xr0 = x + (size_t)row0 * ldx;
+            const T* xr1 = x + (size_t)(two ? row1 : row0) * ldx;
+            float4 v0[NCH], v1[NCH];
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nvec) {
+                    v0[i] = ld4(xr0, c);
+                    v1[i] = ld4(xr1, c);
+                    s0 += (v0[i].x + v0[i].y) + (v0[i].z + v0[i].w);
+                    s1 += (v1[i].x + v1[i].y) + (v1[i].z + v1[i].w);
+                }
+            }
+            const float mean0 = wave_sum(s0) / (float)W, mean1 = wave_sum(s1) / (float)W;
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nvec) {
+                    const float a = v0[i].x - mean0, b = v0[i].y - mean0, cc = v0[i].z - mean0, d = v0[i].w - mean0;
+                    q0 += (a * a + b * b) + (cc * cc + d * d);
+                    const float e = v1[i].x - mean1, f = v1[i].y - mean1, g = v1[i].z - mean1, h = v1[i].w - mean1;
+                    q1 += (e * e + f * f) + (g * g + h * h);
+                }
+            }
+            const float rstd0 = 1.0f / sqrtf(wave_sum(q0) / (float)W + 1e-5f), rstd1 = 1.0f / sqrtf(wave_sum(q1) / (float)W + 1e-5f);
+            T* yr0 = y + (size_t)row0 * ldy;
+            T* yr1 = y + (size_t)(two ? row1 : row0) * ldy;
+            unsigned am0 = 0u, am1 = 0u;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nvec) {
+                    const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+                    const float4 b = reinterpret_cast<const float4*>(beta)[c];
+                    float4 o;
+                    o.x = (v0[i].x - mean0) * rstd0 * g.x + b.x;
+                    o.y = (v0[i].y - mean0) * rstd0 * g.y + b.y;
+                    o.z = (v0[i].z - mean0) * rstd0 * g.z + b.z;
+                    o.w = (v0[i].w - mean0) * rstd0 * g.w + b.w;
+                    st4(yr0, c, o);
+                    am0 = max(am0, mag4(o));
+                    if (two) {
+                        o.x = (v1[i].x - mean1) * rstd1 * g.x + b.x;
+                        o.y = (v1[i].y - mean1) * rstd1 * g.y + b.y;
+                        o.z = (v1[i].z - mean1) * rstd1 * g.z + b.z;
+                        o.w = (v1[i].w - mean1) * rstd1 * g.w + b.w;
+                        st4(yr1, c, o);
+                        am1 = max(am1, mag4(o));
+                    }
+                }
+            }
+            if (STORE_STATS && lane == 0) {
+                mean_out[row0] = mean0;
+                rstd_out[row0] = rstd0;
+                if (two) {
+                    mean_out[row1] = mean1;
+                    rstd_out[row1] = rstd1;
+                }
+            }
+            if (y_amax) {
+                const unsigned m0 = wave_umax(am0), m1 = wave_umax(am1);
+                if (lane == 0) {
+                    y_amax[row0] = m0;
+                    if (two) y_amax[row1] = m1;
+                }
+            }
+        }
+        return;
+    }
+'''
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    src = open(os.path.join(CSRC, "rowwise.hip")).read()
+    assert src.count(MARK) == 1, "rowwise.hip: the one-row loop's comment moved"
+    var = os.path.join(OUT, "rowwise_tworow.hip")
+    open(var, "w").write(src.replace(MARK, TWO_ROWS + MARK))
+    obj = os.path.join(OUT, "rowwise_tworow.o")
+    subprocess.run(HIPCC + ["-c", var, "-o", obj], check=True)
+    base = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".o") and f != "rowwise.o"]
+    so = os.path.join(OUT, "libgrappa_hip_tworow.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, obj, *base], check=True)
+    print(so)
+    knock = {"nomfma": 1, "nosplit": 2, "noglobal": 3, "nolds": 4, "nobarrier": 5, "noepi": 6, "nostore": 7, "nodescale": 8}
+    units = ("gemm_bf16x_h3", "gemm_bf16x_x6", "gemm_bf16x_x3")
+    for name in sys.argv[1:]:
+        objs = []
+        for u in units:
+            o = os.path.join(OUT, f"{u}_{name}.o")
+            subprocess.run(HIPCC + [f"-DGB_KNOCK={knock[name]}", "-c", os.path.join(CSRC, u + ".hip"), "-o", o], check=True)
+            objs.append(o)
+        rest = [b for b in base if os.path.basename(b)[:-2] not in units]
+        so = os.path.join(OUT, f"libgrappa_hip_tworow_{name}.so")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, obj, *objs, *rest], check=True)
+        print(so)
+
+
+if __name__ == "__main__":
+    main()
