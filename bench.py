@@ -403,9 +403,9 @@ def main():
         model.parameter_writer.head_streams = 1
         heads4 = {"value": job.global_batch * args.steps / d_h, "ms_per_step": 1e3 * d_h / args.steps,
                   "note": "GRAPPA_HEAD_STREAMS=4, opt-in and NOT the headline configuration: bond / angle / proper / improper writers on four HIP "
-                          "streams.  Bit-identical to one stream over a 5,000-step soak (tools/head_streams_soak.py) and in tests/test_gpu_e2e.py, "
-                          "but a since-removed kernel deviated under the same concurrency in round 1 for a reason never found "
-                          "(DESIGN.md section 6), so the default keeps compute on one queue"}
+                          "streams.  Bit-identical to one stream over a 5,000-step soak (tools/head_streams_soak.py) and in tests/test_gpu_e2e.py with the "
+                          "shipped kernels, but a correct test kernel still computes deviating rows beside this library's GEMMs on other queues "
+                          "(tools/stream_probe_round2.sh, DESIGN.md section 6), so the default keeps compute on one queue"}
         log(f"writer heads on 4 streams (opt-in): {heads4['ms_per_step']:.1f} ms/step")
 
     # N = 1: the other single-GPU configurations, timed right after the headline measurement: C3 in the headline arithmetic, C3 in the
