@@ -60,3 +60,28 @@ def test_product_has_no_cpu_fallback():
     code = ("import sys, grappa_amd, grappa_amd.ops, grappa_amd.datasets, grappa_amd.optim, grappa_amd.dist, grappa_amd.trainer, grappa_amd.pdb, "
             "grappa_amd.moldata, grappa_amd.dataloader; assert not any(m.startswith('oracle') for m in sys.modules)")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_device_code_has_no_packed_fp32_instructions():
+    """csrc/Makefile compiles the kernels without v_pk_{fma,mul,add}_f32 (2 % faster, and the instruction the
+    multi-queue deviation needs): every gfx950 code object inside the shared library is disassembled and searched"""
+    import re
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    data = open(_lib.LIB_PATH, "rb").read()
+    objects = packed = 0
+    for m in re.finditer(b"\x7fELF", data):
+        blob = data[m.start():]
+        if m.start() == 0 or blob[18:20] != b"\xe0\x00":          # e_machine 224 = EM_AMDGPU
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            out = subprocess.run([objdump, "-d", f.name], capture_output=True, text=True).stdout
+        objects += 1
+        packed += len(re.findall(r"v_pk_(?:fma|mul|add)_f32", out))
+    assert objects >= 10, objects
+    assert packed == 0, packed

@@ -94,6 +94,23 @@ TWO_ROWS = r'''
 '''
 
 
+DPP_SUM = r'''
+__device__ inline float wave_sum_dpp(float v) {
+#define GRAPPA_DPP_ADD(CTRL) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true))
+    GRAPPA_DPP_ADD(0xB1);       // quad_perm [1, 0, 3, 2]
+    GRAPPA_DPP_ADD(0x4E);       // quad_perm [2, 3, 0, 1]
+    GRAPPA_DPP_ADD(0x141);      // row_half_mirror
+    GRAPPA_DPP_ADD(0x140);      // row_mirror: every lane of a row of 16 holds the row's sum
+#undef GRAPPA_DPP_ADD
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+'''
+
+
 def without_maxima(two):
     """the same kernel without the row-maxima code (round 1's form: 58 registers; with it 62)"""
     import re
@@ -112,6 +129,30 @@ def main():
     if "--no-maxima" in sys.argv:
         sys.argv.remove("--no-maxima")
         two = without_maxima(two)
+    for opt, ins in (("--vmcnt-after-store", 'asm volatile("s_waitcnt vmcnt(0)" ::: "memory");'),
+                     ("--nops-after-store", 'asm volatile("s_nop 15\\n s_nop 15\\n s_nop 15\\n s_nop 15" ::: "memory");')):
+        if opt in sys.argv:
+            # between the first row's 16-byte store and the second row's arithmetic (which reuses the store's data registers)
+            sys.argv.remove(opt)
+            assert two.count("st4(yr0, c, o);") == 1
+            two = two.replace("st4(yr0, c, o);", "st4(yr0, c, o);\n                    " + ins)
+    if "--nops-after-load" in sys.argv:
+        # gamma / beta have arrived (vmcnt 0), then 16 idle cycles before the first instruction that reads them
+        sys.argv.remove("--nops-after-load")
+        kg = "                    const float4 g = reinterpret_cast<const float4*>(gamma)[c];\n"
+        kb = "                    const float4 b = reinterpret_cast<const float4*>(beta)[c];\n"
+        assert two.count(kg) == 1 and two.count(kb) == 1
+        two = two.replace(kg, kg.replace("const float4 g", "float4 g"))
+        two = two.replace(kb, kb.replace("const float4 b", "float4 b") +
+                          '                    asm volatile("s_waitcnt vmcnt(0)\\n s_nop 15" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), '
+                          '"+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w) :: "memory");\n')
+    if "--dpp-sums" in sys.argv:
+        # the two-row kernel's wave sums on the DPP data path + v_readlane instead of __shfl_xor (= ds_bpermute, the LDS crossbar)
+        sys.argv.remove("--dpp-sums")
+        two = two.replace("wave_sum(", "wave_sum_dpp(")
+        src = src.replace("template <int NCH, bool STORE_STATS, typename T>\n__global__ __launch_bounds__(256) void layernorm_fwd_kernel(", DPP_SUM +
+                          "template <int NCH, bool STORE_STATS, typename T>\n__global__ __launch_bounds__(256) void layernorm_fwd_kernel(", 1)
+        assert "wave_sum_dpp(float" in src
     open(var, "w").write(src.replace(MARK, two + MARK))
     obj = os.path.join(OUT, "rowwise_tworow.o")
     subprocess.run(HIPCC + ["-c", var, "-o", obj], check=True)

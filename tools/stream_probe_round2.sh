@@ -9,3 +9,5 @@ for k in nomfma nolds noepi noglobal nosplit; do
   [ -f $V/libgrappa_hip_tworow_$k.so ] && { echo "== two-row LayerNorm (constant input) beside GEMMs with $k, bf16x3"; PROBE_CONST_INPUT=1 run $V/libgrappa_hip_tworow_$k.so bf16x3; }
 done
 echo "== shipped library (one row per trip), bf16x3"; GRAPPA_GEMM_PRECISION=bf16x3 timeout -k 10 120 python tools/stream_order_probe.py 2>&1 | tail -1
+# the same two-row kernel with its wave sums on the DPP path + v_readlane instead of ds_bpermute (the LDS crossbar)
+[ -f $V/libgrappa_hip_tworow_dpp.so ] && for p in bf16x3 f32_f16x3; do echo "== two-row LayerNorm, DPP sums (no ds_bpermute), $p"; PROBE_CONST_INPUT=1 run $V/libgrappa_hip_tworow_dpp.so $p; done
