@@ -174,8 +174,9 @@ class RefGNN(nn.Module):
 
     def forward(self, g):
         d = g.nodes["n1"].data
-        x = torch.cat([d[f].float() if d[f].dim() >= 2 else d[f].unsqueeze(-1).float() for f in self.in_feat_name], dim=-1)
-        x = torch.cat([x, charge_encoding(d["partial_charge"]).float()], dim=-1)
+        dt = self.pre_dense[0].weight.dtype          # fp32; float64 when the model was .double()d (tests: the oracle as ground truth)
+        x = torch.cat([d[f].to(dt) if d[f].dim() >= 2 else d[f].unsqueeze(-1).to(dt) for f in self.in_feat_name], dim=-1)
+        x = torch.cat([x, charge_encoding(d["partial_charge"]).to(dt)], dim=-1)
         h = self.initial_dropout(self.pre_dense(x))
         src, dst = n1_edges(g)
         src, dst = src.long(), dst.long()

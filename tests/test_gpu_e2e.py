@@ -84,11 +84,19 @@ def test_production_config_against_reference_golden():
     assert checked > 150
 
 
-def _oracle_step(cfg, sd, g_cpu, loss_kwargs):
+def _oracle_step(cfg, sd, g_cpu, loss_kwargs, double=False):
+    """double: the oracle in float64 -- ground truth instead of a second fp32 evaluation (whose own rounding, which moves with the
+    host's thread count, is of the size of the tolerance for the torsion energies: sums of ~100 signed terms of small k)"""
     from oracle import cpu_ref
     model = cpu_ref.RefGrappaModel(**cfg)
     model.load_state_dict(sd)
     model.eval()
+    if double:
+        model = model.double()
+        for nt in g_cpu.ntypes:
+            for k, v in list(g_cpu.nodes[nt].data.items()):
+                if torch.is_tensor(v) and v.dtype == torch.float32:
+                    g_cpu.nodes[nt].data[k] = v.double()
     g = cpu_ref.RefEnergy()(model(g_cpu))
     loss = cpu_ref.RefMolwiseLoss(**loss_kwargs)(g)
     loss.backward()
@@ -110,7 +118,7 @@ def test_production_config_against_oracle_on_a_larger_batch():
     g = Energy()(model(g))
     loss = MolwiseLoss(**lk)(g)
     loss.backward()
-    ref_model, rg, rloss = _oracle_step(cfg, sd, build_batch_from_pool(ids, n_confs=8, seed=3), lk)
+    ref_model, rg, rloss = _oracle_step(cfg, sd, build_batch_from_pool(ids, n_confs=8, seed=3), lk, double=True)      # float64: ground truth
     out = {"h": rg.nodes["n1"].data["h"].detach().numpy(), "loss": rloss.detach().numpy().reshape(1),
            "energy": rg.nodes["g"].data["energy"].detach().numpy(), "gradient": rg.nodes["n1"].data["gradient"].detach().numpy()}
     for lvl in ["n2", "n3", "n4", "n4_improper"]:
