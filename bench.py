@@ -65,7 +65,7 @@ def kernel_source_hash() -> str:
     h = hashlib.sha256()
     d = os.path.join(ROOT, "grappa_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":       # the Makefile: compile flags are part of what was measured
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
