@@ -1,6 +1,7 @@
 """Builds build/variants/libgrappa_hip_tworow.so: the shipped library with ONE kernel changed -- LayerNorm forward takes two rows per
 wavefront and trip (rows <= 512 wide), the round-1 kernel that returned deviating rows when this library's GEMMs ran on other queues
-("Multi-queue deviation").  Test material for tools/stream_order_probe.py only; nothing ships from here.
+("Multi-queue deviation").  Test material for tools/stream_order_probe.py only; nothing ships from here.  The
+variant is compiled with the compiler's default feature set -- packed fp32 instructions ON, unlike csrc/Makefile: they are what deviates.
 
     python tools/ln_two_rows_variant.py [gemm knock-out name ...]     # also links one library per named GEMM knock-out (GB_KNOCK)
 """
