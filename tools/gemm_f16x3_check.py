@@ -140,7 +140,9 @@ def build_variants():
         built = []
         for unit in mode_units:
             o = os.path.join(outdir, f"{unit}_{name}.o")
-            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-DGB_KNOCK={k}", "-c",
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950",
+                            "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",          # as csrc/Makefile
+                            f"-DGB_KNOCK={k}", "-c",
                             os.path.join(csrc, unit + ".hip"), "-o", o], check=True)
             built.append(o)
         subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, *built, *objs], check=True)

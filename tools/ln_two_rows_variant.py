@@ -167,7 +167,8 @@ def main():
         objs = []
         for u in units:
             o = os.path.join(OUT, f"{u}_{name}.o")
-            subprocess.run(HIPCC + [f"-DGB_KNOCK={knock[name]}", "-c", os.path.join(CSRC, u + ".hip"), "-o", o], check=True)
+            subprocess.run(HIPCC + ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",      # the GEMM neighbours: compiled as csrc/Makefile does
+                                    f"-DGB_KNOCK={knock[name]}", "-c", os.path.join(CSRC, u + ".hip"), "-o", o], check=True)
             objs.append(o)
         rest = [b for b in base if os.path.basename(b)[:-2] not in units]
         so = os.path.join(OUT, f"libgrappa_hip_tworow_{name}.so")
