@@ -21,6 +21,7 @@ using namespace grappa_gemm;
 
 int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool vec_kcontig);   // gemm_bf16x.hip
 int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision);                      // gemm_planes.hip
+int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p);                                      // gemm_pairs.hip
 int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* part, unsigned* out);   // amax.hip
 int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision, bool vec);   // gemm_bf16x.hip
 
@@ -649,6 +650,9 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
         if (np != 0 && np != 1 && np != 3) return GRAPPA_ERR_ARG;
     if (d->a_planes && !d->b_planes) return GRAPPA_ERR_ARG;
     const bool planes = d->b_planes != 0;
+    // pair format (fp16 hi / lo planes + the row maxima that define the power-of-two scale of every row): both operands, K-contiguous
+    const bool pairs = planes && d->precision == GRAPPA_GEMM_F32_F16X3;
+    if (pairs && (!d->a_planes || !d->a_kcontig || !d->b_kcontig || !d->a_amax || !d->b_amax || d->amax_bcast || d->a_colsum)) return GRAPPA_ERR_ARG;
     if (planes) {
         auto ok = [](const void* q, int ld, int cols) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 7) == 0 && ld >= cols; };
         const int kpad = (d->K + 31) / 32 * 32;
@@ -686,7 +690,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_F32_F16X3) return GRAPPA_ERR_ARG;
     const bool bf16x = planes || use_bf16x(d->M, d->N, d->precision);
     // fp16 pieces need the row maxima of both operands (fp32 operands only: the plane format is a bf16 split)
-    if (d->precision == GRAPPA_GEMM_F32_F16X3 && bf16x && (planes || !d->a_amax || !d->b_amax)) return GRAPPA_ERR_ARG;
+    if (d->precision == GRAPPA_GEMM_F32_F16X3 && bf16x && (!d->a_amax || !d->b_amax)) return GRAPPA_ERR_ARG;
     // the native fp32 kernel (precision F32_MFMA, or M / N <= 32) keeps its register-lean fp32-only epilogue walk
     if (!bf16x && (d->Cp || d->C1p || d->resp || d->auxp || !d->C)) return GRAPPA_ERR_ARG;
     Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes);
@@ -717,7 +721,8 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             }
         }
         int rc;
-        if (planes) rc = grappa_launch_gemm_planes(st, p, d->precision);
+        if (pairs) rc = grappa_launch_gemm_pairs(st, p);
+        else if (planes) rc = grappa_launch_gemm_planes(st, p, d->precision);
         else if (bf16x) rc = grappa_launch_gemm_bf16x(st, p, d->precision, vec);
         else if (d->a_kcontig && d->b_kcontig) rc = dispatch<true, true>(st, p, pl.cfg, vec);
         else if (d->a_kcontig) rc = dispatch<true, false>(st, p, pl.cfg, vec);
