@@ -71,15 +71,16 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def cpu_baseline_child(workload: str, n_mols: int, steps: int, warmup: int, threads: int):
-    """the oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same workload; runs in
-    a child process of its own (`bench.py --cpu-baseline-child ...`) that never touches the GPU"""
+def cpu_baseline_child(workload: str, n_mols: int, steps: int, warmup: int, sweep: str, limit_s: float):
+    """the oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same workload; runs in a child
+    process of its own (`bench.py --cpu-baseline-child ...`) that never touches the GPU.  BASELINE.md section 2: a thread sweep (one warm-up +
+    2 steps on a quarter of the sample per setting) picks the thread count, then `warmup` + `steps` timed steps on the whole sample."""
     from grappa_amd import get_default_model_config
     from grappa_amd.datasets import build_batch_from_pool, workload_molecule_ids
     from oracle import cpu_ref
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_utils as gu
-    torch.set_num_threads(threads)
+    t_begin = time.time()
     ids = workload_molecule_ids(workload, seed=0)[:n_mols]
     model = cpu_ref.RefGrappaModel(**get_default_model_config())
     model.load_state_dict(gu.keyed_state_dict(model))
@@ -87,58 +88,69 @@ def cpu_baseline_child(workload: str, n_mols: int, steps: int, warmup: int, thre
     opt = torch.optim.Adam(model.parameters(), lr=1.5e-5)
     loss_fn = cpu_ref.RefMolwiseLoss(**LOSS_KW)
     energy = cpu_ref.RefEnergy()
-    times = []
-    for it in range(steps + warmup):
-        g = build_batch_from_pool(ids, n_confs=32, seed=0)
-        t0 = time.perf_counter()
-        opt.zero_grad()
-        loss = loss_fn(energy(model(g)))
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
-        opt.step()
-        if it >= warmup:
-            times.append(time.perf_counter() - t0)
-    t = sorted(times)[len(times) // 2]
-    print(json.dumps({"value": n_mols / t, "threads": int(torch.get_num_threads()), "median_step_s": t, "steps": steps, "warmup": warmup}), flush=True)
+
+    def run(mol_ids, n_steps, n_warm, deadline):
+        times = []
+        for it in range(n_steps + n_warm):
+            g = build_batch_from_pool(mol_ids, n_confs=32, seed=0)
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            loss = loss_fn(energy(model(g)))
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+            opt.step()
+            if it >= n_warm:
+                times.append(time.perf_counter() - t0)
+            if time.time() > deadline and times:
+                break
+        return sorted(times)[len(times) // 2] if times else None, len(times)
+
+    settings = [int(x) for x in sweep.split(",") if x]
+    tried = []
+    probe = ids[:max(n_mols // 4, 8)]
+    for th in settings:
+        if time.time() - t_begin > 0.45 * limit_s and tried:
+            tried.append({"threads": th, "value": None, "note": "skipped: time limit"})
+            continue
+        torch.set_num_threads(th)
+        t, _ = run(probe, 2, 1, t_begin + 0.55 * limit_s)
+        tried.append({"threads": th, "value": len(probe) / t if t else None, "molecules": len(probe)})
+    ok = [r for r in tried if r.get("value")]
+    best = max(ok, key=lambda r: r["value"])["threads"] if ok else settings[0]
+    torch.set_num_threads(best)
+    t, n_timed = run(ids, steps, warmup, t_begin + limit_s)
+    print(json.dumps({"value": n_mols / t if t else None, "threads": int(torch.get_num_threads()), "median_step_s": t, "steps": n_timed,
+                      "warmup": warmup, "sweep": tried}), flush=True)
 
 
 def cpu_baseline(workload: str, n_mols: int, steps: int, warmup: int, limit_s: float):
-    """the bounded CPU sample in child processes (started before this process touches the GPU): once on 16 threads, once on every
-    core the box reports; the faster one is the baseline (all cores, core count and CPU model recorded)"""
+    """BASELINE.md section 2 on a bounded sample, in ONE child process started before this process touches the GPU: thread sweep over
+    {16, 32, 64, 128} (capped by the host), the best setting timed for `steps` steps after `warmup` on `n_mols` molecules of the workload;
+    `cores` = the threads the reported figure ran on"""
     import subprocess
     ncpu = os.cpu_count() or 1
-    settings = sorted({min(16, ncpu), ncpu})
-    tried, best = [], None
-    t_start = time.time()
-    for threads in settings:
-        left = limit_s - (time.time() - t_start)
-        if threads != settings[0]:
-            left = min(left, 45.0)          # the all-cores attempt only oversubscribes the oracle's small per-op work: bounded
-        if left < 10:
-            tried.append({"threads": threads, "value": None, "note": "skipped: time limit"})
-            continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", workload, str(n_mols), str(steps), str(warmup), str(threads)]
-        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
-        try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=left, env=env)
-            rec = None
-            for line in reversed(out.stdout.splitlines()):
-                if line.startswith("{"):
-                    rec = json.loads(line)
-                    break
-            if rec is None:
-                rec = {"threads": threads, "value": None, "note": f"child failed: {out.stderr[-200:]}"}
-        except subprocess.TimeoutExpired:
-            rec = {"threads": threads, "value": None, "note": f"did not finish within {left:.0f} s"}
-        tried.append(rec)
-        if rec.get("value") and (best is None or rec["value"] > best["value"]):
-            best = rec
-    sample = (f"{n_mols} molecules of {workload} x 32 conformations, production model fp32, full train step (forward, energy+force loss, "
-              f"backward, clip, Adam), median of {steps} steps after {warmup} warm-up (oracle/cpu_ref.py, torch {torch.__version__} CPU); "
-              f"thread settings tried: " + ", ".join(f"{r.get('threads')} -> {r['value']:.1f} mol/s" if r.get("value") else f"{r.get('threads')} -> {r.get('note')}" for r in tried))
-    # `cores` = the threads the reported figure actually ran on (the faster of the settings tried); the host's core count beside it
-    return {"value": best["value"] if best else None, "unit": "molecules/s", "cores": best["threads"] if best else None, "host_cores": ncpu,
-            "threads_used": best["threads"] if best else None, "cpu_model": cpu_model_name(), "kind": "port", "sample": sample}
+    settings = sorted({min(t, ncpu) for t in (16, 32, 64, 128)})
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", workload, str(n_mols), str(steps), str(warmup),
+           ",".join(map(str, settings)), str(limit_s)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(max(settings)))
+    rec = None
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s + 90, env=env)
+        for line in reversed(out.stdout.splitlines()):
+            if line.startswith("{"):
+                rec = json.loads(line)
+                break
+        if rec is None:
+            rec = {"value": None, "note": f"child failed: {out.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        rec = {"value": None, "note": f"did not finish within {limit_s + 90:.0f} s"}
+    sweep = ", ".join(f"{r['threads']} -> {r['value']:.1f} mol/s" if r.get("value") else f"{r['threads']} -> {r.get('note')}" for r in rec.get("sweep", []))
+    sample = (f"{n_mols} molecules of {workload} x 32 conformations in one batch, production model fp32, full train step (forward, energy+force "
+              f"loss, backward, clip, Adam), median of {rec.get('steps')} timed steps after {warmup} warm-up on {rec.get('threads')} threads "
+              f"(oracle/cpu_ref.py, torch {torch.__version__} CPU); thread sweep on {max(n_mols // 4, 8)} molecules (1 warm-up + 2 steps each): {sweep}"
+              + (f"; {rec['note']}" if rec.get("note") else ""))
+    return {"value": rec.get("value"), "unit": "molecules/s", "cores": rec.get("threads"), "host_cores": ncpu, "threads_used": rec.get("threads"),
+            "cpu_model": cpu_model_name(), "kind": "port", "sample": sample, "median_step_s": rec.get("median_step_s")}
 
 
 def log(*a):
@@ -147,7 +159,7 @@ def log(*a):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
-        cpu_baseline_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
+        cpu_baseline_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], float(sys.argv[7]))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,11 +177,28 @@ def main():
                     "BASELINE configs[2] runs; the line's dtype then reads bf16 -- never the default)")
     ap.add_argument("--alt-precision", default="f32,f32_bf16x6", help="also time K steps with these GEMM arithmetics (comma separated; reported beside the default); '' to skip")
     ap.add_argument("--bwd-precision", default="", help="also time K steps with the backward-pass products in this arithmetic (reported beside the default, never as `value`); '' to skip")
-    ap.add_argument("--cpu-sample", type=int, default=32, help="molecules in the CPU baseline sample")
-    ap.add_argument("--cpu-limit", type=float, default=150.0, help="wall-clock limit of the CPU baseline children, seconds")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="molecules in the CPU baseline sample")
+    ap.add_argument("--cpu-limit", type=float, default=150.0, help="wall-clock limit of the CPU baseline child's timed work, seconds")
+    ap.add_argument("--no-scaling-reference", action="store_true", help="N > 1, strong scaling: skip rank 0's single-GPU run of the whole global batch")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (functional test of the N>1 path on one GPU)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu: TEST ONLY (tests/test_bench_launch.py) -- the host logic of the "
+                    "N-rank path on a machine without a GPU; the caller must have installed a test backend (the product has none for the CPU), "
+                    "no kernel timing, never a measurement")
+    ap.add_argument("--tiny-model", action="store_true", help="TEST ONLY: a 60 k-parameter model instead of the production one (with --device cpu)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: this process has not touched the GPU; it starts the N ranks (one process per GPU) as children and
+        # relays their output (rank 0 prints the JSON line) and exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("launching", " ".join(cmd))
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,17 +206,24 @@ def main():
     workload = args.workload or ("C4-espaloma-b4096" if strong else "C2-pubchem-b256")
     # CPU baseline first, in child processes, before this process initialises the GPU (rank 0 at N = 1 only)
     cpu_base = None
-    if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+    if world == 1 and args.gpus == 1 and not args.no_cpu_baseline and args.device == "cuda":
         log(f"cpu baseline (oracle, {args.cpu_sample} molecules, limit {args.cpu_limit:.0f} s) ...")
-        cpu_base = cpu_baseline(workload, args.cpu_sample, 3, 2, args.cpu_limit)
+        cpu_base = cpu_baseline(workload, args.cpu_sample, 5, 2, args.cpu_limit)
         log(f"cpu baseline: {cpu_base}")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    on_gpu = args.device == "cuda"
+    if not on_gpu and not args.tiny_model:
+        raise SystemExit("--device cpu is a host-logic test mode: it needs --tiny-model")
     if args.dist_backend == "gloo":          # test mode: all ranks share the visible device(s)
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.dist_backend)
@@ -205,7 +241,12 @@ def main():
         be.set_gemm_precision("bf16")
     if args.gemm_precision:
         be.set_gemm_precision(args.gemm_precision)
-    model = model_from_config(get_default_model_config())
+    model_cfg = get_default_model_config()
+    if args.tiny_model:
+        model_cfg.update(graph_node_features=16, gnn_width=32, gnn_attentional_layers=1, gnn_attention_heads=2,
+                         **{f"{h}_{k}": v for h in ("bond", "angle", "proper", "improper")
+                            for k, v in (("transformer_depth", 1), ("n_heads", 2), ("transformer_width", 32), ("symmetriser_depth", 2), ("symmetriser_width", 16))})
+    model = model_from_config(model_cfg)
     keyed_init(model)
     model = model.to(dev).train()
     flat = FlatParams(model)
@@ -227,6 +268,7 @@ def main():
             self.atoms = sum(g.plan().N for g in self.graphs)
             self.tuples = {k: sum(int(g.plan().T[k]) for g in self.graphs) for k in self.graphs[0].plan().T}
             self.allreduce_events = None
+            self.solo = False          # True: this rank alone (the single-GPU reference of the strong-scaling curve): no collective
 
         def step(self):
             opt.zero_grad()
@@ -236,12 +278,18 @@ def main():
                         g.nodes[lvl].data.pop(k, None)
                 loss = self.loss_fn(energy(model(g)))
                 loss.backward()
-            if self.allreduce_events is not None:
+            if self.solo:
+                reducer._flush_queued_wgrads()
+            elif self.allreduce_events is not None and on_gpu:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 reducer.finish()
                 e1.record()
                 self.allreduce_events.append((e0, e1))
+            elif self.allreduce_events is not None:
+                t_ar = time.perf_counter()
+                reducer.finish()
+                self.allreduce_events.append(1e3 * (time.perf_counter() - t_ar))
             else:
                 reducer.finish()       # all-reduce of the flat gradient buffer (both buckets here unless the overlap is switched on)
             opt.step()
@@ -249,29 +297,31 @@ def main():
 
         def timed(self, steps, warmup):
             """-> (seconds for `steps` steps as the MAX over ranks, last loss)"""
+            multi = world > 1 and not self.solo
             for _ in range(warmup):
                 loss = self.step()
-            torch.cuda.synchronize()
-            if world > 1:
+            sync()
+            if multi:
                 dist.barrier()
-            torch.cuda.synchronize()
+            sync()
             t0 = time.perf_counter()
             for _ in range(steps):
                 loss = self.step()
-            torch.cuda.synchronize()
-            if world > 1:
+            sync()
+            if multi:
                 dist.barrier()
-            torch.cuda.synchronize()
+            sync()
             dt = time.perf_counter() - t0
-            if world > 1:
+            if multi:
                 t = torch.tensor([dt], device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t)
             return dt, float(loss.detach())
 
         def describe(self):
-            return {"workload": f"{self.name}: {WORKLOAD_DESCRIPTIONS[self.name]}, {WORKLOADS[self.name][3]} conformations, production "
-                                f"GrappaModel 40.8M params (keyed init), train mode (dropout on), Adam + clip 10"
+            mdl = "TINY TEST MODEL (not a measurement)" if args.tiny_model else "production GrappaModel 40.8M params"
+            return {"workload": f"{self.name}: {WORKLOAD_DESCRIPTIONS[self.name]}, {WORKLOADS[self.name][3]} conformations, {mdl} "
+                                f"(keyed init), train mode (dropout on), Adam + clip 10"
                                 + (f"; this rank: {self.n_local} molecules in {len(self.graphs)} chunks of <= {args.chunk}, gradients accumulated, one optimiser step"
                                    if len(self.graphs) > 1 else ""),
                     "global_batch": self.global_batch, "molecules_rank0": self.n_local, "conformations": WORKLOADS[self.name][3],
@@ -295,9 +345,9 @@ def main():
 
     GEMM_PEAK_NOTE = ("achieved = algorithmic 2MNK FLOPs / HIP-event time of the calls; peak = bf16 dense MFMA peak (16 x 157.3 TFLOP/s, "
                       "MI355X_MICROARCH.md; the fp16 one is the same) / partial products issued per fp32 product; the time of the operands' "
-                      "maxima passes (f32_f16x3) is charged to the products; algorithmic FLOPs = SURVEY 8(d)'s per-token count (`tflop_per_step`); the first "
-                      "layer of the proper and angle writers runs its LayerNorm + QKV product on (atom, position) rows, so ~5 % of them are never "
-                      "launched (`tflop_per_step_launched`, `achieved_launched_flops_only` = the rate over the launched FLOPs alone)")
+                      "maxima passes (f32_f16x3) is charged to the products; `achieved` counts the products LAUNCHED (`tflop_per_step_launched`); SURVEY "
+                      "8(d)'s per-token count (`tflop_per_step`) is ~5 % larger because the first layer of the proper and angle writers runs its "
+                      "LayerNorm + QKV product on (atom, position) rows (`achieved_with_algorithmic_credit` = that count over the same time)")
 
     def instrument(j, steps):
         """instrumented repetition of a job's steps: HIP events around every GEMM / GAT launch on the launch stream (one stream:
@@ -306,15 +356,16 @@ def main():
         hs = model.parameter_writer.head_streams
         model.parameter_writer.head_streams = 1
         j.step()
-        torch.cuda.synchronize()
+        sync()
         j.allreduce_events = []
-        be.start_profile()
+        if on_gpu:
+            be.start_profile()
         t1 = time.perf_counter()
         for _ in range(steps):
             j.step()
-        prof = be.stop_profile()
+        prof = be.stop_profile() if on_gpu else {}
         dtp = time.perf_counter() - t1
-        ar_ms = sum(a.elapsed_time(b) for a, b in j.allreduce_events) / max(len(j.allreduce_events), 1)
+        ar_ms = sum((ev[0].elapsed_time(ev[1]) if on_gpu else ev) for ev in j.allreduce_events) / max(len(j.allreduce_events), 1)
         j.allreduce_events = None
         model.parameter_writer.head_streams = hs
         n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
@@ -327,8 +378,11 @@ def main():
         # formulation of the first writer layer did not have to launch (ops.ProjFirstLayerFn); both rates are reported
         fl_launched = fl
         fl += prof.get("gemm_saved", (0, 0.0, 0.0, 0.0))[2]
-        achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
-        kname, nprod = GEMM_KERNELS[be.gemm_precision_name]
+        # `achieved` / `frac`: the FLOPs of the products actually launched over their time; the rate with the un-launched
+        # first-layer products credited (SURVEY 8(d)'s per-token count) is the secondary field
+        achieved = (fl_launched / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        achieved_credit = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        kname, nprod = GEMM_KERNELS[getattr(be, "gemm_precision_name", "f32")]
         if ops.act_dtype() is not None:
             kname = "gemm_planes_kernel<1,*> (bf16 operands by LDS-DMA, v_mfma_f32_32x32x16_bf16, fp32 accumulate) + gemm_bf16x_kernel<1,*> for the fp32-operand products"
         # `achieved` counts the ALGORITHMIC FLOPs (2MNK); the split kernels issue `nprod` bf16 MFMAs per fp32 product, so the
@@ -336,15 +390,15 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if nprod == 0 else PEAK_BF16_MFMA_TFLOPS / nprod
         roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "frac_of_native_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of_bf16x6_ceiling": achieved / (PEAK_BF16_MFMA_TFLOPS / 6),
-                "gemm_precision": be.gemm_precision_name,
+                "gemm_precision": getattr(be, "gemm_precision_name", None),
                 "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": by / max(n, 1),
                 "launches_per_step": n / steps, "avg_launch_us": 1e3 * ms / max(n, 1), "gflop_per_launch": fl / max(n, 1) / 1e9,
                 "kernel_ms_per_step": ms / steps, "tflop_per_step": fl / steps / 1e12, "tflop_per_step_launched": fl_launched / steps / 1e12,
-                "achieved_launched_flops_only": (fl_launched / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0, "note": GEMM_PEAK_NOTE}
+                "achieved_with_algorithmic_credit": achieved_credit, "frac_with_algorithmic_credit": achieved_credit / peak, "note": GEMM_PEAK_NOTE}
         if n_amax:
             roof.update({"maxima_pass_ms_per_step": ms_amax / steps, "maxima_pass_launches_per_step": n_amax / steps,
                          "products_only_ms_per_step": ms_products / steps,
-                         "products_only_tflops": (fl / (ms_products * 1e-3)) / 1e12 if ms_products > 0 else 0.0})
+                         "products_only_tflops": (fl_launched / (ms_products * 1e-3)) / 1e12 if ms_products > 0 else 0.0})
         gat = {}
         for fam in ("gat_fwd", "gat_bwd"):
             n_, ms_, fl_, by_ = prof.get(fam, (0, 0.0, 0.0, 0.0))
@@ -365,7 +419,7 @@ def main():
 
     # the same K steps with the dense products on the native fp32 matrix instruction, for reference next to the default
     alt = {}
-    for name in [a for a in args.alt_precision.split(",") if a and a != be.gemm_precision_name]:
+    for name in [a for a in args.alt_precision.split(",") if on_gpu and a and a != be.gemm_precision_name]:
         default_precision = be.gemm_precision_name
         alt[name] = alt_run(lambda: be.set_gemm_precision(name), lambda: be.set_gemm_precision(default_precision))
         alt[name]["gemm_precision"] = name
@@ -380,7 +434,7 @@ def main():
 
     # opt-in kernel (GRAPPA_WEIGHT_PLANES): the same steps with the weights read from their pre-split bf16 planes by LDS-DMA
     wpl = None
-    if world == 1 and not args.no_extras and not be.weight_planes and args.act_dtype == "f32":
+    if on_gpu and world == 1 and not args.no_extras and not be.weight_planes and args.act_dtype == "f32":
         default_precision = be.gemm_precision_name
         be.set_gemm_precision("f32_bf16x6")            # the plane format is a bf16 split: it rides on the bf16x6 arithmetic
         be.weight_planes = True
@@ -394,7 +448,7 @@ def main():
 
     # opt-in configuration (never `value`): the four writer heads on four HIP streams
     heads4 = None
-    if world == 1 and args.head_streams_extra and args.act_dtype == "f32" and model.parameter_writer.head_streams == 1:
+    if on_gpu and world == 1 and args.head_streams_extra and args.act_dtype == "f32" and model.parameter_writer.head_streams == 1:
         import warnings
         model.parameter_writer.head_streams = 4
         with warnings.catch_warnings():
@@ -411,18 +465,18 @@ def main():
     # N = 1: the other single-GPU configurations, timed right after the headline measurement: C3 in the headline arithmetic, C3 in the
     # bf16 STORAGE configuration BASELINE configs[2] names (never `value`), and the 4096-molecule batch of C4 on one GPU
     extras = {}
-    if world == 1 and not args.no_extras and not strong and workload == "C2-pubchem-b256" and args.act_dtype == "f32":
+    if on_gpu and world == 1 and not args.no_extras and not strong and workload == "C2-pubchem-b256" and args.act_dtype == "f32":
         headline_graphs = job.graphs
         default_precision = be.gemm_precision_name
-        for key, name, steps, bf16 in (("c3", "C3-espaloma-b1024", 3, False), ("c3_bf16", "C3-espaloma-b1024", 3, True),
-                                       ("c4_strong_n1", "C4-espaloma-b4096", 2, False)):
+        for key, name, steps, bf16 in (("c3", "C3-espaloma-b1024", 5, False), ("c3_bf16", "C3-espaloma-b1024", 5, True),
+                                       ("c4_strong_n1", "C4-espaloma-b4096", 5, False)):
             try:
                 if bf16:
                     ops.set_activation_dtype("bf16")
                     be.set_gemm_precision("bf16")
                 j2 = Job(name, WORKLOADS[name][0], workload_molecule_ids(name, seed=0), seed=0)
-                d2, l2 = j2.timed(steps, 1)
-                extras[key] = {"value": j2.global_batch * steps / d2, "unit": "molecules/s", "ms_per_step": 1e3 * d2 / steps, "steps": steps, "warmup": 1,
+                d2, l2 = j2.timed(steps, 2)
+                extras[key] = {"value": j2.global_batch * steps / d2, "unit": "molecules/s", "ms_per_step": 1e3 * d2 / steps, "steps": steps, "warmup": 2,
                                "scaling": "strong" if key.startswith("c4") else None, "n_gpus": 1, "gemm_precision": be.gemm_precision_name,
                                "activation_storage": "bf16" if bf16 else "f32", "final_loss": l2, "config": j2.describe()}
                 if key != "c4_strong_n1":
@@ -442,6 +496,29 @@ def main():
                 be.set_gemm_precision(default_precision)
                 torch.cuda.empty_cache()
         job.graphs = headline_graphs
+
+    # N > 1, strong scaling: the same-workload N = 1 point.  Rank 0 alone runs the WHOLE global batch (chunks of --chunk molecules, gradients
+    # accumulated, one optimiser step, no collective) while the other ranks wait at the barrier that follows; last, so that nothing
+    # measured above sees rank 0's parameters drift from the others'
+    scaling_ref = None
+    if world > 1 and strong and not args.no_scaling_reference:
+        if rank == 0:
+            try:
+                total = job.global_batch
+                _, lo_, hi_, _ = WORKLOADS[job.name]
+                all_ids = workload_molecule_ids(job.name, seed=0) if total == WORKLOADS[job.name][0] else select_molecules(total, seed=0, min_atoms=lo_, max_atoms=hi_)
+                jr = Job(job.name, total, all_ids, seed=0)
+                jr.solo = True
+                ref_steps = 3 if total > 2048 else 5
+                d_r, _ = jr.timed(ref_steps, 1)
+                scaling_ref = {"value": total * ref_steps / d_r, "unit": "molecules/s", "ms_per_step": 1e3 * d_r / ref_steps, "steps": ref_steps, "warmup": 1,
+                               "n_gpus": 1, "config": jr.describe(),
+                               "note": "the same global batch on rank 0's GPU alone, measured in this run right after the N-rank measurement"}
+                log(f"single-GPU reference of the same global batch: {scaling_ref['ms_per_step']:.1f} ms/step = {scaling_ref['value']:.0f} molecules/s")
+                del jr
+            except Exception as e:  # noqa: BLE001
+                scaling_ref = {"value": None, "error": repr(e)[:300]}
+        dist.barrier()
 
     if rank == 0:
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process; the committed
@@ -471,7 +548,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16" if args.act_dtype == "bf16" else "f32", "data": "synthetic",
             "config": cfg,
-            "gemm_arithmetic": {"default": be.gemm_precision_name,
+            "gemm_arithmetic": {"default": getattr(be, "gemm_precision_name", None),
                                 "note": "inputs, outputs, accumulation and every non-GEMM kernel are fp32; f32_f16x3 scales every row of an "
                                         "fp32 operand by a power of two (largest magnitude -> [2^14, 2^15)), splits it into 2 fp16 pieces "
                                         "(24 significant bits) and sums the 3 largest partial products on the fp16 matrix cores; f32_bf16x6 "
@@ -483,6 +560,9 @@ def main():
             "writer_heads_on_4_streams": heads4,
         }
         out.update(extras)
+        if scaling_ref is not None:
+            out["strong_scaling_reference"] = scaling_ref
+            out["scaling_factor"] = (out["value"] / scaling_ref["value"]) if scaling_ref.get("value") else None
         out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if world > 1:

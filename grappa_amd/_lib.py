@@ -68,7 +68,7 @@ SIGNATURES = {
     "grappa_abi_version": (_i, []),
     "grappa_build_arch": (C.c_char_p, []),
     "grappa_split_planes_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _sz, _i]),
-    "grappa_split_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _sz, _i]),
+    "grappa_split_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i]),
     "grappa_amax_f32_workspace_bytes": (_sz, [_i, _i]),
     "grappa_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz]),
     "grappa_amax_f32_batched": (_i, [_vp, _i, _vp]),

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -125,7 +126,7 @@ class HipBackend:
         self._wq = []                  # (dz, x, dW, db) kept alive until the flush
         self.defer_ln = os.environ.get("GRAPPA_DEFER_LN_REDUCTIONS", "1") not in ("0", "")      # tuning: 0 = reduce every LayerNorm's parameter gradients at once
         self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta)
-        self._wq_callback = False
+        self._wq_task = None           # autograd graph task id of the backward pass the queues belong to
         self.weight_planes = os.environ.get("GRAPPA_WEIGHT_PLANES", "0") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
         self._wepoch = 0
@@ -156,6 +157,13 @@ class HipBackend:
         """the parameters were changed behind torch's back (fused Adam writes the flat buffer through the C ABI)"""
         self._wepoch += 1
 
+    def invalidate_weights(self) -> None:
+        """PUBLIC: call after writing parameters through anything torch's version counters do not see -- the flat buffer
+        (`FlatParams.data[...]`, a broadcast or an EMA into it), `p.data.*`, a raw-pointer writer.  Everything cached per weight (row /
+        column maxima = the scales of the fp16-split products, bf16 planes, fp16 pairs) is rebuilt at its next use.  In-place torch ops on
+        the parameter itself (`p.copy_`, `load_state_dict`) and `FusedAdam.step` need no call."""
+        self._wepoch += 1
+
     def _planes_of_weight(self, w: torch.Tensor, transposed: bool) -> torch.Tensor:
         """bf16 planes (3, rows_pad, cols_pad) of W (rows x cols) or of W^T; zero padded to multiples of 32, cached per weight and
         refreshed when the weight changed (torch's version counter for in-place torch ops, the epoch for the fused Adam)"""
@@ -163,6 +171,10 @@ class HipBackend:
         key = (w.data_ptr(), R, Cc, transposed)
         ver = (w._version, self._wepoch)
         hit = self._wplanes.get(key)
+        # an entry belongs to ONE tensor object (weak reference): a weight freed and another allocated at the same address with the same
+        # shape and version count must not be served the old one's planes (two models loaded one after the other, no optimiser step between)
+        if hit is not None and hit[2]() is not w:
+            hit = None
         if hit is not None and hit[0] == ver:
             return hit[1]
         rows, cols = (Cc, R) if transposed else (R, Cc)
@@ -170,9 +182,11 @@ class HipBackend:
             planes = hit[1]
         else:
             planes = torch.zeros((3, (rows + 31) // 32 * 32, (cols + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
+            for k in [k for k, e in self._wplanes.items() if e[2]() is None]:      # entries of weights that no longer exist
+                del self._wplanes[k]
         _chk(self.lib.grappa_split_planes_f32(self._stream(), R, Cc, w.data_ptr(), _f32_2d(w, "W", w.device), planes.data_ptr(), planes.stride(1),
                                               planes.stride(0), int(transposed)), "grappa_split_planes_f32")
-        self._wplanes[key] = (ver, planes)
+        self._wplanes[key] = (ver, planes, weakref.ref(w))
         return planes
 
     # ------------------------------------------------------------------ row / column maxima (scales of the fp16-split products)
@@ -500,7 +514,7 @@ class HipBackend:
                 am, bm = sa.tmax, self.amax(b, b_scales, tmax=True).tmax
                 d.amax_bcast = 3
             d.a_amax, d.b_amax = am.data_ptr(), bm.data_ptr()
-        if out_amax and final.dtype == torch.float32:
+        if out_amax is True and final.dtype == torch.float32:          # (out_amax == "pair": the caller only wants the pair returned)
             so = Amax(row=torch.empty(M, dtype=torch.int32, device=dev))
             d.out_amax = so.row.data_ptr()
         need = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
@@ -540,8 +554,9 @@ class HipBackend:
             else:
                 sdz = self.amax(dz, dz_scales, rows=True)
                 am = (sdz, self.amax(x, x_scales, rows=True))
+        in_pass = self._queue_flush()             # (first: a new pass discards what an aborted one left in the queue)
         self._wq.append((dz, x, dw, db, am))
-        if not self._queue_flush():               # not inside a backward pass: nothing will call back
+        if not in_pass:                           # not inside a backward pass: nothing will call back
             self.flush_wgrads()
             return sdz
         if len(self._wq) >= _lib.GEMM_GROUP_MAX:
@@ -549,18 +564,29 @@ class HipBackend:
         return sdz
 
     def _queue_flush(self) -> bool:
-        """ask autograd to call flush_wgrads when the running backward pass ends; False outside a backward pass"""
-        if not self._wq_callback:
+        """ask autograd to call flush_wgrads when the running backward pass ends; False outside a backward pass.  The queues belong to ONE
+        pass (autograd's graph task id): if the pass that filled them died (an exception inside backward drops autograd's end-of-pass
+        callbacks), what it left behind is discarded -- its gradient buffer was abandoned with it -- and this pass registers its own
+        callback."""
+        task = torch._C._current_graph_task_id()
+        if task < 0:
+            return False
+        if task != self._wq_task:
+            self.drop_deferred()
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(self.flush_wgrads)
-                self._wq_callback = True
             except RuntimeError:
                 return False
+            self._wq_task = task
         return True
+
+    def drop_deferred(self) -> None:
+        """forget queued weight-gradient products and LayerNorm reductions without launching them (leftovers of an aborted backward pass)"""
+        self._wq, self._lnq, self._wq_task = [], [], None
 
     def flush_wgrads(self) -> None:
         """launch what a backward pass has queued: the grouped weight gradients and the LayerNorm parameter-gradient reductions"""
-        self._wq_callback = False
+        self._wq_task = None
         if self._wq:
             self._launch_wgrad_group()
         if self._lnq:

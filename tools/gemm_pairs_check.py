@@ -33,11 +33,11 @@ def amax(x, rows=True):
 
 
 def split_pairs(x, am, transpose=False):
-    """fp32 (R, C) + maxima of the output rows -> fp16 (2, rows, round_up(cols, 32)), zero padded"""
+    """fp32 (R, C) + maxima of the output rows -> fp16 (rows, 2 * round_up(cols, 32)) in the pair layout, zero padded"""
     R, Cc = x.shape
     rows, cols = (Cc, R) if transpose else (R, Cc)
-    out = torch.zeros((2, rows, (cols + 31) // 32 * 32), dtype=torch.float16, device=dev)
-    rc = lib.grappa_split_pairs_f32(stream(), R, Cc, x.data_ptr(), x.stride(0), am.data_ptr(), out.data_ptr(), out.stride(1), out.stride(0), int(transpose))
+    out = torch.zeros((rows, 2 * ((cols + 31) // 32 * 32)), dtype=torch.float16, device=dev)
+    rc = lib.grappa_split_pairs_f32(stream(), R, Cc, x.data_ptr(), x.stride(0), am.data_ptr(), out.data_ptr(), out.stride(0), int(transpose))
     assert rc == 0, rc
     return out
 
@@ -50,8 +50,8 @@ def gemm(a, b, out, M, N, K, a_amax, b_amax, pairs, b_kcontig=True, ws=None, **k
     d = _lib.GemmDesc()
     d.M, d.N, d.K, d.a_kcontig, d.b_kcontig = M, N, K, 1, int(b_kcontig)
     if pairs:
-        d.A, d.lda, d.a_planes, d.a_plane_stride = a.data_ptr(), a.stride(1), 1, a.stride(0)
-        d.B, d.ldb, d.b_planes, d.b_plane_stride = b.data_ptr(), b.stride(1), 1, b.stride(0)
+        d.A, d.lda, d.a_planes = a.data_ptr(), a.stride(0), 1
+        d.B, d.ldb, d.b_planes = b.data_ptr(), b.stride(0), 1
         d.b_kcontig = 1
     else:
         d.A, d.lda, d.B, d.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
