@@ -170,7 +170,6 @@ def main():
     ap.add_argument("--strong-global-batch", type=int, default=0, help="strong scaling of this many molecules of the workload's molecule range (default at N > 1: 4096 of C4)")
     ap.add_argument("--chunk", type=int, default=1024, help="molecules per forward/backward pass of a rank (larger shards are accumulated over chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--head-streams-extra", action="store_true", help="N = 1: also time K steps with the writer heads on four HIP streams (opt-in mode, reported beside, never as `value`)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the C3 and C4-on-one-GPU timings that follow the headline measurement")
     ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_f16x3)")
     ap.add_argument("--act-dtype", default="f32", choices=["f32", "bf16"], help="bf16: the bf16 STORAGE configuration for the main job (profiling / "
@@ -272,6 +271,8 @@ def main():
 
         def step(self):
             opt.zero_grad()
+            # the overlapped all-reduce bucket leaves with the LAST chunk's backward pass (never from a rank that runs alone)
+            reducer.begin_step(10 ** 9 if self.solo else len(self.graphs))
             for g in self.graphs:                                      # gradients accumulate in the flat buffer over the chunks
                 for lvl in ("n2", "n3", "n4", "n4_improper"):         # drop last step's outputs
                     for k in ("k", "eq"):
@@ -291,7 +292,7 @@ def main():
                 reducer.finish()
                 self.allreduce_events.append(1e3 * (time.perf_counter() - t_ar))
             else:
-                reducer.finish()       # all-reduce of the flat gradient buffer (both buckets here unless the overlap is switched on)
+                reducer.finish()       # all-reduce of what the backward pass has not sent yet (the GNN bucket), wait for both
             opt.step()
             return loss
 
@@ -446,21 +447,19 @@ def main():
                        "split once per optimiser step (csrc/gemm_planes.hip gemm_wplanes_kernel); results equal f32_bf16x6 to rounding; not the default"}
         log(f"weight planes: {wpl['ms_per_step']:.1f} ms/step")
 
-    # opt-in configuration (never `value`): the four writer heads on four HIP streams
-    heads4 = None
-    if on_gpu and world == 1 and args.head_streams_extra and args.act_dtype == "f32" and model.parameter_writer.head_streams == 1:
-        import warnings
-        model.parameter_writer.head_streams = 4
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            d_h, _ = job.timed(args.steps, 2)
-        model.parameter_writer.head_streams = 1
-        heads4 = {"value": job.global_batch * args.steps / d_h, "ms_per_step": 1e3 * d_h / args.steps,
-                  "note": "GRAPPA_HEAD_STREAMS=4, opt-in and NOT the headline configuration: bond / angle / proper / improper writers on four HIP "
-                          "streams.  Bit-identical to one stream over a 5,000-step soak (tools/head_streams_soak.py) and in tests/test_gpu_e2e.py with the "
-                          "shipped kernels, but a correct test kernel still computes deviating rows beside this library's GEMMs on other queues "
-                          "(tools/stream_probe_round2.sh, DESIGN.md section 6), so the default keeps compute on one queue"}
-        log(f"writer heads on 4 streams (opt-in): {heads4['ms_per_step']:.1f} ms/step")
+    # the other stream setting of the writer heads beside the default (four HIP streams since round 3), never `value`
+    heads_alt = None
+    if on_gpu and world == 1 and not args.no_extras and args.act_dtype == "f32":
+        default_streams = model.parameter_writer.head_streams
+        other = 1 if default_streams > 1 else 4
+        model.parameter_writer.head_streams = other
+        d_h, _ = job.timed(args.steps, 2)
+        model.parameter_writer.head_streams = default_streams
+        heads_alt = {"value": job.global_batch * args.steps / d_h, "ms_per_step": 1e3 * d_h / args.steps, "writer_head_streams": other,
+                     "note": f"GRAPPA_HEAD_STREAMS={other} (the default is {default_streams}): bond / angle / proper / improper writers on "
+                             f"{'one HIP stream' if other == 1 else 'four HIP streams'}; bit-identical gradients with grouped launches off "
+                             "(tests/test_gpu_e2e.py, tools/head_streams_soak.py)"}
+        log(f"writer heads on {other} stream(s): {heads_alt['ms_per_step']:.1f} ms/step")
 
     # N = 1: the other single-GPU configurations, timed right after the headline measurement: C3 in the headline arithmetic, C3 in the
     # bf16 STORAGE configuration BASELINE configs[2] names (never `value`), and the 4096-molecule batch of C4 on one GPU
@@ -557,7 +556,7 @@ def main():
                                         "end-to-end parity: tests/test_gpu_e2e.py, tests/test_gpu_configs.py",
                                 "native_f32_mfma": alt.get("f32"), "f32_bf16x6": alt.get("f32_bf16x6"), "backward_reduced": bwd, "weight_planes": wpl},
             "roofline": roof, "roofline_gat": gat, "ms_per_step_instrumented": ms_instr, "final_loss": final_loss,
-            "writer_heads_on_4_streams": heads4,
+            "writer_heads_other_stream_setting": heads_alt,
         }
         out.update(extras)
         if scaling_ref is not None:

@@ -123,7 +123,7 @@ class HipBackend:
         # weight-gradient products of a backward pass are queued and launched together (grappa_gemm_f32_grouped): alone, each must
         # cut its K (= tokens) 10 - 32 ways to fill the chip and pays for that many partial tiles per output tile
         self.defer_wgrads = os.environ.get("GRAPPA_DEFER_WGRADS", "1") not in ("0", "")
-        self._wq = []                  # (dz, x, dW, db) kept alive until the flush
+        self._wq = {}                  # stream handle -> (stream, [(dz, x, dW, db, maxima) kept alive until the launch])
         self.defer_ln = os.environ.get("GRAPPA_DEFER_LN_REDUCTIONS", "1") not in ("0", "")      # tuning: 0 = reduce every LayerNorm's parameter gradients at once
         self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta)
         self._wq_task = None           # autograd graph task id of the backward pass the queues belong to
@@ -535,7 +535,7 @@ class HipBackend:
         Np, Kp, T = dz.shape[1], x.shape[1], dz.shape[0]
         prec = self.gemm_precision if self.gemm_precision_bwd is None else self.gemm_precision_bwd
         ok = (self.defer_wgrads and dz.dtype == torch.float32 and x.dtype == torch.float32 and Np > 32 and Kp > 32 and T > 0
-              and prec != _lib.GEMM_PRECISIONS["f32"] and torch.cuda.current_stream() == torch.cuda.default_stream())
+              and prec != _lib.GEMM_PRECISIONS["f32"])
         if not ok:
             return self.gemm(dz, x, dw, M=Np, N=Kp, K=T, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=db,
                              a_scales=dz_scales, b_scales=x_scales)
@@ -555,12 +555,17 @@ class HipBackend:
                 sdz = self.amax(dz, dz_scales, rows=True)
                 am = (sdz, self.amax(x, x_scales, rows=True))
         in_pass = self._queue_flush()             # (first: a new pass discards what an aborted one left in the queue)
-        self._wq.append((dz, x, dw, db, am))
+        # one queue per HIP stream (the writer heads run their backward passes on streams of their own): a full queue is launched on the
+        # stream that filled it, what is left when the pass ends is launched together by flush_wgrads
+        st = torch.cuda.current_stream()
+        q = self._wq.setdefault(st.cuda_stream, (st, []))[1]
+        q.append((dz, x, dw, db, am))
         if not in_pass:                           # not inside a backward pass: nothing will call back
             self.flush_wgrads()
             return sdz
-        if len(self._wq) >= _lib.GEMM_GROUP_MAX:
-            self._launch_wgrad_group()
+        if len(q) >= _lib.GEMM_GROUP_MAX:
+            del self._wq[st.cuda_stream]
+            self._launch_wgrad_group(q)
         return sdz
 
     def _queue_flush(self) -> bool:
@@ -582,22 +587,32 @@ class HipBackend:
 
     def drop_deferred(self) -> None:
         """forget queued weight-gradient products and LayerNorm reductions without launching them (leftovers of an aborted backward pass)"""
-        self._wq, self._lnq, self._wq_task = [], [], None
+        self._wq, self._lnq, self._wq_task = {}, [], None
 
     def flush_wgrads(self) -> None:
         """launch what a backward pass has queued: the grouped weight gradients and the LayerNorm parameter-gradient reductions"""
         self._wq_task = None
+        cur = torch.cuda.current_stream()
         if self._wq:
-            self._launch_wgrad_group()
+            queues, self._wq = self._wq, {}
+            items = []
+            for st, q in queues.values():
+                if st != cur:
+                    cur.wait_stream(st)           # (operands queued on another stream: normally already ordered before this point, see ops.SplitHeadsFn)
+                items += q
+            for i in range(0, len(items), _lib.GEMM_GROUP_MAX):
+                self._launch_wgrad_group(items[i:i + _lib.GEMM_GROUP_MAX])
         if self._lnq:
-            items, self._lnq = self._lnq, []
+            for it in self._lnq:
+                if it[7] != cur:
+                    cur.wait_stream(it[7])
+            items, self._lnq = [it[:7] for it in self._lnq], []
             arr = (_lib.ColsumItem * len(items))()
             for d, (ws, nrows, W, pg, pb, _g, _b) in zip(arr, items):
                 d.part, d.nrows, d.n, d.out, d.out2, d.n_first, d.accumulate = ws.data_ptr(), nrows, 2 * W, pg, pb, W, 1
             _chk(self.lib.grappa_colsum_partials_batched(self._stream(), arr, len(items)), "grappa_colsum_partials_batched")
 
-    def _launch_wgrad_group(self) -> None:
-        items, self._wq = self._wq, []
+    def _launch_wgrad_group(self, items) -> None:
         # one grid per load style: products whose operands allow 16-byte loads along their rows (aligned, leading dimension % 4 == 0
         # and covering round_up(columns, 4)) run the faster kernel together; an odd one (513-wide tuple features) would drag its whole
         # group onto the dword-load kernel
@@ -706,8 +721,8 @@ class HipBackend:
         dt = _same_dtype(dy, x, dx)
         # inside a backward pass the parameter gradients wait: the kernel leaves its per-block partial sums in a buffer of their own and
         # ONE launch reduces those of all LayerNorms when the pass ends (flush_wgrads) instead of two small launches per LayerNorm
-        defer = (accumulate and self.defer_wgrads and self.defer_ln and M > 0 and torch.cuda.current_stream() == torch.cuda.default_stream()
-                 and all(q[3] != dgamma.data_ptr() for q in self._lnq) and self._queue_flush())
+        defer = accumulate and self.defer_wgrads and self.defer_ln and M > 0 and self._queue_flush()      # (first: a new pass empties a dead one's queue)
+        defer = defer and all(q[3] != dgamma.data_ptr() for q in self._lnq)
         need = self.lib.grappa_layernorm_bwd_workspace_bytes(M, W)
         ws = torch.empty(need, dtype=torch.uint8, device=dev) if defer else self._workspace(need, dev)
         row = self._new_row_amax(dx, True, amax)
@@ -715,7 +730,8 @@ class HipBackend:
                 mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _f32_2d(dx, "dx", dev, dt),
                 dgamma.data_ptr(), dbeta.data_ptr(), 2 if defer else int(accumulate), ws.data_ptr(), ws.numel())
         if defer:
-            self._lnq.append((ws, self.lib.grappa_layernorm_bwd_partial_rows(M), W, dgamma.data_ptr(), dbeta.data_ptr(), dgamma, dbeta))
+            self._lnq.append((ws, self.lib.grappa_layernorm_bwd_partial_rows(M), W, dgamma.data_ptr(), dbeta.data_ptr(), dgamma, dbeta,
+                              torch.cuda.current_stream()))
         if row is not None:
             _chk(self.lib.grappa_layernorm_bwd_amax_f32(*args, row.data_ptr()), "grappa_layernorm_bwd_amax_f32")
             return Amax(row=row)

@@ -51,12 +51,12 @@ class BucketedGradReducer:
         self.head_range = flat.range_of(model.parameter_writer)
         self._work = []
         self._heads_sent = False
-        # overlap=True sends the writer-head bucket from inside the backward pass.  OFF by default (GRAPPA_OVERLAP_ALLREDUCE=1 turns
-        # it on): on this platform kernels of THIS library running on two hardware queues at once were seen to break the
-        # producer -> consumer order inside a stream ("Streams"); RCCL's kernels on a second queue are probably
-        # harmless (unrelated library kernels were), but that cannot be verified on a one-GPU box, so the default keeps the
-        # compute stream alone: both buckets are reduced after backward().
-        self.overlap = (os.environ.get("GRAPPA_OVERLAP_ALLREDUCE", "0") not in ("0", "")) if overlap is None else bool(overlap)
+        self._passes_left = 1          # backward passes still to come before the step's gradients are final (begin_step)
+        # overlap (default since round 3; GRAPPA_OVERLAP_ALLREDUCE=0 reduces both buckets after backward()): the writer-head bucket is
+        # sent from inside the backward pass, the moment the gradient of h is complete -- ops.SplitHeadsFn, which runs on the caller's
+        # stream behind every head's stream, so the collective (RCCL orders its own stream behind the caller's at the call) sees final
+        # values.  Same sums either way: tests/test_host_train.py holds the two bit-equal.
+        self.overlap = (os.environ.get("GRAPPA_OVERLAP_ALLREDUCE", "1") not in ("0", "")) if overlap is None else bool(overlap)
         model.on_heads_backward_done = self._on_heads_done if self.overlap else None
 
     @staticmethod
@@ -70,7 +70,15 @@ class BucketedGradReducer:
         if hasattr(be, "flush_wgrads"):
             be.flush_wgrads()                      # weight gradients still queued for a grouped launch belong in the buffer first
 
+    def begin_step(self, backward_passes: int = 1) -> None:
+        """declare how many backward passes accumulate into the gradient buffer before `finish()` (a batch processed in chunks): the
+        writer-head bucket is sent from inside the LAST of them only.  Without this call every step is one backward pass."""
+        self._passes_left = int(backward_passes)
+
     def _on_heads_done(self) -> None:
+        self._passes_left -= 1
+        if self._passes_left > 0:
+            return
         if self._active() and not self._heads_sent:
             self._flush_queued_wgrads()
             a, b = self.head_range
@@ -91,3 +99,4 @@ class BucketedGradReducer:
                 w.wait()
         self._work = []
         self._heads_sent = False
+        self._passes_left = 1

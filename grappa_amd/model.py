@@ -476,14 +476,14 @@ class WriteParameters(nn.Module):
                                                       cfg["gated_torsion"], cfg["wrong_symmetry"], cfg["torsion_cutoff"],
                                                       layer_norm=cfg.get("layer_norm", True), learnable_statistics=cfg.get("learnable_statistics", False))
 
-        # The four writers read the same atom embedding and write disjoint tuple levels: on the GPU each CAN run on its own HIP stream
-        # (largest first), so that the tail rounds and launch gaps of one head's kernels are filled by another head's; autograd
-        # replays every backward node on the stream of its forward, which gives the same overlap in the backward pass (+2.8 % at C2).
-        # OFF by default (GRAPPA_HEAD_STREAMS=1).  With a two-rows-per-trip LayerNorm kernel (since removed) concurrent heads gave
-        # sporadically deviating rows; the cause sits below this library and is not understood.  With the
-        # shipped kernels 20 of 20 four-stream train steps were bit-identical to the single-stream ones, but until the mechanism is
-        # known the default path keeps compute on one queue.
-        self.head_streams = int(os.environ.get("GRAPPA_HEAD_STREAMS", "1"))
+        # The four writers read the same atom embedding and write disjoint tuple levels: on the GPU each runs on its own HIP stream
+        # (largest first), so that the tail rounds and launch gaps of one head's kernels are filled by another head's; autograd replays
+        # every backward node on the stream of its forward, which gives the same overlap in the backward pass (-1.7 .. -2.0 ms of a 38 ms
+        # C2 step).  Default since round 3 (GRAPPA_HEAD_STREAMS=1 puts everything back on one stream).  History: a
+        # since-removed LayerNorm kernel computed deviating rows beside MFMA wavefronts of another queue; the trigger -- packed fp32
+        # instructions -- is compiled out of this library, and the gradients of h are joined by the library's own kernel
+        # (ops.SplitHeadsFn), so no torch arithmetic kernel runs on a side stream.
+        self.head_streams = int(os.environ.get("GRAPPA_HEAD_STREAMS", "4"))
         self._streams = None
 
     def _writers_largest_first(self):
@@ -491,31 +491,35 @@ class WriteParameters(nn.Module):
 
     def forward(self, g):
         h = g.nodes["n1"].data["h"]
-        if self.head_streams <= 1 or not h.is_cuda:
-            for w in self._writers_largest_first():         # same host order (hence dropout seeds) as the multi-stream path
-                g = w(g)
-            return g
-        main = torch.cuda.current_stream(h.device)
-        if self._streams is None or self._streams[0].device != h.device:
-            import warnings
-            warnings.warn("GRAPPA_HEAD_STREAMS > 1: the writer heads run on several HIP streams.  This opt-in is not the validated "
-                          "configuration (DESIGN.md section 6, multi-queue deviation); the default of one stream is.")
-            self._streams = [torch.cuda.Stream(device=h.device) for _ in range(min(self.head_streams, 4) - 1)]
-        lanes = [main] + self._streams                     # the largest head stays on the caller's stream
         writers = self._writers_largest_first()
-        for s in self._streams:
-            s.wait_stream(main)
-        for i, w in enumerate(writers):
-            with torch.cuda.stream(lanes[i % len(lanes)]):
-                g = w(g)
-        for s in self._streams:
-            main.wait_stream(s)
-        # the parameters were allocated on the side streams and are consumed on the caller's: tell the caching allocator
-        for lvl in ("n2", "n3", "n4", "n4_improper"):
-            for key, t in g.nodes[lvl].data.items():
-                if key.startswith(("k", "eq")) and torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(main)
-        return g
+        # every head reads an alias of h of its own, so that its gradient of h arrives alone at the node that adds the four
+        aliases = ops.SplitHeadsFn.apply(h, len(writers)) if (torch.is_grad_enabled() and h.requires_grad) else (h,) * len(writers)
+        try:
+            if self.head_streams <= 1 or not h.is_cuda:
+                for w, a in zip(writers, aliases):          # same host order (hence dropout seeds) as the multi-stream path
+                    g.nodes["n1"].data["h"] = a
+                    g = w(g)
+                return g
+            main = torch.cuda.current_stream(h.device)
+            if self._streams is None or self._streams[0].device != h.device:
+                self._streams = [torch.cuda.Stream(device=h.device) for _ in range(min(self.head_streams, 4) - 1)]
+            lanes = [main] + self._streams                     # the largest head stays on the caller's stream
+            for s in self._streams:
+                s.wait_stream(main)
+            for i, (w, a) in enumerate(zip(writers, aliases)):
+                with torch.cuda.stream(lanes[i % len(lanes)]):
+                    g.nodes["n1"].data["h"] = a
+                    g = w(g)
+            for s in self._streams:
+                main.wait_stream(s)
+            # the parameters were allocated on the side streams and are consumed on the caller's: tell the caching allocator
+            for lvl in ("n2", "n3", "n4", "n4_improper"):
+                for key, t in g.nodes[lvl].data.items():
+                    if key.startswith(("k", "eq")) and torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(main)
+            return g
+        finally:
+            g.nodes["n1"].data["h"] = h
 
 
 class GrappaModel(nn.Module):

@@ -351,6 +351,32 @@ class ConvBlockFn(Function):
         return (dh,) + (None,) * 13
 
 
+class SplitHeadsFn(Function):
+    """h -> one alias of the atom embedding per writer head.  The four heads read the same h (reference models/interaction_parameters.py:
+    125-135) and, with GRAPPA_HEAD_STREAMS > 1, run forward and backward on HIP streams of their own.  Each head's backward pass delivers
+    ITS gradient of h to this node, which adds them with the library's own kernel on the caller's stream: autograd orders that stream
+    behind every head's stream first, so this node is also the join of the streams, and no torch kernel accumulates gradients on a side
+    stream (multi-queue)."""
+
+    @staticmethod
+    def forward(ctx, h, n):
+        ctx.set_materialize_grads(False)
+        return tuple(h.view_as(h) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        be = get_backend()
+        gs = [_c(g) for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        for g in gs[1:]:
+            out = acc if acc is not gs[0] else torch.empty_like(acc)
+            be.add(acc.reshape(-1), g.reshape(-1), out.reshape(-1))
+            acc = out
+        return acc, None
+
+
 class ProjGatherFn(Function):
     """a = ELU(h W^T + b) (N, Wp); x[pos*T+t] = [a[idx[t,pos]], pe[pos]] (s*T, Wp + has_pe)."""
 

@@ -122,15 +122,34 @@ def _dp_worker(rank, world, port, ids, sd, out_q):
     assert reducer._heads_sent and len(reducer._work) == 1
     reducer.finish()
     assert torch.equal(flat.grad, one_bucket)
-    # and the default (no overlap: both buckets after backward)
-    plain = BucketedGradReducer(model, flat)
+    # and without the overlap (both buckets after backward); the default is the overlap
+    assert BucketedGradReducer(model, flat).overlap is True
+    plain = BucketedGradReducer(model, flat, overlap=False)
     assert plain.overlap is False and model.on_heads_backward_done is None
     flat.zero_grad()
     _loss(model, mine, 5, global_b=len(ids)).backward()
     plain.finish()
     assert torch.equal(flat.grad, one_bucket)
+    result = flat.grad.clone()
+    # a shard processed in two chunks (gradient accumulation): the overlapped bucket must leave with the LAST backward pass only
+    half = len(mine) // 2
+    assert half >= 1
+    flat.zero_grad()
+    for part in (mine[:half], mine[half:]):
+        _loss(model, part, 5, global_b=len(ids)).backward()
+    want2 = flat.grad.clone()
+    all_reduce_gradients(want2)
+    chunked = BucketedGradReducer(model, flat, overlap=True)
+    flat.zero_grad()
+    chunked.begin_step(2)
+    _loss(model, mine[:half], 5, global_b=len(ids)).backward()
+    assert not chunked._heads_sent
+    _loss(model, mine[half:], 5, global_b=len(ids)).backward()
+    assert chunked._heads_sent
+    chunked.finish()
+    assert torch.equal(flat.grad, want2)
     if rank == 0:
-        out_q.put(flat.grad.clone().numpy())
+        out_q.put(result.numpy())
     dist.barrier()
     dist.destroy_process_group()
 

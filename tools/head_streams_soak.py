@@ -21,8 +21,12 @@ from grappa_amd.optim import FlatParams, FusedAdam  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    # "exact" (default): grouped launches off, 1 stream vs 4 streams bit for bit.  "deferred": the shipped configuration (weight gradients
+    # and LayerNorm reductions queued per stream and launched in groups): four streams twice from the same state must give the same
+    # bits (the grouping differs from one stream's, so 1 vs 4 is compared to 1e-5 of the largest gradient entry instead)
+    mode = sys.argv[2] if len(sys.argv) > 2 else "exact"
     be = get_backend()
-    be.defer_wgrads = False
+    be.defer_wgrads = mode == "deferred"
     model = model_from_config(get_default_model_config())
     bench.keyed_init(model)
     model = model.to("cuda").train()
@@ -49,7 +53,12 @@ def main():
     for i in range(steps):
         l1, g1 = run(1, 1000 + i)
         l4, g4 = run(4, 1000 + i)
-        same = torch.equal(l1, l4) and torch.equal(g1, g4)
+        if mode == "deferred":
+            l4b, g4b = run(4, 1000 + i)
+            close = float((g1 - g4).abs().max()) <= 1e-5 * float(g1.abs().max())
+            same = torch.equal(l4, l4b) and torch.equal(g4, g4b) and torch.equal(l1, l4) and close
+        else:
+            same = torch.equal(l1, l4) and torch.equal(g1, g4)
         if not same:
             bad += 1
             d = (g1 - g4).abs()
