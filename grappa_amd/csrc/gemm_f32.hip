@@ -315,18 +315,27 @@ PlanOverride g_override;
 // ceil(workgroups / (256*CONC_c)) such rounds.  Split-K adds the slab round trip and two launches.  With an unsplit K the
 // tiles beyond the last full 256 can run as a second, split-K "tail" launch (rem * ts workgroups, each 1/ts long) instead of
 // costing a whole extra round.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
+// CUs a product plans for.  Experiment only (GRAPPA_PLAN_CUS, tools/plan_cus_ab.sh): with the writer heads on four streams each product
+// could plan for a share of the chip (fewer K cuts); measured 36.1 -> 37.1 ms per C2 step at 128, 37.2 at 64 -- every product keeps
+// planning for all 256 (profiles/r3_plan_cus_rejected.txt)
+long plan_cus() {
+    static const int env = getenv("GRAPPA_PLAN_CUS") ? atoi(getenv("GRAPPA_PLAN_CUS")) : 0;
+    return env >= 32 && env <= 256 ? env : 256;
+}
+
 struct CostModel {
     // MACs per cycle per CU sustained in the main loop, and the per-tile prologue + epilogue expressed in columns of K
     const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0};
     const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0};
     double grid(int c, long wgs, int kps) const {
         const int conc = CFG_CONC[c];
+        const long ncu = plan_cus();
         const double t = (double)CFG_BM[c] * CFG_BN[c] * (kps + k0[c]) / rate[c];
-        if (wgs <= 256L * conc) {
-            const double per_cu = (double)((wgs + 255) / 256);
+        if (wgs <= ncu * conc) {
+            const double per_cu = (double)((wgs + ncu - 1) / ncu);
             return per_cu * t * (per_cu < 2 && conc > 1 ? 1.3 : 1.0);   // a lone workgroup of a multi-resident tile cannot hide its barrier bubbles
         }
-        return (double)((wgs + 256L * conc - 1) / (256L * conc)) * conc * t;
+        return (double)((wgs + ncu * conc - 1) / (ncu * conc)) * conc * t;
     }
     static double splitk(int nsplit, double elems) { return 12000.0 + nsplit * elems / 200.0; }   // two launches + slab write / reduce
 };
@@ -369,9 +378,10 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
             cand.main_tiles = (int)tiles;
             cand.tail_nsplit = 0;
             cand.tail_k_per_split = 0;
-            const long rem = tiles % 256;
-            if (nsplit == 1 && tiles > 256 && rem > 0 && rem <= 160 && g_override.tail != 0) {
-                int ts = (int)(256 / rem);
+            const long ncu = plan_cus();
+            const long rem = tiles % ncu;
+            if (nsplit == 1 && tiles > ncu && rem > 0 && rem <= ncu * 5 / 8 && g_override.tail != 0) {
+                int ts = (int)(ncu / rem);
                 if (ts > max_tail_split) ts = max_tail_split;
                 int tkps = (K + ts - 1) / ts;
                 tkps = (tkps + BK - 1) / BK * BK;
