@@ -11,8 +11,10 @@ from .grappa import Grappa
 from .evaluation import FastEvaluator
 from .schedule import TrainSchedule
 from .device_dataset import DeviceDataset
+from .dataset import Dataset
+from .moldata import MolData
 from .trainer import Trainer
 
 __all__ = ["MolBatch", "batch", "unbatch", "set_number_confs", "delete_dummy_confs", "Molecule", "Parameters", "GrappaModel",
            "Energy", "MolwiseLoss", "get_default_model_config", "model_from_config", "model_from_dict", "Grappa", "FastEvaluator",
-           "TrainSchedule", "DeviceDataset", "Trainer"]
+           "TrainSchedule", "DeviceDataset", "Dataset", "MolData", "Trainer"]

@@ -132,10 +132,12 @@ class MolData:
         pk = np.asarray(p.get("proper_ks", nan(T["n4"], constants.N_PERIODICITY_PROPER)))
         pp = np.asarray(p.get("proper_phases", nan(T["n4"], constants.N_PERIODICITY_PROPER)))
         assert np.all((pk >= 0) + np.isnan(pk)), "The proper torsion force constants must be positive"
-        g.nodes["n4"].data["k_ref"] = _fit_columns(torch.tensor(_signed_k(pk, pp, True), dtype=torch.float32).reshape(T["n4"], -1),
+        # (explicit widths: an empty level has no rows to infer a width from)
+        g.nodes["n4"].data["k_ref"] = _fit_columns(torch.tensor(_signed_k(pk, pp, True), dtype=torch.float32).reshape(T["n4"], pk.shape[-1] if pk.ndim > 1 else 1),
                                                    constants.N_PERIODICITY_PROPER)
         ik = np.asarray(p.get("improper_ks", nan(T["n4_improper"], constants.N_PERIODICITY_IMPROPER)))
         ip = np.asarray(p.get("improper_phases", nan(T["n4_improper"], constants.N_PERIODICITY_IMPROPER)))
         assert np.all((ik >= 0) + np.isnan(ik)), "The improper torsion force constants must be positive."
         g.nodes["n4_improper"].data["k_ref"] = _fit_columns(
-            torch.tensor(_signed_k(ik, ip, False), dtype=torch.float32).reshape(T["n4_improper"], -1), constants.N_PERIODICITY_IMPROPER)
+            torch.tensor(_signed_k(ik, ip, False), dtype=torch.float32).reshape(T["n4_improper"], ik.shape[-1] if ik.ndim > 1 else 1),
+            constants.N_PERIODICITY_IMPROPER)

@@ -462,8 +462,56 @@ def make_options_golden():
         save(name, cfg, mols, out, sd, extra)
 
 
+def make_dataset_golden():
+    """the reference's dataset-level logic (data/Dataset.py:80-112 `split`, :236-258 k-fold / partition splits through
+    utils/torch_utils.py:11-135, :141-345, :259-294 `where` / `shuffle` / `subsampled`) on synthetic (mol_id, subdataset) lists with
+    duplicated ids across subdatasets: the graphs are placeholders (the index in the list), so what is pinned is which item goes where."""
+    import json
+    from grappa.data import Dataset as RefDataset
+    rng = np.random.default_rng(9)
+    names, ids = [], []
+    for ds, n in (("spice-dipeptide", 37), ("spice-pubchem", 61), ("rna-diverse", 9), ("gen2", 23)):
+        for i in range(n):
+            names.append(ds)
+            ids.append(f"{ds}-{i:03d}")
+    # duplicated molecules: the same id in two subdatasets (gen2 / spice-pubchem) and twice inside one (conformation sets)
+    for i in range(7):
+        names.append("gen2")
+        ids.append(f"spice-pubchem-{3 * i:03d}")
+    for i in range(3):
+        names.append("spice-dipeptide")
+        ids.append(f"spice-dipeptide-{5 * i:03d}")
+    order = rng.permutation(len(ids))
+    ids, names = [ids[i] for i in order], [names[i] for i in order]
+    ds = RefDataset(graphs=list(range(len(ids))), mol_ids=list(ids), subdataset=list(names))
+    out = {"mol_ids": np.array(ids), "subdataset": np.array(names)}
+    cases = {}
+    cases["partition_tuple_seed0"] = ds.calc_split_ids(partition=(0.8, 0.1, 0.1), seed=0)
+    cases["partition_tuple_seed3"] = ds.calc_split_ids(partition=(0.6, 0.2, 0.2), seed=3)
+    cases["partition_dict"] = ds.calc_split_ids(partition=((0.8, 0.1, 0.1), {"rna-diverse": (1.0, 0.0, 0.0), "spice-dipeptide": (0.8, 0.1, 0.1)}), seed=1)
+    existing = {"train": [i for i in ids if i.startswith("gen2-00")], "val": ["spice-pubchem-000"], "test": ["rna-diverse-001", "not-in-this-dataset"]}
+    cases["existing_split"] = ds.calc_split_ids(partition=(0.8, 0.1, 0.1), seed=2, existing_split={k: list(v) for k, v in existing.items()})
+    out["existing_split_input"] = np.array(json.dumps(existing))
+    for k, v in cases.items():
+        out["calc::" + k] = np.array(json.dumps(v))
+    folds = ds.get_k_fold_split_ids(k=5, seed=4)
+    out["kfold::k5_seed4"] = np.array(json.dumps(folds))
+    out["kfold::k4_seed1_folds2"] = np.array(json.dumps(ds.get_k_fold_split_ids(k=4, seed=1, num_folds=2)))
+    # Dataset.split: items by membership of their id; ids in no list go to the test set
+    sp = cases["partition_tuple_seed0"]
+    tr, vl, te = ds.split(sp["train"], sp["val"][: len(sp["val"]) // 2], [])
+    out["split::train"], out["split::val"], out["split::test"] = np.array(tr.graphs), np.array(vl.graphs), np.array(te.graphs)
+    out["shuffle::seed5"] = np.array(RefDataset(list(range(len(ids))), list(ids), list(names)).shuffle(seed=5).graphs)
+    out["subsampled::0.3_seed2"] = np.array(RefDataset(list(range(len(ids))), list(ids), list(names)).subsampled(0.3, seed=2).graphs)
+    out["slice::10_20"] = np.array(ds.slice(10, 20).graphs)
+    np.savez_compressed(os.path.join(OUT, "ref_dataset.npz"), **out)
+    print("wrote ref_dataset.npz:", {k: {s: len(v[s]) for s in v} for k, v in cases.items()})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "options":
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        make_dataset_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "options":
         make_options_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "eval":
         make_eval_golden()
@@ -477,3 +525,4 @@ if __name__ == "__main__":
         make_tuple_golden()
         make_predict_golden()
         make_options_golden()
+        make_dataset_golden()
