@@ -29,6 +29,17 @@ class FastEvaluator:
         self._acc: Optional[torch.Tensor] = None          # (n_datasets, 8) float64 on the graphs' device: se_E, n_E, se_G, n_G, then the
         #                                                   same four for the classical force field vs the PREDICTION (evaluation.py:80-87)
 
+    def register(self, dsnames: List[str], device) -> None:
+        """fix the row of every dataset name up front (data parallel validation: every rank must use the same rows, whatever share of
+        the batches it sees, so that `all_reduce()` adds like to like)"""
+        self._index_of(list(dsnames), device)
+
+    def all_reduce(self) -> None:
+        """sum the accumulators over the ranks of the default process group (each rank has stepped through ITS share of the batches)"""
+        import torch.distributed as tdist
+        if self._acc is not None and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            tdist.all_reduce(self._acc, op=tdist.ReduceOp.SUM)
+
     def _index_of(self, dsnames: List[str], device) -> torch.Tensor:
         for n in dsnames:
             if n not in self._ds_index:

@@ -113,9 +113,17 @@ class Trainer:
         if self.val_set is None:
             return None
         self.model.eval()
-        for ids in epoch_batches(self.val_set.names, self.val_batch_size, shuffle=False):
+        # data parallel: the validation batches are dealt to the ranks round-robin and the per-dataset squared-error sums added over the
+        # ranks before they are pooled (every rank ends with the same metrics, hence the same schedule decisions)
+        if self.world > 1:
+            self.evaluator.register(sorted(set(self.val_set.names)), self.flat.data.device)
+        for b, ids in enumerate(epoch_batches(self.val_set.names, self.val_batch_size, shuffle=False)):
+            if b % self.world != self.rank:
+                continue
             g, names = self.val_set.collate(ids, self.val_conf_strategy)
             self.evaluator.step(self.energy(self.model(g)), list(names))
+        if self.world > 1:
+            self.evaluator.all_reduce()
         metrics = self.evaluator.pool()
         es = self.schedule.on_validation_epoch_end(epoch, metrics)
         return metrics, es

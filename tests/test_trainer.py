@@ -100,10 +100,21 @@ def _dp_trainer_worker(rank, world, port, out_q):
     ops.manual_seed(5)
     model = GrappaModel(**TINY)
     train = DeviceDataset(_items(list(range(300, 309))), device="cpu")          # 9 molecules, batches of 4: 9 % 4 == 1 < 2 ranks
-    tr = Trainer(model, train, None, batch_size=4, conf_strategy=4, lr=2e-3, start_qm_epochs=0, warmup_steps=2, energy_weight=1.0,
-                 gradient_weight=0.8, param_weight=0.0)
+    val = DeviceDataset(_items(list(range(340, 347))), device="cpu")            # 7 molecules, batches of 2: four batches dealt to the two ranks
+    tr = Trainer(model, train, val, batch_size=4, conf_strategy=4, val_batch_size=2, val_conf_strategy="max", lr=2e-3, start_qm_epochs=0,
+                 warmup_steps=2, energy_weight=1.0, gradient_weight=0.8, param_weight=0.0)
     hist = tr.fit(2)
-    out_q.put((rank, [h["train_loss"] for h in hist], float(tr.flat.data.double().sum())))
+    # the sharded validation (each rank a share of the batches, squared-error sums added over the ranks) against this rank alone on all batches
+    sharded, _ = tr.validate(2)
+    keep = (tr.world, tr.rank)
+    tr.world, tr.rank = 1, 0
+    alone, _ = tr.validate(2)
+    tr.world, tr.rank = keep
+    for ds in alone:
+        for k, v in alone[ds].items():
+            assert abs(sharded[ds][k] - v) <= 1e-6 * abs(v), (ds, k, sharded[ds][k], v)
+    out_q.put((rank, [h["train_loss"] for h in hist] + [hist[-1]["val_metrics"]["avg"]["rmse_gradients"], hist[-1]["early_stopping_loss"]],
+               float(tr.flat.data.double().sum())))
     dist.barrier()
     dist.destroy_process_group()
 
