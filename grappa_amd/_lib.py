@@ -95,6 +95,7 @@ SIGNATURES = {
     "grappa_gat_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "grappa_gat_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "grappa_neighbor_mean_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i]),
+    "grappa_neighbor_mean_bf16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
     "grappa_charge_encoding_f32": (_i, [_vp, _i, _vp, _i, _f, _f, _vp, _i, _i]),
     "grappa_tuple_gather_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i]),
     "grappa_tuple_gather_bwd_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i]),

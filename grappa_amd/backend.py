@@ -784,9 +784,16 @@ class HipBackend:
         dev = out.device
         N, F = x.shape
         self._csr_check(plan, N, dev)
-        _flat(x, "x", dev), _flat(out, "out", dev)
         if out.shape != x.shape:
             raise ValueError("neighbor_mean: shapes")
+        if x.dtype == torch.bfloat16:                  # bf16 storage configuration: out bf16 (a product's operand) or fp32 (a product's addend)
+            _flat(x, "x", dev, torch.bfloat16), _flat(out, "out", dev, out.dtype)
+            if out.dtype not in _ACT_DTYPES:
+                raise ValueError("neighbor_mean: out must be bfloat16 or float32")
+            _chk(self.lib.grappa_neighbor_mean_bf16(self._stream(), N, F, plan.indptr.data_ptr(), plan.indices.data_ptr(), x.data_ptr(), out.data_ptr(),
+                                                    int(out.dtype == torch.float32), int(scale_by_neighbor)), "grappa_neighbor_mean_bf16")
+            return
+        _flat(x, "x", dev), _flat(out, "out", dev)
         _chk(self.lib.grappa_neighbor_mean_f32(self._stream(), N, F, plan.indptr.data_ptr(), plan.indices.data_ptr(), x.data_ptr(), out.data_ptr(),
                                                int(scale_by_neighbor)), "grappa_neighbor_mean_f32")
 

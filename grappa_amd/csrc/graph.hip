@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256) void gat_bwd_kernel_e(int N, int H, int D, con
     }
 }
 
-template <int NC>
+template <int NC, typename T, typename U>
 __global__ __launch_bounds__(256) void neighbor_mean_kernel(int N, int F, const int* __restrict__ indptr, const int* __restrict__ indices,
-                                                            const float* __restrict__ x, float* __restrict__ out, int scale_by_neighbor) {
+                                                            const T* __restrict__ x, U* __restrict__ out, int scale_by_neighbor) {
     const int lane = threadIdx.x & 63;
     const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (v >= N) return;
@@ -321,11 +321,11 @@ __global__ __launch_bounds__(256) void neighbor_mean_kernel(int N, int F, const 
             acc[i].x += sc * r[i].x; acc[i].y += sc * r[i].y; acc[i].z += sc * r[i].z; acc[i].w += sc * r[i].w;
         }
     }
-    float4* o = reinterpret_cast<float4*>(out + (size_t)v * F);
+    U* o = out + (size_t)v * F;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
-        if (c < nvec) o[c] = acc[i];
+        if (c < nvec) st4(o, c, acc[i]);
     }
 }
 
@@ -443,6 +443,36 @@ extern "C" int grappa_neighbor_mean_f32(void* stream, int N, int F, const int* i
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((N + 3) / 4);
-    DISPATCH_NC(chunks_for(F), neighbor_mean_kernel, grid, st, N, F, indptr, indices, x, out, scale_by_neighbor);
+    switch (chunks_for(F)) {
+        case 1: hipLaunchKernelGGL((neighbor_mean_kernel<1, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
+        case 2: hipLaunchKernelGGL((neighbor_mean_kernel<2, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
+        case 4: hipLaunchKernelGGL((neighbor_mean_kernel<4, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
+        default: hipLaunchKernelGGL((neighbor_mean_kernel<8, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
+    }
+    return grappa_launch_status();
+}
+
+// bf16 storage configuration: bf16 rows in; out bf16 (the aggregate is the A operand of a dense product) or fp32 (out_f32 != 0: the
+// transposed aggregation of the backward pass, an fp32 addend of the product that follows)
+extern "C" int grappa_neighbor_mean_bf16(void* stream, int N, int F, const int* indptr, const int* indices, const uint16_t* x, void* out, int out_f32,
+                                         int scale_by_neighbor) {
+    if (N < 0 || F <= 0 || (F & 3) || F > 2048) return GRAPPA_ERR_ARG;
+    if (N == 0) return GRAPPA_OK;
+    if (!indptr || !indices || !x || !out) return GRAPPA_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(out) & (out_f32 ? 15 : 7))) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((N + 3) / 4);
+#define NM_LAUNCH(NC)                                                                                                                           \
+    if (out_f32) hipLaunchKernelGGL((neighbor_mean_kernel<NC, grappa_bf16_t, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x,          \
+                                    reinterpret_cast<float*>(out), scale_by_neighbor);                                                          \
+    else hipLaunchKernelGGL((neighbor_mean_kernel<NC, grappa_bf16_t, grappa_bf16_t>), grid, dim3(256), 0, st, N, F, indptr, indices, x,          \
+                            reinterpret_cast<grappa_bf16_t*>(out), scale_by_neighbor);
+    switch (chunks_for(F)) {
+        case 1: NM_LAUNCH(1) break;
+        case 2: NM_LAUNCH(2) break;
+        case 4: NM_LAUNCH(4) break;
+        default: NM_LAUNCH(8) break;
+    }
+#undef NM_LAUNCH
     return grappa_launch_status();
 }

@@ -154,8 +154,6 @@ class GrappaGNN(nn.Module):
         plan = g.plan()
         x = self.input_features(g)
         p0 = self.p_initial if self.training else 0.0
-        if ops.act_dtype() is not None and len(getattr(self, "conv_blocks", [])):
-            raise NotImplementedError("the bf16 storage configuration covers the attention blocks (no SAGE conv blocks)")
         h = ops.LinearFn.apply(x, self.pre_dense[0].weight, self.pre_dense[0].bias, ops.ELU, p0, ops.next_seed() if p0 > 0 else 0, ops.act_dtype())
         if not self.no_convs:
             for blk in self.blocks:

@@ -303,7 +303,7 @@ class ConvBlockFn(Function):
         h1, mean1, rstd1, sh1 = _ln_fwd(be, h, ln_w, ln_b)
         mn = _new((N, Fd), h)
         be.neighbor_mean(plan, h1, mn, False)
-        t = _new((N, Fd), h)
+        t = _new((N, Fd), h, F32)                   # the pre-activation addend of the next product: fp32 in every configuration
         smn = be.gemm(mn, w_neigh, t, M=N, N=Fd, K=Fd)
         y1 = _new((N, Fd), h)          # ELU output before dropout
         h3 = _new((N, Fd), h)
@@ -345,8 +345,14 @@ class ConvBlockFn(Function):
         dmn = _new(mn.shape, mn)
         be.gemm(dz1, w_neigh, dmn, M=N, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)
         dh1 = _new(h1.shape, h1)
-        be.neighbor_mean(plan, dmn, dh1, True)                         # transpose of the mean aggregation
-        be.gemm(dz1, w_self, dh1, M=N, N=Fd, K=Fd, b_kcontig=False, res=dh3, accumulate=True, a_scales=sz)
+        if h1.dtype == F32:
+            be.neighbor_mean(plan, dmn, dh1, True)                     # transpose of the mean aggregation
+            be.gemm(dz1, w_self, dh1, M=N, N=Fd, K=Fd, b_kcontig=False, res=dh3, accumulate=True, a_scales=sz)
+        else:
+            # bf16 storage: a bf16 output cannot be accumulated into; the aggregated gradient enters the product as its fp32 addend
+            agg = _new(h1.shape, h1, F32)
+            be.neighbor_mean(plan, dmn, agg, True)
+            be.gemm(dz1, w_self, dh1, M=N, N=Fd, K=Fd, b_kcontig=False, pre=agg, res=dh3, a_scales=sz)
         dh, _ = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
         return (dh,) + (None,) * 13
 

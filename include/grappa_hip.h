@@ -262,6 +262,9 @@ int grappa_gat_bwd_f32(void* stream, int N, int E, int H, int D, const int* indp
  * forward: scale_by_neighbor = 0; backward (symmetric graph): scale_by_neighbor = 1 on d(out). */
 int grappa_neighbor_mean_f32(void* stream, int N, int F, const int* indptr, const int* indices,
                              const float* x, float* out, int scale_by_neighbor);
+/* ABI 5, the bf16 storage configuration of the SAGE block: bf16 rows in (8-byte aligned), out bf16 (out_f32 == 0) or fp32 (16-byte aligned) */
+int grappa_neighbor_mean_bf16(void* stream, int N, int F, const int* indptr, const int* indices,
+                              const uint16_t* x, void* out, int out_f32, int scale_by_neighbor);
 
 /* ------------------------------------------------------------------------------------------------
  * Input featurisation: sinusoidal encoding of the partial charge, graph_attention.py:428-444.

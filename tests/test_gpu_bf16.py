@@ -163,12 +163,17 @@ def _bf16_mode(on: bool):
     be.set_gemm_precision("bf16" if on else "f32_bf16x6")
 
 
-def test_bf16_configuration_end_to_end_against_the_oracle():
+@pytest.mark.parametrize("n_conv", [0, 2])
+def test_bf16_configuration_end_to_end_against_the_oracle(n_conv):
+    """n_conv = 0: the production model (grappa-1.2, seven attention blocks); n_conv = 2: two SAGE blocks in front of them (the
+    grappa-1.1 layout, reference models/graph_attention.py:383-415) -- the bf16 storage configuration covers both (round 3)"""
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.datasets import build_batch_from_pool
     from grappa_amd.optim import FlatParams
     from oracle import cpu_ref
     cfg = get_default_model_config()
+    if n_conv:
+        cfg.update(gnn_convolutions=n_conv, gnn_attentional_layers=3)
     model = model_from_config(cfg)
     sd = gu.keyed_state_dict(model)
     model.load_state_dict(sd)
