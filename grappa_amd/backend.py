@@ -127,6 +127,9 @@ class HipBackend:
         self.defer_ln = os.environ.get("GRAPPA_DEFER_LN_REDUCTIONS", "1") not in ("0", "")      # tuning: 0 = reduce every LayerNorm's parameter gradients at once
         self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta)
         self._wq_task = None           # autograd graph task id of the backward pass the queues belong to
+        self.wgrads_aside = os.environ.get("GRAPPA_WGRADS_ASIDE", "1") not in ("0", "")      # tuning: 0 = every queued product waits for the end of the pass
+        self._side_streams = {}        # (device, caller's stream handle) -> the side stream of launch_wgrads_aside
+        self._aside = []               # (side stream, items kept alive) since the last flush
         self.weight_planes = os.environ.get("GRAPPA_WEIGHT_PLANES", "0") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
         self._wepoch = 0
@@ -587,7 +590,43 @@ class HipBackend:
 
     def drop_deferred(self) -> None:
         """forget queued weight-gradient products and LayerNorm reductions without launching them (leftovers of an aborted backward pass)"""
+        self._join_aside()
         self._wq, self._lnq, self._wq_task = {}, [], None
+
+    # ---- weight gradients beside the pass.  The GNN's backward pass is a chain of small products (8,233 atom rows at C2: 132 workgroups on
+    # 256 CUs) that leaves half of the chip idle, and the weight gradients nobody waits for pile up behind it.  launch_wgrads_aside() takes
+    # what is queued and launches it AT ONCE as grouped grids on a side stream, ordered behind the streams that produced the operands; the
+    # operands stay referenced until flush_wgrads() has put the caller's stream behind the side stream again.
+    def launch_wgrads_aside(self, all_streams: bool = False) -> None:
+        if not self.wgrads_aside or not self._wq:
+            return
+        cur = torch.cuda.current_stream()
+        if all_streams:
+            queues, self._wq = list(self._wq.values()), {}
+        else:
+            ent = self._wq.pop(cur.cuda_stream, None)
+            queues = [ent] if ent else []
+        items = [it for _, q in queues for it in q]
+        if not items:
+            return
+        key = (cur.device, cur.cuda_stream)
+        side = self._side_streams.get(key)
+        if side is None:
+            side = self._side_streams[key] = torch.cuda.Stream(device=cur.device)
+        for st, _ in queues:
+            side.wait_stream(st)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for i in range(0, len(items), _lib.GEMM_GROUP_MAX):
+                self._launch_wgrad_group(items[i:i + _lib.GEMM_GROUP_MAX])
+        self._aside.append((side, items))
+
+    def _join_aside(self) -> None:
+        if self._aside:
+            cur = torch.cuda.current_stream()
+            for side, _ in self._aside:
+                cur.wait_stream(side)
+            self._aside = []
 
     def flush_wgrads(self) -> None:
         """launch what a backward pass has queued: the grouped weight gradients and the LayerNorm parameter-gradient reductions"""
@@ -611,6 +650,7 @@ class HipBackend:
             for d, (ws, nrows, W, pg, pb, _g, _b) in zip(arr, items):
                 d.part, d.nrows, d.n, d.out, d.out2, d.n_first, d.accumulate = ws.data_ptr(), nrows, 2 * W, pg, pb, W, 1
             _chk(self.lib.grappa_colsum_partials_batched(self._stream(), arr, len(items)), "grappa_colsum_partials_batched")
+        self._join_aside()                        # the gradients launched beside the pass are complete for whatever follows on this stream
 
     def _launch_wgrad_group(self, items) -> None:
         # one grid per load style: products whose operands allow 16-byte loads along their rows (aligned, leading dimension % 4 == 0

@@ -108,6 +108,14 @@ def _wants_amax(be, backward: bool):
     return True if f is None else (True if f(backward) else "pair")
 
 
+def _wgrads_aside(be, all_streams: bool = False) -> None:
+    """end of a GNN block's backward pass (or of the writer heads'): the weight gradients queued so far go out on a side stream beside
+    the small products that follow (backend.launch_wgrads_aside)"""
+    f = getattr(be, "launch_wgrads_aside", None)
+    if f is not None:
+        f(all_streams)
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -289,6 +297,7 @@ class AttBlockFn(Function):
         dh1 = _new(h1.shape, h1)
         be.gemm(dft, w_fc, dh1, M=N, N=Fd, K=ft.shape[1], b_kcontig=False, res=dh3, a_scales=sz)        # + residual branch
         dh, _ = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
+        _wgrads_aside(be)
         return (dh,) + (None,) * 16
 
 
@@ -354,6 +363,7 @@ class ConvBlockFn(Function):
             be.neighbor_mean(plan, dmn, agg, True)
             be.gemm(dz1, w_self, dh1, M=N, N=Fd, K=Fd, b_kcontig=False, pre=agg, res=dh3, a_scales=sz)
         dh, _ = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
+        _wgrads_aside(be)
         return (dh,) + (None,) * 13
 
 
@@ -372,6 +382,7 @@ class SplitHeadsFn(Function):
     @staticmethod
     def backward(ctx, *gs):
         be = get_backend()
+        _wgrads_aside(be, all_streams=True)          # every head is done: what they left queued runs beside the GNN's backward pass
         gs = [_c(g) for g in gs if g is not None]
         if not gs:
             return None, None
