@@ -290,10 +290,10 @@ struct Plan {
 
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
 // cfg 5, 6: the 128x128 and 256x128 tiles of the bf16-split kernel (gemm_bf16x_impl.h), one 512-thread workgroup per CU
-constexpr int NCFG = 7;
-constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256};
-constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128};
-constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
+constexpr int NCFG = 8;                 // cfg 7: the 256 x 256 tile of the pair-format kernel (GRAPPA_PAIRS_TILE=256)
+constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256, 256};
+constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128, 256};
+constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
 
 // split-K summed by a launch of gemm_splitk_reduce_kernel behind the product (default) or inside the product's own launch by the last
 // workgroup of each tile (GRAPPA_SPLITK_IN_KERNEL=1 / grappa_gemm_f32_set_splitk_reduce_launch(0)).  Same bits; the second is the
@@ -325,8 +325,8 @@ long plan_cus() {
 
 struct CostModel {
     // MACs per cycle per CU sustained in the main loop, and the per-tile prologue + epilogue expressed in columns of K
-    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0};
-    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0};
+    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0, 450.0};
+    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0, 200.0};
     double grid(int c, long wgs, int kps) const {
         const int conc = CFG_CONC[c];
         const long ncu = plan_cus();
@@ -340,7 +340,12 @@ struct CostModel {
     static double splitk(int nsplit, double elems) { return 12000.0 + nsplit * elems / 200.0; }   // two launches + slab write / reduce
 };
 
-Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool planes = false) {
+int pairs_cfg() {
+    static const int t = getenv("GRAPPA_PAIRS_TILE") ? atoi(getenv("GRAPPA_PAIRS_TILE")) : 128;
+    return t == 256 ? 7 : 6;
+}
+
+Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false) {
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
@@ -357,7 +362,8 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
     for (int c = 0; c < NCFG; ++c) {
         if (g_override.cfg >= 0 && c != g_override.cfg && !planes) continue;
         if (bf16x != (c >= 5)) continue;
-        if (planes && c != 6) continue;                  // the plane-format kernel has the 256 x 128 tile only
+        if (planes && c != (pairs ? pairs_cfg() : 6)) continue;      // the plane-format kernels have one tile shape each
+        if (!planes && c == 7) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
@@ -452,6 +458,8 @@ extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
         if (c > a) a = c;
         const size_t e = plan_workspace_floats(make_plan(M, N, K, true, true, true), M, N);
         if (e > a) a = e;
+        const size_t f = plan_workspace_floats(make_plan(M, N, K, true, true, true, true), M, N);
+        if (f > a) a = f;
     }
     return a * sizeof(float) + amax_part_bytes(M, N);
 }
@@ -703,7 +711,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     if (d->precision == GRAPPA_GEMM_F32_F16X3 && bf16x && (!d->a_amax || !d->b_amax)) return GRAPPA_ERR_ARG;
     // the native fp32 kernel (precision F32_MFMA, or M / N <= 32) keeps its register-lean fp32-only epilogue walk
     if (!bf16x && (d->Cp || d->C1p || d->resp || d->auxp || !d->C)) return GRAPPA_ERR_ARG;
-    Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes);
+    Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes, pairs);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
     if (need > 0 && (!ws || ws_bytes < need)) return GRAPPA_ERR_WORKSPACE;

@@ -37,12 +37,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int QBM = 256, QBN = 128, QSLAB = 16, QNT = 256, QNSTAGE = 3;
+constexpr int QBM = 256, QSLAB = 16, QNSTAGE = 3;
 constexpr int QROWB = 64;                       // bytes of a row in a stage: 16 k x (hi, lo)
 constexpr int QA_BYTES = QBM * QROWB;           // 16 KB
-constexpr int QSTAGE = (QBM + QBN) * QROWB;     // 24 KB
-constexpr int QPIECES = 6;                      // LDS-DMA instructions per wavefront and slab: 4 of A + 2 of B (1 KB = 16 rows each)
-constexpr int QTM = 4, QTN = 2;                 // 32 x 32 accumulators per wavefront
+constexpr int QTM = 4, QTN = 2;                 // 32 x 32 accumulators per wavefront (128 x 64)
+// two shapes: BN = 128 on 256 threads (24 KB stages, TWO workgroups per CU: the default) and BN = 256 on 512 threads (32 KB stages, one
+// workgroup per CU, 21 instead of 32 operand bytes per MFMA-cycle: GRAPPA_PAIRS_TILE=256)
+template <int BN> struct QShape {
+    static constexpr int NT = BN * 2;                               // 4 or 8 wavefronts, two rows of them
+    static constexpr int NW = NT / 64, NWN = BN / 64;
+    static constexpr int STAGE = (QBM + BN) * QROWB;
+    static constexpr int A_PIECES = (QBM / 16) / NW, B_PIECES = (BN / 16) / NW;      // 1 KB pieces (16 rows) per wavefront and slab
+    static constexpr int PIECES = A_PIECES + B_PIECES;
+};
 
 __device__ inline int amax_shift(unsigned bits) { return 141 - (int)((bits >> 23) & 0xffu); }
 
@@ -53,23 +60,27 @@ __device__ inline void glds16(const char* g, char* lds_wave_base) {
 // per-lane source offsets (bytes, without the slab's uniform part) of a wavefront's pieces.  A piece = 16 rows x 64 B: lane -> (row =
 // lane >> 2, physical chunk = lane & 3); logical chunk (0, 1: hi k 0..7, 8..15; 2, 3: lo) = physical ^ ((row >> 2) & 3), so that the 16
 // lanes of a ds_read_b128 group (rows r..r+3, r+12.., r+20..) hit 16 distinct 16-byte slots of the 256-byte bank row
-struct QLaneSrc { unsigned a[4], b[2]; };
-__device__ inline QLaneSrc qlane_sources(const grappa_gemm_desc& d, int m0, int n0, int wave, int lane) {
-    QLaneSrc s;
+template <int BN> struct QLaneSrc { unsigned a[QShape<BN>::A_PIECES], b[QShape<BN>::B_PIECES]; };
+template <int BN>
+__device__ inline QLaneSrc<BN> qlane_sources(const grappa_gemm_desc& d, int m0, int n0, int wave, int lane) {
+    using S = QShape<BN>;
+    QLaneSrc<BN> s;
     const int rin = lane >> 2, c = (lane & 3) ^ ((lane >> 4) & 3);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s.a[q] = ((unsigned)min(m0 + (wave + 4 * q) * 16 + rin, d.M - 1) * (unsigned)d.lda + 8u * c) * 2u;
+    for (int q = 0; q < S::A_PIECES; ++q) s.a[q] = ((unsigned)min(m0 + (wave + S::NW * q) * 16 + rin, d.M - 1) * (unsigned)d.lda + 8u * c) * 2u;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) s.b[q] = ((unsigned)min(n0 + (wave + 4 * q) * 16 + rin, d.N - 1) * (unsigned)d.ldb + 8u * c) * 2u;
+    for (int q = 0; q < S::B_PIECES; ++q) s.b[q] = ((unsigned)min(n0 + (wave + S::NW * q) * 16 + rin, d.N - 1) * (unsigned)d.ldb + 8u * c) * 2u;
     return s;
 }
 
-__device__ inline void qissue_slab(const char* __restrict__ A, const char* __restrict__ B, size_t k_bytes, const QLaneSrc& s, char* __restrict__ stage,
+template <int BN>
+__device__ inline void qissue_slab(const char* __restrict__ A, const char* __restrict__ B, size_t k_bytes, const QLaneSrc<BN>& s, char* __restrict__ stage,
                                    int wave) {
+    using S = QShape<BN>;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(A + k_bytes + s.a[q], stage + (wave + 4 * q) * 1024);
+    for (int q = 0; q < S::A_PIECES; ++q) glds16(A + k_bytes + s.a[q], stage + (wave + S::NW * q) * 1024);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) glds16(B + k_bytes + s.b[q], stage + QA_BYTES + (wave + 4 * q) * 1024);
+    for (int q = 0; q < S::B_PIECES; ++q) glds16(B + k_bytes + s.b[q], stage + QA_BYTES + (wave + S::NW * q) * 1024);
 }
 
 struct QFrags { f16x8 a[QTM][2], b[QTN][2]; };      // [32-row block][hi / lo]
@@ -101,14 +112,17 @@ __device__ inline void qmfma(const QFrags& f, f32x16 (&acc)[QTM][QTN]) {
     }
 }
 
-__global__ __launch_bounds__(QNT, 2) void gemm_pairs_kernel(GemmParams p) {
+template <int QBN>
+__global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_kernel(GemmParams p) {
+    using S = QShape<QBN>;
+    constexpr int QSTAGE = S::STAGE, QPIECES = S::PIECES;
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
     const TileCoord tc = map_workgroup(p);
     const int split = tc.split, tile_local = tc.tile_local;
     const int m0 = tc.tile_m * QBM, n0 = tc.tile_n * QBN;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave / S::NWN) * 128, wn0 = (wave % S::NWN) * 64;
     const int lr = lane & 31, lh = lane >> 5;
     const int kbeg = split * p.k_per_split;
     const int kend = min(d.K, kbeg + p.k_per_split);
@@ -126,14 +140,14 @@ __global__ __launch_bounds__(QNT, 2) void gemm_pairs_kernel(GemmParams p) {
         const char* A = reinterpret_cast<const char*>(d.A);
         const char* B = reinterpret_cast<const char*>(d.B);
         const size_t kb0 = (size_t)kbeg * 4;                  // 16 k = 64 bytes of a row
-        const QLaneSrc src = qlane_sources(d, m0, n0, wave, lane);
+        const QLaneSrc<QBN> src = qlane_sources<QBN>(d, m0, n0, wave, lane);
         const unsigned swz = (lr >> 2) & 3;
         const unsigned off[2] = {lr * QROWB + ((lh ^ swz) << 4), lr * QROWB + (((2 + lh) ^ swz) << 4)};
         QFrags f0, f1;
 
 #pragma unroll
         for (int u = 0; u < QNSTAGE; ++u)
-            if (u < nslab) qissue_slab(A, B, kb0 + (size_t)u * QROWB, src, smem + u * QSTAGE, wave);
+            if (u < nslab) qissue_slab<QBN>(A, B, kb0 + (size_t)u * QROWB, src, smem + u * QSTAGE, wave);
         if (nslab >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QPIECES) : "memory");
         else if (nslab == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(QNT, 2) void gemm_pairs_kernel(GemmParams p) {
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
             __builtin_amdgcn_s_barrier();                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            if ((T) + QNSTAGE < nslab && GQ_KNOCK != 1) qissue_slab(A, B, kb0 + (size_t)((T) + QNSTAGE) * QROWB, src, cur_, wave);      \
+            if ((T) + QNSTAGE < nslab && GQ_KNOCK != 1) qissue_slab<QBN>(A, B, kb0 + (size_t)((T) + QNSTAGE) * QROWB, src, cur_, wave); \
             qread_frags(smem + st * QSTAGE, off, wm0, wn0, FN);                                                                        \
         }                                                                                                                              \
         qmfma(FC, acc);                                                                                                                \
@@ -233,18 +247,20 @@ __global__ __launch_bounds__(QNT, 2) void gemm_pairs_kernel(GemmParams p) {
     for (int i = 0; i < QTM; ++i) epilogue_band<QBM, QBN, QTN>(p, acc[i], wave_buf, m0, n0, mb + 32 * i, n, lane, b4, split, tile_local, p.vec_io != 0);
 }
 
+template <int BN>
 int launch_pairs(hipStream_t st, GemmParams& p) {
-    constexpr size_t ring = (size_t)QNSTAGE * QSTAGE, staging = (QNT / 64) * (size_t)EPI_WAVE_BYTES;
+    using S = QShape<BN>;
+    constexpr size_t ring = (size_t)QNSTAGE * S::STAGE, staging = S::NW * (size_t)EPI_WAVE_BYTES;
     constexpr size_t smem = ring > staging ? ring : staging;
-    static_assert(smem <= 80 * 1024, "two workgroups per CU");
-    auto kern = gemm_pairs_kernel;
+    static_assert(BN != 128 || smem <= 80 * 1024, "two workgroups per CU");
+    auto kern = gemm_pairs_kernel<BN>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return GRAPPA_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles_launch * p.nsplit), dim3(QNT), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.ntiles_launch * p.nsplit), dim3(S::NT), smem, st, p);
     return grappa_launch_status();
 }
 
@@ -302,4 +318,4 @@ extern "C" int grappa_split_pairs_f32(void* stream, int R, int C, const float* x
 }
 
 // called by grappa_gemm_f32 (gemm_f32.hip) when both operands are in the pair format (precision F32_F16X3); tile 256 x 128
-int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p) { return launch_pairs(st, p); }
+int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p) { return p.bn == 256 ? launch_pairs<256>(st, p) : launch_pairs<128>(st, p); }
