@@ -127,6 +127,7 @@ class HipBackend:
         self.defer_ln = os.environ.get("GRAPPA_DEFER_LN_REDUCTIONS", "1") not in ("0", "")      # tuning: 0 = reduce every LayerNorm's parameter gradients at once
         self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta)
         self._wq_task = None           # autograd graph task id of the backward pass the queues belong to
+        self.wgrad_queue_bytes = int(float(os.environ.get("GRAPPA_WGRAD_QUEUE_GB", "12")) * 2 ** 30)
         self.wgrads_aside = os.environ.get("GRAPPA_WGRADS_ASIDE", "1") not in ("0", "")      # tuning: 0 = every queued product waits for the end of the pass
         self._side_streams = {}        # (device, caller's stream handle) -> the side stream of launch_wgrads_aside
         self._aside = []               # (side stream, items kept alive) since the last flush
@@ -566,7 +567,9 @@ class HipBackend:
         if not in_pass:                           # not inside a backward pass: nothing will call back
             self.flush_wgrads()
             return sdz
-        if len(q) >= _lib.GEMM_GROUP_MAX:
+        # a queue is launched when it is full -- or when the operands it keeps alive exceed the byte budget (at C3 / C4 sizes
+        # sixteen (dz, x) pairs are tens of GB)
+        if len(q) >= _lib.GEMM_GROUP_MAX or sum(it[0].numel() + it[1].numel() for it in q) * 4 > self.wgrad_queue_bytes:
             del self._wq[st.cuda_stream]
             self._launch_wgrad_group(q)
         return sdz
