@@ -351,11 +351,14 @@ def main():
                       "LayerNorm + QKV product on (atom, position) rows (`achieved_with_algorithmic_credit` = that count over the same time)")
 
     def instrument(j, steps):
-        """instrumented repetition of a job's steps: HIP events around every GEMM / GAT launch on the launch stream (one stream:
-        GRAPPA_HEAD_STREAMS=1 semantics; profiles/ rocprof runs use the same setting) and around the gradient all-reduce
+        """instrumented repetition of a job's steps: HIP events around every GEMM / GAT launch on the launch stream (ONE stream:
+        GRAPPA_HEAD_STREAMS=1 and GRAPPA_WGRADS_ASIDE=0 semantics; profiles/ rocprof runs use the same settings) and around the gradient all-reduce
         -> (gemm roofline dict, gat roofline dict, ms per instrumented step, all-reduce ms per step)"""
         hs = model.parameter_writer.head_streams
         model.parameter_writer.head_streams = 1
+        aside = getattr(be, "wgrads_aside", False)
+        if on_gpu:
+            be.wgrads_aside = False           # one queue: a launch's HIP-event time is the kernel's own, not its share of a busy chip
         j.step()
         sync()
         j.allreduce_events = []
@@ -369,6 +372,8 @@ def main():
         ar_ms = sum((ev[0].elapsed_time(ev[1]) if on_gpu else ev) for ev in j.allreduce_events) / max(len(j.allreduce_events), 1)
         j.allreduce_events = None
         model.parameter_writer.head_streams = hs
+        if on_gpu:
+            be.wgrads_aside = aside
         n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
         # the passes that find the operands' row / column maxima (precision f32_f16x3) are part of that arithmetic's price: their time
         # is charged to the products (the launch count and the bytes stay those of the products)
