@@ -670,13 +670,17 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool planes = d->b_planes != 0;
     // pair format (fp16 hi / lo planes + the row maxima that define the power-of-two scale of every row): both operands, K-contiguous
     const bool pairs = planes && d->precision == GRAPPA_GEMM_F32_F16X3;
-    if (pairs && (!d->a_planes || !d->a_kcontig || !d->b_kcontig || !d->a_amax || !d->b_amax || d->amax_bcast || d->a_colsum)) return GRAPPA_ERR_ARG;
+    if (pairs && (!d->a_kcontig || !d->b_kcontig || !d->a_amax || !d->b_amax || d->amax_bcast || d->a_colsum)) return GRAPPA_ERR_ARG;
+    // "weight pairs": fp32 A (whole slabs of 16 in K, 16-byte aligned rows) with the weight in pairs
+    if (pairs && !d->a_planes && ((d->K & 15) != 0 || (reinterpret_cast<uintptr_t>(d->A) & 15) != 0 || (d->lda & 3) != 0 || d->lda < d->K)) return GRAPPA_ERR_ARG;
     if (planes) {
         auto ok = [](const void* q, int ld, int cols) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 7) == 0 && ld >= cols; };
         const int kpad = (d->K + 31) / 32 * 32;
         if (d->M <= 32 || d->N <= 32 || d->a_kcontig != d->b_kcontig) return GRAPPA_ERR_ARG;
         if (d->a_planes) {
             if (d->a_kcontig ? !(ok(d->A, d->lda, kpad) && ok(d->B, d->ldb, kpad)) : !(ok(d->A, d->lda, d->M) && ok(d->B, d->ldb, d->N))) return GRAPPA_ERR_ARG;
+        } else if (pairs) {
+            if (!ok(d->B, d->ldb, kpad)) return GRAPPA_ERR_ARG;
         } else {
             // fp32 A [M][K] + weight planes B [N][K]: whole slabs of 32 in K (fp32 rows are not zero padded), 16-byte aligned rows
             if (!d->a_kcontig || (d->K & 31) != 0 || (reinterpret_cast<uintptr_t>(d->A) & 15) != 0 || (d->lda & 3) != 0 || d->lda < d->K) return GRAPPA_ERR_ARG;

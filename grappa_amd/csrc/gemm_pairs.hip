@@ -247,6 +247,229 @@ __global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_kernel(GemmPara
     for (int i = 0; i < QTM; ++i) epilogue_band<QBM, QBN, QTN>(p, acc[i], wave_buf, m0, n0, mb + 32 * i, n, lane, b4, split, tile_local, p.vec_io != 0);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// "Weight pairs": A = fp32 activations [M][K] AS EVERY PRODUCER WRITES THEM, B = a weight matrix in the pair format (split once per
+// optimiser step).  Same ring, same two workgroups per CU; the A tile reaches the LDS as raw fp32 rows by LDS-DMA (16 k = one 64-byte
+// granule per row, the bytes of a pair granule), the wavefronts stand 4 x 1 -- each owns 64 rows x all 128 columns -- so that every A
+// fragment is read, scaled and split into its (hi, lo) by exactly ONE wavefront, in registers: 64 vector instructions per slab beside
+// 24 MFMAs (the fp32-operand kernel: ~200 per 24 across its two wavefronts of a SIMD, plus the LDS stores of the split tile), nothing
+// staged in registers, and the producer side of the model untouched.
+constexpr int WTM = 2, WTN = 4;                 // 32 x 32 accumulators per wavefront (64 x 128)
+struct WRaw { float4 a[WTM][2]; };              // raw fp32 of a lane's 8 k per 32-row block
+struct WBFrags { f16x8 b[WTN][2]; };            // [column block][hi / lo]
+
+__device__ inline void wread_a(const char* __restrict__ stage, const unsigned (&aoff)[2], int wm0, WRaw& f) {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) f.a[i][e] = *reinterpret_cast<const float4*>(stage + (wm0 + i * 32) * QROWB + aoff[e]);
+}
+__device__ inline void wread_b(const char* __restrict__ stage, const unsigned (&boff)[2], WBFrags& f) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) f.b[j][p] = *reinterpret_cast<const f16x8*>(stage + QA_BYTES + j * 32 * QROWB + boff[p]);
+}
+
+// 8 consecutive-k fp32 values of one row -> its hi / lo fp16 fragments, scaled by the row's power of two (exact) first
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ inline void wsplit(const float4 (&raw)[2], int shift, f16x8& hi, f16x8& lo) {
+    const float r[8] = {__builtin_ldexpf(raw[0].x, shift), __builtin_ldexpf(raw[0].y, shift), __builtin_ldexpf(raw[0].z, shift), __builtin_ldexpf(raw[0].w, shift),
+                        __builtin_ldexpf(raw[1].x, shift), __builtin_ldexpf(raw[1].y, shift), __builtin_ldexpf(raw[1].z, shift), __builtin_ldexpf(raw[1].w, shift)};
+    unsigned uh[4], ul[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f16x2 h, l;
+        h[0] = (_Float16)r[2 * e];                                // round to nearest even; |r| < 2^15 never overflows
+        h[1] = (_Float16)r[2 * e + 1];
+        l[0] = (_Float16)(r[2 * e] - (float)h[0]);
+        l[1] = (_Float16)(r[2 * e + 1] - (float)h[1]);
+        uh[e] = __builtin_bit_cast(unsigned, h);
+        ul[e] = __builtin_bit_cast(unsigned, l);
+    }
+    hi = __builtin_bit_cast(f16x8, make_uint4(uh[0], uh[1], uh[2], uh[3]));
+    lo = __builtin_bit_cast(f16x8, make_uint4(ul[0], ul[1], ul[2], ul[3]));
+}
+
+struct WLaneSrc { unsigned a[4], b[2]; };
+__device__ inline void wissue(const char* __restrict__ A, const char* __restrict__ B, size_t kb, const WLaneSrc& s, char* __restrict__ stage, int wave) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16(A + kb + s.a[q], stage + (wave + 4 * q) * 1024);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) glds16(B + kb + s.b[q], stage + QA_BYTES + (wave + 4 * q) * 1024);
+}
+
+// CLS 1 .. 4: the straight-line fp32 classes of gemm_common.h; 0: the general walk (and split-K slabs).  Every loop has constant
+// bounds and no branch on the class inside: the accumulators stay in registers (a runtime-indexed array would go to scratch)
+template <int CLS>
+__device__ __forceinline__ void wpairs_epilogue(const GemmParams& p, const f32x16 (&acc)[WTM][WTN], float* __restrict__ wave_buf, int m0, int n0, int wm0,
+                                                int lane, int split, int tile_local) {
+    const grappa_gemm_desc& d = p.d;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = n0 + 64 * h + ((lane & 15) << 2);
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias && p.nsplit == 1) {
+            b4.x = n < d.N ? d.bias[n] : 0.f;
+            b4.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
+            b4.z = n + 2 < d.N ? d.bias[n + 2] : 0.f;
+            b4.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) {
+            const f32x16 band[2] = {acc[i][2 * h], acc[i][2 * h + 1]};
+            const int mb = m0 + wm0 + 32 * i;
+            if (CLS != 0) epilogue_band_fast<2, CLS == 0 ? 1 : CLS, float, 4>(p, band, wave_buf, mb, n, lane, b4);
+            else epilogue_band<QBM, 128, 2>(p, band, wave_buf, m0, n0, mb, n, lane, b4, split, tile_local, p.vec_io != 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_wpairs_kernel(GemmParams p) {
+    constexpr int QBN = 128, QSTAGE = (QBM + QBN) * QROWB, QPIECES = 6;
+    extern __shared__ char smem[];
+    const grappa_gemm_desc& d = p.d;
+    const TileCoord tc = map_workgroup(p);
+    const int split = tc.split, tile_local = tc.tile_local;
+    const int m0 = tc.tile_m * QBM, n0 = tc.tile_n * QBN;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wm0 = wave * 64;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(d.K, kbeg + p.k_per_split);
+    const int nslab = (kend - kbeg + QSLAB - 1) / QSLAB;      // K % 16 == 0 (host-checked: fp32 rows carry no padding)
+
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    int sh[WTM];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) sh[i] = amax_shift(d.a_amax[min(m0 + wm0 + i * 32 + lr, d.M - 1)]);
+
+    if (nslab > 0) {
+        const char* A = reinterpret_cast<const char*>(d.A);
+        const char* B = reinterpret_cast<const char*>(d.B);
+        const size_t kb0 = (size_t)kbeg * 4;                  // 16 k = 64 bytes of a row, fp32 and pairs alike
+        // LDS-DMA pieces of 16 rows x 64 B: A rows are fp32 (lda floats apart), B rows pairs (ldb fp16 apart)
+        WLaneSrc src;
+        {
+            const int rin = lane >> 2, c = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) src.a[q] = ((unsigned)min(m0 + (wave + 4 * q) * 16 + rin, d.M - 1) * (unsigned)d.lda + 4u * c) * 4u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) src.b[q] = ((unsigned)min(n0 + (wave + 4 * q) * 16 + rin, d.N - 1) * (unsigned)d.ldb + 8u * c) * 2u;
+        }
+        const unsigned swz = (lr >> 2) & 3;
+        const unsigned aoff[2] = {lr * QROWB + (((2 * lh) ^ swz) << 4), lr * QROWB + (((2 * lh + 1) ^ swz) << 4)};     // floats 8 lh .. + 3, + 4 .. + 7
+        const unsigned boff[2] = {lr * QROWB + ((lh ^ swz) << 4), lr * QROWB + (((2 + lh) ^ swz) << 4)};
+        WRaw r0, r1;              // raw A of even / odd slabs (the next slab's is read under this slab's MFMAs)
+        WBFrags fb;               // B fragments of the current slab only: re-read behind the MFMAs that consumed them (registers: 128
+                                  // accumulators + 32 + 2 x 16 + 16 split = 224; the other workgroup of the CU covers the read latency)
+
+#pragma unroll
+        for (int u = 0; u < QNSTAGE; ++u)
+            if (u < nslab) wissue(A, B, kb0 + (size_t)u * QROWB, src, smem + u * QSTAGE, wave);
+        if (nslab >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QPIECES) : "memory");
+        else if (nslab == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        wread_a(smem, aoff, wm0, r0);
+        wread_b(smem, boff, fb);
+        int st = 0;
+#define GW_STEP(T, RC, RN)                                                                                                             \
+    do {                                                                                                                               \
+        char* cur_ = smem + st * QSTAGE;                                                                                               \
+        st = st == QNSTAGE - 1 ? 0 : st + 1;                                                                                           \
+        if ((T) + 1 < nslab) {                                                                                                         \
+            if ((T) + 2 < nslab) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(QPIECES) : "memory");                             \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
+            __builtin_amdgcn_s_barrier();                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            if ((T) + QNSTAGE < nslab && GQ_KNOCK != 1) wissue(A, B, kb0 + (size_t)((T) + QNSTAGE) * QROWB, src, cur_, wave);           \
+            wread_a(smem + st * QSTAGE, aoff, wm0, RN);                                                                                \
+        }                                                                                                                              \
+        f16x8 ah_[WTM], al_[WTM];                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < WTM; ++i) wsplit(RC.a[i], sh[i], ah_[i], al_[i]);                                        \
+        _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)                                                                               \
+            _Pragma("unroll") for (int i = 0; i < WTM; ++i)                                                                            \
+                _Pragma("unroll") for (int j = 0; j < WTN; ++j) {                                                                      \
+                    if (GQ_KNOCK == 2) asm volatile("" ::"v"(fb.b[j][pr == 0 ? 1 : 0]), "v"(pr == 1 ? al_[i] : ah_[i]));                \
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.b[j][pr == 0 ? 1 : 0], pr == 1 ? al_[i] : ah_[i], acc[i][j], 0, 0, 0); \
+                }                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+        if ((T) + 1 < nslab) wread_b(smem + st * QSTAGE, boff, fb);                                                                    \
+    } while (0)
+        int t = 0;
+        for (; t + 1 < nslab; t += 2) {
+            GW_STEP(t, r0, r1);
+            GW_STEP(t + 1, r1, r0);
+        }
+        if (t < nslab) GW_STEP(t, r0, r1);
+#undef GW_STEP
+    }
+
+    // undo the row scales: element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, 32 j + 8 (e / 4) + 4 lh + e % 4)
+    {
+        const bool b_vec = (reinterpret_cast<uintptr_t>(d.b_amax) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + j * 32 + g * 8 + lh * 4;
+                int eb[4];
+                if (b_vec && n + 3 < d.N) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(d.b_amax + n);
+                    eb[0] = amax_shift(u.x); eb[1] = amax_shift(u.y); eb[2] = amax_shift(u.z); eb[3] = amax_shift(u.w);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) eb[q] = amax_shift(d.b_amax[min(n + q, d.N - 1)]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < WTM; ++i) acc[i][j][4 * g + q] = __builtin_ldexpf(acc[i][j][4 * g + q], -(sh[i] + eb[q]));
+            }
+    }
+    __syncthreads();                                         // the ring is dead: reuse as epilogue staging
+    if (GQ_KNOCK == 3) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    // the wavefront's 64 x 128 block as 2 x 2 bands of 32 rows x 64 columns of the shared row epilogue
+    float* wave_buf = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
+    const int cls = p.nsplit == 1 ? p.epi_class : 0;
+    switch (cls) {
+        case 1: wpairs_epilogue<1>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
+        case 2: wpairs_epilogue<2>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
+        case 3: wpairs_epilogue<3>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
+        case 4: wpairs_epilogue<4>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
+        default: wpairs_epilogue<0>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
+    }
+}
+
+int launch_wpairs(hipStream_t st, GemmParams& p) {
+    constexpr size_t ring = (size_t)QNSTAGE * (QBM + 128) * QROWB, staging = 4 * (size_t)EPI_WAVE_BYTES;
+    constexpr size_t smem = ring > staging ? ring : staging;
+    static_assert(smem <= 80 * 1024, "two workgroups per CU");
+    auto kern = gemm_wpairs_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return GRAPPA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.ntiles_launch * p.nsplit), dim3(256), smem, st, p);
+    return grappa_launch_status();
+}
+
 template <int BN>
 int launch_pairs(hipStream_t st, GemmParams& p) {
     using S = QShape<BN>;
@@ -318,4 +541,7 @@ extern "C" int grappa_split_pairs_f32(void* stream, int R, int C, const float* x
 }
 
 // called by grappa_gemm_f32 (gemm_f32.hip) when both operands are in the pair format (precision F32_F16X3); tile 256 x 128
-int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p) { return p.bn == 256 ? launch_pairs<256>(st, p) : launch_pairs<128>(st, p); }
+int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p) {
+    if (!p.d.a_planes) return launch_wpairs(st, p);          // fp32 A, weight pairs
+    return p.bn == 256 ? launch_pairs<256>(st, p) : launch_pairs<128>(st, p);
+}

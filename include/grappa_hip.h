@@ -131,7 +131,10 @@ typedef struct grappa_gemm_desc {
      * aligned, zeros beyond C up to the next multiple of 32.  precision F32_F16X3 with a_planes != 0 and b_planes != 0
      * (a_kcontig = b_kcontig = 1: forward with the pairs of W, dgrad with the pairs of W^T; lda / ldb = the rows' ld, plane strides
      * unused) reads both operands as pairs by LDS-DMA, a_amax / b_amax being the rows' amax_r; the result is bit-identical to the
-     * fp32-operand F32_F16X3 product of the same scales and K split.  M, N > 32; rows * ld * 2 < 2^32. */
+     * fp32-operand F32_F16X3 product of the same scales and K split.  M, N > 32; rows * ld * 2 < 2^32.
+     * b_planes != 0 alone ("weight pairs": A = fp32 activations [M][K], K % 16 == 0, lda % 4 == 0, 16-byte aligned, a_kcontig =
+     * b_kcontig = 1) takes A as it is -- raw fp32 rows by LDS-DMA, each wavefront splits the fragments of its own 64 rows -- and gives
+     * the same bits as the all-pairs product.  a_planes != 0 alone is refused. */
 } grappa_gemm_desc;
 
 /* Largest magnitudes of an fp32 matrix x[R][C] (leading dimension ldx), as fp32 bit patterns: row_amax[r] = max_c |x[r][c]|,

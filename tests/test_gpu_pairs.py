@@ -1,6 +1,7 @@
 """GPU (-m gpu): the pair-format product (csrc/gemm_pairs.hip; include/grappa_hip.h, ABI 5) through the C ABI: operands split once by
 grappa_split_pairs_f32 (rows of A, rows of W or -- for the input-gradient layout -- rows of W^T) give the SAME BITS as the fp32-operand
-fp16-split product of the same K split, and float64-grade errors on ragged shapes, scaled rows and the fused epilogues."""
+fp16-split product of the same K split, and float64-grade errors on ragged shapes, scaled rows and the fused epilogues.  Where K % 16 == 0
+`check` also runs the "weight pairs" form (fp32 A as it is + the pairs of W) and asserts the all-pairs product's bits."""
 import os
 import sys
 

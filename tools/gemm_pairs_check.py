@@ -49,7 +49,11 @@ def ws_for(M, N, K):
 def gemm(a, b, out, M, N, K, a_amax, b_amax, pairs, b_kcontig=True, ws=None, **kw):
     d = _lib.GemmDesc()
     d.M, d.N, d.K, d.a_kcontig, d.b_kcontig = M, N, K, 1, int(b_kcontig)
-    if pairs:
+    if pairs == "b":                        # "weight pairs": fp32 A, the weight in pairs
+        d.A, d.lda = a.data_ptr(), a.stride(0)
+        d.B, d.ldb, d.b_planes = b.data_ptr(), b.stride(0), 1
+        d.b_kcontig = 1
+    elif pairs:
         d.A, d.lda, d.a_planes = a.data_ptr(), a.stride(0), 1
         d.B, d.ldb, d.b_planes = b.data_ptr(), b.stride(0), 1
         d.b_kcontig = 1
@@ -96,6 +100,11 @@ def check(M, N, K, gen, dgrad=False, scale_rows=False, **epi):
     o_split = torch.full((M, N), float("nan"), device=dev)
     gemm(ap, bp, o_pairs, M, N, K, am_a, am_b, True, **kw)
     gemm(A, W, o_split, M, N, K, am_a, am_b, False, b_kcontig=not dgrad, **kw)
+    if K % 16 == 0:                         # fp32 A + weight pairs: the same bits as the all-pairs product (same tile, same K cuts)
+        o_wp = torch.full((M, N), float("nan"), device=dev)
+        gemm(A, bp, o_wp, M, N, K, am_a, am_b, "b", **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(o_wp, o_pairs), ("weight-pairs kernel differs from the pair kernel", float((o_wp - o_pairs).abs().max()))
     torch.cuda.synchronize()
     scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
     e_pairs = ((o_pairs.double() - ref).abs() / scale).max().item()
@@ -138,10 +147,12 @@ def bench(M, N, K, gen, dgrad=False, **epi):
     ws = ws_for(M, N, K)
     t_split = timeit(lambda: gemm(A, W, out, M, N, K, am_a, am_b, False, b_kcontig=not dgrad, ws=ws, **kw))
     t_pairs = timeit(lambda: gemm(ap, bp, out, M, N, K, am_a, am_b, True, ws=ws, **kw))
+    t_wp = timeit(lambda: gemm(A, bp, out, M, N, K, am_a, am_b, "b", ws=ws, **kw))
     fl = 2.0 * M * N * K
     print(f"  M={M:6d} N={N:5d} K={K:5d} dgrad={int(dgrad)} epi={sorted(epi)}: split {t_split:.3f} ms {fl / t_split / 1e9:7.1f} TFLOP/s | "
-          f"pairs {t_pairs:.3f} ms {fl / t_pairs / 1e9:7.1f} TFLOP/s | x{t_split / t_pairs:.2f}", flush=True)
-    return t_split, t_pairs
+          f"pairs {t_pairs:.3f} ms {fl / t_pairs / 1e9:7.1f} TFLOP/s x{t_split / t_pairs:.2f} | fp32 A + weight pairs {t_wp:.3f} ms {fl / t_wp / 1e9:7.1f} TFLOP/s "
+          f"x{t_split / t_wp:.2f}", flush=True)
+    return t_split, t_pairs, t_wp
 
 
 def main():
@@ -166,14 +177,15 @@ def main():
     if "--no-timing" in sys.argv:
         return
     print("timing (ms, TFLOP/s of algorithmic fp32 work)")
-    tot_s = tot_p = 0.0
+    tot_s = tot_p = tot_w = 0.0
     for M in (83328, 44325, 17158, 28248):
         for (N, K, dg, epi) in [(1536, 512, False, dict(bias=1)), (512, 512, False, dict(bias=1, drop=1, res=1)), (512, 512, False, dict(bias=1, act=1)),
                                 (512, 512, True, dict()), (512, 1536, True, dict(res=1))]:
-            s, p = bench(M, N, K, gen, dgrad=dg, **epi)
+            s, p, w = bench(M, N, K, gen, dgrad=dg, **epi)
             tot_s += s
             tot_p += p
-    print(f"sum over the shapes: split {tot_s:.2f} ms, pairs {tot_p:.2f} ms, x{tot_s / tot_p:.2f}")
+            tot_w += w
+    print(f"sum over the shapes: split {tot_s:.2f} ms, pairs {tot_p:.2f} ms (x{tot_s / tot_p:.2f}), fp32 A + weight pairs {tot_w:.2f} ms (x{tot_s / tot_w:.2f})")
     for M in (8233,):
         for (N, K) in [(512, 512), (2048, 512), (512, 2048), (256, 512)]:
             bench(M, N, K, gen, bias=1, act=1)
