@@ -500,6 +500,35 @@ def main():
                 be.set_gemm_precision(default_precision)
                 torch.cuda.empty_cache()
         job.graphs = headline_graphs
+        # BASELINE configs[4] / SURVEY 8(d): single-graph inference latency, ONE 50,046-atom protein graph (19 x T4 lysozyme), eval mode
+        try:
+            from grappa_amd.datasets import protein_graph_t4
+            g5 = protein_graph_t4(19).to(dev)
+            model.eval()
+            lat = []
+            with torch.no_grad():
+                for i in range(2 + 5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    model(g5)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if i >= 2:
+                        lat.append(e0.elapsed_time(e1))
+            lat.sort()
+            extras["c5_inference"] = {"value": lat[len(lat) // 2], "unit": "ms per forward (median of 5 after 2 warm-up)", "higher_is_better": False,
+                                      "min_ms": lat[0], "max_ms": lat[-1], "atoms": int(g5.num_nodes("n1")),
+                                      "tuples": {lv: int(g5.num_nodes(lv)) for lv in ("n2", "n3", "n4", "n4_improper")},
+                                      "atoms_per_s": 1e3 * g5.num_nodes("n1") / lat[len(lat) // 2], "gemm_precision": be.gemm_precision_name,
+                                      "config": "C5: ONE graph of 19 disjoint all-atom T4 lysozymes, production GrappaModel (keyed init), eval mode, no_grad; "
+                                                "parameters vs the oracle: tests/test_gpu_e2e.py::test_c5_protein_size_inference_matches_oracle"}
+            log(f"c5_inference: {extras['c5_inference']['value']:.1f} ms per forward")
+            del g5
+        except Exception as e:  # noqa: BLE001
+            extras["c5_inference"] = {"value": None, "error": repr(e)[:300]}
+        finally:
+            model.train()
+            torch.cuda.empty_cache()
 
     # N > 1, strong scaling: the same-workload N = 1 point.  Rank 0 alone runs the WHOLE global batch (chunks of --chunk molecules, gradients
     # accumulated, one optimiser step, no collective) while the other ranks wait at the barrier that follows; last, so that nothing

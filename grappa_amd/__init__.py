@@ -8,6 +8,7 @@ from .energy import Energy
 from .loss import MolwiseLoss
 from .deploy import get_default_model_config, model_from_config, model_from_dict
 from .grappa import Grappa
+from .loading import model_from_tag, model_from_path
 from .evaluation import FastEvaluator
 from .schedule import TrainSchedule
 from .device_dataset import DeviceDataset
@@ -16,5 +17,5 @@ from .moldata import MolData
 from .trainer import Trainer
 
 __all__ = ["MolBatch", "batch", "unbatch", "set_number_confs", "delete_dummy_confs", "Molecule", "Parameters", "GrappaModel",
-           "Energy", "MolwiseLoss", "get_default_model_config", "model_from_config", "model_from_dict", "Grappa", "FastEvaluator",
+           "Energy", "MolwiseLoss", "get_default_model_config", "model_from_config", "model_from_dict", "model_from_tag", "model_from_path", "Grappa", "FastEvaluator",
            "TrainSchedule", "DeviceDataset", "Dataset", "MolData", "Trainer"]

@@ -36,4 +36,5 @@ def model_from_dict(model_dict: Dict):
     """Load the reference's exported `.pth` container {'state_dict','config',...} (utils/loading_utils.py:64-73)."""
     model = model_from_config(model_dict["config"]["model_config"])
     model.load_state_dict(model_dict["state_dict"])
+    model.eval()
     return model

@@ -16,6 +16,18 @@ class Grappa:
         self.device = device
         self.field_of_view = model.field_of_view
 
+    @classmethod
+    def from_tag(cls, tag: str = "latest", max_element=constants.MAX_ELEMENT, device: str = "cuda", models_dir=None) -> "Grappa":
+        """a released model ('latest', 'grappa-1.2', 'grappa-1.1', ...) or a `.pth` exported into the models directory (grappa.py:26-35)"""
+        from .loading import model_from_tag
+        return cls(model_from_tag(tag, models_dir), max_element, device)
+
+    @classmethod
+    def from_file(cls, path, max_element=constants.MAX_ELEMENT, device: str = "cuda", config=None) -> "Grappa":
+        """an exported `.pth` container or a training checkpoint (`best-model.ckpt`) of the reference or of `grappa_amd.trainer`"""
+        from .loading import model_from_path
+        return cls(model_from_path(path, config), max_element, device)
+
     def predict(self, molecule: Molecule) -> Parameters:
         self.model.eval()
         g = molecule.to_dgl(max_element=self.max_element, exclude_feats=[])
