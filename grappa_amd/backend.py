@@ -128,6 +128,10 @@ class HipBackend:
         self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta)
         self._wq_task = None           # autograd graph task id of the backward pass the queues belong to
         self.wgrad_queue_bytes = int(float(os.environ.get("GRAPPA_WGRAD_QUEUE_GB", "12")) * 2 ** 30)
+        self._tails = None             # what set_tail_launches last told the library (None: the library's default)
+        self._tails_pinned = False
+        if os.environ.get("GRAPPA_PLAN_TAILS", "") != "":
+            self.pin_tail_launches(os.environ["GRAPPA_PLAN_TAILS"] != "0")
         self.wgrads_aside = os.environ.get("GRAPPA_WGRADS_ASIDE", "1") not in ("0", "")      # tuning: 0 = every queued product waits for the end of the pass
         self._side_streams = {}        # (device, caller's stream handle) -> the side stream of launch_wgrads_aside
         self._aside = []               # (side stream, items kept alive) since the last flush
@@ -600,6 +604,26 @@ class HipBackend:
     # 256 CUs) that leaves half of the chip idle, and the weight gradients nobody waits for pile up behind it.  launch_wgrads_aside() takes
     # what is queued and launches it AT ONCE as grouped grids on a side stream, ordered behind the streams that produced the operands; the
     # operands stay referenced until flush_wgrads() has put the caller's stream behind the side stream again.
+    def set_tail_launches(self, on: bool) -> None:
+        """split-K tail launches of the products that follow (include/grappa_hip.h grappa_gemm_f32_set_tail_launches).  The model turns
+        them off while the writer heads keep several streams busy (a partial last round then runs beside another head's kernels: C2 step
+        36.4 -> 36.0 ms) and on again on one stream (37.5 -> 37.4).  Ignored while pinned (pin_tail_launches; GRAPPA_PLAN_TAILS in the
+        environment pins at start-up)."""
+        if self._tails_pinned:
+            return
+        on = bool(on)
+        if on != self._tails:
+            self.lib.grappa_gemm_f32_set_tail_launches(int(on))
+            self._tails = on
+
+    def pin_tail_launches(self, on: Optional[bool]) -> None:
+        """True / False: tail launches on / off whatever the model asks for (comparisons that need the same K cuts on one stream and on
+        four); None: back to the model's choice"""
+        self._tails_pinned = False
+        if on is not None:
+            self.set_tail_launches(on)
+            self._tails_pinned = True
+
     def launch_wgrads_aside(self, all_streams: bool = False) -> None:
         if not self.wgrads_aside or not self._wq:
             return

@@ -323,6 +323,16 @@ long plan_cus() {
     return env >= 32 && env <= 256 ? env : 256;
 }
 
+// Tail launches on / off (grappa_gemm_f32_set_tail_launches; environment GRAPPA_PLAN_TAILS as the default).  A caller that keeps several
+// streams busy turns them off: a product's partial last round then overlaps with another stream's kernels, and the tail's two extra
+// launches and slab round trip cost more than they return (C2 step, writer heads on four streams: 36.4 -> 36.0 ms; on one stream
+// 37.4 -> 37.5; profiles/r3_plan_tails_ab.txt)
+int g_tails = -1;
+bool plan_tails() {
+    static const bool env_on = !(getenv("GRAPPA_PLAN_TAILS") && atoi(getenv("GRAPPA_PLAN_TAILS")) == 0);
+    return g_tails < 0 ? env_on : g_tails != 0;
+}
+
 struct CostModel {
     // MACs per cycle per CU sustained in the main loop, and the per-tile prologue + epilogue expressed in columns of K
     const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0, 450.0};
@@ -386,7 +396,7 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
             cand.tail_k_per_split = 0;
             const long ncu = plan_cus();
             const long rem = tiles % ncu;
-            if (nsplit == 1 && tiles > ncu && rem > 0 && rem <= ncu * 5 / 8 && g_override.tail != 0) {
+            if (nsplit == 1 && tiles > ncu && rem > 0 && rem <= ncu * 5 / 8 && g_override.tail != 0 && plan_tails()) {
                 int ts = (int)(ncu / rem);
                 if (ts > max_tail_split) ts = max_tail_split;
                 int tkps = (K + ts - 1) / ts;
@@ -478,6 +488,8 @@ extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* til
 }
 
 extern "C" void grappa_gemm_f32_set_splitk_reduce_launch(int on) { g_splitk_launch = on < 0 ? -1 : (on != 0); }
+
+extern "C" void grappa_gemm_f32_set_tail_launches(int on) { g_tails = on < 0 ? -1 : (on != 0); }
 
 extern "C" void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail) {
     g_override.cfg = cfg;

@@ -492,6 +492,10 @@ class WriteParameters(nn.Module):
         writers = self._writers_largest_first()
         # every head reads an alias of h of its own, so that its gradient of h arrives alone at the node that adds the four
         aliases = ops.SplitHeadsFn.apply(h, len(writers)) if (torch.is_grad_enabled() and h.requires_grad) else (h,) * len(writers)
+        be = get_backend()
+        if hasattr(be, "set_tail_launches"):
+            # several streams busy: a product's partial last round overlaps with another head's kernels, its split-K tail launch is a loss
+            be.set_tail_launches(not (self.head_streams > 1 and h.is_cuda))
         try:
             if self.head_streams <= 1 or not h.is_cuda:
                 for w, a in zip(writers, aliases):          # same host order (hence dropout seeds) as the multi-stream path

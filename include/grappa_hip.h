@@ -27,7 +27,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 5
+#define GRAPPA_ABI_VERSION 6
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -177,6 +177,11 @@ int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* t
 /* tuning and tests only, not thread safe: force the tile configuration index (0..6, -1 = model's choice), the split-K factor
  * (0 = model's choice) and the tail launch (1 on, 0 off, -1 = model's choice) of every following plan */
 void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail);
+/* not thread safe: tail launches of the following plans on (1), off (0) or back to the default (-1: on, unless the environment has
+ * GRAPPA_PLAN_TAILS=0).  A caller that keeps several streams busy turns them off: the partial last round of a product then runs beside
+ * another stream's kernels and the tail's extra launches and slab round trip are a loss (HipBackend does, for the writer heads on
+ * four streams).  Results differ only in the summation order of the tail tiles' K slices */
+void grappa_gemm_f32_set_tail_launches(int on);
 /* tuning and tests only, not thread safe: where a split-K product of the fp32-operand split kernels sums its K slices.  1 (default):
  * a launch of the reduction kernel behind the product; 0: inside the product's own launch -- the last workgroup of a tile to
  * arrive (a ticket per tile in the workspace) adds the slabs in the fixed order 0, 1, ... and runs the epilogue.  Same bits either

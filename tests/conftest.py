@@ -31,3 +31,17 @@ def ref_backend():
     backend.set_backend(RefBackend())
     yield backend.get_backend()
     backend.set_backend(old)
+
+
+@pytest.fixture(autouse=True)
+def _library_defaults(request):
+    """GPU tests: every test starts from the library's default plan settings (split-K tail launches on; a model on four head streams turns
+    them off for the products that follow, which would otherwise leak into the product-level tests behind it)"""
+    if request.node.get_closest_marker("gpu") is not None:
+        from grappa_amd import backend
+        be = backend._BACKEND
+        if be is not None and hasattr(be, "pin_tail_launches"):
+            be.pin_tail_launches(None)
+            be.lib.grappa_gemm_f32_set_tail_launches(-1)
+            be._tails = None
+    yield

@@ -371,10 +371,9 @@ def test_backward_products_in_bf16x3_leave_the_forward_untouched():
 
 
 def test_writer_heads_on_streams_match_single_stream():
-    """opt-in GRAPPA_HEAD_STREAMS=4 (the default is one stream): loss, parameters and gradients agree with the single-stream
-    result to the path's tolerance (with the shipped kernels the runs have been bit-identical; the tolerance is there because a
-    since-removed LayerNorm kernel deviated under concurrent queues for reasons below this library, DESIGN.md section 6, which is
-    also why the option is off by default); single-stream runs must be bit-reproducible."""
+    """the writer heads on four HIP streams (the default) against GRAPPA_HEAD_STREAMS=1: loss, parameters and gradients are
+    bit-identical when both plan the same K cuts (grouped launches off, split-K tails pinned); single-stream runs must be
+    bit-reproducible.  (History: a since-removed LayerNorm kernel deviated under concurrent queues)"""
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.datasets import build_batch_from_pool
     from grappa_amd.optim import FlatParams
@@ -387,6 +386,7 @@ def test_writer_heads_on_streams_match_single_stream():
     from grappa_amd.backend import get_backend
     be = get_backend()
     defer, be.defer_wgrads = be.defer_wgrads, False        # grouped weight gradients exist on the caller's stream only: another summation order
+    be.pin_tail_launches(False)                            # (the model plans without split-K tails on four streams, with them on one: same K cuts here)
     for streams in (1, 1, 4):
         model.parameter_writer.head_streams = streams
         ops.manual_seed(77)
@@ -402,6 +402,7 @@ def test_writer_heads_on_streams_match_single_stream():
     loss4, grad4, k44, eq4 = res[2]
     model.parameter_writer.head_streams = 1
     be.defer_wgrads = defer
+    be.pin_tail_launches(None)
     # with the shipped kernels the four-stream step has always been bit-identical; anything else is the multi-queue deviation of
     # DESIGN.md section 6 coming back and must be seen, not absorbed by a tolerance
     assert torch.equal(loss4, loss1) and torch.equal(k44, k41) and torch.equal(eq4, eq1) and torch.equal(grad4, grad1)

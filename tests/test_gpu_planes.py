@@ -170,6 +170,49 @@ def test_split_k_finished_inside_the_launch_equals_the_reduction_launch_bit_for_
             assert torch.equal(a, b)
 
 
+def test_tail_launches_can_be_switched_off_and_the_model_does_so_on_four_streams():
+    """grappa_gemm_f32_set_tail_launches: the planner stops cutting the K of the last partial round; the product is the same to fp32
+    summation order; `WriteParameters` turns the tails off while its heads keep four streams busy and on again on one stream, unless pinned"""
+    from grappa_amd import GrappaModel
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    from test_host_train import TINY
+    be = get_backend()
+
+    def plan(M, N, K):
+        v = [ctypes.c_int() for _ in range(5)]
+        be.lib.grappa_gemm_f32_plan(M, N, K, 5, *[ctypes.byref(x) for x in v])
+        return [x.value for x in v]
+
+    try:
+        assert plan(50000, 512, 512)[4] > 1                          # library default: a tail of 16 tiles, K cut 4 ways
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        x, w = torch.randn(50000, 512, generator=gen, device="cuda"), torch.randn(512, 512, generator=gen, device="cuda") * 0.05
+        with_tail, without = torch.empty(50000, 512, device="cuda"), torch.empty(50000, 512, device="cuda")
+        be.gemm(x, w, with_tail, M=50000, N=512, K=512)
+        be.pin_tail_launches(False)
+        assert plan(50000, 512, 512)[3:] == [0, 0]
+        be.gemm(x, w, without, M=50000, N=512, K=512)
+        torch.cuda.synchronize()
+        assert float((with_tail - without).abs().max()) <= 2e-6 * float(with_tail.abs().max())
+        be.pin_tail_launches(None)
+        model = GrappaModel(**TINY).to("cuda").eval()
+        g = build_batch_from_pool([30, 31], n_confs=2, seed=1).to("cuda")
+        with torch.no_grad():
+            model.parameter_writer.head_streams = 4
+            model(g)
+            assert be._tails is False and plan(50000, 512, 512)[4] == 0
+            model.parameter_writer.head_streams = 1
+            model(g)
+            assert be._tails is True and plan(50000, 512, 512)[4] > 1
+            be.pin_tail_launches(True)
+            model.parameter_writer.head_streams = 4
+            model(g)
+            assert be._tails is True and plan(50000, 512, 512)[4] > 1       # pinned: the model's request is ignored
+    finally:
+        be.pin_tail_launches(None)
+
+
 def test_train_step_with_and_without_grouped_weight_gradients():
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.backend import get_backend

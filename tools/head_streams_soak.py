@@ -27,6 +27,7 @@ def main():
     mode = sys.argv[2] if len(sys.argv) > 2 else "exact"
     be = get_backend()
     be.defer_wgrads = mode == "deferred"
+    be.pin_tail_launches(False)            # the four-stream setting of the split-K tails for both runs: the same K cuts
     model = model_from_config(get_default_model_config())
     bench.keyed_init(model)
     model = model.to("cuda").train()
