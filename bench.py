@@ -357,8 +357,12 @@ def main():
         hs = model.parameter_writer.head_streams
         model.parameter_writer.head_streams = 1
         aside = getattr(be, "wgrads_aside", False)
+        pinned = False
         if on_gpu:
             be.wgrads_aside = False           # one queue: a launch's HIP-event time is the kernel's own, not its share of a busy chip
+            if getattr(be, "_tails", None) is not None and not be._tails_pinned:
+                be.pin_tail_launches(be._tails)      # the products keep the plans of the measured configuration (split-K tails off under four streams)
+                pinned = True
         j.step()
         sync()
         j.allreduce_events = []
@@ -374,6 +378,8 @@ def main():
         model.parameter_writer.head_streams = hs
         if on_gpu:
             be.wgrads_aside = aside
+            if pinned:
+                be.pin_tail_launches(None)
         n, ms, fl, by = prof.get("gemm_f32", (0, 0.0, 0.0, 0.0))
         # the passes that find the operands' row / column maxima (precision f32_f16x3) are part of that arithmetic's price: their time
         # is charged to the products (the launch count and the bytes stay those of the products)

@@ -1,12 +1,13 @@
 #!/bin/bash
 # tools/profile_round.sh TAG -- on the GPU box: the rocprofv3 kernel-trace summary of the bench command, the two PMC passes (HBM
 # traffic) and then the default bench line, written under gpurun_out/ (copy what is to be judged into profiles/).
-# Everything runs on ONE stream while profiling (GRAPPA_HEAD_STREAMS=1, GRAPPA_WGRADS_ASIDE=0): per-kernel durations are then the kernels' own.
+# Everything runs on ONE stream while profiling (GRAPPA_HEAD_STREAMS=1, GRAPPA_WGRADS_ASIDE=0): per-kernel durations are then the kernels' own;
+# GRAPPA_PLAN_TAILS=0 keeps the products' plans those of the shipped four-stream configuration (no split-K tail launches).
 set -e
 TAG=$1
 R=$PWD
 mkdir -p gpurun_out
-export TMPDIR=/tmp GRAPPA_HEAD_STREAMS=1 GRAPPA_WGRADS_ASIDE=0
+export TMPDIR=/tmp GRAPPA_HEAD_STREAMS=1 GRAPPA_WGRADS_ASIDE=0 GRAPPA_PLAN_TAILS=0
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python3 $R/bench.py --no-cpu-baseline --no-extras --alt-precision "" --steps 5 > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/${TAG}_rocprof.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc/FETCH_SIZE -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --alt-precision "" > /dev/null 2> $R/gpurun_out/${TAG}_pmc_fetch.err
@@ -16,7 +17,7 @@ python tools/pmc_traffic.py gpurun_out/${TAG}_pmc/FETCH_SIZE gpurun_out/${TAG}_p
 # the default bench line last, with the traffic file of THIS build in place (bench.py reports `roofline.traffic` only when the file's
 # kernel-source hash matches the running sources)
 cp gpurun_out/${TAG}_pmc_traffic_c2.json profiles/pmc_traffic_c2.json
-( unset GRAPPA_HEAD_STREAMS GRAPPA_WGRADS_ASIDE; python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err )
+( unset GRAPPA_HEAD_STREAMS GRAPPA_WGRADS_ASIDE GRAPPA_PLAN_TAILS; python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err )
 cp $(find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_bench_c2_kernel_stats.csv
 # BASELINE configs[2] in the bf16 storage configuration: kernel-trace summary of the same train step
 cd /tmp
