@@ -72,6 +72,30 @@ def test_trainer_gpu():
     _run("cuda")
 
 
+@pytest.mark.gpu
+def test_training_trajectory_on_the_gpu_tracks_the_cpu_host_path():
+    """four epochs of the same training run (train mode: dropout masks from the same counter-based hash, weighted sampling, schedule,
+    fused Adam + clip) on the HIP path and on the CPU through the test-only backend: the epoch losses and the validation metrics of
+    every epoch agree -- state that lives across steps (weight maxima / plane caches keyed on the parameters' versions, deferred
+    reductions, the optimiser's flat buffers) is what a single-step comparison cannot see"""
+    from grappa_amd import backend
+    from oracle.ops_ref import RefBackend
+    gpu = _run("cuda")
+    old = backend._BACKEND
+    backend.set_backend(RefBackend())
+    try:
+        cpu = _run("cpu")
+    finally:
+        backend.set_backend(old)
+    for e, (a, b) in enumerate(zip(gpu, cpu)):
+        assert abs(a["train_loss"] - b["train_loss"]) <= 2e-3 * abs(b["train_loss"]), (e, a["train_loss"], b["train_loss"])
+        for ds in b["val_metrics"]:
+            for k, v in b["val_metrics"][ds].items():
+                if v is not None:
+                    assert abs(a["val_metrics"][ds][k] - v) <= 5e-3 * abs(v), (e, ds, k, a["val_metrics"][ds][k], v)
+        assert a["lr"] == b["lr"] if "lr" in a else True
+
+
 def test_epoch_batches_merge_a_short_tail_for_data_parallel_runs():
     from grappa_amd.trainer import epoch_batches
     names = ["a"] * 9
