@@ -6,6 +6,6 @@ import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
         r = json.loads(line)
-        print('ms/step', round(r['ms_per_step'], 2))
+        print('ms/step', round(r['ms_per_step'], 2), 'loss', r['final_loss'])
 "
 done

@@ -9,7 +9,7 @@ import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
         r = json.loads(line)
-        print('ms/step', round(r['ms_per_step'], 2), 'gemm ms (one queue)', round(r['roofline']['kernel_ms_per_step'], 2), 'launches', r['roofline']['launches_per_step'])
+        print('ms/step', round(r['ms_per_step'], 2), 'loss', r['final_loss'], 'gemm ms (one queue)', round(r['roofline']['kernel_ms_per_step'], 2), 'launches', r['roofline']['launches_per_step'])
 "
 done
 done
