@@ -528,8 +528,11 @@ class HipBackend:
         need = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
         ws = self._workspace(need, dev) if need else None
         el = lambda t: 0 if t is None else t.element_size()      # noqa: E731
+        # algorithmic bytes of the fused call: both operands once, the result, and what the epilogue has to read / write beside it
+        # (residual, saved activation for ELU', fp32 addend, the second output, an accumulated result's old value)
+        epi = M * N * (el(res) + el(aux) + el(pre) + (el(out) if out2 is not None else 0) + (el(final) if accumulate else 0))
         self._timed("gemm_f32", 2.0 * M * N * K, float(M * K * el(a if planes_a is None else planes_a) + N * K * (2 if planes_b is not None else 4)
-                                                         + M * N * el(final)),
+                                                         + M * N * el(final) + epi),
                     lambda: _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0),
                                  "grappa_gemm_f32"))
         return (sa, so) if out_amax else sa
