@@ -160,6 +160,29 @@ def test_production_config_against_oracle_on_a_larger_batch():
     with open("gpurun_out/parity_distance_fp32_vs_fp64_oracle.txt", "w") as fh:
         fh.write(report.replace("; ", "\n") + "\n")
     assert all(v < 3e-4 for (k, lab), v in dist32.items() if lab == "fp32"), report
+    # The same quantities at SURVEY 8(d)'s own floors (k 1e-3 incl. the torsion constants, eq 1e-4, E 1e-3 kcal/mol, G 1e-2 kcal/mol/A --
+    # absolute, not scaled with the tensor): three distances each -- GPU to float64, the fp32 ORACLE to float64 (what the reference's own
+    # arithmetic can hold at these floors), GPU to the fp32 oracle.  Where the fp32 oracle itself is beyond 1e-4 of float64 the floors of
+    # this file are fp32's, not this engine's: gate = the GPU is no further from float64 than 3x the fp32 oracle is
+    # (or inside the contract).
+    def contract(got_g, ref_g):
+        gd, rd = got_g.nodes["g"].data, ref_g.nodes["g"].data
+        m = {}
+        for lvl in ["n2", "n3", "n4", "n4_improper"]:
+            m[f"{lvl}_k"] = gu.rel_err(got_g.nodes[lvl].data["k"].detach().cpu().double(), ref_g.nodes[lvl].data["k"].detach().double().numpy(), 1e-3)
+            if lvl in ("n2", "n3"):
+                m[f"{lvl}_eq"] = gu.rel_err(got_g.nodes[lvl].data["eq"].detach().cpu().double(), ref_g.nodes[lvl].data["eq"].detach().double().numpy(), 1e-4)
+            m[f"energy_{lvl}"] = gu.rel_err(gd[f"energy_{lvl}"].detach().cpu().double(), rd[f"energy_{lvl}"].detach().double().numpy(), 1e-3)
+        m["energy"] = gu.rel_err(gd["energy"].detach().cpu().double(), rd["energy"].detach().double().numpy(), 1e-3)
+        m["gradient"] = gu.rel_err(got_g.nodes["n1"].data["gradient"].detach().cpu().double(), ref_g.nodes["n1"].data["gradient"].detach().double().numpy(), 1e-2)
+        return m
+    gpu64, ora64, gpu32 = contract(g, rg), contract(rg32, rg), contract(g, rg32)
+    lines = [f"{k}: GPU vs fp64 {gpu64[k]:.2e} | fp32 oracle vs fp64 {ora64[k]:.2e} | GPU vs fp32 oracle {gpu32[k]:.2e}" for k in sorted(gpu64)]
+    print("at SURVEY 8(d)'s floors --", "; ".join(lines))
+    with open("gpurun_out/parity_distance_fp32_vs_fp64_oracle.txt", "a") as fh:
+        fh.write("# at SURVEY 8(d)'s floors (k 1e-3, eq 1e-4, E 1e-3, G 1e-2, absolute)\n" + "\n".join(lines) + "\n")
+    for k in gpu64:
+        assert gpu64[k] < max(TOL, 3.0 * ora64[k]), (k, gpu64[k], ora64[k])
 
 
 def test_train_step_decreases_loss_and_matches_oracle_adam():
