@@ -10,7 +10,7 @@ global batch (same seed) and keeps its size-balanced share of it (`dist.shard_in
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Union
+from typing import Sequence, Dict, List, Optional, Union
 
 import numpy as np
 import torch
@@ -26,9 +26,14 @@ from .schedule import TrainSchedule
 
 
 def epoch_batches(names: List[str], batch_size: int, shuffle: bool = True, weights: Dict[str, float] = {}, balance_factor: float = 0.,
-                  generator: Optional[torch.Generator] = None, min_last: int = 1) -> List[np.ndarray]:
+                  generator: Optional[torch.Generator] = None, min_last: int = 1, sizes: Optional[Sequence[int]] = None,
+                  size_window: int = 0) -> List[np.ndarray]:
     """molecule ids of every batch of one epoch (the last batch may be smaller), GraphDataLoader semantics.  A trailing batch of
-    fewer than `min_last` molecules is appended to the batch before it (data parallel: every rank needs at least one molecule)."""
+    fewer than `min_last` molecules is appended to the batch before it (data parallel: every rank needs at least one molecule).
+    size_window = W >= 2 with `sizes` (atoms per molecule): the size-aware sampler of SURVEY 8(f) N1.  Batches are ragged
+    concatenations -- nothing is padded -- so what sizes can buy is EQUAL WORK per step, not less padding: the draws of every W
+    consecutive batches are sorted by size and dealt to those W batches in snake order, which keeps the epoch's draws (and every
+    window's) exactly as sampled and evens out the atoms per batch (step time, workspace high-water mark, rank balance)."""
     n = len(names)
     assert 0 <= balance_factor <= 1, f"balance_factor must be between 0 and 1, but got {balance_factor}"
     if shuffle and (len(weights) or balance_factor > 0):
@@ -46,6 +51,25 @@ def epoch_batches(names: List[str], batch_size: int, shuffle: bool = True, weigh
     else:
         order = np.arange(n)
     batches = [order[i:i + batch_size] for i in range(0, n, batch_size)]
+    if size_window >= 2 and sizes is not None and len(batches) > 1:
+        sz = np.asarray(sizes)
+        for w0 in range(0, len(batches), size_window):
+            group = batches[w0:w0 + size_window]
+            full = [b for b in group if len(b) == batch_size]          # a short last batch keeps its draws
+            if len(full) < 2:
+                continue
+            pool = np.concatenate(full)
+            pool = pool[np.argsort(-sz[pool], kind="stable")]
+            lanes = [[] for _ in full]
+            for r in range(0, len(pool), len(full)):                     # snake deal: 0..W-1, W-1..0, ...
+                chunk = pool[r:r + len(full)]
+                idx = range(len(chunk)) if (r // len(full)) % 2 == 0 else range(len(full) - 1, len(full) - 1 - len(chunk), -1)
+                for lane, m in zip(idx, chunk):
+                    lanes[lane].append(m)
+            it = iter(lanes)
+            for i, b in enumerate(group):
+                if len(b) == batch_size:
+                    batches[w0 + i] = np.asarray(next(it), dtype=order.dtype)
     if len(batches) > 1 and len(batches[-1]) < min_last:
         tail = batches.pop()
         batches[-1] = np.concatenate([batches[-1], tail])
@@ -59,11 +83,12 @@ class Trainer:
                  conf_strategy: Union[str, int] = 32, val_batch_size: int = 32, val_conf_strategy: Union[str, int] = "max",
                  lr: float = 1.5e-5, weight_decay: float = 0., gradient_clip_val: Optional[float] = 10.0,
                  proper_regularisation: float = 1e-3, improper_regularisation: float = 0., param_weights_by_dataset: Dict[str, float] = {},
-                 weights: Dict[str, float] = {}, balance_factor: float = 0., seed: int = 0, **schedule_kwargs):
+                 weights: Dict[str, float] = {}, balance_factor: float = 0., seed: int = 0, size_window: int = 0, **schedule_kwargs):
         self.model, self.train_set, self.val_set = model, train_set, val_set
         self.batch_size, self.conf_strategy = batch_size, conf_strategy
         self.val_batch_size, self.val_conf_strategy = val_batch_size, val_conf_strategy
         self.weights, self.balance_factor = dict(weights), balance_factor
+        self.size_window = int(size_window)            # >= 2: batches of equal work (epoch_batches)
         self.schedule = TrainSchedule(lr=lr, **schedule_kwargs)
         self.loss_fn = MolwiseLoss(proper_regularisation=proper_regularisation, improper_regularisation=improper_regularisation,
                                    param_weights_by_dataset=param_weights_by_dataset, **self.schedule.initial_loss_weights())
@@ -100,7 +125,8 @@ class Trainer:
         self.model.train()
         self.schedule.on_train_epoch_start(epoch, self.loss_fn, self.opt)
         total, count = None, 0
-        for ids in epoch_batches(self.train_set.names, self.batch_size, True, self.weights, self.balance_factor, self.gen, min_last=self.world):
+        for ids in epoch_batches(self.train_set.names, self.batch_size, True, self.weights, self.balance_factor, self.gen, min_last=self.world,
+                                 sizes=self.train_set.count["n1"] if self.size_window >= 2 else None, size_window=self.size_window):
             loss = self.train_step(ids)
             total = loss * len(ids) if total is None else total + loss * len(ids)      # stays on the device
             count += len(ids)

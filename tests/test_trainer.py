@@ -96,6 +96,29 @@ def test_training_trajectory_on_the_gpu_tracks_the_cpu_host_path():
         assert a["lr"] == b["lr"] if "lr" in a else True
 
 
+def test_size_window_evens_out_the_work_per_batch_and_keeps_the_draws():
+    from grappa_amd.trainer import epoch_batches
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(5, 120, size=403)
+    names = ["a"] * 403
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    plain = epoch_batches(names, 16, True, {}, 0.0, g1)
+    even = epoch_batches(names, 16, True, {}, 0.0, g2, sizes=sizes, size_window=6)
+    assert [len(b) for b in plain] == [len(b) for b in even] == [16] * 25 + [3]
+    for w0 in range(0, 26, 6):                                   # every window of 6 batches holds exactly the molecules that were drawn for it
+        assert sorted(np.concatenate(plain[w0:w0 + 6]).tolist()) == sorted(np.concatenate(even[w0:w0 + 6]).tolist())
+    assert np.array_equal(plain[-1], even[-1])                   # the short last batch keeps its draws
+    spread = lambda bs: np.std([sizes[b].sum() for b in bs if len(b) == 16])      # noqa: E731
+    for w0 in range(0, 24, 6):                                   # within a window the batches carry (almost) the same number of atoms
+        assert spread(even[w0:w0 + 6]) < 0.1 * spread(plain[w0:w0 + 6]), (w0, spread(even[w0:w0 + 6]), spread(plain[w0:w0 + 6]))
+    assert spread(even) < 0.6 * spread(plain)                    # (what is left over the epoch is the difference between the windows' draws)
+    # weighted sampling with replacement goes through the same path; size_window < 2 or no sizes: the reference's batches
+    g1, g2 = torch.Generator().manual_seed(4), torch.Generator().manual_seed(4)
+    a = epoch_batches(names, 16, True, {"a": 2.0}, 0.0, g1)
+    b = epoch_batches(names, 16, True, {"a": 2.0}, 0.0, g2, sizes=sizes, size_window=1)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def test_epoch_batches_merge_a_short_tail_for_data_parallel_runs():
     from grappa_amd.trainer import epoch_batches
     names = ["a"] * 9
