@@ -10,7 +10,9 @@ global batch (same seed) and keeps its size-balanced share of it (`dist.shard_in
 """
 from __future__ import annotations
 
-from typing import Sequence, Dict, List, Optional, Union
+import os
+import time
+from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -101,6 +103,7 @@ class Trainer:
         self.world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
         self.rank = tdist.get_rank() if self.world > 1 else 0
         self.history: List[Dict] = []
+        self.next_epoch = 0
 
     # ------------------------------------------------------------------------------------------------------------------
     def _my_share(self, ids: np.ndarray) -> np.ndarray:
@@ -154,18 +157,67 @@ class Trainer:
         es = self.schedule.on_validation_epoch_end(epoch, metrics)
         return metrics, es
 
-    def fit(self, max_epochs: int, log=None) -> List[Dict]:
-        for epoch in range(max_epochs):
+    def fit(self, max_epochs: int, log=None, checkpoint: Optional[str] = None, checkpoint_every: int = 1) -> List[Dict]:
+        """epochs [next_epoch, max_epochs): a fresh trainer starts at 0, one that has loaded a checkpoint where that run stopped.
+        checkpoint: path of the resumable state written every `checkpoint_every` epochs (the reference's `last.ckpt`)"""
+        for epoch in range(self.next_epoch, max_epochs):
             rec = {"epoch": epoch, "train_loss": self.train_epoch(epoch), "lr": self.schedule.lr}
             val = self.validate(epoch)
             if val is not None:
                 rec["val_metrics"], rec["early_stopping_loss"] = val
             self.history.append(rec)
+            self.next_epoch = epoch + 1
             if log is not None:
                 log(rec)
+            if checkpoint is not None and (self.next_epoch % max(int(checkpoint_every), 1) == 0 or self.schedule.should_stop):
+                self.save_checkpoint(checkpoint)
             if self.schedule.should_stop:
                 break
         return self.history
+
+    # ---- resumable state (reference: Lightning's last.ckpt + resume_trainrun.py; here one file, written by rank 0)
+    _SCHEDULE_STATE = ("lr", "warmup_step", "param_weight", "tuplewise_weight", "best_early_stopping_loss", "epochs_without_improvement", "should_stop")
+
+    def checkpoint_dict(self) -> Dict:
+        """everything the next epoch depends on: parameters, Adam moments and step count, the schedule's counters and the loss weights
+        it has set, the samplers' generators (batch order; dropout seeds), elapsed time, history.  A run resumed from it repeats the
+        uninterrupted run bit for bit (tests/test_trainer.py)."""
+        from . import ops
+        self.schedule.elapsed_time += time.time() - self.schedule.time_start
+        self.schedule.time_start = time.time()
+        return {"format": "grappa_amd.trainer/1", "next_epoch": self.next_epoch, "model": self.model_dict(),
+                "optimizer": {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in self.opt.state_dict().items()},
+                "schedule": {k: getattr(self.schedule, k) for k in self._SCHEDULE_STATE}, "elapsed_time": self.schedule.elapsed_time,
+                "loss_weights": {k: getattr(self.loss_fn, k) for k in ("gradient_weight", "energy_weight", "param_weight", "tuplewise_weight")},
+                "sampler_generator": self.gen.get_state(), "dropout_seed": dict(ops._SEED), "torch_rng": torch.get_rng_state(),
+                "history": list(self.history)}
+
+    def save_checkpoint(self, path: str) -> None:
+        if self.rank == 0:
+            tmp = f"{path}.tmp"
+            torch.save(self.checkpoint_dict(), tmp)
+            os.replace(tmp, path)              # a run killed while writing leaves the previous checkpoint intact
+
+    def load_checkpoint(self, path: str) -> int:
+        """-> the epoch the run continues with (`fit(max_epochs)` picks it up).  Every rank loads the same file."""
+        from . import ops
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        if ck.get("format") != "grappa_amd.trainer/1":
+            raise ValueError(f"{path} is not a trainer checkpoint of this engine (format {ck.get('format')!r})")
+        self.model.load_state_dict(ck["model"]["state_dict"])
+        self.flat.invalidate()                  # the parameters changed under the flat buffer's feet: cached weight maxima / planes are stale
+        self.opt.load_state_dict({k: (v.to(self.flat.data.device) if torch.is_tensor(v) else v) for k, v in ck["optimizer"].items()})
+        for k, v in ck["schedule"].items():
+            setattr(self.schedule, k, v)
+        self.schedule.elapsed_time, self.schedule.time_start = float(ck["elapsed_time"]), time.time()
+        for k, v in ck["loss_weights"].items():
+            setattr(self.loss_fn, k, v)
+        self.gen.set_state(ck["sampler_generator"])
+        ops._SEED.update(ck["dropout_seed"])
+        torch.set_rng_state(ck["torch_rng"])
+        self.history = list(ck["history"])
+        self.next_epoch = int(ck["next_epoch"])
+        return self.next_epoch
 
     # ---- export in the reference's container format (utils/loading_utils.py:64-73, training/export_model.py:84-97)
     def model_dict(self) -> Dict:

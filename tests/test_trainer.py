@@ -1,6 +1,8 @@
 """The training loop on a resident dataset (grappa_amd/trainer.py): sampling semantics of the reference's GraphDataLoader, loss
 decreasing over epochs, validation metrics feeding the schedule, export in the reference's container format.
 CPU: through the test-only backend (tiny model); GPU (-m gpu): the same loop on the HIP kernels."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -117,6 +119,50 @@ def test_size_window_evens_out_the_work_per_batch_and_keeps_the_draws():
     a = epoch_batches(names, 16, True, {"a": 2.0}, 0.0, g1)
     b = epoch_batches(names, 16, True, {"a": 2.0}, 0.0, g2, sizes=sizes, size_window=1)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def _resume(device, tmp_path):
+    """four epochs in one go == two epochs, checkpoint, a NEW trainer (fresh model, optimiser, generators) loading it, two more"""
+    from grappa_amd import GrappaModel, ops
+    from grappa_amd.device_dataset import DeviceDataset
+    from grappa_amd.trainer import Trainer
+    kw = dict(batch_size=8, conf_strategy=4, val_batch_size=4, val_conf_strategy="max", lr=2e-3, proper_regularisation=1e-3, start_qm_epochs=1,
+              warmup_steps=2, energy_weight=1.0, gradient_weight=0.8, param_weight=1e-3, patience=0, lr_decay=0.5, weights={"ds1": 2.0})
+
+    def make(seed):
+        torch.manual_seed(seed)
+        ops.manual_seed(5)
+        model = GrappaModel(**TINY).to(device)
+        train = DeviceDataset(_items(list(range(300, 324))), device=device)
+        val = DeviceDataset(_items(list(range(340, 348))), device=device)
+        return Trainer(model, train, val, **kw)
+
+    whole = make(0)
+    whole.fit(4)
+    first = make(0)
+    ck = str(tmp_path / "last.ckpt")
+    first.fit(2, checkpoint=ck)
+    assert os.path.exists(ck) and not os.path.exists(ck + ".tmp")
+    second = make(123)                                  # other initial weights and generator states: everything must come from the file
+    assert second.load_checkpoint(ck) == 2
+    second.fit(4)
+    assert [h["epoch"] for h in second.history] == [0, 1, 2, 3]
+    for a, b in zip(whole.history, second.history):
+        assert a["train_loss"] == b["train_loss"] and a["lr"] == b["lr"], (a, b)
+        assert a["val_metrics"]["avg"] == b["val_metrics"]["avg"]
+    assert torch.equal(whole.flat.data, second.flat.data) and torch.equal(whole.opt.m, second.opt.m) and whole.opt.step_count == second.opt.step_count
+    with pytest.raises(ValueError, match="not a trainer checkpoint"):
+        torch.save({"state_dict": {}}, str(tmp_path / "other.pth"))
+        second.load_checkpoint(str(tmp_path / "other.pth"))
+
+
+def test_trainer_resumes_bit_for_bit_cpu(ref_backend, tmp_path):
+    _resume("cpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_trainer_resumes_bit_for_bit_gpu(tmp_path):
+    _resume("cuda", tmp_path)
 
 
 def test_epoch_batches_merge_a_short_tail_for_data_parallel_runs():
