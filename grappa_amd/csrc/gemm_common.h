@@ -222,6 +222,10 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;     // private staging region pe
 // tensors exist, their element types, ...): at K = 512 that walk was a quarter of the kernel (knock-outs: profiles/r2z_gemm_f16x3_*).
 // Here the case is a template parameter, every LDS read and every load of res / aux is issued before the first use, and a lane works
 // on whole float4s only (host: N % 4 == 0, all tensors 16-byte aligned, fp32, one output tensor, no pre-activation addend).
+#ifndef GB_NT_STORE
+#define GB_NT_STORE 2        // 1 = nontemporal stores of the fp32 result, 2 = + nontemporal loads of residual / saved activation (each read once): the
+                             // 4 MB L2 of an XCD keeps the operand panels instead (C2 step -0.3 .. -0.5 ms, tools/nt_store_ab.sh; 0 = plain)
+#endif
 //   CLS 1: v + bias            2: elu(v + bias)            3: drop(v + bias) + res (drop_p may be 0, res may be NULL)
 //   CLS 4: v * elu'(aux) (+ res)
 template <int TN, int CLS, typename T, int HB>
@@ -258,8 +262,20 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
             v[k] = *reinterpret_cast<const float4*>(wave_buf + (it * ROWS_PER_IT + rrow) * EPI_LD + rc4);
             t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             r4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (GB_NT_STORE >= 2 && !BF) {
+                typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+                if ((CLS == 3 || CLS == 4) && side && col_ok && m < d.M) {
+                    const nt_f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(reinterpret_cast<const float*>(side) + (size_t)m * ldside + n));
+                    t[k] = make_float4(w[0], w[1], w[2], w[3]);
+                }
+                if (CLS == 4 && resq && col_ok && m < d.M) {
+                    const nt_f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(reinterpret_cast<const float*>(resq) + (size_t)m * ldr + n));
+                    r4[k] = make_float4(w[0], w[1], w[2], w[3]);
+                }
+            } else {
             if ((CLS == 3 || CLS == 4) && side && col_ok && m < d.M) t[k] = ld4(side + (size_t)m * ldside + n, 0);
             if (CLS == 4 && resq && col_ok && m < d.M) r4[k] = ld4(resq + (size_t)m * ldr + n, 0);
+            }
         }
 #pragma unroll
         for (int k = 0; k < HB; ++k) {
@@ -283,7 +299,15 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
                 x[2] = x[2] * grappa_elu_grad_from_out(t[k].z) + r4[k].z; x[3] = x[3] * grappa_elu_grad_from_out(t[k].w) + r4[k].w;
             }
             const bool ok = col_ok && m < d.M;
-            if (ok) st4(out + (size_t)m * ldo + n, 0, make_float4(x[0], x[1], x[2], x[3]));
+            if (ok) {
+                if (GB_NT_STORE && !BF) {
+                    typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+                    nt_f32x4 w = {x[0], x[1], x[2], x[3]};
+                    __builtin_nontemporal_store(w, reinterpret_cast<nt_f32x4*>(reinterpret_cast<float*>(out) + (size_t)m * ldo + n));
+                } else {
+                    st4(out + (size_t)m * ldo + n, 0, make_float4(x[0], x[1], x[2], x[3]));
+                }
+            }
             if (!BF && p.amax_part) {
                 unsigned am = ok ? max(max(mag_bits(x[0]), mag_bits(x[1])), max(mag_bits(x[2]), mag_bits(x[3]))) : 0u;
                 am = group_umax<TN == 2 ? 16 : 8>(am);
