@@ -163,8 +163,8 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, help="default: C2-pubchem-b256 at N = 1 (and with --weak), C4-espaloma-b4096 (strong scaling) at N > 1")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling, the workload's batch on every GPU (default at N > 1 is strong scaling of C4)")
     ap.add_argument("--strong-global-batch", type=int, default=0, help="strong scaling of this many molecules of the workload's molecule range (default at N > 1: 4096 of C4)")
