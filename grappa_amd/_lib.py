@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hip.so")   # override: kernel A/B builds (tools/)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
 GEMM_GROUP_MAX = 16
 GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4, "f32_f16x3": 5}
@@ -31,7 +31,9 @@ class GemmDesc(C.Structure):
                 ("resp", C.c_void_p), ("ldresp", C.c_int), ("resp_plane_stride", C.c_size_t),
                 ("auxp", C.c_void_p), ("ldauxp", C.c_int), ("auxp_plane_stride", C.c_size_t),
                 ("cp_nplanes", C.c_int), ("resp_nplanes", C.c_int), ("auxp_nplanes", C.c_int), ("C1p", C.c_void_p), ("ldc1p", C.c_int),
-                ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("amax_bcast", C.c_int), ("out_amax", C.c_void_p)]
+                ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("amax_bcast", C.c_int), ("out_amax", C.c_void_p),
+                # ABI 7: residual = LayerNorm(res) recomputed by the epilogue
+                ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p)]
 
 
 class ColsumItem(C.Structure):
@@ -87,6 +89,7 @@ SIGNATURES = {
     "grappa_act_dropout_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp]),
     "grappa_add_f32": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "grappa_layernorm_fwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "grappa_layernorm_fwd_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
     "grappa_layernorm_fwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "grappa_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "grappa_layernorm_bwd_partial_rows": (_i, [_i]),
@@ -101,6 +104,7 @@ SIGNATURES = {
     "grappa_tuple_gather_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i]),
     "grappa_tuple_gather_bwd_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i]),
     "grappa_seqattn_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "grappa_seqattn_fwd_pairs_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "grappa_seqattn_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "grappa_seqattn_fwd_amax_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "grappa_seqattn_bwd_amax_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

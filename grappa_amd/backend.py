@@ -92,10 +92,13 @@ class Amax:
     """largest magnitudes of a 2-d fp32 tensor as int32 tensors of fp32 bit patterns: per row (activations: written by the kernel
     that produced the tensor, or by one pass of grappa_amax_f32), per column (weights), and of the whole tensor (`tmax`, one value:
     max over the rows, for the weight-gradient products whose reduction runs over the rows)"""
-    __slots__ = ("row", "col", "tmax")
+    __slots__ = ("row", "col", "tmax", "pairs")
 
-    def __init__(self, row=None, col=None, tmax=None):
+    def __init__(self, row=None, col=None, tmax=None, pairs=None):
         self.row, self.col, self.tmax = row, col, tmax
+        # the tensor itself in the PAIR format (include/grappa_hip.h ABI 5; (rows, 2 * round_up(cols, 32)) float16), written by its
+        # producer beside -- or instead of -- the fp32 tensor: a product that gets this record as a_scales reads the pairs
+        self.pairs = pairs
 
 
 class HipBackend:
@@ -128,6 +131,9 @@ class HipBackend:
         self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta)
         self._wq_task = None           # autograd graph task id of the backward pass the queues belong to
         self.wgrad_queue_bytes = int(float(os.environ.get("GRAPPA_WGRAD_QUEUE_GB", "12")) * 2 ** 30)
+        # inference (no gradient asked for): LayerNorm and the tuple attention write the A operand of the product behind them in the pair
+        # format and the product reads operands split once (csrc/gemm_pairs.hip) -- same bits as the fp32-operand product of the same K cuts
+        self.inference_pairs = os.environ.get("GRAPPA_INFERENCE_PAIRS", "1") not in ("0", "")
         self._tails = None             # what set_tail_launches last told the library (None: the library's default)
         self._tails_pinned = False
         if os.environ.get("GRAPPA_PLAN_TAILS", "") != "":
@@ -196,6 +202,27 @@ class HipBackend:
                                               planes.stride(0), int(transposed)), "grappa_split_planes_f32")
         self._wplanes[key] = (ver, planes, weakref.ref(w))
         return planes
+
+    def _pairs_of_weight(self, w: torch.Tensor) -> torch.Tensor:
+        """W (rows x cols) in the pair format, rows scaled by their own maxima (the forward orientation: out features x in features);
+        cached per weight like the planes"""
+        R, Cc = w.shape
+        key = (w.data_ptr(), R, Cc, "pairs")
+        ver = (w._version, self._wepoch)
+        hit = self._wplanes.get(key)
+        if hit is not None and hit[2]() is not w:
+            hit = None
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        pairs = hit[1] if hit is not None else torch.zeros((R, 2 * ((Cc + 31) // 32 * 32)), dtype=torch.float16, device=w.device)
+        _chk(self.lib.grappa_split_pairs_f32(self._stream(), R, Cc, w.data_ptr(), _f32_2d(w, "W", w.device), self._amax_of_weight(w).row.data_ptr(),
+                                             pairs.data_ptr(), pairs.stride(0), 0), "grappa_split_pairs_f32")
+        self._wplanes[key] = (ver, pairs, weakref.ref(w))
+        return pairs
+
+    def pairs_ok(self, x: torch.Tensor, width: int) -> bool:
+        """can a producer of `x` (rows of `width` columns) hand the following forward product its operand in the pair format?"""
+        return (self.inference_pairs and x.dtype == torch.float32 and x.shape[0] > 32 and width % 32 == 0 and self.gemm_precision_name == "f32_f16x3")
 
     # ------------------------------------------------------------------ row / column maxima (scales of the fp16-split products)
     def _amax_launch(self, t: torch.Tensor, rows: bool, cols: bool):
@@ -373,7 +400,8 @@ class HipBackend:
         return t.data_ptr() % 16 == 0 and ld % 8 == 0
 
     def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
-             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None, a_scales=None, b_scales=None, out_amax=False):
+             drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None, a_scales=None, b_scales=None, out_amax=False,
+             res_ln=None):
         """C = epilogue(A B^T) (include/grappa_hip.h).  Operands and epilogue tensors may be float32 or -- the bf16 storage
         configuration -- bfloat16: a bf16 A (and, for the wgrad layout, B) is read by the LDS-DMA plane kernels as a one-plane
         operand when the shape allows it, otherwise converted to fp32 first; out / out2 / res / aux are written / read in their own
@@ -386,7 +414,15 @@ class HipBackend:
         d.M, d.N, d.K = M, N, K
         ar, ac = (M, K) if a_kcontig else (K, M)
         br, bc = (N, K) if b_kcontig else (K, N)
-        if tuple(a.shape) != (ar, ac) or tuple(b.shape) != (br, bc) or tuple(out.shape) != (M, N):
+        # A in the pair format (its producer wrote it: a_scales.pairs): forward layout, default arithmetic; `a` itself may then be None
+        a_pairs = getattr(a_scales, "pairs", None) if a_scales is not None else None
+        if a_pairs is not None and not (a_kcontig and b_kcontig and M > 32 and N > 32 and K % 32 == 0 and precision is None
+                                        and self.gemm_precision_name == "f32_f16x3" and b.dtype == torch.float32 and a_colsum is None
+                                        and tuple(a_pairs.shape) == (M, 2 * K)):
+            if a is None:
+                raise ValueError("gemm: A was given in the pair format only, which this product cannot read")
+            a_pairs = None
+        if (a_pairs is None and tuple(a.shape) != (ar, ac)) or tuple(b.shape) != (br, bc) or tuple(out.shape) != (M, N):
             raise ValueError(f"gemm: shapes A{tuple(a.shape)} B{tuple(b.shape)} C{tuple(out.shape)} do not match M={M} N={N} K={K}")
         if M == 0 or N == 0:
             return (None, None) if out_amax else None
@@ -402,7 +438,9 @@ class HipBackend:
         big = M > 32 and N > 32
         # ---- operands
         planes_a = planes_b = None
-        if a_kcontig:
+        if a_pairs is not None:
+            pass                                     # both operands are set below, from the pairs
+        elif a_kcontig:
             # forward / dgrad: B is a weight matrix (fp32 parameter)
             if b.dtype != torch.float32:
                 raise ValueError("gemm: the weight operand must be float32")
@@ -425,12 +463,20 @@ class HipBackend:
                 d.precision = _lib.GEMM_PRECISIONS["bf16"]
             else:
                 a, b = self.to_f32(a), self.to_f32(b)
-        if planes_a is not None:
+        if a_pairs is not None:
+            w_pairs = self._pairs_of_weight(b)
+            d.A, d.lda, d.a_planes = a_pairs.data_ptr(), a_pairs.stride(0), 1
+            d.B, d.ldb, d.b_planes = w_pairs.data_ptr(), w_pairs.stride(0), 1
+            d.a_kcontig, d.b_kcontig = 1, 1
+            d.a_amax, d.b_amax = a_scales.row.data_ptr(), self._amax_of_weight(b).row.data_ptr()
+        elif planes_a is not None:
             d.A, d.lda, d.a_planes, d.a_plane_stride = planes_a.data_ptr(), planes_a.stride(0), 1, 0
             _f32_2d(planes_a, "A", dev, bf16)
         else:
             d.A, d.lda = a.data_ptr(), _f32_2d(a, "A", dev)
-        if planes_b is not None and planes_b.dim() == 3:                             # weight planes (3, rows_pad, cols_pad)
+        if a_pairs is not None:
+            pass
+        elif planes_b is not None and planes_b.dim() == 3:                           # weight planes (3, rows_pad, cols_pad)
             d.B, d.ldb, d.b_planes, d.b_plane_stride = planes_b.data_ptr(), planes_b.stride(1), 1, planes_b.stride(0)
             d.a_kcontig, d.b_kcontig = 1, 1
         elif planes_b is not None:
@@ -440,7 +486,7 @@ class HipBackend:
             d.B, d.ldb = b.data_ptr(), _f32_2d(b, "B", dev)
             d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
         # ---- the native fp32 kernel (precision "f32", or M / N <= 32) has no bf16 epilogue: run it on fp32 copies (tiny or non-default)
-        native = planes_a is None and (not big or d.precision == _lib.GEMM_PRECISIONS["f32"])
+        native = planes_a is None and a_pairs is None and (not big or d.precision == _lib.GEMM_PRECISIONS["f32"])
         if native and any(t is not None and t.dtype == bf16 for t in (out, out2, res, aux)):
             f = lambda t: None if t is None else (self.to_f32(t) if t.dtype == bf16 else t)      # noqa: E731
             o32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out.dtype == bf16 else out
@@ -487,6 +533,16 @@ class HipBackend:
                 d.resp, d.ldresp, d.resp_nplanes = res.data_ptr(), plane_ok(res, "res"), 1
             else:
                 d.res, d.ldres = res.data_ptr(), _f32_2d(res, "res", dev)
+        if res_ln is not None:
+            # res holds the rows BEFORE a LayerNorm; the epilogue adds LayerNorm(res) = what the LayerNorm kernel would have written
+            mean_, rstd_, gamma_, beta_ = res_ln
+            if res is None or res.dtype != torch.float32 or not big or d.precision == _lib.GEMM_PRECISIONS["f32"]:
+                raise ValueError("gemm: res_ln needs a float32 residual and a product of the split kernels (M, N > 32, not the native fp32 MFMA)")
+            for t_, n_, k_ in ((mean_, "mean", M), (rstd_, "rstd", M), (gamma_, "gamma", N), (beta_, "beta", N)):
+                _flat(t_, f"res_ln {n_}", dev)
+                if t_.numel() != k_:
+                    raise ValueError(f"gemm: res_ln {n_} length")
+            d.res_ln_mean, d.res_ln_rstd, d.res_ln_gamma, d.res_ln_beta = mean_.data_ptr(), rstd_.data_ptr(), gamma_.data_ptr(), beta_.data_ptr()
         if aux is not None:
             if tuple(aux.shape) != (M, N):
                 raise ValueError("gemm: aux shape")
@@ -505,7 +561,9 @@ class HipBackend:
             d.a_colsum = a_colsum.data_ptr()
         d.act, d.drop_p, d.drop_seed, d.accumulate = int(act), float(drop_p), int(drop_seed) & (2 ** 64 - 1), int(accumulate)
         sa = so = None
-        if d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] and big and planes_a is None and planes_b is None:
+        if a_pairs is not None:
+            sa = a_scales
+        elif d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] and big and planes_a is None and planes_b is None:
             # power-of-two scales of both operands from their largest magnitudes along the reduced dimension
             if a_kcontig:
                 sa = self.amax(a, a_scales, rows=True)
@@ -531,7 +589,7 @@ class HipBackend:
         # algorithmic bytes of the fused call: both operands once, the result, and what the epilogue has to read / write beside it
         # (residual, saved activation for ELU', fp32 addend, the second output, an accumulated result's old value)
         epi = M * N * (el(res) + el(aux) + el(pre) + (el(out) if out2 is not None else 0) + (el(final) if accumulate else 0))
-        self._timed("gemm_f32", 2.0 * M * N * K, float(M * K * el(a if planes_a is None else planes_a) + N * K * (2 if planes_b is not None else 4)
+        self._timed("gemm_f32", 2.0 * M * N * K, float(M * K * (4 if a_pairs is not None else el(a if planes_a is None else planes_a)) + N * K * (2 if planes_b is not None else 4)
                                                          + M * N * el(final) + epi),
                     lambda: _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0),
                                  "grappa_gemm_f32"))
@@ -759,12 +817,25 @@ class HipBackend:
         _chk(self.lib.grappa_add_f32(self._stream(), x.numel(), x.data_ptr(), z.data_ptr(), y.data_ptr()), "grappa_add_f32")
 
     # ------------------------------------------------------------------ layer norm
-    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, amax=None):
-        dev = y.device
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, amax=None, pairs=False):
+        """pairs=True (fp32, W % 32 == 0): the rows are ALSO written in the pair format (returned record's `.pairs`); y may then be None"""
+        dev = x.device
         M, W = x.shape
         _flat(gamma, "gamma", dev), _flat(beta, "beta", dev)
-        if gamma.numel() != W or beta.numel() != W or tuple(y.shape) != (M, W):
+        if gamma.numel() != W or beta.numel() != W or (y is not None and tuple(y.shape) != (M, W)):
             raise ValueError("layernorm: shapes")
+        if pairs:
+            if x.dtype != torch.float32 or W % 32 or (y is not None and y.dtype != torch.float32):
+                raise ValueError("layernorm: the pair format needs float32 rows of W % 32 == 0 columns")
+            row = torch.empty(M, dtype=torch.int32, device=dev)
+            pr = torch.empty((M, 2 * W), dtype=torch.float16, device=dev)
+            if M:
+                _chk(self.lib.grappa_layernorm_fwd_pairs_f32(self._stream(), M, W, x.data_ptr(), _f32_2d(x, "x", dev), gamma.data_ptr(), beta.data_ptr(),
+                                                             _ptr(y), _f32_2d(y, "y", dev) if y is not None else 0, _ptr(mean), _ptr(rstd),
+                                                             row.data_ptr(), pr.data_ptr(), pr.stride(0)), "grappa_layernorm_fwd_pairs_f32")
+            return Amax(row=row, pairs=pr)
+        if y is None:
+            raise ValueError("layernorm: y is required without pairs")
         if mean is not None:
             _flat(mean, "mean", dev), _flat(rstd, "rstd", dev)
             if mean.numel() != M or rstd.numel() != M:
@@ -907,7 +978,19 @@ class HipBackend:
                 _f32_2d(dx, "dx", dev, dt), da.data_ptr(), _f32_2d(da, "da", dev, dt), int(has_pe), int(accumulate)),
              "grappa_tuple_gather_bwd")
 
-    def seqattn_fwd(self, qkv, s, T, nheads, out, amax=None):
+    def seqattn_fwd(self, qkv, s, T, nheads, out, amax=None, pairs=False):
+        if pairs:               # the output in the pair format ONLY (`out` is not written and may be None): inference
+            dev = qkv.device
+            F = qkv.shape[1] // 3
+            if qkv.dtype != torch.float32 or qkv.shape != (s * T, 3 * F) or F % nheads or F % 32 or F > 512:
+                raise ValueError("seqattn_fwd: the pair format needs float32 q, k, v of F % 32 == 0, F <= 512 columns each")
+            _flat(qkv, "qkv", dev)
+            row = torch.empty(s * T, dtype=torch.int32, device=dev)
+            pr = torch.empty((s * T, 2 * F), dtype=torch.float16, device=dev)
+            if T:
+                _chk(self.lib.grappa_seqattn_fwd_pairs_f32(self._stream(), s, T, nheads, F // nheads, qkv.data_ptr(), pr.data_ptr(), pr.stride(0),
+                                                           row.data_ptr()), "grappa_seqattn_fwd_pairs_f32")
+            return Amax(row=row, pairs=pr)
         dev = out.device
         dt = _same_dtype(qkv, out)
         _flat(qkv, "qkv", dev, dt), _flat(out, "out", dev, dt)

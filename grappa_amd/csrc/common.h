@@ -52,6 +52,43 @@ __device__ inline void st4(grappa_bf16_t* __restrict__ row, int c, const float4&
     b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
     reinterpret_cast<uint2*>(row)[c] = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
 }
+// one element of LayerNorm's output -- ONE expression for the kernels that write it and the product epilogue that recomputes it as a
+// residual (grappa_gemm_desc.res_ln_*): the same bits everywhere
+__device__ inline float grappa_ln_apply(float x, float mean, float rstd, float g, float b) { return __builtin_fmaf((x - mean) * rstd, g, b); }
+
+// ---- the PAIR format (include/grappa_hip.h, ABI 5): an fp32 row as fp16 (HI, LO) halves scaled by 2^shift, shift = 141 - the exponent
+// field of the row's largest magnitude; blocks of 16 k as [16 x HI | 16 x LO].  st_pairs4: elements k = 4c .. 4c + 3 of one row.
+__device__ inline int grappa_amax_shift(unsigned bits) { return 141 - (int)((bits >> 23) & 0xffu); }
+__device__ inline void st_pairs4(uint16_t* __restrict__ row, int c, const float4& v, int shift) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float r0 = __builtin_ldexpf(v.x, shift), r1 = __builtin_ldexpf(v.y, shift), r2 = __builtin_ldexpf(v.z, shift), r3 = __builtin_ldexpf(v.w, shift);
+    h2 h01, h23, l01, l23;
+    h01[0] = (_Float16)r0; h01[1] = (_Float16)r1; h23[0] = (_Float16)r2; h23[1] = (_Float16)r3;     // round to nearest even; |r| < 2^15
+    l01[0] = (_Float16)(r0 - (float)h01[0]); l01[1] = (_Float16)(r1 - (float)h01[1]);
+    l23[0] = (_Float16)(r2 - (float)h23[0]); l23[1] = (_Float16)(r3 - (float)h23[1]);
+    uint16_t* p = row + 32 * (c >> 2) + 4 * (c & 3);
+    *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    *reinterpret_cast<uint2*>(p + 16) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+// The same for a wavefront whose lanes hold CONSECUTIVE c (lane l: c = c0 + l, c0 even) and are all active up to an even count: lanes
+// 2j and 2j + 1 trade halves so that each issues ONE 16-byte store (the even lane both HI quads, the odd lane both LO quads) instead of
+// two 8-byte ones.  `ok` = this lane holds an element (lanes beyond the row end must still execute the exchange).
+__device__ inline void st_pairs4_paired(uint16_t* __restrict__ row, int c, const float4& v, int shift, bool ok) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float r0 = __builtin_ldexpf(v.x, shift), r1 = __builtin_ldexpf(v.y, shift), r2 = __builtin_ldexpf(v.z, shift), r3 = __builtin_ldexpf(v.w, shift);
+    h2 h01, h23, l01, l23;
+    h01[0] = (_Float16)r0; h01[1] = (_Float16)r1; h23[0] = (_Float16)r2; h23[1] = (_Float16)r3;
+    l01[0] = (_Float16)(r0 - (float)h01[0]); l01[1] = (_Float16)(r1 - (float)h01[1]);
+    l23[0] = (_Float16)(r2 - (float)h23[0]); l23[1] = (_Float16)(r3 - (float)h23[1]);
+    const unsigned H0 = __builtin_bit_cast(unsigned, h01), H1 = __builtin_bit_cast(unsigned, h23);
+    const unsigned L0 = __builtin_bit_cast(unsigned, l01), L1 = __builtin_bit_cast(unsigned, l23);
+    const bool odd = (c & 1) != 0;
+    const unsigned g0 = (unsigned)__shfl_xor((int)(odd ? H0 : L0), 1, 64), g1 = (unsigned)__shfl_xor((int)(odd ? H1 : L1), 1, 64);
+    if (!ok) return;
+    const int ce = c & ~1;                                       // the pair's even c: its quad starts the 16-byte run
+    uint16_t* p = row + 32 * (ce >> 2) + 4 * (ce & 3) + (odd ? 16 : 0);
+    *reinterpret_cast<uint4*>(p) = odd ? make_uint4(g0, g1, L0, L1) : make_uint4(H0, H1, g0, g1);
+}
 __device__ inline float ld1(const float* __restrict__ p, size_t i) { return p[i]; }
 __device__ inline float ld1(const grappa_bf16_t* __restrict__ p, size_t i) { return __uint_as_float((unsigned)p[i] << 16); }
 __device__ inline void st1(float* __restrict__ p, size_t i, float v) { p[i] = v; }

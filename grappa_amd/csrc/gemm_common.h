@@ -104,7 +104,8 @@ __device__ inline float epilogue_store(const GemmParams& p, int m, int n, float 
     }
     if (d.C1p) planes_store1(d.C1p, 0, (size_t)m * d.ldc1p + n, v, 1);
     if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
-    if (d.res) v += d.res[(size_t)m * d.ldres + n];
+    if (d.res && d.res_ln_mean) v += grappa_ln_apply(d.res[(size_t)m * d.ldres + n], d.res_ln_mean[m], d.res_ln_rstd[m], d.res_ln_gamma[n], d.res_ln_beta[n]);
+    else if (d.res) v += d.res[(size_t)m * d.ldres + n];
     else if (d.resp) v += planes_load1(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, d.resp_nplanes ? d.resp_nplanes : 3);
     if (out) {
         float* o = out + (size_t)m * ldo + n;
@@ -228,6 +229,7 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;     // private staging region pe
 #endif
 //   CLS 1: v + bias            2: elu(v + bias)            3: drop(v + bias) + res (drop_p may be 0, res may be NULL)
 //   CLS 4: v * elu'(aux) (+ res)
+//   CLS 5: drop(v + bias) + LayerNorm(res) (fp32 only: grappa_gemm_desc.res_ln_*, the residual recomputed from the rows before normalisation)
 template <int TN, int CLS, typename T, int HB>
 __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f32x16 (&acc_i)[TN], float* __restrict__ wave_buf, int mband, int n, int lane,
                                                    const float4& b4) {
@@ -249,8 +251,13 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
     const int ldo = BF ? d.ldcp : d.ldc;
     const T* resq = BF ? reinterpret_cast<const T*>(d.resp) : reinterpret_cast<const T*>(d.res);
     const int ldr = BF ? d.ldresp : d.ldres;
-    const T* side = CLS == 3 ? resq : (CLS == 4 ? (BF ? reinterpret_cast<const T*>(d.auxp) : reinterpret_cast<const T*>(d.aux)) : nullptr);
-    const int ldside = CLS == 3 ? ldr : (BF ? d.ldauxp : d.ldaux);
+    const T* side = (CLS == 3 || CLS == 5) ? resq : (CLS == 4 ? (BF ? reinterpret_cast<const T*>(d.auxp) : reinterpret_cast<const T*>(d.aux)) : nullptr);
+    const int ldside = (CLS == 3 || CLS == 5) ? ldr : (BF ? d.ldauxp : d.ldaux);
+    float4 lng = make_float4(0.f, 0.f, 0.f, 0.f), lnb = lng;           // CLS 5: gamma, beta of this lane's four columns
+    if (CLS == 5 && col_ok) {
+        lng = *reinterpret_cast<const float4*>(d.res_ln_gamma + n);
+        lnb = *reinterpret_cast<const float4*>(d.res_ln_beta + n);
+    }
     // HB trips per batch: the LDS reads and the loads of a batch are in flight together (4: 48 registers; the one-plane kernel, which
     // lives on 128 registers for two workgroups per CU, takes 2)
 #pragma unroll
@@ -264,7 +271,7 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
             r4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (GB_NT_STORE >= 2 && !BF) {
                 typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
-                if ((CLS == 3 || CLS == 4) && side && col_ok && m < d.M) {
+                if ((CLS == 3 || CLS == 4 || CLS == 5) && side && col_ok && m < d.M) {
                     const nt_f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(reinterpret_cast<const float*>(side) + (size_t)m * ldside + n));
                     t[k] = make_float4(w[0], w[1], w[2], w[3]);
                 }
@@ -273,7 +280,7 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
                     r4[k] = make_float4(w[0], w[1], w[2], w[3]);
                 }
             } else {
-            if ((CLS == 3 || CLS == 4) && side && col_ok && m < d.M) t[k] = ld4(side + (size_t)m * ldside + n, 0);
+            if ((CLS == 3 || CLS == 4 || CLS == 5) && side && col_ok && m < d.M) t[k] = ld4(side + (size_t)m * ldside + n, 0);
             if (CLS == 4 && resq && col_ok && m < d.M) r4[k] = ld4(resq + (size_t)m * ldr + n, 0);
             }
         }
@@ -286,7 +293,12 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
 #pragma unroll
                 for (int q = 0; q < 4; ++q) x[q] = grappa_elu(x[q]);
             }
-            if (CLS == 3) {
+            if (CLS == 5 && col_ok && m < d.M) {                       // the residual is LayerNorm of the rows just loaded
+                const float mu = d.res_ln_mean[m], rs = d.res_ln_rstd[m];
+                t[k] = make_float4(grappa_ln_apply(t[k].x, mu, rs, lng.x, lnb.x), grappa_ln_apply(t[k].y, mu, rs, lng.y, lnb.y),
+                                   grappa_ln_apply(t[k].z, mu, rs, lng.z, lnb.z), grappa_ln_apply(t[k].w, mu, rs, lng.w, lnb.w));
+            }
+            if (CLS == 3 || CLS == 5) {
                 if (d.drop_p > 0.0f) {
                     const uint64_t idx = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
 #pragma unroll
@@ -379,7 +391,13 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, const f32x16 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = grappa_keep(d.drop_seed, idx + q, d.drop_p) ? v[q] * p.drop_scale : 0.0f;
                 }
-                if (d.res) {
+                if (d.res && d.res_ln_mean) {
+                    const float4 t = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
+                    const float4 g = *reinterpret_cast<const float4*>(d.res_ln_gamma + n), be = *reinterpret_cast<const float4*>(d.res_ln_beta + n);
+                    const float mu = d.res_ln_mean[m], rs = d.res_ln_rstd[m];
+                    v[0] += grappa_ln_apply(t.x, mu, rs, g.x, be.x); v[1] += grappa_ln_apply(t.y, mu, rs, g.y, be.y);
+                    v[2] += grappa_ln_apply(t.z, mu, rs, g.z, be.z); v[3] += grappa_ln_apply(t.w, mu, rs, g.w, be.w);
+                } else if (d.res) {
                     const float4 t = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
                     v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
                 } else if (d.resp) {
@@ -430,6 +448,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmParams& p, const f3
             case 2: GRAPPA_FAST(2, float);
             case 3: GRAPPA_FAST(3, float);
             case 4: GRAPPA_FAST(4, float);
+            case 5: GRAPPA_FAST(5, float);
             case 9: GRAPPA_FAST(1, grappa_bf16_t);
             case 10: GRAPPA_FAST(2, grappa_bf16_t);
             case 11: GRAPPA_FAST(3, grappa_bf16_t);

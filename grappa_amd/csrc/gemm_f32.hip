@@ -727,6 +727,13 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     if (d->precision == GRAPPA_GEMM_F32_F16X3 && bf16x && (!d->a_amax || !d->b_amax)) return GRAPPA_ERR_ARG;
     // the native fp32 kernel (precision F32_MFMA, or M / N <= 32) keeps its register-lean fp32-only epilogue walk
     if (!bf16x && (d->Cp || d->C1p || d->resp || d->auxp || !d->C)) return GRAPPA_ERR_ARG;
+    if (d->res_ln_mean) {
+        // residual = LayerNorm(res): fp32 rows, all four arrays, the split kernels' shared epilogue only (not the native fp32 kernel's walk)
+        if (!bf16x || !d->res || !d->res_ln_rstd || !d->res_ln_gamma || !d->res_ln_beta || (d->N & 3) ||
+            ((reinterpret_cast<uintptr_t>(d->res_ln_gamma) | reinterpret_cast<uintptr_t>(d->res_ln_beta)) & 15) != 0 || (planes && !pairs))
+            return GRAPPA_ERR_ARG;
+        if (pairs && !d->a_planes) return GRAPPA_ERR_ARG;               // (the weight-pairs kernel has its own epilogue dispatch)
+    }
     Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes, pairs);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
@@ -785,6 +792,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             if (has_aux) cls = (!d->bias && d->act == GRAPPA_ACT_NONE && d->drop_p == 0.0f) ? 4 : 0;
             else if (d->act == GRAPPA_ACT_ELU) cls = (d->drop_p == 0.0f && !has_res) ? 2 : 0;
             else cls = (d->drop_p > 0.0f || has_res) ? 3 : 1;
+            if (cls == 3 && d->res_ln_mean) cls = f32_only ? 5 : 0;             // the residual recomputed from the rows before their LayerNorm
             p.epi_class = cls == 0 ? 0 : cls + (bf16_only ? 8 : 0);
         }
     }

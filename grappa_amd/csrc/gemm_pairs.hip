@@ -235,6 +235,7 @@ __global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_kernel(GemmPara
             case 2: GQ_FAST(2, float);
             case 3: GQ_FAST(3, float);
             case 4: GQ_FAST(4, float);
+            case 5: GQ_FAST(5, float);
             case 9: GQ_FAST(1, grappa_bf16_t);
             case 10: GQ_FAST(2, grappa_bf16_t);
             case 11: GQ_FAST(3, grappa_bf16_t);

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
                 const float4 g = reinterpret_cast<const float4*>(gamma)[c];
                 const float4 b = reinterpret_cast<const float4*>(beta)[c];
                 float4 o;
-                o.x = (v[i].x - mean) * rstd * g.x + b.x;
-                o.y = (v[i].y - mean) * rstd * g.y + b.y;
-                o.z = (v[i].z - mean) * rstd * g.z + b.z;
-                o.w = (v[i].w - mean) * rstd * g.w + b.w;
+                o.x = grappa_ln_apply(v[i].x, mean, rstd, g.x, b.x);
+                o.y = grappa_ln_apply(v[i].y, mean, rstd, g.y, b.y);
+                o.z = grappa_ln_apply(v[i].z, mean, rstd, g.z, b.z);
+                o.w = grappa_ln_apply(v[i].w, mean, rstd, g.w, b.w);
                 st4(yr, c, o);
                 am = max(am, mag4(o));
             }
@@ -79,6 +79,75 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
         if (y_amax) {                                    // largest |y| of the row (fp32 bit pattern): scale of an F32_F16X3 product
             am = wave_umax(am);
             if (lane == 0) y_amax[row] = am;
+        }
+    }
+}
+
+// The same rows also written in the PAIR format (fp16 hi / lo halves scaled by the row's largest magnitude, common.h st_pairs4): the A
+// operand of a following F32_F16X3 product split ONCE, by the kernel that has the whole row -- and its maximum -- in registers.  y (fp32)
+// is optional: inference needs it only where the normalised rows are also a residual.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_pairs_kernel(int M, int W, const float* __restrict__ x, int ldx,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float* __restrict__ y, int ldy, float* __restrict__ mean_out,
+                                                                  float* __restrict__ rstd_out, unsigned* __restrict__ y_amax,
+                                                                  uint16_t* __restrict__ pairs, int ldp) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nvec = W >> 2;
+    for (int row = wave_global; row < M; row += nwaves) {
+        const float* xr = x + (size_t)row * ldx;
+        float4 v[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                v[i] = ld4(xr, c);
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        }
+        const float mean = wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
+        unsigned am = 0u;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+                const float4 b = reinterpret_cast<const float4*>(beta)[c];
+                float4 o;                                    // the same expressions as layernorm_fwd_kernel: the same bits
+                o.x = grappa_ln_apply(v[i].x, mean, rstd, g.x, b.x);
+                o.y = grappa_ln_apply(v[i].y, mean, rstd, g.y, b.y);
+                o.z = grappa_ln_apply(v[i].z, mean, rstd, g.z, b.z);
+                o.w = grappa_ln_apply(v[i].w, mean, rstd, g.w, b.w);
+                v[i] = o;
+                am = max(am, mag4(o));
+            }
+        }
+        am = wave_umax(am);
+        const int shift = grappa_amax_shift(am);
+        uint16_t* pr = pairs + (size_t)row * ldp;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec && y) st4(y + (size_t)row * ldy, c, v[i]);
+            st_pairs4_paired(pr, c, v[i], shift, c < nvec);         // (W % 32 == 0: nvec is even, a lane and its partner are in range together)
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+            y_amax[row] = am;
         }
     }
 }
@@ -494,6 +563,24 @@ __global__ __launch_bounds__(256) void convert_kernel(int M, int N, const TI* __
 extern "C" int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
                                         float* y, int ldy, float* mean, float* rstd) {
     return layernorm_fwd_impl<float>(stream, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd);
+}
+extern "C" int grappa_layernorm_fwd_pairs_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
+                                              float* y, int ldy, float* mean, float* rstd, uint32_t* y_amax, uint16_t* pairs, int ldp) {
+    if (M < 0 || W <= 0 || (W & 31) || W > 2048 || (ldx & 3) || (y && (ldy & 3)) || ldp < 2 * W || (ldp & 7)) return GRAPPA_ERR_ARG;
+    if (M == 0) return GRAPPA_OK;
+    if (!x || !gamma || !beta || !y_amax || !pairs) return GRAPPA_ERR_ARG;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+          reinterpret_cast<uintptr_t>(pairs)) & 15) != 0)
+        return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = W <= 1024 ? ((M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4) : ln_blocks(M);
+#define GRAPPA_LN_FWD_PAIRS(NCH) hipLaunchKernelGGL((layernorm_fwd_pairs_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax, pairs, ldp)
+    if (W <= 256) GRAPPA_LN_FWD_PAIRS(1);
+    else if (W <= 512) GRAPPA_LN_FWD_PAIRS(2);
+    else if (W <= 1024) GRAPPA_LN_FWD_PAIRS(4);
+    else GRAPPA_LN_FWD_PAIRS(8);
+#undef GRAPPA_LN_FWD_PAIRS
+    return grappa_launch_status();
 }
 extern "C" int grappa_layernorm_fwd_bf16(void* stream, int M, int W, const uint16_t* x, int ldx, const float* gamma, const float* beta,
                                          uint16_t* y, int ldy, float* mean, float* rstd) {

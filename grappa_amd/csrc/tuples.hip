@@ -129,6 +129,71 @@ __global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, 
     }
 }
 
+// The attention output straight in the PAIR format (common.h st_pairs4): in inference nothing but the out-projection product reads it.
+// The S x F outputs of a tuple stay in registers until their rows' maxima are known (F <= 512: two trips of 64 lanes x 4 columns).
+template <int S>
+__global__ __launch_bounds__(256) void seqattn_fwd_pairs_kernel(int T, int F, int dh, const float* __restrict__ qkv, uint16_t* __restrict__ pairs, int ldp,
+                                                                unsigned* __restrict__ row_amax) {
+    const int lane = threadIdx.x & 63;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= T) return;
+    const int nvec = F >> 2, lph = dh >> 2;
+    const float scale = 1.0f / sqrtf((float)dh);
+    unsigned am[S];
+    float4 keep[2][S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) am[i] = 0u;
+#pragma unroll
+    for (int trip = 0; trip < 2; ++trip) {
+        const int c = trip * 64 + lane;
+        const bool ok = c < nvec;
+        float4 q[S], k[S], v[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const float* row = qkv + ((size_t)i * T + t) * 3 * F;
+            q[i] = ok ? ld4(row, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            k[i] = ok ? ld4(row, nvec + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i] = ok ? ld4(row, 2 * nvec + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {                       // the same expressions as seqattn_fwd_kernel: the same bits
+            float sc[S], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                sc[j] = group_sum(dot4(q[i], k[j]), lph) * scale;
+                mx = fmaxf(mx, sc[j]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                sc[j] = expf(sc[j] - mx);
+                den += sc[j];
+            }
+            const float inv = 1.0f / den;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const float p = sc[j] * inv;
+                o.x += p * v[j].x; o.y += p * v[j].y; o.z += p * v[j].z; o.w += p * v[j].w;
+            }
+            keep[trip][i] = o;
+            if (ok) am[i] = max(am[i], mag4(o));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const unsigned m = wave_umax(am[i]);
+        const int shift = grappa_amax_shift(m);
+        uint16_t* pr = pairs + ((size_t)i * T + t) * ldp;
+#pragma unroll
+        for (int trip = 0; trip < 2; ++trip) {
+            const int c = trip * 64 + lane;
+            st_pairs4_paired(pr, c, keep[trip][i], shift, c < nvec);
+        }
+        if (lane == 0) row_amax[(size_t)i * T + t] = m;
+    }
+}
+
 template <int S, typename TE>
 __global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, const TE* __restrict__ dout,
                                                           TE* __restrict__ dqkv, unsigned* __restrict__ row_amax) {
@@ -632,6 +697,23 @@ extern "C" int grappa_seqattn_fwd_amax_f32(void* stream, int s, int T, int nhead
 extern "C" int grappa_seqattn_bwd_amax_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv,
                                            uint32_t* dqkv_amax) {
     return seqattn_bwd_impl<float>(stream, s, T, nheads, dh, qkv, dout, dqkv, dqkv_amax);
+}
+extern "C" int grappa_seqattn_fwd_pairs_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, uint16_t* pairs, int ldp,
+                                            uint32_t* out_amax) {
+    const int F = nheads * dh;
+    if (s < 1 || s > 4 || T < 0 || nheads <= 0 || dh <= 0 || (dh & 3) || !pow2(dh / 4) || dh / 4 > 64 || F > 512 || (F & 31) || ldp < 2 * F || (ldp & 7))
+        return GRAPPA_ERR_ARG;
+    if (T == 0) return GRAPPA_OK;
+    if (!qkv || !pairs || !out_amax || !aligned_el<float>(qkv) || (reinterpret_cast<uintptr_t>(pairs) & 15)) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((T + 3) / 4);
+    switch (s) {
+        case 1: hipLaunchKernelGGL((seqattn_fwd_pairs_kernel<1>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
+        case 2: hipLaunchKernelGGL((seqattn_fwd_pairs_kernel<2>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
+        case 3: hipLaunchKernelGGL((seqattn_fwd_pairs_kernel<3>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
+        default: hipLaunchKernelGGL((seqattn_fwd_pairs_kernel<4>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
+    }
+    return grappa_launch_status();
 }
 extern "C" int grappa_seqattn_fwd_bf16(void* stream, int s, int T, int nheads, int dh, const uint16_t* qkv, uint16_t* out) {
     return seqattn_fwd_impl<grappa_bf16_t>(stream, s, T, nheads, dh, qkv, out);

@@ -152,6 +152,7 @@ class GrappaGNN(nn.Module):
 
     def forward(self, g):
         plan = g.plan()
+        ops.set_inference(not torch.is_grad_enabled())
         x = self.input_features(g)
         p0 = self.p_initial if self.training else 0.0
         h = ops.LinearFn.apply(x, self.pre_dense[0].weight, self.pre_dense[0].bias, ops.ELU, p0, ops.next_seed() if p0 > 0 else 0, ops.act_dtype())
@@ -489,6 +490,7 @@ class WriteParameters(nn.Module):
 
     def forward(self, g):
         h = g.nodes["n1"].data["h"]
+        ops.set_inference(not torch.is_grad_enabled())
         writers = self._writers_largest_first()
         # every head reads an alias of h of its own, so that its gradient of h arrives alone at the node that adds the four
         aliases = ops.SplitHeadsFn.apply(h, len(writers)) if (torch.is_grad_enabled() and h.requires_grad) else (h,) * len(writers)

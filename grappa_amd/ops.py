@@ -143,12 +143,35 @@ def _linear_bwd_params(be, dz, x, w, b, xs=None, zs=None):
     return zs
 
 
-def _ln_fwd(be, x, w, b):
+def _pairs(be, x, infer) -> bool:
+    """inference on the HIP backend: may the producer of the rows `x` (or of rows of its shape) hand them on in the pair format?"""
+    return bool(infer) and hasattr(be, "pairs_ok") and x.dim() == 2 and be.pairs_ok(x, x.shape[1])
+
+
+_INFERENCE = {"on": False}
+
+
+def set_inference(on: bool) -> None:
+    """told by the model at the top of its forward: gradients are disabled (torch.no_grad()), so no node will run backward.  (Inside
+    Function.forward the grad mode is always off, and ctx.needs_input_grad is True for every parameter whatever the mode.)"""
+    _INFERENCE["on"] = bool(on)
+
+
+def _infer(ctx) -> bool:
+    return _INFERENCE["on"]
+
+
+def _ln_fwd(be, x, w, b, infer=False, need_y=True):
+    """-> (y, mean, rstd, record).  need_y=False (inference, pair format): y is NOT written (returned None) -- the product behind reads the
+    pairs, and whoever adds these rows as a residual has its epilogue recompute them from x (backend.gemm res_ln)"""
     if w is None:                                   # layer_norm=False: the block works on its input as it is
         return x, None, None, None
     M = x.shape[0]
-    y = _new(x.shape, x)
     mean, rstd = _new((M,), x, F32), _new((M,), x, F32)
+    if _pairs(be, x, infer):                        # the pair format (the record's .pairs): the product behind reads operands split once
+        y = _new(x.shape, x) if need_y else None
+        return y, mean, rstd, be.layernorm_fwd(x, w, b, y, mean, rstd, pairs=True)
+    y = _new(x.shape, x)
     sy = be.layernorm_fwd(x, w, b, y, mean, rstd)          # (HIP backend, fp16-split products: the row maxima of y; else None)
     return y, mean, rstd, sy
 
@@ -167,21 +190,28 @@ def _ln_bwd(be, dy, x, mean, rstd, w, b):
     return dx, sdx
 
 
-def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip):
+def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip, infer=False):
     """FeedForward: xn = LN(x); u = ELU(xn W1^T + b1); y = act2(u W2^T + b2); out = drop(y) (+ xn)."""
     M = x.shape[0]
-    xn, mean, rstd, sxn = _ln_fwd(be, x, norm_w, norm_b)
     Hd, Nout = w1.shape[0], w2.shape[0]
     narrow = Nout <= 32                       # the output maps' last product (2 .. 12 columns): fp32 kernels, fp32 operands and result
+    # inference through the pair format: the normalised rows are written as pairs only when the product that adds them back (skip) can
+    # recompute them in its epilogue -- or nobody adds them back
+    lean = _pairs(be, x, infer) and norm_w is not None and Hd > 32 and M > 32 and (not skip or not narrow)
+    xn, mean, rstd, sxn = _ln_fwd(be, x, norm_w, norm_b, infer, need_y=not lean)
     u = _new((M, Hd), x, F32 if narrow else None)
     # u feeds the next product: its row maxima come out of this product's epilogue -- where a product will read them (ADVICE r2)
     sxn, su = be.gemm(xn, w1, u, M=M, N=Hd, K=x.shape[1], bias=b1, act=ELU, a_scales=sxn, out_amax=_wants_amax(be, False))
     out = _new((M, Nout), x, F32 if narrow else None)
     res = xn if skip else None
     pre = None
+    ln_res = (mean, rstd, norm_w, norm_b) if (skip and xn is None) else None      # (lean) the residual = LayerNorm(x), recomputed by the epilogue from x
     if act2:
         pre = _new((M, Nout), x)
-        su = be.gemm(u, w2, pre, M=M, N=Nout, K=Hd, bias=b2, act=ELU, drop_p=drop_p, drop_seed=seed, res=res, out2=out, a_scales=su)
+        kw = dict(res=x, res_ln=ln_res) if ln_res else dict(res=res)
+        su = be.gemm(u, w2, pre, M=M, N=Nout, K=Hd, bias=b2, act=ELU, drop_p=drop_p, drop_seed=seed, out2=out, a_scales=su, **kw)
+    elif skip and xn is None:                  # (lean) the residual = LayerNorm(x), recomputed by the epilogue from x
+        su = be.gemm(u, w2, out, M=M, N=Nout, K=Hd, bias=b2, drop_p=drop_p, drop_seed=seed, res=x, res_ln=(mean, rstd, norm_w, norm_b), a_scales=su)
     else:
         su = be.gemm(u, w2, out, M=M, N=Nout, K=Hd, bias=b2, drop_p=drop_p, drop_seed=seed, res=res, a_scales=su)
     return out, (x, mean, rstd, xn, u, pre, sxn, su)
@@ -253,18 +283,23 @@ class AttBlockFn(Function):
         be = get_backend()
         h = _c(h)
         N, Fd = h.shape
-        h1, mean1, rstd1, sh1 = _ln_fwd(be, h, ln_w, ln_b)
+        infer = _infer(ctx)
+        lean = _pairs(be, h, infer) and ln_w is not None and N > 32 and w_fc.shape[0] > 32 and Fd > 32      # h1 as pairs only (see _ff_fwd)
+        h1, mean1, rstd1, sh1 = _ln_fwd(be, h, ln_w, ln_b, infer, need_y=not lean)
         ft = _new((N, w_fc.shape[0]), h)
         sh1 = be.gemm(h1, w_fc, ft, M=N, N=w_fc.shape[0], K=Fd, a_scales=sh1)
         m = _new(ft.shape, h)
         alpha = _new((plan.E, heads), h, F32)
         be.gat_fwd(plan, ft, heads, ft.shape[1] // heads, m, alpha)
         h3 = _new((N, Fd), h)
-        sm = be.gemm(m, w_r, h3, M=N, N=Fd, K=m.shape[1], bias=b_r, drop_p=drop_p, drop_seed=seed1, res=h1)
+        if h1 is None:
+            sm = be.gemm(m, w_r, h3, M=N, N=Fd, K=m.shape[1], bias=b_r, drop_p=drop_p, drop_seed=seed1, res=h, res_ln=(mean1, rstd1, ln_w, ln_b))
+        else:
+            sm = be.gemm(m, w_r, h3, M=N, N=Fd, K=m.shape[1], bias=b_r, drop_p=drop_p, drop_seed=seed1, res=h1)
         if w1 is None:                              # self_interaction=False: attention + head reducer + skip only
             out, ff_saved = h3, None
         else:
-            out, ff_saved = _ff_fwd(be, h3, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
+            out, ff_saved = _ff_fwd(be, h3, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True, infer)
         ctx.plan, ctx.cfg, ctx.scales = plan, (heads, drop_p, seed1, seed2), (sh1, sm)
         ctx.ff_saved = ff_saved
         ctx.save_for_backward(h, mean1, rstd1, h1, ft, m, alpha, ln_w, ln_b, w_fc, w_r, b_r, ln2_w, ln2_b, w1, b1, w2, b2)
@@ -394,6 +429,18 @@ class SplitHeadsFn(Function):
         return acc, None
 
 
+def _attention(be, qkv, s, T, nheads, like, infer):
+    """-> (att or None, record of att's row maxima): the s <= 4 tokens of every tuple attend to each other.  Inference on the HIP
+    backend: the output is written in the pair format only (the record's .pairs) -- nothing but the out-projection reads it."""
+    M, Fd = qkv.shape[0], qkv.shape[1] // 3
+    if not T:
+        return _new((M, Fd), like), None
+    if infer and hasattr(be, "pairs_ok") and be.pairs_ok(qkv, Fd) and 32 < Fd <= 512 and M > 32:        # (the out-projection must be able to read pairs: M, N > 32)
+        return None, be.seqattn_fwd(qkv, s, T, nheads, None, pairs=True)
+    att = _new((M, Fd), like)
+    return att, be.seqattn_fwd(qkv, s, T, nheads, att)
+
+
 class ProjGatherFn(Function):
     """a = ELU(h W^T + b) (N, Wp); x[pos*T+t] = [a[idx[t,pos]], pe[pos]] (s*T, Wp + has_pe)."""
 
@@ -441,14 +488,18 @@ class TransformerLayerFn(Function):
         be = get_backend()
         x = _c(x)
         M, Fd = x.shape
-        x1, mean1, rstd1, sx1 = _ln_fwd(be, x, n1_w, n1_b)
+        infer = _infer(ctx)
+        lean = _pairs(be, x, infer) and n1_w is not None and M > 32 and Fd > 32      # x1 as pairs only; the out-projection recomputes it as its residual
+        x1, mean1, rstd1, sx1 = _ln_fwd(be, x, n1_w, n1_b, infer, need_y=not lean)
         qkv = _new((M, 3 * Fd), x)
         sx1 = be.gemm(x1, w_in, qkv, M=M, N=3 * Fd, K=Fd, bias=b_in, a_scales=sx1)
-        att = _new((M, Fd), x)
-        satt = be.seqattn_fwd(qkv, s, T, nheads, att) if T else None
+        att, satt = _attention(be, qkv, s, T, nheads, x, infer)
         x2 = _new((M, Fd), x)
-        satt = be.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x1, a_scales=satt)
-        out, ff_saved = _ff_fwd(be, x2, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        if x1 is None:
+            satt = be.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x, res_ln=(mean1, rstd1, n1_w, n1_b), a_scales=satt)
+        else:
+            satt = be.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x1, a_scales=satt)
+        out, ff_saved = _ff_fwd(be, x2, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True, infer)
         ctx.cfg, ctx.scales = (s, T, nheads, drop_p, seed1, seed2), (sx1, satt)
         ctx.ff_saved = ff_saved
         ctx.save_for_backward(x, mean1, rstd1, x1, qkv, att, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)
@@ -504,7 +555,8 @@ class ProjFirstLayerFn(Function):
         sh = be.gemm(h, w, a[:, :Wp], M=N, N=Wp, K=R, bias=b, act=ELU)
         tab = _new((s * N, Fd), a)
         be.tuple_gather_fwd(a, idx_id, s, pe, tab)                 # tab[pos*N + n] = [a[n], pe[pos]]
-        x1_tab, mean1, rstd1, sx1 = _ln_fwd(be, tab, n1_w, n1_b)
+        infer = _infer(ctx)
+        x1_tab, mean1, rstd1, sx1 = _ln_fwd(be, tab, n1_w, n1_b, infer)
         qkv_tab = _new((s * N, 3 * Fd), tab)
         sx1 = be.gemm(x1_tab, w_in, qkv_tab, M=s * N, N=3 * Fd, K=Fd, bias=b_in, a_scales=sx1)
         M = s * T
@@ -514,12 +566,11 @@ class ProjFirstLayerFn(Function):
         be.tuple_gather_fwd(x1_tab, idx_tab, s, None, x1)          # x1[pos*T + t] = x1_tab[pos*N + idx[t, pos]]
         be.tuple_gather_fwd(qkv_tab, idx_tab, s, None, qkv)
         del qkv_tab
-        att = _new((M, Fd), tab)
-        satt = be.seqattn_fwd(qkv, s, T, nheads, att)
+        att, satt = _attention(be, qkv, s, T, nheads, tab, infer)
         x2 = _new((M, Fd), tab)
         satt = be.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x1, a_scales=satt)
         del x1
-        out, ff_saved = _ff_fwd(be, x2, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        out, ff_saved = _ff_fwd(be, x2, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True, infer)
         ctx.cfg, ctx.scales = (s, T, N, Wp, pe is not None, nheads, drop_p, seed1, seed2), (sh, sx1, satt)
         ctx.ff_saved = ff_saved
         ctx.save_for_backward(h, a, tab, mean1, rstd1, x1_tab, qkv, att, invid_ptr, invid_rows, invtab_ptr, invtab_rows,
@@ -586,7 +637,7 @@ class SymmetriserFn(Function):
         cur = z
         for i, (nw, nb, w1, b1, w2, b2) in enumerate(layers):
             skip = (i != 0) and (i != n_layers - 1)
-            cur, sv = _ff_fwd(be, cur, nw, nb, w1, b1, w2, b2, False, 0.0, 0, skip)
+            cur, sv = _ff_fwd(be, cur, nw, nb, w1, b1, w2, b2, False, 0.0, 0, skip, _infer(ctx))
             saved.append(sv)
         ctx.cfg = (s, T, perms, n_layers, tuple(x.shape), x.dtype)
         ctx.saved_layers = saved

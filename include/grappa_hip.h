@@ -27,7 +27,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 6
+#define GRAPPA_ABI_VERSION 7
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -135,6 +135,13 @@ typedef struct grappa_gemm_desc {
      * b_planes != 0 alone ("weight pairs": A = fp32 activations [M][K], K % 16 == 0, lda % 4 == 0, 16-byte aligned, a_kcontig =
      * b_kcontig = 1) takes A as it is -- raw fp32 rows by LDS-DMA, each wavefront splits the fragments of its own 64 rows -- and gives
      * the same bits as the all-pairs product.  a_planes != 0 alone is refused. */
+    /* ---- ABI 7: the residual given as the INPUT of a LayerNorm.  res_ln_mean != NULL: `res` holds x, the rows BEFORE normalisation, and the
+     * epilogue adds LayerNorm(x)(m, n) = fma((x(m, n) - mean[m]) * rstd[m], gamma[n], beta[n]) -- the very bits grappa_layernorm_fwd_*
+     * writes -- so that a producer that hands its normalised rows on in the pair format need not write them in fp32 as well (inference).
+     * fp32 `res` (not resp), N % 4 == 0, gamma / beta 16-byte aligned, the split kernels only (M, N > 32, precision other than F32_MFMA; fp32
+     * operands or both in the pair format): every epilogue form of those (straight-line classes, the generic row walk with C2 / activation,
+     * the split-K reduction) adds the recomputed rows; anything else is refused (GRAPPA_ERR_ARG). */
+    const float* res_ln_mean; const float* res_ln_rstd; const float* res_ln_gamma; const float* res_ln_beta;
 } grappa_gemm_desc;
 
 /* Largest magnitudes of an fp32 matrix x[R][C] (leading dimension ldx), as fp32 bit patterns: row_amax[r] = max_c |x[r][c]|,
@@ -226,6 +233,12 @@ int grappa_layernorm_fwd_f32(void* stream, int M, int W, const float* x, int ldx
                              float* y, int ldy, float* mean, float* rstd);
 int grappa_layernorm_fwd_amax_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
                                   float* y, int ldy, float* mean, float* rstd, uint32_t* y_amax);
+/* ABI 7: the same rows ALSO written in the pair format (grappa_gemm_desc, ABI 5: the A operand of a following F32_F16X3 product, split once
+ * by the kernel that holds the whole row and its maximum): pairs[M][ldp] fp16, ldp >= 2 * W, ldp % 8 == 0, 16-byte aligned; W % 32 == 0.
+ * y (fp32; NULL: not written), mean, rstd (NULL: not written) as above and bit-identical to them; y_amax is required (the pairs' scales).
+ * Inference: LayerNorm -> product chains without a second pass over the activation and without a split in the product. */
+int grappa_layernorm_fwd_pairs_f32(void* stream, int M, int W, const float* x, int ldx, const float* gamma, const float* beta,
+                                   float* y, int ldy, float* mean, float* rstd, uint32_t* y_amax, uint16_t* pairs, int ldp);
 size_t grappa_layernorm_bwd_workspace_bytes(int M, int W);
 /* dx may alias dy.  dgamma/dbeta: accumulate = 1 adds to the existing values, 0 overwrites.  accumulate = 2 defers them: the
  * kernel leaves its per-block partial sums at the start of `ws` -- grappa_layernorm_bwd_partial_rows(M) rows of 2 W floats,
@@ -299,6 +312,10 @@ int grappa_seqattn_fwd_f32(void* stream, int s, int T, int nheads, int dh, const
 int grappa_seqattn_bwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv);
 /* ABI 4: the same kernels, also writing the largest magnitude of every row of out (s*T values) / of dqkv (s*T values) */
 int grappa_seqattn_fwd_amax_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out, uint32_t* out_amax);
+/* ABI 7: the attention output in the pair format only (inference: nothing but the out-projection product reads it): pairs[s*T][ldp],
+ * F = nheads * dh <= 512, F % 32 == 0, ldp >= 2 * F; out_amax (s*T values, required) = the rows' scales; values bit-identical to
+ * grappa_seqattn_fwd_amax_f32 followed by grappa_split_pairs_f32 */
+int grappa_seqattn_fwd_pairs_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, uint16_t* pairs, int ldp, uint32_t* out_amax);
 int grappa_seqattn_bwd_amax_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, const float* dout, float* dqkv,
                                 uint32_t* dqkv_amax);
 

@@ -44,4 +44,11 @@ def _library_defaults(request):
             be.pin_tail_launches(None)
             be.lib.grappa_gemm_f32_set_tail_launches(-1)
             be._tails = None
+            # ... and from the default arithmetic and storage (a test that switches them and fails before restoring must not move the rest)
+            from grappa_amd import ops
+            default = os.environ.get("GRAPPA_GEMM_PRECISION", backend.DEFAULT_GEMM_PRECISION)
+            if be.gemm_precision_name != default:
+                be.set_gemm_precision(default)
+            be.set_gemm_precision_bwd(None)
+            ops.set_activation_dtype("f32")
     yield

@@ -6,6 +6,8 @@ Activations and activation gradients live in HBM as bf16; every kernel computes 
   * end to end: parameters vs the oracle within SURVEY 8(d)'s bf16 gate (2e-2 relative, floors as in tests/test_gpu_configs.py),
     a full train step (finite loss and gradients, gradient direction = the fp32-grade one), and bit-reproducibility.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -160,7 +162,8 @@ def _bf16_mode(on: bool):
     from grappa_amd.backend import get_backend
     be = get_backend()
     ops.set_activation_dtype("bf16" if on else "f32")
-    be.set_gemm_precision("bf16" if on else "f32_bf16x6")
+    from grappa_amd.backend import DEFAULT_GEMM_PRECISION
+    be.set_gemm_precision("bf16" if on else os.environ.get("GRAPPA_GEMM_PRECISION", DEFAULT_GEMM_PRECISION))      # off = the backend's own default
 
 
 @pytest.mark.parametrize("n_conv", [0, 2])

@@ -59,3 +59,113 @@ def test_pair_layout_and_rejections():
     d.precision = _lib.GEMM_PRECISIONS["f32_f16x3"]
     ws = gp.ws_for(37, 37, 50)
     assert gp.lib.grappa_gemm_f32(gp.stream(), C.byref(d), ws.data_ptr(), ws.numel()) == -1
+
+
+@pytest.mark.parametrize("M,W", [(1000, 512), (77, 256), (4097, 2048), (300, 32), (5, 512)])
+def test_layernorm_writes_its_rows_in_the_pair_format(M, W):
+    """grappa_layernorm_fwd_pairs_f32: y, mean, rstd and the row maxima are the bits of the plain kernel; the pairs are the bits of
+    grappa_split_pairs_f32 on that y; y = NULL writes the pairs alone"""
+    import gemm_pairs_check as gp
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(M + W)
+    x = torch.randn((M, W), generator=gen, device="cuda") * torch.exp2(torch.randint(-6, 6, (M, 1), generator=gen, device="cuda").float())
+    g, b = torch.randn(W, generator=gen, device="cuda"), torch.randn(W, generator=gen, device="cuda")
+    y0, m0, r0 = torch.empty_like(x), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    s0 = be.layernorm_fwd(x, g, b, y0, m0, r0, amax=True)
+    y1, m1, r1 = torch.full_like(x, float("nan")), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    s1 = be.layernorm_fwd(x, g, b, y1, m1, r1, pairs=True)
+    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1) and torch.equal(s0.row, s1.row)
+    assert s1.pairs.shape == (M, 2 * W) and torch.equal(s1.pairs, gp.split_pairs(y0, s0.row))
+    s2 = be.layernorm_fwd(x, g, b, None, None, None, pairs=True)
+    assert torch.equal(s2.pairs, s1.pairs) and torch.equal(s2.row, s1.row)
+    with pytest.raises(ValueError):
+        be.layernorm_fwd(x[:, :24].contiguous(), g[:24].contiguous(), b[:24].contiguous(), None, None, None, pairs=True)
+
+
+@pytest.mark.parametrize("s,T,heads,F", [(4, 500, 8, 512), (3, 77, 8, 512), (2, 1000, 4, 256), (1, 40, 2, 64), (4, 3, 8, 512)])
+def test_tuple_attention_writes_its_output_in_the_pair_format(s, T, heads, F):
+    import gemm_pairs_check as gp
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(s * 1000 + T)
+    qkv = torch.randn((s * T, 3 * F), generator=gen, device="cuda")
+    att = torch.empty((s * T, F), device="cuda")
+    s0 = be.seqattn_fwd(qkv, s, T, heads, att, amax=True)
+    s1 = be.seqattn_fwd(qkv, s, T, heads, None, pairs=True)
+    assert torch.equal(s0.row, s1.row) and torch.equal(s1.pairs, gp.split_pairs(att, s0.row))
+
+
+def test_inference_through_the_pair_format_equals_the_fp32_operand_path():
+    """eval / no_grad: LayerNorm and the tuple attention hand their rows to the product behind them in the pair format (the default);
+    GRAPPA_INFERENCE_PAIRS=0 (be.inference_pairs = False) keeps fp32 operands.  Same values: the pair kernel computes the same partial
+    products, bit for bit where both kernels cut K alike.  With gradients enabled nothing changes (the pairs are an inference path)."""
+    from grappa_amd import get_default_model_config, model_from_config
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    import golden_utils as gu
+    be = get_backend()
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").eval()
+    g_cpu = build_batch_from_pool(list(range(100, 164)), n_confs=2, seed=3)
+    outs = {}
+    taken = {"n": 0}
+    ln = be.layernorm_fwd
+    be.layernorm_fwd = lambda *a, **k: (taken.__setitem__("n", taken["n"] + bool(k.get("pairs"))), ln(*a, **k))[1]
+    try:
+        for flag in (True, False):
+            be.inference_pairs = flag
+            with torch.no_grad():
+                g = model(g_cpu.to("cuda"))
+            outs[flag] = {(lvl, k): g.nodes[lvl].data[k].clone() for lvl in ("n2", "n3", "n4", "n4_improper") for k in ("k", "eq") if k in g.nodes[lvl].data}
+            outs[flag]["h"] = g.nodes["n1"].data["h"].clone()
+    finally:
+        be.inference_pairs = True
+        del be.layernorm_fwd
+    from grappa_amd import ops
+    assert taken["n"] >= 40, (taken, be.gemm_precision_name, be.inference_pairs, ops.act_dtype(), ops._INFERENCE)      # the pair path was taken (and only with the flag on)
+    for key, a in outs[True].items():
+        b = outs[False][key]
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), key
+    # with gradients enabled the model does not use the pairs: the training forward is untouched
+    taken["n"] = 0
+    be.layernorm_fwd = lambda *a, **k: (taken.__setitem__("n", taken["n"] + bool(k.get("pairs"))), ln(*a, **k))[1]
+    try:
+        model(g_cpu.to("cuda"))
+    finally:
+        del be.layernorm_fwd
+    assert taken["n"] == 0
+
+
+@pytest.mark.parametrize("M,N,K,drop", [(1000, 512, 512, 0.0), (5000, 256, 512, 0.3), (257, 512, 256, 0.0), (40, 64, 64, 0.0)])
+def test_product_recomputes_a_layernorm_residual_in_its_epilogue(M, N, K, drop):
+    """res_ln: the residual is given as the rows BEFORE a LayerNorm and the epilogue adds LayerNorm(rows) -- the bits of the product that
+    is handed the normalised rows themselves (fast class, generic row walk and split-K reduction alike)"""
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(M + N)
+    a, w, bias = torch.randn((M, K), generator=gen, device="cuda"), torch.randn((N, K), generator=gen, device="cuda") * 0.05, torch.randn(N, generator=gen, device="cuda")
+    x = torch.randn((M, N), generator=gen, device="cuda") * 3 + 1
+    g, b = torch.randn(N, generator=gen, device="cuda"), torch.randn(N, generator=gen, device="cuda")
+    y, mean, rstd = torch.empty_like(x), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    be.layernorm_fwd(x, g, b, y, mean, rstd)
+    want, got = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+    be.gemm(a, w, want, M=M, N=N, K=K, bias=bias, drop_p=drop, drop_seed=7, res=y)
+    be.gemm(a, w, got, M=M, N=N, K=K, bias=bias, drop_p=drop, drop_seed=7, res=x, res_ln=(mean, rstd, g, b))
+    assert torch.equal(want, got)
+    if M > 64:                       # forced split-K: the reduction kernel applies the epilogue
+        be.lib.grappa_gemm_f32_set_plan_override(-1, 2, -1)
+        try:
+            be.gemm(a, w, got, M=M, N=N, K=K, bias=bias, drop_p=drop, drop_seed=7, res=x, res_ln=(mean, rstd, g, b))
+            be.gemm(a, w, want, M=M, N=N, K=K, bias=bias, drop_p=drop, drop_seed=7, res=y)
+        finally:
+            be.lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+        assert torch.equal(want, got)
+    if M > 64:                       # the generic row walk: activation + second output (the GNN's feed-forward form)
+        pre_w, pre_g = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+        be.gemm(a, w, pre_w, M=M, N=N, K=K, bias=bias, act=1, drop_p=drop, drop_seed=7, res=y, out2=want)
+        be.gemm(a, w, pre_g, M=M, N=N, K=K, bias=bias, act=1, drop_p=drop, drop_seed=7, res=x, res_ln=(mean, rstd, g, b), out2=got)
+        assert torch.equal(want, got) and torch.equal(pre_w, pre_g)
+    with pytest.raises(ValueError):
+        be.gemm(a, w, got, M=M, N=N, K=K, res=None, res_ln=(mean, rstd, g, b))
