@@ -3,6 +3,12 @@
 #pragma once
 #include "common.h"
 
+// residual = LayerNorm(res) recomputed by the epilogue (grappa_gemm_desc.res_ln_*): compiled out of the translation units whose kernels
+// never get it (gemm_planes.hip: its one-plane kernel lives on <= 128 registers for two workgroups per CU, and the branch costs 10)
+#ifndef GRAPPA_EPI_RES_LN
+#define GRAPPA_EPI_RES_LN 1
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef GB_KNOCK
@@ -104,7 +110,7 @@ __device__ inline float epilogue_store(const GemmParams& p, int m, int n, float 
     }
     if (d.C1p) planes_store1(d.C1p, 0, (size_t)m * d.ldc1p + n, v, 1);
     if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
-    if (d.res && d.res_ln_mean) v += grappa_ln_apply(d.res[(size_t)m * d.ldres + n], d.res_ln_mean[m], d.res_ln_rstd[m], d.res_ln_gamma[n], d.res_ln_beta[n]);
+    if (GRAPPA_EPI_RES_LN && d.res && d.res_ln_mean) v += grappa_ln_apply(d.res[(size_t)m * d.ldres + n], d.res_ln_mean[m], d.res_ln_rstd[m], d.res_ln_gamma[n], d.res_ln_beta[n]);
     else if (d.res) v += d.res[(size_t)m * d.ldres + n];
     else if (d.resp) v += planes_load1(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, d.resp_nplanes ? d.resp_nplanes : 3);
     if (out) {
@@ -391,7 +397,7 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, const f32x16 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = grappa_keep(d.drop_seed, idx + q, d.drop_p) ? v[q] * p.drop_scale : 0.0f;
                 }
-                if (d.res && d.res_ln_mean) {
+                if (GRAPPA_EPI_RES_LN && d.res && d.res_ln_mean) {
                     const float4 t = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);
                     const float4 g = *reinterpret_cast<const float4*>(d.res_ln_gamma + n), be = *reinterpret_cast<const float4*>(d.res_ln_beta + n);
                     const float mu = d.res_ln_mean[m], rs = d.res_ln_rstd[m];
@@ -448,7 +454,9 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmParams& p, const f3
             case 2: GRAPPA_FAST(2, float);
             case 3: GRAPPA_FAST(3, float);
             case 4: GRAPPA_FAST(4, float);
+#if GRAPPA_EPI_RES_LN
             case 5: GRAPPA_FAST(5, float);
+#endif
             case 9: GRAPPA_FAST(1, grappa_bf16_t);
             case 10: GRAPPA_FAST(2, grappa_bf16_t);
             case 11: GRAPPA_FAST(3, grappa_bf16_t);

@@ -27,6 +27,7 @@
 // the straight-line epilogue classes (gemm_common.h) cost this file's one-plane kernel 30 registers, i.e. its second workgroup per CU
 // (115 -> 145 VGPRs: the bf16 storage configuration's step went 86 -> 91 ms with them, 99 ms with the registers but without the classes)
 #define GRAPPA_NO_FAST_EPI
+#define GRAPPA_EPI_RES_LN 0          // (the host refuses res_ln for the plane kernels)
 #include "gemm_common.h"
 
 using namespace grappa_gemm;

@@ -85,3 +85,41 @@ def test_device_code_has_no_packed_fp32_instructions():
         packed += len(re.findall(r"v_pk_(?:fma|mul|add)_f32", out))
     assert objects >= 10, objects
     assert packed == 0, packed
+
+
+def test_kernels_keep_the_register_budgets_their_occupancy_needs():
+    """two workgroups per CU are part of these kernels' design: the one-plane bf16 product (512 threads: <= 128
+    registers), the pair-format products (256 threads: <= 256) -- and none of the product kernels spills.  Read from the code objects'
+    metadata (a shared epilogue change that costs ten registers otherwise shows up as a 15 % slower bf16 configuration, as in round 3)."""
+    import re
+    import subprocess
+    import tempfile
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not found")
+    data = open(_lib.LIB_PATH, "rb").read()
+    kernels = {}
+    for m in re.finditer(b"\x7fELF", data):
+        blob = data[m.start():]
+        if m.start() == 0 or blob[18:20] != b"\xe0\x00":
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            out = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True).stdout
+        for blk in out.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+            sp = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if name and vg:
+                kernels[name.group(1)] = (int(vg.group(1)), int(sp.group(1)) if sp else 0)
+    planes1 = {k: v for k, v in kernels.items() if "gemm_planes_kernelILi1E" in k}
+    pairs = {k: v for k, v in kernels.items() if "gemm_pairs_kernel" in k or "gemm_wpairs_kernel" in k}
+    # the kernels of the default arithmetic (mode 103 = two fp16 pieces), of the bf16 storage configuration and of the pair format
+    hot = {k: v for k, v in kernels.items() if re.search(r"gemm_bf16x_(grouped_)?kernelILi512ELi103E", k)}
+    hot.update(planes1)
+    hot.update(pairs)
+    assert len(planes1) == 2 and len(pairs) >= 3 and len(hot) >= 19, (len(planes1), len(pairs), len(hot))
+    assert all(v[0] <= 128 for v in planes1.values()), planes1
+    assert all(v[0] <= 256 for v in pairs.values()), pairs
+    assert all(v[1] == 0 for v in hot.values()), {k: v for k, v in hot.items() if v[1]}
