@@ -77,6 +77,7 @@ class ResidualAttentionBlock(nn.Module):
         s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
         si = self.self_interaction
         si_params = (None,) * 4 if si is None else (si[0].weight, si[0].bias, si[2].weight, si[2].bias)
+        ops.mark_mode()
         return ops.AttBlockFn.apply(h, plan, self.num_heads, p, s1, s2, *_wb(getattr(self, "layer_norm", None)),
                                     self.graph_module.fc.weight, self.head_reducer.weight, self.head_reducer.bias,
                                     *_wb(getattr(self, "interaction_norm", None)), *si_params)
@@ -152,7 +153,6 @@ class GrappaGNN(nn.Module):
 
     def forward(self, g):
         plan = g.plan()
-        ops.set_inference(not torch.is_grad_enabled())
         x = self.input_features(g)
         p0 = self.p_initial if self.training else 0.0
         h = ops.LinearFn.apply(x, self.pre_dense[0].weight, self.pre_dense[0].bias, ops.ELU, p0, ops.next_seed() if p0 > 0 else 0, ops.act_dtype())
@@ -193,6 +193,7 @@ class DottedAttWithMLP(nn.Module):
     def forward(self, x, s, T):
         p = self.p if self.training else 0.0
         s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+        ops.mark_mode()
         return ops.TransformerLayerFn.apply(x, s, T, self.num_heads, p, s1, s2, *_wb(getattr(self, "norm1", None)),
                                             self.attn.in_proj_weight, self.attn.in_proj_bias, self.attn.out_proj.weight,
                                             self.attn.out_proj.bias, *self.ff.params())
@@ -250,6 +251,7 @@ class SymmetrisedTransformer(nn.Module):
                 x = layer(x, s, T)
         sym = self.symmetriser
         flat = [t for ff in sym.mlp for t in ff.params()]
+        ops.mark_mode()
         return ops.SymmetriserFn.apply(x, s, T, sym._perm_list, len(sym.mlp), *flat)
 
 
@@ -326,6 +328,7 @@ class _WriterBase(nn.Module):
             l0 = layers[0]
             p = l0.p if l0.training else 0.0
             s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+            ops.mark_mode()
             x = ops.ProjFirstLayerFn.apply(h, lin.weight, lin.bias, plan.position_tables(lvl), self.s, T, pe, ops.act_dtype(), l0.num_heads, p, s1, s2,
                                            *_wb(getattr(l0, "norm1", None)), l0.attn.in_proj_weight, l0.attn.in_proj_bias,
                                            l0.attn.out_proj.weight, l0.attn.out_proj.bias, *l0.ff.params())
@@ -490,7 +493,6 @@ class WriteParameters(nn.Module):
 
     def forward(self, g):
         h = g.nodes["n1"].data["h"]
-        ops.set_inference(not torch.is_grad_enabled())
         writers = self._writers_largest_first()
         # every head reads an alias of h of its own, so that its gradient of h arrives alone at the node that adds the four
         aliases = ops.SplitHeadsFn.apply(h, len(writers)) if (torch.is_grad_enabled() and h.requires_grad) else (h,) * len(writers)

@@ -151,14 +151,16 @@ def _pairs(be, x, infer) -> bool:
 _INFERENCE = {"on": False}
 
 
-def set_inference(on: bool) -> None:
-    """told by the model at the top of its forward: gradients are disabled (torch.no_grad()), so no node will run backward.  (Inside
-    Function.forward the grad mode is always off, and ctx.needs_input_grad is True for every parameter whatever the mode.)"""
-    _INFERENCE["on"] = bool(on)
+def mark_mode() -> None:
+    """called by the modules right before they apply one of the functions below: are gradients disabled (torch.no_grad()), so that no
+    node will run backward?  (Inside Function.forward the grad mode is always off, and ctx.needs_input_grad is True for every parameter
+    whatever the mode -- the function cannot see it by itself.)"""
+    _INFERENCE["on"] = not torch.is_grad_enabled()
 
 
 def _infer(ctx) -> bool:
-    return _INFERENCE["on"]
+    # (second condition: whatever the flag says, an input activation that asks for a gradient means a backward pass will come)
+    return _INFERENCE["on"] and not ctx.needs_input_grad[0]
 
 
 def _ln_fwd(be, x, w, b, infer=False, need_y=True):
