@@ -144,17 +144,25 @@ __global__ __launch_bounds__(256) void amax_combine_kernel(int M, int nseg, cons
     out[m] = v;
 }
 
-// one workgroup per matrix (weights: at most a few MB each); column maxima meet in LDS (ds_max_u32)
+// BATCH_SLICES workgroups per matrix (weights: at most a few MB each; one workgroup per matrix left 100 - 200 of 256 CUs idle for 0.2 ms
+// per optimiser step), each a share of the rows; column maxima meet in LDS (ds_max_u32), then across the slices in the output array by
+// atomic maxima of the bit patterns (order-free: the same bits every run), which amax_batched_zero_kernel cleared
+constexpr int BATCH_SLICES = 8;
+__global__ __launch_bounds__(256) void amax_batched_zero_kernel(const grappa_amax_item* __restrict__ descs) {
+    const grappa_amax_item d = descs[blockIdx.x];
+    for (int c = threadIdx.x; c < d.C; c += 256) d.col_amax[c] = 0u;
+}
 __global__ __launch_bounds__(1024) void amax_batched_kernel(const grappa_amax_item* __restrict__ descs) {
     __shared__ unsigned colmax[2048];
     const grappa_amax_item d = descs[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.y * 16 >= d.R) return;                  // (a slice without rows: nothing to add)
     for (int c = threadIdx.x; c < 2048; c += 1024) colmax[c] = 0u;
     __syncthreads();
     uint4 cm[8];
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) cm[ch] = make_uint4(0u, 0u, 0u, 0u);
-    for (int r = wave; r < d.R; r += 16) {
+    for (int r = blockIdx.y * 16 + wave; r < d.R; r += 16 * BATCH_SLICES) {
         const unsigned* row = reinterpret_cast<const unsigned*>(d.x) + (size_t)r * d.ld;
         unsigned rm = 0u;
 #pragma unroll
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(1024) void amax_batched_kernel(const grappa_amax_it
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < d.C; c += 1024) d.col_amax[c] = colmax[c];
+    for (int c = threadIdx.x; c < d.C; c += 1024) atomicMax(&d.col_amax[c], colmax[c]);
 }
 
 int amax_blocks(int R) {
@@ -263,6 +271,7 @@ int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* 
 extern "C" int grappa_amax_f32_batched(void* stream, int count, const grappa_amax_item* descs) {
     if (count < 0 || (count > 0 && !descs)) return GRAPPA_ERR_ARG;
     if (count == 0) return GRAPPA_OK;
-    hipLaunchKernelGGL(amax_batched_kernel, dim3(count), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), descs);
+    hipLaunchKernelGGL(amax_batched_zero_kernel, dim3(count), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), descs);
+    hipLaunchKernelGGL(amax_batched_kernel, dim3(count, BATCH_SLICES), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), descs);
     return grappa_launch_status();
 }

@@ -224,7 +224,7 @@ def test_train_step_matches_default_arithmetic(wl, n):
 
 def test_weight_maxima_follow_the_optimiser(hip):
     """weights: maxima cached per optimiser step; the step after, one batched launch refreshes every registered weight"""
-    ws = [torch.randn(r, c, device="cuda").requires_grad_() for r, c in ((512, 512), (1536, 512), (256, 2048), (300, 85), (512, 2052))]
+    ws = [torch.randn(r, c, device="cuda").requires_grad_() for r, c in ((512, 512), (1536, 512), (256, 2048), (300, 85), (512, 2052), (40, 512), (129, 64), (6, 256))]
     x = {w.shape[1]: torch.randn(100, w.shape[1], device="cuda") for w in ws}
 
     def run():
