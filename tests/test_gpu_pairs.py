@@ -169,3 +169,43 @@ def test_product_recomputes_a_layernorm_residual_in_its_epilogue(M, N, K, drop):
         assert torch.equal(want, got) and torch.equal(pre_w, pre_g)
     with pytest.raises(ValueError):
         be.gemm(a, w, got, M=M, N=N, K=K, res=None, res_ln=(mean, rstd, g, b))
+
+
+@pytest.mark.parametrize("variant", ["plain", "no_layer_norm", "no_self_interaction", "conv_blocks", "wide_attention", "odd_width", "wrong_symmetry"])
+def test_inference_pair_path_on_model_variants(variant):
+    """the constructor options of the reference's model under no_grad with the pair path on and off: same parameters (the path must step
+    aside by itself where a width, a missing LayerNorm or an attention wider than 512 columns rules it out)"""
+    from grappa_amd import GrappaModel
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    be = get_backend()
+    cfg = dict(graph_node_features=64, in_feat_name=["atomic_number", "partial_charge", "ring_encoding", "degree", "charge_model"],
+               gnn_width=128, gnn_attentional_layers=2, gnn_convolutions=0, gnn_attention_heads=4,
+               **{f"{h}_{k}": v for h in ("bond", "angle", "proper", "improper")
+                  for k, v in (("transformer_depth", 2), ("n_heads", 4), ("transformer_width", 128), ("symmetriser_depth", 3), ("symmetriser_width", 64))})
+    if variant == "no_layer_norm":
+        cfg["layer_norm"] = False
+    elif variant == "no_self_interaction":
+        cfg["self_interaction"] = False
+    elif variant == "conv_blocks":
+        cfg.update(gnn_convolutions=2, gnn_attentional_layers=1)
+    elif variant == "wide_attention":
+        cfg.update(bond_transformer_width=1024, bond_n_heads=8)          # attention rows of 1024 columns (> 512: no pair output); 2 x 1024 = the widest LayerNorm row
+    elif variant == "odd_width":
+        cfg.update(angle_transformer_width=80, angle_n_heads=5, angle_symmetriser_width=40)            # 80, 40: not multiples of 32 (head width 16)
+    elif variant == "wrong_symmetry":
+        cfg["wrong_symmetry"] = True
+    torch.manual_seed(1)
+    model = GrappaModel(**cfg).to("cuda").eval()
+    g_cpu = build_batch_from_pool(list(range(200, 232)), n_confs=1, seed=5)
+    outs = {}
+    try:
+        for flag in (True, False):
+            be.inference_pairs = flag
+            with torch.no_grad():
+                g = model(g_cpu.to("cuda"))
+            outs[flag] = [g.nodes[lvl].data[k].clone() for lvl in ("n2", "n3", "n4", "n4_improper") for k in ("k", "eq") if k in g.nodes[lvl].data]
+    finally:
+        be.inference_pairs = True
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 5e-6 * max(float(b.abs().max()), 1e-6), variant
