@@ -30,7 +30,7 @@ from grappa_amd.dist import BucketedGradReducer
 from grappa_amd.optim import FlatParams
 torch.manual_seed(0)
 model = GrappaModel(**TINY).to("cuda").train()
-assert model.parameter_writer.head_streams == 4
+assert model.parameter_writer.head_streams == int(os.environ.get("GRAPPA_HEAD_STREAMS", "4"))      # (the default: four)
 flat = FlatParams(model)
 be = get_backend()
 ids = [30, 31, 32, 33, 34, 35, 36, 37]
