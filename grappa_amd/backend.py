@@ -115,6 +115,7 @@ class HipBackend:
             raise RuntimeError("grappa_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self._ws = {}
+        self._ws_need = {}             # (M, N, K, tail-launch setting) -> workspace bytes of a product of that shape
         # arithmetic of the dense products (include/grappa_hip.h GRAPPA_GEMM_*): "f32_f16x3" = fp32 operands, every row scaled by a
         # power of two, split into two fp16 pieces (3 partial products on the fp16 matrix cores, fp32 accumulation); "f32_bf16x6" =
         # three bf16 pieces, 6 products (the default until round 2).  Both are at least as close to the exact product as the native
@@ -591,7 +592,9 @@ class HipBackend:
         if out_amax is True and final.dtype == torch.float32:          # (out_amax == "pair": the caller only wants the pair returned)
             so = Amax(row=torch.empty(M, dtype=torch.int32, device=dev))
             d.out_amax = so.row.data_ptr()
-        need = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
+        need = self._ws_need.get((M, N, K, self._tails))
+        if need is None:                         # (the query plans the product for every kernel family: 5 - 10 us, the same answer per shape)
+            need = self._ws_need[(M, N, K, self._tails)] = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
         ws = self._workspace(need, dev) if need else None
         el = lambda t: 0 if t is None else t.element_size()      # noqa: E731
         # algorithmic bytes of the fused call: both operands once, the result, and what the epilogue has to read / write beside it
@@ -599,9 +602,16 @@ class HipBackend:
         epi = M * N * (el(res) + el(aux) + el(pre) + (el(out) if out2 is not None else 0) + (el(final) if accumulate else 0))
         self._timed("gemm_f32", 2.0 * M * N * K, float(M * K * (4 if a_pairs is not None else el(a if planes_a is None else planes_a)) + N * K * (2 if planes_b is not None else 4)
                                                          + M * N * el(final) + epi),
-                    lambda: _chk(self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0),
-                                 "grappa_gemm_f32"))
+                    lambda: self._launch_gemm(d, ws, dev, (M, N, K)))
         return (sa, so) if out_amax else sa
+
+    def _launch_gemm(self, d, ws, dev, shape) -> None:
+        rc = self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0)
+        if rc == -3:                             # GRAPPA_ERR_WORKSPACE: the cached size predates a plan setting (override, environment): ask again
+            need = self._ws_need[shape + (self._tails,)] = self.lib.grappa_gemm_f32_workspace_bytes(*shape)
+            ws = self._workspace(need, dev) if need else None
+            rc = self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0)
+        _chk(rc, "grappa_gemm_f32")
 
     # ------------------------------------------------------------------ weight gradients, grouped
     def gemm_wgrad(self, dz, x, dw, db=None, dz_scales=None, x_scales=None):
