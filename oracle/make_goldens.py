@@ -109,12 +109,12 @@ class zero_dihedral_noise:
         torch.randn_like = self._orig
 
 
-def run_reference(cfg, mols, n_confs, state_dict=None, loss_kwargs=None, with_param_refs=True, noise=False, grads="all"):
+def run_reference(cfg, mols, n_confs, state_dict=None, loss_kwargs=None, with_param_refs=True, noise=False, grads="all", energy_kwargs=None):
     torch.manual_seed(0)
     model = RefGrappaModel(**cfg)
     sd = keyed_state_dict(model) if state_dict is None else state_dict
     model.load_state_dict(sd)
-    full = torch.nn.Sequential(model, RefEnergy(suffix="", gradients=True))
+    full = torch.nn.Sequential(model, RefEnergy(suffix="", gradients=True, **(energy_kwargs or {})))
     full.eval()
     graphs = [ref_graph(m, n_confs, with_param_refs, (cfg["n_periodicity_proper"], cfg["n_periodicity_improper"]))[0] for m in mols]
     g = ref_dgl_utils.batch(graphs)
@@ -462,6 +462,36 @@ def make_options_golden():
         save(name, cfg, mols, out, sd, extra)
 
 
+def tiny_config(**opts):
+    """a model small enough that a fixture with its weights and every parameter gradient stays well under 1 MB"""
+    cfg = small_config(n_conv=0, gated=False, n_att=1)
+    cfg.update(graph_node_features=16, gnn_width=32, gnn_attention_heads=2)
+    for lvl in ("bond", "angle", "proper", "improper"):
+        cfg.update({f"{lvl}_transformer_depth": 1, f"{lvl}_n_heads": 2, f"{lvl}_transformer_width": 32, f"{lvl}_symmetriser_depth": 2,
+                    f"{lvl}_symmetriser_width": 16})
+    cfg.update(opts)
+    return cfg
+
+
+def make_variants_golden():
+    """constructor / Energy variants of the reference that had no reference-generated fixture (VERDICT r3 missing #2):
+    wrong_symmetry=True (models/interaction_parameters.py:502-507: six permutations of the improper tokens, positional code [0,0,1,0]),
+    harmonic_gate=True (:257-264, :352-360: a third output column per bond / angle that the written k ignores), n_periodicity_proper=3
+    (experiments/train-grappa-1.2.1/grappa_config.yaml:98-99) and Energy(offset_torsion=True) (models/energy.py:79) end to end,
+    i.e. with the loss and every parameter gradient behind it."""
+    mols = build_inputs(pick_small(4, 9, 22, start=60), n_confs=4, seed=31, charge_model="amber99")
+    lk = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=1e-3, proper_regularisation=1e-3, improper_regularisation=1e-3)
+    for name, opts, ek in (("ref_tiny_wrongsym.npz", dict(wrong_symmetry=True), None),
+                           ("ref_tiny_harmonic_gate.npz", dict(harmonic_gate=True), None),
+                           ("ref_tiny_nper3.npz", dict(n_periodicity_proper=3, gated_torsion=True), None),
+                           ("ref_tiny_offset_torsion.npz", dict(), dict(offset_torsion=True))):
+        cfg = tiny_config(**opts)
+        out, sd, g = run_reference(cfg, mols, 4, loss_kwargs=lk, energy_kwargs=ek)
+        extra = {"loss_kwargs_keys": np.array(list(lk.keys())), "loss_kwargs_vals": np.array(list(lk.values())),
+                 "energy_kwargs_keys": np.array(list((ek or {}).keys())), "energy_kwargs_vals": np.array([repr(v) for v in (ek or {}).values()])}
+        save(name, cfg, mols, out, None, extra)         # weights: golden_utils.keyed_state_dict on both sides (derived from the state-dict keys)
+
+
 def make_dataset_golden():
     """the reference's dataset-level logic (data/Dataset.py:80-112 `split`, :236-258 k-fold / partition splits through
     utils/torch_utils.py:11-135, :141-345, :259-294 `where` / `shuffle` / `subsampled`) on synthetic (mol_id, subdataset) lists with
@@ -513,6 +543,8 @@ if __name__ == "__main__":
         make_dataset_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "options":
         make_options_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "variants":
+        make_variants_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "eval":
         make_eval_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "tuples":
@@ -525,4 +557,5 @@ if __name__ == "__main__":
         make_tuple_golden()
         make_predict_golden()
         make_options_golden()
+        make_variants_golden()
         make_dataset_golden()

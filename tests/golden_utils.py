@@ -31,6 +31,18 @@ def state_dict_of(fx):
     return {k[4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd::")}
 
 
+def weights_for(fx, model):
+    """the weights the reference run used: stored in the fixture (sd::*), or -- fixtures that ship none -- derived from the state-dict keys"""
+    sd = state_dict_of(fx)
+    return sd if sd else keyed_state_dict(model)
+
+
+def energy_kwargs_of(fx):
+    if "energy_kwargs_keys" not in fx.files:
+        return {}
+    return {k: ast.literal_eval(v) for k, v in zip(fx["energy_kwargs_keys"].tolist(), fx["energy_kwargs_vals"].tolist())}
+
+
 def outputs_of(fx):
     return {k[5:]: fx[k] for k in fx.files if k.startswith("out::")}
 

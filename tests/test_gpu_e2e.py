@@ -35,7 +35,9 @@ def _check_graph(g, out, loss):
 
 @pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False),
                                                  ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False),
-                                                 ("ref_small_learnstats.npz", 5, False)])     # last three: layer_norm=False / self_interaction=False / learnable_statistics=True
+                                                 ("ref_small_learnstats.npz", 5, False),     # last three: layer_norm=False / self_interaction=False / learnable_statistics=True
+                                                 ("ref_tiny_wrongsym.npz", 4, True), ("ref_tiny_harmonic_gate.npz", 4, True),
+                                                 ("ref_tiny_nper3.npz", 4, True), ("ref_tiny_offset_torsion.npz", 4, True)])     # wrong_symmetry / harmonic_gate / n_periodicity_proper=3 / Energy(offset_torsion=True)
 def test_small_configs_against_reference_goldens(name, n_confs, refs):
     from grappa_amd import Energy, GrappaModel, MolwiseLoss
     _assert_loaded()
@@ -43,9 +45,9 @@ def test_small_configs_against_reference_goldens(name, n_confs, refs):
     cfg = gu.config_of(fx)
     g = gu.build_batch(gu.molecules_of(fx), n_confs, refs, (cfg["n_periodicity_proper"], cfg["n_periodicity_improper"])).to("cuda")
     model = GrappaModel(**cfg)
-    model.load_state_dict(gu.state_dict_of(fx))
+    model.load_state_dict(gu.weights_for(fx, model))
     model = model.to("cuda").eval()
-    g = Energy()(model(g))
+    g = Energy(**gu.energy_kwargs_of(fx))(model(g))
     loss = MolwiseLoss(**gu.loss_kwargs_of(fx))(g)
     loss.backward()
     out = gu.outputs_of(fx)
@@ -163,7 +165,7 @@ def test_production_config_against_oracle_on_a_larger_batch():
     # The same quantities at SURVEY 8(d)'s own floors (k 1e-3 incl. the torsion constants, eq 1e-4, E 1e-3 kcal/mol, G 1e-2 kcal/mol/A --
     # absolute, not scaled with the tensor): three distances each -- GPU to float64, the fp32 ORACLE to float64 (what the reference's own
     # arithmetic can hold at these floors), GPU to the fp32 oracle.  Where the fp32 oracle itself is beyond 1e-4 of float64 the floors of
-    # this file are fp32's, not this engine's: gate = the GPU's distance from float64 is of the order of the fp32 oracle's own (within 10x: at these floors the measure sits on
+    # this file are fp32's, not this engine's: gate = the GPU's distance from float64 is of the order of the fp32 oracle's own (within 3x -- measured <= 1.8x over the boxes and split-K plans of rounds 3 and 4; at these floors the measure sits on
     # a few elements that cancel to ~0, and moves by 2x with the summation order of a product -- split-K plan, thread count of the oracle)
     # (or inside the contract).
     def contract(got_g, ref_g):
@@ -183,7 +185,7 @@ def test_production_config_against_oracle_on_a_larger_batch():
     with open("gpurun_out/parity_distance_fp32_vs_fp64_oracle.txt", "a") as fh:
         fh.write("# at SURVEY 8(d)'s floors (k 1e-3, eq 1e-4, E 1e-3, G 1e-2, absolute)\n" + "\n".join(lines) + "\n")
     for k in gpu64:
-        assert gpu64[k] < max(TOL, 10.0 * ora64[k]), (k, gpu64[k], ora64[k])
+        assert gpu64[k] < max(TOL, 3.0 * ora64[k]), (k, gpu64[k], ora64[k])
 
 
 def test_train_step_decreases_loss_and_matches_oracle_adam():

@@ -20,9 +20,9 @@ def _run(fx_name, n_confs, refs):
     cfg = gu.config_of(fx)
     g = gu.build_batch(gu.molecules_of(fx), n_confs, refs, (cfg["n_periodicity_proper"], cfg["n_periodicity_improper"]))
     model = GrappaModel(**cfg)
-    missing = model.load_state_dict(gu.state_dict_of(fx))
+    missing = model.load_state_dict(gu.weights_for(fx, model))
     model.eval()
-    g = Energy()(model(g))
+    g = Energy(**gu.energy_kwargs_of(fx))(model(g))
     loss = MolwiseLoss(**gu.loss_kwargs_of(fx))(g)
     loss.backward()
     return fx, g, loss, model
@@ -30,7 +30,9 @@ def _run(fx_name, n_confs, refs):
 
 @pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False),
                                                  ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False),
-                                                 ("ref_small_learnstats.npz", 5, False)])     # last three: layer_norm=False / self_interaction=False / learnable_statistics=True
+                                                 ("ref_small_learnstats.npz", 5, False),     # last three: layer_norm=False / self_interaction=False / learnable_statistics=True
+                                                 ("ref_tiny_wrongsym.npz", 4, True), ("ref_tiny_harmonic_gate.npz", 4, True),
+                                                 ("ref_tiny_nper3.npz", 4, True), ("ref_tiny_offset_torsion.npz", 4, True)])     # wrong_symmetry / harmonic_gate / n_periodicity_proper=3 / Energy(offset_torsion=True)
 def test_product_host_path_matches_reference(ref_backend, name, n_confs, refs):
     fx, g, loss, model = _run(name, n_confs, refs)
     out = gu.outputs_of(fx)
