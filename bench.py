@@ -282,11 +282,15 @@ def main():
             if self.solo:
                 reducer._flush_queued_wgrads()
             elif self.allreduce_events is not None and on_gpu:
+                # HIP events around the collectives of BOTH buckets: the reducer records one where the heads' bucket leaves
+                # (only with the overlap on) and a pair around what finish() sends and waits for
+                reducer.time_events = []
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 reducer.finish()
                 e1.record()
-                self.allreduce_events.append((e0, e1))
+                self.allreduce_events.append((e0, e1, reducer.time_events))
+                reducer.time_events = None
             elif self.allreduce_events is not None:
                 t_ar = time.perf_counter()
                 reducer.finish()
@@ -374,6 +378,9 @@ def main():
         prof = be.stop_profile() if on_gpu else {}
         dtp = time.perf_counter() - t1
         ar_ms = sum((ev[0].elapsed_time(ev[1]) if on_gpu else ev) for ev in j.allreduce_events) / max(len(j.allreduce_events), 1)
+        # with the overlap on: how long before finish() the heads' bucket left (the collective had that long to run beside the GNN's backward pass)
+        leads = [te[1].elapsed_time(ev[0]) for ev in j.allreduce_events if on_gpu for te in ev[2] if te[0] == "heads_sent"]
+        j.heads_bucket_lead_ms = sum(leads) / len(leads) if leads else None
         j.allreduce_events = None
         model.parameter_writer.head_streams = hs
         if on_gpu:
@@ -536,6 +543,59 @@ def main():
             model.train()
             torch.cuda.empty_cache()
 
+    # N > 1: what the collective layer actually saw, so that the first real multi-GPU run checks itself
+    dist_info = None
+    if world > 1:
+        me = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device() if on_gpu else None, "pid": os.getpid(),
+              "device_name": torch.cuda.get_device_name() if on_gpu else "cpu",
+              "device_uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")) if on_gpu else None}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        distinct = len({(r["device_index"], r["device_uuid"]) for r in everyone})
+        if on_gpu and args.dist_backend == "nccl" and distinct != world:
+            raise SystemExit(f"{world} ranks over RCCL but only {distinct} distinct devices: {everyone}")
+        # overlapped vs post-backward reduction of the SAME gradients, bit for bit: the same batch and dropout seeds through both
+        # orders, no optimiser step in between; the two orders cut the buffer alike (dist.BucketedGradReducer.finish)
+        n_check = min(args.steps, 10)
+        mism, t_modes = 0, {}
+        for mode in (False, True):
+            red2 = BucketedGradReducer(model, flat, overlap=mode)
+            grads = []
+            sync()
+            dist.barrier()
+            t_m = time.perf_counter()
+            for s_ in range(n_check):
+                ops.manual_seed(777 + 13 * s_ + rank)
+                flat.zero_grad()
+                red2.begin_step(len(job.graphs))
+                for g_ in job.graphs:
+                    for lvl in ("n2", "n3", "n4", "n4_improper"):
+                        for k_ in ("k", "eq"):
+                            g_.nodes[lvl].data.pop(k_, None)
+                    job.loss_fn(energy(model(g_))).backward()
+                red2.finish()
+                if s_ < 3:
+                    grads.append(flat.grad.clone())
+            sync()
+            t_modes[mode] = 1e3 * (time.perf_counter() - t_m) / n_check
+            if mode:
+                mism = sum(int(not torch.equal(a_, b_)) for a_, b_ in zip(grads, kept))
+            kept = grads
+        model.on_heads_backward_done = reducer._on_heads_done if reducer.overlap else None
+        mm = torch.tensor([mism], device=dev)
+        dist.all_reduce(mm, op=dist.ReduceOp.SUM)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": everyone, "distinct_devices": distinct,
+                     "rccl_version": (".".join(map(str, torch.cuda.nccl.version())) if on_gpu and hasattr(torch.cuda, "nccl") else None),
+                     "env": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
+                     "allreduce_overlap_default": reducer.overlap,
+                     "allreduce_bit_check": {"steps_compared": 3, "mismatching_steps_summed_over_ranks": int(mm),
+                                             "ms_per_step_post_backward": t_modes[False], "ms_per_step_overlapped": t_modes[True],
+                                             "note": "gradient buffers after the all-reduce, heads' bucket sent from inside the backward pass vs both "
+                                                     "buckets after it, same batch and dropout seeds, torch.equal; untimed forward+backward+all-reduce "
+                                                     "loops of both orders beside it (no optimiser step)"}}
+        log(f"dist self-check: {dist_info['backend']} world {dist_info['world_size']}, {distinct} distinct devices, overlap bit check mismatches {int(mm)}, "
+            f"post-backward {t_modes[False]:.1f} ms vs overlapped {t_modes[True]:.1f} ms per forward+backward+all-reduce")
+
     # N > 1, strong scaling: the same-workload N = 1 point.  Rank 0 alone runs the WHOLE global batch (chunks of --chunk molecules, gradients
     # accumulated, one optimiser step, no collective) while the other ranks wait at the barrier that follows; last, so that nothing
     # measured above sees rank 0's parameters drift from the others'
@@ -579,13 +639,15 @@ def main():
             except Exception:
                 pass
         cfg = job.describe()
-        cfg.update({"parallelism": f"dp{world}", "world_size": world, "dist_backend": args.dist_backend if world > 1 else None,
+        cfg.update({"parallelism": f"dp{world}", "world_size": dist.get_world_size() if world > 1 else 1, "dist_backend": dist.get_backend() if world > 1 else None,
                     "allreduce_ms_per_step": allreduce_ms if world > 1 else None, "allreduce_bytes": 4 * flat.numel if world > 1 else None,
+                    "allreduce_overlap": reducer.overlap if world > 1 else None,
+                    "heads_bucket_lead_ms": getattr(job, "heads_bucket_lead_ms", None) if world > 1 else None,
                     "writer_head_streams": head_streams})
         out = {
             "metric": "molecules/sec (train step, energy+force loss)", "value": job.global_batch * args.steps / dt, "unit": "molecules/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16" if args.act_dtype == "bf16" else "f32", "data": "synthetic",
+            "scaling": ("strong" if strong else "weak") if world > 1 else None, "vs_baseline": None, "dtype": "bf16" if args.act_dtype == "bf16" else "f32", "data": "synthetic",
             "config": cfg,
             "gemm_arithmetic": {"default": getattr(be, "gemm_precision_name", None),
                                 "note": "inputs, outputs, accumulation and every non-GEMM kernel are fp32; f32_f16x3 scales every row of an "
@@ -599,6 +661,8 @@ def main():
             "writer_heads_other_stream_setting": heads_alt,
         }
         out.update(extras)
+        if dist_info is not None:
+            out["dist"] = dist_info
         if scaling_ref is not None:
             out["strong_scaling_reference"] = scaling_ref
             out["scaling_factor"] = (out["value"] / scaling_ref["value"]) if scaling_ref.get("value") else None

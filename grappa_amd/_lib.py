@@ -69,6 +69,7 @@ _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 SIGNATURES = {
     "grappa_abi_version": (_i, []),
     "grappa_build_arch": (C.c_char_p, []),
+    "grappa_launch_count": (C.c_longlong, [_i]),
     "grappa_split_planes_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _sz, _i]),
     "grappa_split_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i]),
     "grappa_amax_f32_workspace_bytes": (_sz, [_i, _i]),

@@ -133,10 +133,10 @@ class HipBackend:
         # weight-gradient products of a backward pass are queued and launched together (grappa_gemm_f32_grouped): alone, each must
         # cut its K (= tokens) 10 - 32 ways to fill the chip and pays for that many partial tiles per output tile
         self.defer_wgrads = os.environ.get("GRAPPA_DEFER_WGRADS", "1") not in ("0", "")
-        self._wq = {}                  # stream handle -> (stream, [(dz, x, dW, db, maxima) kept alive until the launch])
+        self._wq = {}                  # (autograd graph task id, stream handle) -> (stream, [(dz, x, dW, db, maxima) kept alive until the launch])
         self.defer_ln = os.environ.get("GRAPPA_DEFER_LN_REDUCTIONS", "1") not in ("0", "")      # tuning: 0 = reduce every LayerNorm's parameter gradients at once
-        self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta)
-        self._wq_task = None           # autograd graph task id of the backward pass the queues belong to
+        self._lnq = []                 # deferred LayerNorm parameter gradients: (partials, rows, W, dgamma ptr, dbeta ptr, dgamma, dbeta, stream, task id)
+        self._tasks = set()            # autograd graph task ids (backward passes) that have an end-of-pass callback registered and not yet run
         self.wgrad_queue_bytes = int(float(os.environ.get("GRAPPA_WGRAD_QUEUE_GB", "12")) * 2 ** 30)
         # inference (no gradient asked for): LayerNorm and the tuple attention write the A operand of the product behind them in the pair
         # format and the product reads operands split once (csrc/gemm_pairs.hip) -- same bits as the fp32-operand product of the same K cuts
@@ -641,43 +641,52 @@ class HipBackend:
             else:
                 sdz = self.amax(dz, dz_scales, rows=True)
                 am = (sdz, self.amax(x, x_scales, rows=True))
-        in_pass = self._queue_flush()             # (first: a new pass discards what an aborted one left in the queue)
-        # one queue per HIP stream (the writer heads run their backward passes on streams of their own): a full queue is launched on the
-        # stream that filled it, what is left when the pass ends is launched together by flush_wgrads
+        task = self._queue_flush()                # the backward pass (autograd graph task) this product belongs to; -1 outside of one
+        # one queue per backward pass and HIP stream (the writer heads run their backward passes on streams of their own): a full queue is
+        # launched on the stream that filled it, what is left when the pass ends is launched together by flush_wgrads
         st = torch.cuda.current_stream()
-        q = self._wq.setdefault(st.cuda_stream, (st, []))[1]
+        q = self._wq.setdefault((task, st.cuda_stream), (st, []))[1]
         q.append((dz, x, dw, db, am))
-        if not in_pass:                           # not inside a backward pass: nothing will call back
-            self.flush_wgrads()
+        if task < 0:                              # not inside a backward pass: nothing will call back
+            self.flush_wgrads(-1)
             return sdz
         # a queue is launched when it is full -- or when the operands it keeps alive exceed the byte budget (at C3 / C4 sizes
         # sixteen (dz, x) pairs are tens of GB)
         if len(q) >= _lib.GEMM_GROUP_MAX or sum(it[0].numel() + it[1].numel() for it in q) * 4 > self.wgrad_queue_bytes:
-            del self._wq[st.cuda_stream]
+            del self._wq[(task, st.cuda_stream)]
             self._launch_wgrad_group(q)
         return sdz
 
-    def _queue_flush(self) -> bool:
-        """ask autograd to call flush_wgrads when the running backward pass ends; False outside a backward pass.  The queues belong to ONE
-        pass (autograd's graph task id): if the pass that filled them died (an exception inside backward drops autograd's end-of-pass
-        callbacks), what it left behind is discarded -- its gradient buffer was abandoned with it -- and this pass registers its own
-        callback."""
+    @property
+    def _wq_task(self):
+        """the backward pass whose end-of-pass callback is pending (None: none) -- tests / tools"""
+        return max(self._tasks) if self._tasks else None
+
+    def _queue_flush(self) -> int:
+        """-> autograd's graph task id of the running backward pass (-1 outside of one), after asking autograd to call flush_wgrads for
+        that pass when it ends.  Every pass has queues of its own: a re-entrant pass inside a running one
+        (torch.utils.checkpoint, torch.autograd.grad in a hook) launches its own products at its own end and leaves the outer pass's alone.
+        A pass that DIED (an exception inside backward drops autograd's end-of-pass callbacks) leaves its queues behind; they are never
+        launched -- its gradient buffer was abandoned with it -- and are discarded by `drop_deferred` (FlatParams.zero_grad) or by the
+        first flush outside of any pass (FusedAdam.step, the gradient reducer)."""
         task = torch._C._current_graph_task_id()
         if task < 0:
-            return False
-        if task != self._wq_task:
-            self.drop_deferred()
+            return -1
+        if task not in self._tasks:
             try:
-                torch.autograd.Variable._execution_engine.queue_callback(self.flush_wgrads)
+                torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: self.flush_wgrads(t))
             except RuntimeError:
-                return False
-            self._wq_task = task
-        return True
+                return -1
+            # a TOP-LEVEL pass that starts while older ids are still pending: those passes are dead unless this one runs inside them;
+            # a nested pass always starts from inside a running node of the outer one, i.e. with the engine's current task still alive --
+            # which is not observable from here, so the older queues are only dropped where it is certain (see above)
+            self._tasks.add(task)
+        return task
 
     def drop_deferred(self) -> None:
         """forget queued weight-gradient products and LayerNorm reductions without launching them (leftovers of an aborted backward pass)"""
         self._join_aside()
-        self._wq, self._lnq, self._wq_task = {}, [], None
+        self._wq, self._lnq, self._tasks = {}, [], set()
 
     # ---- weight gradients beside the pass.  The GNN's backward pass is a chain of small products (8,233 atom rows at C2: 132 workgroups on
     # 256 CUs) that leaves half of the chip idle, and the weight gradients nobody waits for pile up behind it.  launch_wgrads_aside() takes
@@ -707,11 +716,9 @@ class HipBackend:
         if not self.wgrads_aside or not self._wq:
             return
         cur = torch.cuda.current_stream()
-        if all_streams:
-            queues, self._wq = list(self._wq.values()), {}
-        else:
-            ent = self._wq.pop(cur.cuda_stream, None)
-            queues = [ent] if ent else []
+        task = torch._C._current_graph_task_id()
+        keys = [k for k in self._wq if k[0] == task and (all_streams or k[1] == cur.cuda_stream)]      # this pass's queues only
+        queues = [self._wq.pop(k) for k in keys]
         items = [it for _, q in queues for it in q]
         if not items:
             return
@@ -734,24 +741,37 @@ class HipBackend:
                 cur.wait_stream(side)
             self._aside = []
 
-    def flush_wgrads(self) -> None:
-        """launch what a backward pass has queued: the grouped weight gradients and the LayerNorm parameter-gradient reductions"""
-        self._wq_task = None
+    def flush_wgrads(self, task: Optional[int] = None) -> None:
+        """launch what a backward pass has queued: the grouped weight gradients and the LayerNorm parameter-gradient reductions.
+        task: the pass (its end-of-pass callback passes its id); None: the running pass -- or, outside of any pass, nothing is left to
+        launch (passes that ended launched their own) and whatever is still queued belongs to passes that died: discarded."""
+        if task is None:
+            task = torch._C._current_graph_task_id()
+            if task < 0:
+                if self._wq or self._lnq or self._tasks:
+                    self._wq = {k: v for k, v in self._wq.items() if k[0] < 0}
+                    self._lnq = [it for it in self._lnq if it[8] < 0]
+                    self._tasks = set()
+                task = -1
+        self._tasks.discard(task)
         cur = torch.cuda.current_stream()
-        if self._wq:
-            queues, self._wq = self._wq, {}
+        keys = [k for k in self._wq if k[0] == task]
+        if keys:
             items = []
-            for st, q in queues.values():
+            for k in keys:
+                st, q = self._wq.pop(k)
                 if st != cur:
                     cur.wait_stream(st)           # (operands queued on another stream: normally already ordered before this point, see ops.SplitHeadsFn)
                 items += q
             for i in range(0, len(items), _lib.GEMM_GROUP_MAX):
                 self._launch_wgrad_group(items[i:i + _lib.GEMM_GROUP_MAX])
-        if self._lnq:
-            for it in self._lnq:
+        mine = [it for it in self._lnq if it[8] == task]
+        if mine:
+            self._lnq = [it for it in self._lnq if it[8] != task]
+            for it in mine:
                 if it[7] != cur:
                     cur.wait_stream(it[7])
-            items, self._lnq = [it[:7] for it in self._lnq], []
+            items = [it[:7] for it in mine]
             arr = (_lib.ColsumItem * len(items))()
             for d, (ws, nrows, W, pg, pb, _g, _b) in zip(arr, items):
                 d.part, d.nrows, d.n, d.out, d.out2, d.n_first, d.accumulate = ws.data_ptr(), nrows, 2 * W, pg, pb, W, 1
@@ -880,8 +900,8 @@ class HipBackend:
         dt = _same_dtype(dy, x, dx)
         # inside a backward pass the parameter gradients wait: the kernel leaves its per-block partial sums in a buffer of their own and
         # ONE launch reduces those of all LayerNorms when the pass ends (flush_wgrads) instead of two small launches per LayerNorm
-        defer = accumulate and self.defer_wgrads and self.defer_ln and M > 0 and self._queue_flush()      # (first: a new pass empties a dead one's queue)
-        defer = defer and all(q[3] != dgamma.data_ptr() for q in self._lnq)
+        task = self._queue_flush() if (accumulate and self.defer_wgrads and self.defer_ln and M > 0) else -1
+        defer = task >= 0 and all(q[3] != dgamma.data_ptr() for q in self._lnq)
         need = self.lib.grappa_layernorm_bwd_workspace_bytes(M, W)
         ws = torch.empty(need, dtype=torch.uint8, device=dev) if defer else self._workspace(need, dev)
         row = self._new_row_amax(dx, True, amax)
@@ -890,7 +910,7 @@ class HipBackend:
                 dgamma.data_ptr(), dbeta.data_ptr(), 2 if defer else int(accumulate), ws.data_ptr(), ws.numel())
         if defer:
             self._lnq.append((ws, self.lib.grappa_layernorm_bwd_partial_rows(M), W, dgamma.data_ptr(), dbeta.data_ptr(), dgamma, dbeta,
-                              torch.cuda.current_stream()))
+                              torch.cuda.current_stream(), task))
         if row is not None:
             _chk(self.lib.grappa_layernorm_bwd_amax_f32(*args, row.data_ptr()), "grappa_layernorm_bwd_amax_f32")
             return Amax(row=row)

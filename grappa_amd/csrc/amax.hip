@@ -203,11 +203,11 @@ int part_stride_of(int C) { return (C + 3) / 4 * 4; }
 template <int NCH>
 void launch_amax(hipStream_t st, dim3 grid, bool cols, bool vec, const float* x, int R, int C, int ld, unsigned* row_amax, unsigned* part, int stride, int row_atomic) {
     if (cols) {
-        if (vec) hipLaunchKernelGGL((amax_kernel<NCH, true, true>), grid, dim3(AMAX_THREADS), 0, st, x, R, C, ld, row_amax, part, stride, row_atomic);
-        else hipLaunchKernelGGL((amax_kernel<NCH, true, false>), grid, dim3(AMAX_THREADS), 0, st, x, R, C, ld, row_amax, part, stride, row_atomic);
+        if (vec) GRAPPA_LAUNCH((amax_kernel<NCH, true, true>), grid, dim3(AMAX_THREADS), 0, st, x, R, C, ld, row_amax, part, stride, row_atomic);
+        else GRAPPA_LAUNCH((amax_kernel<NCH, true, false>), grid, dim3(AMAX_THREADS), 0, st, x, R, C, ld, row_amax, part, stride, row_atomic);
     } else {
-        if (vec) hipLaunchKernelGGL((amax_kernel<NCH, false, true>), grid, dim3(AMAX_THREADS), 0, st, x, R, C, ld, row_amax, part, stride, row_atomic);
-        else hipLaunchKernelGGL((amax_kernel<NCH, false, false>), grid, dim3(AMAX_THREADS), 0, st, x, R, C, ld, row_amax, part, stride, row_atomic);
+        if (vec) GRAPPA_LAUNCH((amax_kernel<NCH, false, true>), grid, dim3(AMAX_THREADS), 0, st, x, R, C, ld, row_amax, part, stride, row_atomic);
+        else GRAPPA_LAUNCH((amax_kernel<NCH, false, false>), grid, dim3(AMAX_THREADS), 0, st, x, R, C, ld, row_amax, part, stride, row_atomic);
     }
 }
 
@@ -240,7 +240,7 @@ extern "C" int grappa_amax_f32(void* stream, int R, int C, const float* x, int l
     else launch_amax<8>(st, grid, col_amax != nullptr, vec, x, R, C, ldx, row_amax, part, stride, row_atomic);
     if (grappa_launch_status() != GRAPPA_OK) return GRAPPA_ERR_LAUNCH;
     if (col_amax) {
-        hipLaunchKernelGGL(amax_colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, nb, stride, C, col_amax);
+        GRAPPA_LAUNCH(amax_colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, nb, stride, C, col_amax);
         return grappa_launch_status();
     }
     return GRAPPA_OK;
@@ -257,21 +257,21 @@ extern "C" int grappa_amax_reduce(void* stream, int count, const uint32_t* const
             b.in[i] = in[b0 + i];
             b.n[i] = n[b0 + i];
         }
-        hipLaunchKernelGGL(amax_reduce_kernel, dim3(c), dim3(1024), 0, st, b, out + b0);
+        GRAPPA_LAUNCH(amax_reduce_kernel, dim3(c), dim3(1024), 0, st, b, out + b0);
     }
     return grappa_launch_status();
 }
 
 // called by grappa_gemm_f32 (gemm_f32.hip) after a product that wrote per-segment row maxima
 int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* part, unsigned* out) {
-    hipLaunchKernelGGL(amax_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, nseg, part, out);
+    GRAPPA_LAUNCH(amax_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, nseg, part, out);
     return grappa_launch_status();
 }
 
 extern "C" int grappa_amax_f32_batched(void* stream, int count, const grappa_amax_item* descs) {
     if (count < 0 || (count > 0 && !descs)) return GRAPPA_ERR_ARG;
     if (count == 0) return GRAPPA_OK;
-    hipLaunchKernelGGL(amax_batched_zero_kernel, dim3(count), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), descs);
-    hipLaunchKernelGGL(amax_batched_kernel, dim3(count, BATCH_SLICES), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), descs);
+    GRAPPA_LAUNCH(amax_batched_zero_kernel, dim3(count), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), descs);
+    GRAPPA_LAUNCH(amax_batched_kernel, dim3(count, BATCH_SLICES), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), descs);
     return grappa_launch_status();
 }

@@ -77,6 +77,6 @@ extern "C" int grappa_collate_batch(void* stream, const grappa_collate_desc* des
         if ((d.mode == GRAPPA_COLLATE_INV_ROWS || d.mode == GRAPPA_COLLATE_CONF) && !d.p1) return GRAPPA_ERR_ARG;
         if (d.mode == GRAPPA_COLLATE_INV_ROWS && d.width != 1) return GRAPPA_ERR_ARG;
     }
-    hipLaunchKernelGGL(collate_kernel, dim3(B, n_tables), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), descs_device, B);
+    GRAPPA_LAUNCH(collate_kernel, dim3(B, n_tables), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), descs_device, B);
     return grappa_launch_status();
 }

@@ -6,6 +6,15 @@
 
 #define GRAPPA_WAVE 64
 
+// every kernel launch of the library goes through this macro: the process-wide counter behind grappa_launch_count() (include/grappa_hip.h)
+// is what bench.py reports as launches per step
+extern "C" void grappa_count_launch(void);
+#define GRAPPA_LAUNCH(...)               \
+    do {                                 \
+        grappa_count_launch();           \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 static inline int grappa_launch_status() {
     return hipGetLastError() == hipSuccess ? GRAPPA_OK : GRAPPA_ERR_LAUNCH;
 }

@@ -539,7 +539,7 @@ int launch_mode(hipStream_t st, GemmParams& p) {
             return GRAPPA_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles_launch * p.nsplit), dim3(NT), smem, st, p);
+    GRAPPA_LAUNCH(kern, dim3(p.ntiles_launch * p.nsplit), dim3(NT), smem, st, p);
     return grappa_launch_status();
 }
 
@@ -573,7 +573,7 @@ int launch_grouped_wgrad(hipStream_t st, const GemmParams* d_ps, const int* d_wg
             return GRAPPA_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(total_wgs), dim3(NT), smem, st, d_ps, d_wg_begin, nprob);
+    GRAPPA_LAUNCH(kern, dim3(total_wgs), dim3(NT), smem, st, d_ps, d_wg_begin, nprob);
     return grappa_launch_status();
 }
 

@@ -562,7 +562,7 @@ inline int launch_splitk_reduce(hipStream_t st, const GemmParams& p) {
     const size_t total = (size_t)p.ntiles_launch * p.bm * p.bn;
     int blocks = (int)((total / 4 + REDUCE_THREADS - 1) / REDUCE_THREADS);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(REDUCE_THREADS), 0, st, p);
+    GRAPPA_LAUNCH(gemm_splitk_reduce_kernel, dim3(blocks), dim3(REDUCE_THREADS), 0, st, p);
     return grappa_launch_status();
 }
 

@@ -277,7 +277,7 @@ int launch_cfg(hipStream_t st, GemmParams& p) {
         attr_set = true;
     }
     dim3 grid(p.ntiles_launch * p.nsplit);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, st, p);
+    GRAPPA_LAUNCH(kern, grid, dim3(NTHREADS), smem, st, p);
     return grappa_launch_status();
 }
 
@@ -658,14 +658,14 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
             ix.blk_begin[i + 1] = ix.blk_begin[i] + blocks;
             total_blocks = ix.blk_begin[i + 1];
         }
-        hipLaunchKernelGGL(group_upload_kernel, dim3(1), dim3(256), 0, st, up, cnt, d_ps + i0);
+        GRAPPA_LAUNCH(group_upload_kernel, dim3(1), dim3(256), 0, st, up, cnt, d_ps + i0);
     }
-    hipLaunchKernelGGL(group_index_kernel, dim3(1), dim3(256), 0, st, ix, n, d_wg, d_blk, tickets, in_kernel ? g.total_tickets : 0);
+    GRAPPA_LAUNCH(group_index_kernel, dim3(1), dim3(256), 0, st, ix, n, d_wg, d_blk, tickets, in_kernel ? g.total_tickets : 0);
     if (grappa_launch_status() != GRAPPA_OK) return GRAPPA_ERR_LAUNCH;
     int rc = grappa_launch_gemm_bf16x_grouped(st, d_ps, d_wg, n, g.total_wgs, precision, vec);
     if (rc != GRAPPA_OK) return rc;
     if (total_blocks > 0) {
-        hipLaunchKernelGGL(gemm_splitk_reduce_grouped_kernel, dim3(total_blocks), dim3(REDUCE_THREADS), 0, st, d_ps, d_blk, n);
+        GRAPPA_LAUNCH(gemm_splitk_reduce_grouped_kernel, dim3(total_blocks), dim3(REDUCE_THREADS), 0, st, d_ps, d_blk, n);
         rc = grappa_launch_status();
     }
     return rc;
@@ -688,11 +688,12 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     if (planes) {
         auto ok = [](const void* q, int ld, int cols) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 7) == 0 && ld >= cols; };
         const int kpad = (d->K + 31) / 32 * 32;
+        const int krow = pairs ? 2 * kpad : kpad;          // fp16 elements of a K-contiguous row: the pair format holds hi AND lo
         if (d->M <= 32 || d->N <= 32 || d->a_kcontig != d->b_kcontig) return GRAPPA_ERR_ARG;
         if (d->a_planes) {
-            if (d->a_kcontig ? !(ok(d->A, d->lda, kpad) && ok(d->B, d->ldb, kpad)) : !(ok(d->A, d->lda, d->M) && ok(d->B, d->ldb, d->N))) return GRAPPA_ERR_ARG;
+            if (d->a_kcontig ? !(ok(d->A, d->lda, krow) && ok(d->B, d->ldb, krow)) : !(ok(d->A, d->lda, d->M) && ok(d->B, d->ldb, d->N))) return GRAPPA_ERR_ARG;
         } else if (pairs) {
-            if (!ok(d->B, d->ldb, kpad)) return GRAPPA_ERR_ARG;
+            if (!ok(d->B, d->ldb, krow)) return GRAPPA_ERR_ARG;
         } else {
             // fp32 A [M][K] + weight planes B [N][K]: whole slabs of 32 in K (fp32 rows are not zero padded), 16-byte aligned rows
             if (!d->a_kcontig || (d->K & 31) != 0 || (reinterpret_cast<uintptr_t>(d->A) & 15) != 0 || (d->lda & 3) != 0 || d->lda < d->K) return GRAPPA_ERR_ARG;
@@ -729,6 +730,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     if (!bf16x && (d->Cp || d->C1p || d->resp || d->auxp || !d->C)) return GRAPPA_ERR_ARG;
     if (d->res_ln_mean) {
         // residual = LayerNorm(res): fp32 rows, all four arrays, the split kernels' shared epilogue only (not the native fp32 kernel's walk)
+        if (d->aux || d->auxp) return GRAPPA_ERR_ARG;                   // (the ELU' class adds its residual raw: refused, not computed wrongly)
         if (!bf16x || !d->res || !d->res_ln_rstd || !d->res_ln_gamma || !d->res_ln_beta || (d->N & 3) ||
             ((reinterpret_cast<uintptr_t>(d->res_ln_gamma) | reinterpret_cast<uintptr_t>(d->res_ln_beta)) & 15) != 0 || (planes && !pairs))
             return GRAPPA_ERR_ARG;

@@ -467,7 +467,7 @@ int launch_wpairs(hipStream_t st, GemmParams& p) {
             return GRAPPA_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles_launch * p.nsplit), dim3(256), smem, st, p);
+    GRAPPA_LAUNCH(kern, dim3(p.ntiles_launch * p.nsplit), dim3(256), smem, st, p);
     return grappa_launch_status();
 }
 
@@ -484,7 +484,7 @@ int launch_pairs(hipStream_t st, GemmParams& p) {
             return GRAPPA_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles_launch * p.nsplit), dim3(S::NT), smem, st, p);
+    GRAPPA_LAUNCH(kern, dim3(p.ntiles_launch * p.nsplit), dim3(S::NT), smem, st, p);
     return grappa_launch_status();
 }
 
@@ -536,7 +536,7 @@ extern "C" int grappa_split_pairs_f32(void* stream, int R, int C, const float* x
     if (R == 0 || C == 0) return GRAPPA_OK;
     const int kk = transpose ? R : C;
     if (!x || !amax || !pairs || ldx < C || ldp < 2 * ((kk + 15) / 16 * 16)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(split_pairs_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), R, C, x, ldx,
+    GRAPPA_LAUNCH(split_pairs_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), R, C, x, ldx,
                        amax, pairs, ldp, transpose);
     return grappa_launch_status();
 }

@@ -590,7 +590,7 @@ int launch_wplanes(hipStream_t st, GemmParams& p) {
         attr_set = true;
     }
     const int total = p.ntiles_launch * p.nsplit;
-    hipLaunchKernelGGL(kern, dim3(GP_PERSIST && total > 256 ? 256 : total), dim3(PNT), smem, st, p);
+    GRAPPA_LAUNCH(kern, dim3(GP_PERSIST && total > 256 ? 256 : total), dim3(PNT), smem, st, p);
     return grappa_launch_status();
 }
 
@@ -605,7 +605,7 @@ int launch_planes(hipStream_t st, GemmParams& p) {
             return GRAPPA_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles_launch * p.nsplit), dim3(PNT), smem, st, p);
+    GRAPPA_LAUNCH(kern, dim3(p.ntiles_launch * p.nsplit), dim3(PNT), smem, st, p);
     return grappa_launch_status();
 }
 
@@ -654,7 +654,7 @@ extern "C" int grappa_split_planes_f32(void* stream, int R, int C, const float* 
     if (R < 0 || C < 0) return GRAPPA_ERR_ARG;
     if (R == 0 || C == 0) return GRAPPA_OK;
     if (!x || !planes || ldx < C || ldp < (transpose ? R : C)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(split_planes_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), R, C, x, ldx,
+    GRAPPA_LAUNCH(split_planes_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), R, C, x, ldx,
                        planes, ldp, plane_stride, transpose);
     return grappa_launch_status();
 }

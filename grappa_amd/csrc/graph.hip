@@ -352,17 +352,17 @@ inline bool head_shape_ok(int H, int D) {
 
 #define DISPATCH_NC(nc, KERN, grid, st, ...)                                                    \
     switch (nc) {                                                                               \
-        case 1: hipLaunchKernelGGL(KERN<1>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
-        case 2: hipLaunchKernelGGL(KERN<2>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
-        case 4: hipLaunchKernelGGL(KERN<4>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
-        default: hipLaunchKernelGGL(KERN<8>, grid, dim3(256), 0, st, __VA_ARGS__); break;       \
+        case 1: GRAPPA_LAUNCH(KERN<1>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
+        case 2: GRAPPA_LAUNCH(KERN<2>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
+        case 4: GRAPPA_LAUNCH(KERN<4>, grid, dim3(256), 0, st, __VA_ARGS__); break;        \
+        default: GRAPPA_LAUNCH(KERN<8>, grid, dim3(256), 0, st, __VA_ARGS__); break;       \
     }
 #define DISPATCH_NC_T(nc, KERN, T, grid, st, ...)                                                     \
     switch (nc) {                                                                                     \
-        case 1: hipLaunchKernelGGL((KERN<1, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
-        case 2: hipLaunchKernelGGL((KERN<2, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
-        case 4: hipLaunchKernelGGL((KERN<4, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
-        default: hipLaunchKernelGGL((KERN<8, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;        \
+        case 1: GRAPPA_LAUNCH((KERN<1, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
+        case 2: GRAPPA_LAUNCH((KERN<2, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
+        case 4: GRAPPA_LAUNCH((KERN<4, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;         \
+        default: GRAPPA_LAUNCH((KERN<8, T>), grid, dim3(256), 0, st, __VA_ARGS__); break;        \
     }
 
 template <typename T>
@@ -376,9 +376,9 @@ int gat_fwd_impl(void* stream, int N, int E, int H, int D, const int* indptr, co
     if constexpr (sizeof(T) == 2) {
         if (wide_ok(H, D, ft, out)) {               // 16-byte accesses: 8 bf16 per lane
             const int nc8 = chunks_for8(H * D);
-            if (nc8 == 1) hipLaunchKernelGGL((gat_fwd_kernel_e<1, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
-            else if (nc8 == 2) hipLaunchKernelGGL((gat_fwd_kernel_e<2, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
-            else hipLaunchKernelGGL((gat_fwd_kernel_e<4, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
+            if (nc8 == 1) GRAPPA_LAUNCH((gat_fwd_kernel_e<1, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
+            else if (nc8 == 2) GRAPPA_LAUNCH((gat_fwd_kernel_e<2, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
+            else GRAPPA_LAUNCH((gat_fwd_kernel_e<4, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, ft, out, alpha);
             return grappa_launch_status();
         }
     }
@@ -400,8 +400,8 @@ int gat_bwd_impl(void* stream, int N, int E, int H, int D, const int* indptr, co
         if (wide_ok(H, D, ft, out) && wide_ok(H, D, dout, dft)) {
             const int nc8 = chunks_for8(H * D);
 #define GRAPPA_GAT_BWD8(NC8)                                                                                                                  \
-    hipLaunchKernelGGL((gat_delta_kernel_e<NC8, 8, T>), grid, dim3(256), 0, st, N, H, D, out, dout, delta);                                    \
-    hipLaunchKernelGGL((gat_bwd_kernel_e<NC8, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, rev, ft, alpha, dout, delta, dft)
+    GRAPPA_LAUNCH((gat_delta_kernel_e<NC8, 8, T>), grid, dim3(256), 0, st, N, H, D, out, dout, delta);                                    \
+    GRAPPA_LAUNCH((gat_bwd_kernel_e<NC8, 8, T>), grid, dim3(256), 0, st, N, H, D, indptr, indices, rev, ft, alpha, dout, delta, dft)
             if (nc8 == 1) { GRAPPA_GAT_BWD8(1); }
             else if (nc8 == 2) { GRAPPA_GAT_BWD8(2); }
             else { GRAPPA_GAT_BWD8(4); }
@@ -444,10 +444,10 @@ extern "C" int grappa_neighbor_mean_f32(void* stream, int N, int F, const int* i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((N + 3) / 4);
     switch (chunks_for(F)) {
-        case 1: hipLaunchKernelGGL((neighbor_mean_kernel<1, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
-        case 2: hipLaunchKernelGGL((neighbor_mean_kernel<2, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
-        case 4: hipLaunchKernelGGL((neighbor_mean_kernel<4, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
-        default: hipLaunchKernelGGL((neighbor_mean_kernel<8, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
+        case 1: GRAPPA_LAUNCH((neighbor_mean_kernel<1, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
+        case 2: GRAPPA_LAUNCH((neighbor_mean_kernel<2, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
+        case 4: GRAPPA_LAUNCH((neighbor_mean_kernel<4, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
+        default: GRAPPA_LAUNCH((neighbor_mean_kernel<8, float, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x, out, scale_by_neighbor); break;
     }
     return grappa_launch_status();
 }
@@ -463,9 +463,9 @@ extern "C" int grappa_neighbor_mean_bf16(void* stream, int N, int F, const int* 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((N + 3) / 4);
 #define NM_LAUNCH(NC)                                                                                                                           \
-    if (out_f32) hipLaunchKernelGGL((neighbor_mean_kernel<NC, grappa_bf16_t, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x,          \
+    if (out_f32) GRAPPA_LAUNCH((neighbor_mean_kernel<NC, grappa_bf16_t, float>), grid, dim3(256), 0, st, N, F, indptr, indices, x,          \
                                     reinterpret_cast<float*>(out), scale_by_neighbor);                                                          \
-    else hipLaunchKernelGGL((neighbor_mean_kernel<NC, grappa_bf16_t, grappa_bf16_t>), grid, dim3(256), 0, st, N, F, indptr, indices, x,          \
+    else GRAPPA_LAUNCH((neighbor_mean_kernel<NC, grappa_bf16_t, grappa_bf16_t>), grid, dim3(256), 0, st, N, F, indptr, indices, x,          \
                             reinterpret_cast<grappa_bf16_t*>(out), scale_by_neighbor);
     switch (chunks_for(F)) {
         case 1: NM_LAUNCH(1) break;

@@ -176,7 +176,7 @@ extern "C" int grappa_loss_ef_fwd_bwd_f32(void* stream, int B, int C, int N, con
     if (B <= 0 || C <= 0 || N < 0 || !atom_molptr || !loss_mol) return GRAPPA_ERR_ARG;
     if (wE != 0.f && (!energy || !energy_ref)) return GRAPPA_ERR_ARG;
     if (wG != 0.f && (!grad || !grad_ref)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(loss_ef_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), B, C, atom_molptr, energy, energy_ref,
+    GRAPPA_LAUNCH(loss_ef_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), B, C, atom_molptr, energy, energy_ref,
                        is_dummy, grad, grad_ref, wE, wG, inv_B, loss_mol, gE, gG);
     return grappa_launch_status();
 }
@@ -191,7 +191,7 @@ extern "C" int grappa_loss_param_fwd_bwd_f32(void* stream, const grappa_ploss_de
         if (d->p[l] && (!d->mol_ptr[l] || d->width[l] < 1)) return GRAPPA_ERR_ARG;
         if (d->ref[l] && d->ref_width[l] < 1) return GRAPPA_ERR_ARG;
     }
-    hipLaunchKernelGGL(loss_param_kernel, dim3(d->B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    GRAPPA_LAUNCH(loss_param_kernel, dim3(d->B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return grappa_launch_status();
 }
 
@@ -199,7 +199,7 @@ extern "C" int grappa_eval_se_f32(void* stream, int B, int C, int N, const int* 
                                   const float* is_dummy, const float* grad, const float* grad_ref, float* out) {
     if (B <= 0 || C <= 0 || N < 0 || !atom_molptr || !energy || !energy_ref || !out) return GRAPPA_ERR_ARG;
     if ((grad == nullptr) != (grad_ref == nullptr)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(eval_se_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), B, C, atom_molptr, energy, energy_ref, is_dummy,
+    GRAPPA_LAUNCH(eval_se_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), B, C, atom_molptr, energy, energy_ref, is_dummy,
                        grad, grad_ref, out);
     return grappa_launch_status();
 }

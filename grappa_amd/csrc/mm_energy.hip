@@ -312,7 +312,7 @@ extern "C" int grappa_mm_energy_fwd_f32(void* stream, const grappa_mm_desc* d, f
         a.tuple_e[l] = tuple_e ? tuple_e[l] : nullptr;
         a.tuple_x[l] = tuple_x ? tuple_x[l] : nullptr;
     }
-    hipLaunchKernelGGL(mm_energy_kernel, dim3(d->B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    GRAPPA_LAUNCH(mm_energy_kernel, dim3(d->B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return grappa_launch_status();
 }
 
@@ -321,7 +321,7 @@ extern "C" int grappa_mm_gradient_fwd_f32(void* stream, const grappa_mm_desc* d,
     if (d->N == 0) return GRAPPA_OK;
     if (!grad) return GRAPPA_ERR_ARG;
     const size_t total = (size_t)d->N * d->C;
-    hipLaunchKernelGGL(mm_gradient_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *d, grad);
+    GRAPPA_LAUNCH(mm_gradient_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *d, grad);
     return grappa_launch_status();
 }
 
@@ -346,10 +346,10 @@ extern "C" int grappa_mm_bwd_f32(void* stream, const grappa_mm_desc* d, const fl
         const int waves = (d->T[l] + tpw - 1) / tpw;
         const dim3 grid((waves + 3) / 4);
         switch (L) {
-            case 64: hipLaunchKernelGGL(mm_bwd_kernel<64>, grid, dim3(256), 0, st, a, l); break;
-            case 32: hipLaunchKernelGGL(mm_bwd_kernel<32>, grid, dim3(256), 0, st, a, l); break;
-            case 16: hipLaunchKernelGGL(mm_bwd_kernel<16>, grid, dim3(256), 0, st, a, l); break;
-            default: hipLaunchKernelGGL(mm_bwd_kernel<8>, grid, dim3(256), 0, st, a, l); break;
+            case 64: GRAPPA_LAUNCH(mm_bwd_kernel<64>, grid, dim3(256), 0, st, a, l); break;
+            case 32: GRAPPA_LAUNCH(mm_bwd_kernel<32>, grid, dim3(256), 0, st, a, l); break;
+            case 16: GRAPPA_LAUNCH(mm_bwd_kernel<16>, grid, dim3(256), 0, st, a, l); break;
+            default: GRAPPA_LAUNCH(mm_bwd_kernel<8>, grid, dim3(256), 0, st, a, l); break;
         }
     }
     return grappa_launch_status();

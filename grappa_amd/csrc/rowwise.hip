@@ -260,13 +260,13 @@ inline void reduce_rows(hipStream_t st, int nrows, int stride, int n, const floa
                         float* out2 = nullptr, int n_first = 0) {
     const dim3 gx((n + 255) / 256);
     if (nrows <= 2 * REDUCE_GROUPS) {
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, nrows, stride, n, part, out, 0, accumulate, nrows, out2, n_first);
+        GRAPPA_LAUNCH(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, nrows, stride, n, part, out, 0, accumulate, nrows, out2, n_first);
         return;
     }
     const int rpg = (nrows + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
     const int groups = (nrows + rpg - 1) / rpg;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, groups), dim3(256), 0, st, nrows, stride, n, part, scratch, n, 0, rpg, (float*)nullptr, 0);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, groups, n, n, scratch, out, 0, accumulate, groups, out2, n_first);
+    GRAPPA_LAUNCH(reduce_rows_kernel, dim3(gx.x, groups), dim3(256), 0, st, nrows, stride, n, part, scratch, n, 0, rpg, (float*)nullptr, 0);
+    GRAPPA_LAUNCH(reduce_rows_kernel, dim3(gx.x, 1), dim3(256), 0, st, groups, n, n, scratch, out, 0, accumulate, groups, out2, n_first);
 }
 
 // Column sums of many partial sets in one launch (the deferred LayerNorm parameter gradients of a backward pass): a block of 1024
@@ -490,9 +490,9 @@ int layernorm_fwd_impl(void* stream, int M, int W, const T* x, int ldx, const fl
     const int blocks = W <= 1024 ? ((M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4) : ln_blocks(M);
 #define GRAPPA_LN_FWD(NCH)                                                                                                              \
     if (mean && rstd)                                                                                                                   \
-        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, true, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax); \
+        GRAPPA_LAUNCH((layernorm_fwd_kernel<NCH, true, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((layernorm_fwd_kernel<NCH, false, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax)
+        GRAPPA_LAUNCH((layernorm_fwd_kernel<NCH, false, T>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax)
     if (W <= 256) { GRAPPA_LN_FWD(1); }
     else if (W <= 512) { GRAPPA_LN_FWD(2); }
     else if (W <= 1024) { GRAPPA_LN_FWD(4); }
@@ -518,7 +518,7 @@ int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const 
     float* part = reinterpret_cast<float*>(ws);
     float* scratch = part + (size_t)blocks * 2 * W;
     const size_t smem = (size_t)4 * 2 * W * sizeof(float);
-#define GRAPPA_LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, T>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax)
+#define GRAPPA_LN_BWD(NCH) GRAPPA_LAUNCH((layernorm_bwd_kernel<NCH, T>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax)
     if (W <= 256) GRAPPA_LN_BWD(1);
     else if (W <= 512) GRAPPA_LN_BWD(2);
     else if (W <= 1024) GRAPPA_LN_BWD(4);
@@ -541,10 +541,10 @@ int act_dropout_bwd_impl(void* stream, int M, int N, const T* dy, int lddy, cons
     const bool vec = (N & 3) == 0 && (lddy & 3) == 0 && (lddz & 3) == 0 && (!y || (ldy & 3) == 0) &&
                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & amask) == 0;
     if (vec)
-        hipLaunchKernelGGL(act_dropout_bwd_vec_kernel<T>, dim3(grid_for((size_t)M * (N >> 2))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+        GRAPPA_LAUNCH(act_dropout_bwd_vec_kernel<T>, dim3(grid_for((size_t)M * (N >> 2))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
     else
-        hipLaunchKernelGGL(act_dropout_bwd_kernel<T>, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+        GRAPPA_LAUNCH(act_dropout_bwd_kernel<T>, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
     return grappa_launch_status();
 }
@@ -574,7 +574,7 @@ extern "C" int grappa_layernorm_fwd_pairs_f32(void* stream, int M, int W, const 
         return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int blocks = W <= 1024 ? ((M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4) : ln_blocks(M);
-#define GRAPPA_LN_FWD_PAIRS(NCH) hipLaunchKernelGGL((layernorm_fwd_pairs_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax, pairs, ldp)
+#define GRAPPA_LN_FWD_PAIRS(NCH) GRAPPA_LAUNCH((layernorm_fwd_pairs_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, W, x, ldx, gamma, beta, y, ldy, mean, rstd, y_amax, pairs, ldp)
     if (W <= 256) GRAPPA_LN_FWD_PAIRS(1);
     else if (W <= 512) GRAPPA_LN_FWD_PAIRS(2);
     else if (W <= 1024) GRAPPA_LN_FWD_PAIRS(4);
@@ -590,14 +590,14 @@ extern "C" int grappa_convert_f32_to_bf16(void* stream, int M, int N, const floa
     if (M < 0 || N < 0) return GRAPPA_ERR_ARG;
     if (M == 0 || N == 0) return GRAPPA_OK;
     if (!x || !y) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL((convert_kernel<float, grappa_bf16_t>), dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M, N, x, ldx, y, ldy);
+    GRAPPA_LAUNCH((convert_kernel<float, grappa_bf16_t>), dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M, N, x, ldx, y, ldy);
     return grappa_launch_status();
 }
 extern "C" int grappa_convert_bf16_to_f32(void* stream, int M, int N, const uint16_t* x, int ldx, float* y, int ldy) {
     if (M < 0 || N < 0) return GRAPPA_ERR_ARG;
     if (M == 0 || N == 0) return GRAPPA_OK;
     if (!x || !y) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL((convert_kernel<grappa_bf16_t, float>), dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M, N, x, ldx, y, ldy);
+    GRAPPA_LAUNCH((convert_kernel<grappa_bf16_t, float>), dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M, N, x, ldx, y, ldy);
     return grappa_launch_status();
 }
 
@@ -626,7 +626,7 @@ extern "C" int grappa_colsum_partials_batched(void* stream, const grappa_colsum_
             b.it[i] = items[i0 + i];
             b.blk_begin[i + 1] = b.blk_begin[i] + (b.it[i].n + 63) / 64;
         }
-        hipLaunchKernelGGL(colsum_batched_kernel, dim3(b.blk_begin[b.count]), dim3(1024), 0, st, b);
+        GRAPPA_LAUNCH(colsum_batched_kernel, dim3(b.blk_begin[b.count]), dim3(1024), 0, st, b);
     }
     return grappa_launch_status();
 }
@@ -664,7 +664,7 @@ extern "C" int grappa_colsum_f32(void* stream, int M, int N, const float* x, int
     const int rpb = (M + blocks - 1) / blocks;
     const int used = (M + rpb - 1) / rpb;
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(used), dim3(256), 0, st, M, N, x, ldx, rpb, part);
+    GRAPPA_LAUNCH(colsum_partial_kernel, dim3(used), dim3(256), 0, st, M, N, x, ldx, rpb, part);
     reduce_rows(st, used, N, N, part, out, accumulate, part + (size_t)blocks * N);
     return grappa_launch_status();
 }
@@ -688,7 +688,7 @@ extern "C" int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int blocks = (M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4;
-#define GRAPPA_ADB(NCH) hipLaunchKernelGGL((act_dropout_bwd_rows_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz, dz_amax)
+#define GRAPPA_ADB(NCH) GRAPPA_LAUNCH((act_dropout_bwd_rows_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz, dz_amax)
     if (N <= 256) GRAPPA_ADB(1);
     else if (N <= 512) GRAPPA_ADB(2);
     else if (N <= 1024) GRAPPA_ADB(4);
@@ -704,7 +704,7 @@ extern "C" int grappa_act_dropout_bwd_bf16(void* stream, int M, int N, const uin
 extern "C" int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float* y) {
     if (n == 0) return GRAPPA_OK;
     if (!x || !z || !y) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, x, z, y);
+    GRAPPA_LAUNCH(add_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, x, z, y);
     return grappa_launch_status();
 }
 
@@ -717,8 +717,8 @@ extern "C" int grappa_sumsq_f32(void* stream, size_t n, const float* x, float* o
     if (!ws || ws_bytes < (size_t)blocks * sizeof(float)) return GRAPPA_ERR_WORKSPACE;
     if (n > 0 && !x) return GRAPPA_ERR_ARG;
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, n, x, part);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, blocks, part, out, accumulate);
+    GRAPPA_LAUNCH(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, n, x, part);
+    GRAPPA_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), 0, st, blocks, part, out, accumulate);
     return grappa_launch_status();
 }
 
@@ -728,7 +728,7 @@ extern "C" int grappa_adam_step_f32(void* stream, size_t n, float* p, const floa
     if (n == 0) return GRAPPA_OK;
     if (!p || !g || !m || !v || step < 1) return GRAPPA_ERR_ARG;
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, m, v, lr, beta1,
+    GRAPPA_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, m, v, lr, beta1,
                        beta2, eps, weight_decay, bc1, bc2, grad_scale, sumsq, max_norm);
     return grappa_launch_status();
 }
@@ -737,7 +737,7 @@ extern "C" int grappa_charge_encoding_f32(void* stream, int N, const float* q, i
     if (N < 0 || dim <= 0 || (dim & 1) || hi <= lo) return GRAPPA_ERR_ARG;
     if (N == 0) return GRAPPA_OK;
     if (!q || !out) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(charge_encoding_kernel, dim3(grid_for((size_t)N * dim / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    GRAPPA_LAUNCH(charge_encoding_kernel, dim3(grid_for((size_t)N * dim / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        N, q, dim, lo, hi, out, ldo, col0);
     return grappa_launch_status();
 }
@@ -745,3 +745,10 @@ extern "C" int grappa_charge_encoding_f32(void* stream, int N, const float* q, i
 extern "C" int grappa_dropout_keep(uint64_t seed, uint64_t index, float p) { return grappa_keep(seed, index, p) ? 1 : 0; }
 extern "C" int grappa_abi_version(void) { return GRAPPA_ABI_VERSION; }
 extern "C" const char* grappa_build_arch(void) { return "gfx950"; }
+
+#include <atomic>
+static std::atomic<long long> g_launches{0};
+extern "C" void grappa_count_launch(void) { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" long long grappa_launch_count(int reset) {
+    return reset ? g_launches.exchange(0, std::memory_order_relaxed) : g_launches.load(std::memory_order_relaxed);
+}

@@ -598,7 +598,7 @@ int tuple_gather_fwd_impl(void* stream, int T, int s, int W, const TA* a, int ld
     if (T < 0 || s < 1 || s > 4 || W <= 0 || (W & 3) || (lda & 3) || (ldx & 3)) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
     if (!a || !idx || !x || !aligned_el<TA>(a) || !aligned_el<TX>(x)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL((tuple_gather_fwd_kernel<TA, TX>), dim3(wave_grid((long)s * T)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, s, W, a,
+    GRAPPA_LAUNCH((tuple_gather_fwd_kernel<TA, TX>), dim3(wave_grid((long)s * T)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, s, W, a,
                        lda, idx, pe, x, ldx);
     return grappa_launch_status();
 }
@@ -609,7 +609,7 @@ int tuple_gather_bwd_impl(void* stream, int N, int W, const int* inv_ptr, const 
     if (N < 0 || W <= 0 || (W & 3) || (lddx & 3) || (ldda & 3)) return GRAPPA_ERR_ARG;
     if (N == 0) return GRAPPA_OK;
     if (!inv_ptr || !da || !aligned_el<TA>(da) || (dx && !aligned_el<TX>(dx))) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL((tuple_gather_bwd_kernel<TX, TA>), dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), N, W, inv_ptr,
+    GRAPPA_LAUNCH((tuple_gather_bwd_kernel<TX, TA>), dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), N, W, inv_ptr,
                        inv_rows, dx, lddx, da, ldda, has_pe, accumulate);
     return grappa_launch_status();
 }
@@ -625,19 +625,19 @@ int seqattn_fwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* q
     if constexpr (sizeof(TE) == 2) {
         if ((dh & 7) == 0 && pow2(dh / 8) && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {      // 8 bf16 per lane
             switch (s) {
-                case 1: hipLaunchKernelGGL((seqattn_fwd_kernel_e<1, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-                case 2: hipLaunchKernelGGL((seqattn_fwd_kernel_e<2, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-                case 3: hipLaunchKernelGGL((seqattn_fwd_kernel_e<3, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
-                default: hipLaunchKernelGGL((seqattn_fwd_kernel_e<4, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+                case 1: GRAPPA_LAUNCH((seqattn_fwd_kernel_e<1, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+                case 2: GRAPPA_LAUNCH((seqattn_fwd_kernel_e<2, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+                case 3: GRAPPA_LAUNCH((seqattn_fwd_kernel_e<3, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
+                default: GRAPPA_LAUNCH((seqattn_fwd_kernel_e<4, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out); break;
             }
             return grappa_launch_status();
         }
     }
     switch (s) {
-        case 1: hipLaunchKernelGGL((seqattn_fwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
-        case 2: hipLaunchKernelGGL((seqattn_fwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
-        case 3: hipLaunchKernelGGL((seqattn_fwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
-        default: hipLaunchKernelGGL((seqattn_fwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
+        case 1: GRAPPA_LAUNCH((seqattn_fwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
+        case 2: GRAPPA_LAUNCH((seqattn_fwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
+        case 3: GRAPPA_LAUNCH((seqattn_fwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
+        default: GRAPPA_LAUNCH((seqattn_fwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, out, row_amax); break;
     }
     return grappa_launch_status();
 }
@@ -654,19 +654,19 @@ int seqattn_bwd_impl(void* stream, int s, int T, int nheads, int dh, const TE* q
         if ((dh & 7) == 0 && pow2(dh / 8) &&
             ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dqkv)) & 15) == 0) {
             switch (s) {
-                case 1: hipLaunchKernelGGL((seqattn_bwd_kernel_e<1, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-                case 2: hipLaunchKernelGGL((seqattn_bwd_kernel_e<2, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-                case 3: hipLaunchKernelGGL((seqattn_bwd_kernel_e<3, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
-                default: hipLaunchKernelGGL((seqattn_bwd_kernel_e<4, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+                case 1: GRAPPA_LAUNCH((seqattn_bwd_kernel_e<1, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+                case 2: GRAPPA_LAUNCH((seqattn_bwd_kernel_e<2, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+                case 3: GRAPPA_LAUNCH((seqattn_bwd_kernel_e<3, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
+                default: GRAPPA_LAUNCH((seqattn_bwd_kernel_e<4, 8, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv); break;
             }
             return grappa_launch_status();
         }
     }
     switch (s) {
-        case 1: hipLaunchKernelGGL((seqattn_bwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
-        case 2: hipLaunchKernelGGL((seqattn_bwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
-        case 3: hipLaunchKernelGGL((seqattn_bwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
-        default: hipLaunchKernelGGL((seqattn_bwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
+        case 1: GRAPPA_LAUNCH((seqattn_bwd_kernel<1, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
+        case 2: GRAPPA_LAUNCH((seqattn_bwd_kernel<2, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
+        case 3: GRAPPA_LAUNCH((seqattn_bwd_kernel<3, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
+        default: GRAPPA_LAUNCH((seqattn_bwd_kernel<4, TE>), grid, dim3(256), 0, st, T, F, dh, qkv, dout, dqkv, row_amax); break;
     }
     return grappa_launch_status();
 }
@@ -708,10 +708,10 @@ extern "C" int grappa_seqattn_fwd_pairs_f32(void* stream, int s, int T, int nhea
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((T + 3) / 4);
     switch (s) {
-        case 1: hipLaunchKernelGGL((seqattn_fwd_pairs_kernel<1>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
-        case 2: hipLaunchKernelGGL((seqattn_fwd_pairs_kernel<2>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
-        case 3: hipLaunchKernelGGL((seqattn_fwd_pairs_kernel<3>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
-        default: hipLaunchKernelGGL((seqattn_fwd_pairs_kernel<4>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
+        case 1: GRAPPA_LAUNCH((seqattn_fwd_pairs_kernel<1>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
+        case 2: GRAPPA_LAUNCH((seqattn_fwd_pairs_kernel<2>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
+        case 3: GRAPPA_LAUNCH((seqattn_fwd_pairs_kernel<3>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
+        default: GRAPPA_LAUNCH((seqattn_fwd_pairs_kernel<4>), grid, dim3(256), 0, st, T, F, dh, qkv, pairs, ldp, out_amax); break;
     }
     return grappa_launch_status();
 }
@@ -749,7 +749,7 @@ int perm_concat_fwd_impl(void* stream, int s, int T, int F, int P, const int* h_
     if (T < 0 || F <= 0 || (F & 3)) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
     if (!x || !z || !aligned_el<TE>(x) || !aligned_el<TE>(z)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(perm_concat_fwd_kernel<TE>, dim3(wave_grid((long)P * T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P,
+    GRAPPA_LAUNCH(perm_concat_fwd_kernel<TE>, dim3(wave_grid((long)P * T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P,
                        fwd, x, z);
     return grappa_launch_status();
 }
@@ -760,7 +760,7 @@ int perm_concat_bwd_impl(void* stream, int s, int T, int F, int P, const int* h_
     if (T < 0 || F <= 0 || (F & 3)) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
     if (!dz || !dx || !aligned_el<TE>(dz) || !aligned_el<TE>(dx)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(perm_concat_bwd_kernel<TE>, dim3(wave_grid((long)T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P, inv,
+    GRAPPA_LAUNCH(perm_concat_bwd_kernel<TE>, dim3(wave_grid((long)T * s)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, T, F, P, inv,
                        dz, dx);
     return grappa_launch_status();
 }
@@ -786,7 +786,7 @@ extern "C" int grappa_param_out_fwd_f32(void* stream, int kind, int T, int P, in
     if (kind != GRAPPA_OUT_TORSION && ldo < 2) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
     if (!o || !consts || !k || (kind != GRAPPA_OUT_TORSION && !eq)) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(param_out_fwd_kernel, dim3((T + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, T, P, n_per, gated,
+    GRAPPA_LAUNCH(param_out_fwd_kernel, dim3((T + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, T, P, n_per, gated,
                        cutoff, o, ldo, consts, k, eq);
     return grappa_launch_status();
 }
@@ -806,8 +806,8 @@ extern "C" int grappa_param_out_bwd_stats_f32(void* stream, int kind, int T, int
     const int blocks = (T + 255) / 256 > 256 ? 256 : (T + 255) / 256;
     if (!ws || ws_bytes < (size_t)blocks * STATS_MAX * sizeof(float)) return GRAPPA_ERR_WORKSPACE;
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(param_out_stats_kernel, dim3(blocks), dim3(256), 0, st, kind, T, P, n_per, gated, cutoff, o, ldo, consts, dk, deq, part);
-    hipLaunchKernelGGL(param_out_stats_final_kernel, dim3(1), dim3(64), 0, st, blocks, ncst, part, d_consts);
+    GRAPPA_LAUNCH(param_out_stats_kernel, dim3(blocks), dim3(256), 0, st, kind, T, P, n_per, gated, cutoff, o, ldo, consts, dk, deq, part);
+    GRAPPA_LAUNCH(param_out_stats_final_kernel, dim3(1), dim3(64), 0, st, blocks, ncst, part, d_consts);
     return grappa_launch_status();
 }
 extern "C" int grappa_param_out_bwd_f32(void* stream, int kind, int T, int P, int n_per, int gated, float cutoff, const float* o, int ldo,
@@ -817,7 +817,7 @@ extern "C" int grappa_param_out_bwd_f32(void* stream, int kind, int T, int P, in
     if (kind != GRAPPA_OUT_TORSION && ldo < 2) return GRAPPA_ERR_ARG;
     if (T == 0) return GRAPPA_OK;
     if (!o || !consts || !d_o) return GRAPPA_ERR_ARG;
-    hipLaunchKernelGGL(param_out_bwd_kernel, dim3((T + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, T, P, n_per, gated,
+    GRAPPA_LAUNCH(param_out_bwd_kernel, dim3((T + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kind, T, P, n_per, gated,
                        cutoff, ldo, o, ldo, consts, dk, deq, d_o);
     return grappa_launch_status();
 }

@@ -47,10 +47,18 @@ def file_of_tag(tag: str, directory: Union[str, Path, None] = None) -> Path:
     raise ValueError(f"Tag {tag!r} names neither a release ({known}) nor a model file in {d} ({local})")
 
 
-def _torch_load(path: Union[str, Path]):
+def _torch_load(path: Union[str, Path], trusted: Optional[bool] = None):
+    """tensors and plain containers only (`weights_only=True`): a tampered .pth / .ckpt cannot run code.  Files that hold other pickled
+    objects (some of the reference's training checkpoints do) load only for a caller that vouches for them -- `trusted=True`, or
+    GRAPPA_TRUST_CHECKPOINTS=1 in the environment -- and the refusal says why."""
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:       # noqa: BLE001  (containers written by the reference hold plain Python objects beside the tensors)
+    except Exception as e:       # noqa: BLE001
+        if trusted is None:
+            trusted = os.environ.get("GRAPPA_TRUST_CHECKPOINTS", "0") not in ("0", "")
+        if not trusted:
+            raise RuntimeError(f"{path} does not load with weights_only=True ({type(e).__name__}: {e}); if the file is yours, pass trusted=True "
+                               "or set GRAPPA_TRUST_CHECKPOINTS=1 to unpickle it in full") from e
         return torch.load(path, map_location="cpu", weights_only=False)
 
 
@@ -61,7 +69,8 @@ def model_dict_from_tag(tag: str, directory: Union[str, Path, None] = None) -> D
         url = f"{RELEASE_URL}/{release}/{path.name}"
         path.parent.mkdir(parents=True, exist_ok=True)
         try:
-            return torch.hub.load_state_dict_from_url(url, model_dir=str(path.parent), file_name=path.name, map_location="cpu")
+            torch.hub.download_url_to_file(url, str(path))          # fetched, then loaded like any other file: tensors only
+            return _torch_load(path)
         except Exception as e:  # noqa: BLE001
             raise FileNotFoundError(f"{path} does not exist and {url} could not be fetched ({type(e).__name__}: {e}); "
                                     f"put the release file into {path.parent} or point GRAPPA_MODELS_DIR at its directory") from e

@@ -496,10 +496,6 @@ class WriteParameters(nn.Module):
         writers = self._writers_largest_first()
         # every head reads an alias of h of its own, so that its gradient of h arrives alone at the node that adds the four
         aliases = ops.SplitHeadsFn.apply(h, len(writers)) if (torch.is_grad_enabled() and h.requires_grad) else (h,) * len(writers)
-        be = get_backend()
-        if hasattr(be, "set_tail_launches"):
-            # several streams busy: a product's partial last round overlaps with another head's kernels, its split-K tail launch is a loss
-            be.set_tail_launches(not (self.head_streams > 1 and h.is_cuda))
         try:
             if self.head_streams <= 1 or not h.is_cuda:
                 for w, a in zip(writers, aliases):          # same host order (hence dropout seeds) as the multi-stream path
@@ -561,7 +557,13 @@ class GrappaModel(nn.Module):
 
     def forward(self, g):
         # tuple-index consistency (reference grappa.py:122-128) is validated once per batch, on the host, when the plan is built
-        g.plan()
+        plan = g.plan()
+        be = get_backend()
+        if hasattr(be, "set_tail_launches"):
+            # ONE plan setting for every product of the call, the GNN's included, chosen before the first of them (flipping it
+            # in front of the heads planned the first call's GNN differently from every later call's).  Several streams busy: a product's
+            # partial last round overlaps with another head's kernels, its split-K tail launch is a loss
+            be.set_tail_launches(not (self.parameter_writer.head_streams > 1 and plan.device.type == "cuda"))
         g = self.gnn(g)
         h = g.nodes["n1"].data["h"]
         if self.on_heads_backward_done is not None and h.requires_grad:

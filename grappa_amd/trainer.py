@@ -192,16 +192,29 @@ class Trainer:
                 "sampler_generator": self.gen.get_state(), "dropout_seed": dict(ops._SEED), "torch_rng": torch.get_rng_state(),
                 "history": list(self.history)}
 
+    @staticmethod
+    def _plain(o):
+        """numpy scalars -> Python numbers, recursively: the file then holds tensors and plain containers only and loads with weights_only=True"""
+        import numpy as np
+        if isinstance(o, dict):
+            return {k: Trainer._plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(Trainer._plain(v) for v in o)
+        if isinstance(o, np.generic):
+            return o.item()
+        return o
+
     def save_checkpoint(self, path: str) -> None:
         if self.rank == 0:
             tmp = f"{path}.tmp"
-            torch.save(self.checkpoint_dict(), tmp)
+            torch.save(self._plain(self.checkpoint_dict()), tmp)
             os.replace(tmp, path)              # a run killed while writing leaves the previous checkpoint intact
 
     def load_checkpoint(self, path: str) -> int:
         """-> the epoch the run continues with (`fit(max_epochs)` picks it up).  Every rank loads the same file."""
         from . import ops
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        from .loading import _torch_load
+        ck = _torch_load(path)                   # tensors and plain containers only (a tampered file cannot run code)
         if ck.get("format") != "grappa_amd.trainer/1":
             raise ValueError(f"{path} is not a trainer checkpoint of this engine (format {ck.get('format')!r})")
         self.model.load_state_dict(ck["model"]["state_dict"])

@@ -31,6 +31,8 @@ extern "C" {
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
+/* kernels this library has launched in this process since the last reset (reset != 0: returns the count and clears it); measurement only */
+long long grappa_launch_count(int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense blocks (fp32 MFMA v_mfma_f32_32x32x2_f32).  C = epilogue(opA(A) * opB(B)).

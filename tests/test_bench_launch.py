@@ -39,3 +39,28 @@ def test_bench_launches_its_own_ranks_and_reports_the_scaling_factor(tmp_path):
     assert ref["n_gpus"] == 1 and ref["config"]["molecules_rank0"] == 8 and ref["value"] > 0
     assert abs(rec["scaling_factor"] - rec["value"] / ref["value"]) < 1e-9
     assert rec["value"] > 0 and rec["ms_per_step"] > 0
+
+
+def test_bench_eight_gloo_ranks_check_themselves(tmp_path):
+    """the N = 8 launch the driver performs on an 8-GPU node, rehearsed here with eight gloo ranks on the CPU (tiny model): the line carries what the
+    collective layer saw (world size, backend, one entry per rank) and the bit-for-bit comparison of the overlapped and the post-backward
+    gradient reduction"""
+    (tmp_path / "sitecustomize.py").write_text(SITE.format(root=ROOT))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT, os.environ.get("PYTHONPATH", "")]), GRAPPA_TEST_REF_BACKEND="1",
+               OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--device", "cpu", "--tiny-model", "--steps", "2",
+           "--warmup", "1", "--strong-global-batch", "16", "--chunk", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong"
+    assert rec["config"]["world_size"] == 8 and rec["config"]["dist_backend"] == "gloo" and rec["config"]["molecules_rank0"] == 2
+    d = rec["dist"]
+    assert d["world_size"] == 8 and d["backend"] == "gloo" and sorted(r["rank"] for r in d["ranks"]) == list(range(8))
+    assert len({r["pid"] for r in d["ranks"]}) == 8
+    assert d["allreduce_bit_check"]["mismatching_steps_summed_over_ranks"] == 0
+    assert rec["strong_scaling_reference"]["config"]["molecules_rank0"] == 16 and rec["scaling_factor"] > 0

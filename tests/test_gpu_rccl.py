@@ -52,7 +52,8 @@ want = flat.grad.clone()
 assert float(want.abs().max()) > 0
 BucketedGradReducer._active = staticmethod(lambda: True)          # one rank: make the reducer call the collectives anyway
 for chunks in (1, 2):
-    red = BucketedGradReducer(model, flat)                        # default: overlapped
+    assert not BucketedGradReducer(model, flat).overlap           # default since round 4: both buckets after backward()
+    red = BucketedGradReducer(model, flat, overlap=True)          # opt-in: the heads' bucket leaves from inside the backward pass
     assert red.overlap
     flat.zero_grad()
     red.begin_step(chunks)

@@ -122,8 +122,9 @@ def _dp_worker(rank, world, port, ids, sd, out_q):
     assert reducer._heads_sent and len(reducer._work) == 1
     reducer.finish()
     assert torch.equal(flat.grad, one_bucket)
-    # and without the overlap (both buckets after backward); the default is the overlap
-    assert BucketedGradReducer(model, flat).overlap is True
+    # and without the overlap (both buckets after backward): the default since round 4 (the overlap is opt-in until an N >= 2
+    # RCCL run has compared the two orders bit for bit)
+    assert BucketedGradReducer(model, flat).overlap is False
     plain = BucketedGradReducer(model, flat, overlap=False)
     assert plain.overlap is False and model.on_heads_backward_done is None
     flat.zero_grad()
