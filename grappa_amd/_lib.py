@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hip.so")   # override: kernel A/B builds (tools/)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
 GEMM_GROUP_MAX = 16
 GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4, "f32_f16x3": 5}
@@ -33,7 +33,9 @@ class GemmDesc(C.Structure):
                 ("cp_nplanes", C.c_int), ("resp_nplanes", C.c_int), ("auxp_nplanes", C.c_int), ("C1p", C.c_void_p), ("ldc1p", C.c_int),
                 ("a_amax", C.c_void_p), ("b_amax", C.c_void_p), ("amax_bcast", C.c_int), ("out_amax", C.c_void_p),
                 # ABI 7: residual = LayerNorm(res) recomputed by the epilogue
-                ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p)]
+                ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p),
+                # ABI 8: pair-format operands of the weight-gradient products (token maxima of the operand)
+                ("a_rowmax", C.c_void_p), ("b_rowmax", C.c_void_p)]
 
 
 class ColsumItem(C.Structure):
@@ -72,6 +74,7 @@ SIGNATURES = {
     "grappa_launch_count": (C.c_longlong, [_i]),
     "grappa_split_planes_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _sz, _i]),
     "grappa_split_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i]),
+    "grappa_split_pairs_f32_batched": (_i, [_vp, _i, _i, _vp]),
     "grappa_amax_f32_workspace_bytes": (_sz, [_i, _i]),
     "grappa_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz]),
     "grappa_amax_f32_batched": (_i, [_vp, _i, _vp]),

@@ -901,7 +901,7 @@ class HipBackend:
         # inside a backward pass the parameter gradients wait: the kernel leaves its per-block partial sums in a buffer of their own and
         # ONE launch reduces those of all LayerNorms when the pass ends (flush_wgrads) instead of two small launches per LayerNorm
         task = self._queue_flush() if (accumulate and self.defer_wgrads and self.defer_ln and M > 0) else -1
-        defer = task >= 0 and all(q[3] != dgamma.data_ptr() for q in self._lnq)
+        defer = task >= 0 and all(q[3] != dgamma.data_ptr() for q in self._lnq if q[8] == task)      # (once per pass and parameter)
         need = self.lib.grappa_layernorm_bwd_workspace_bytes(M, W)
         ws = torch.empty(need, dtype=torch.uint8, device=dev) if defer else self._workspace(need, dev)
         row = self._new_row_amax(dx, True, amax)

@@ -6,7 +6,7 @@ using namespace grappa_gemm;
 
 #define GRAPPA_DECL(NAME)                                                                   \
     int grappa_bf16x_launch_##NAME(hipStream_t st, GemmParams& p, bool vec_kcontig);        \
-    int grappa_bf16x_launch_grouped_##NAME(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, bool vec)
+    int grappa_bf16x_launch_grouped_##NAME(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, bool vec, int psrc)
 GRAPPA_DECL(x9);
 GRAPPA_DECL(x6);
 GRAPPA_DECL(x3);
@@ -15,13 +15,14 @@ GRAPPA_DECL(h3);
 #undef GRAPPA_DECL
 
 // grouped weight-gradient products (layout a_kcontig = b_kcontig = 0, tile 256 x 128): called by grappa_gemm_f32_grouped
-int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision, bool vec) {
+// psrc: bit 0 / bit 1 = A / B of every product in the pair format (ABI 8, F32_F16X3 only)
+int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision, bool vec, int psrc) {
     switch (precision) {
-        case GRAPPA_GEMM_F32_BF16X9: return grappa_bf16x_launch_grouped_x9(st, d_ps, d_wg_begin, nprob, total_wgs, vec);
-        case GRAPPA_GEMM_F32_BF16X6: return grappa_bf16x_launch_grouped_x6(st, d_ps, d_wg_begin, nprob, total_wgs, vec);
-        case GRAPPA_GEMM_BF16X3: return grappa_bf16x_launch_grouped_x3(st, d_ps, d_wg_begin, nprob, total_wgs, vec);
-        case GRAPPA_GEMM_BF16: return grappa_bf16x_launch_grouped_x1(st, d_ps, d_wg_begin, nprob, total_wgs, vec);
-        case GRAPPA_GEMM_F32_F16X3: return grappa_bf16x_launch_grouped_h3(st, d_ps, d_wg_begin, nprob, total_wgs, vec);
+        case GRAPPA_GEMM_F32_BF16X9: return grappa_bf16x_launch_grouped_x9(st, d_ps, d_wg_begin, nprob, total_wgs, vec, psrc);
+        case GRAPPA_GEMM_F32_BF16X6: return grappa_bf16x_launch_grouped_x6(st, d_ps, d_wg_begin, nprob, total_wgs, vec, psrc);
+        case GRAPPA_GEMM_BF16X3: return grappa_bf16x_launch_grouped_x3(st, d_ps, d_wg_begin, nprob, total_wgs, vec, psrc);
+        case GRAPPA_GEMM_BF16: return grappa_bf16x_launch_grouped_x1(st, d_ps, d_wg_begin, nprob, total_wgs, vec, psrc);
+        case GRAPPA_GEMM_F32_F16X3: return grappa_bf16x_launch_grouped_h3(st, d_ps, d_wg_begin, nprob, total_wgs, vec, psrc);
         default: return GRAPPA_ERR_ARG;
     }
 }

@@ -60,7 +60,7 @@ template <int MODE> struct Pieces {
 // (zero / denormal rows: 2^141, still finite after scaling; Inf / NaN rows stay Inf / NaN)
 __device__ inline int amax_shift(unsigned bits) { return 141 - (int)((bits >> 23) & 0xffu); }
 
-struct Quad { float x[4]; };
+struct Quad { float x[4]; unsigned rm; };      // rm: pair-format sources only (the token row's largest magnitude); dead otherwise
 
 // slab element (row, kq..kq+3) owned by this thread for quad slot j of an operand with ROWS rows.
 // K-contiguous source: 4 lanes cover the 64 bytes of one row; k-major source: 64 lanes cover 64 consecutive rows of one k.
@@ -115,6 +115,73 @@ __device__ inline void load_quads(const float* __restrict__ src, int ld, int row
 }
 
 __device__ inline float u2f(unsigned x) { return __uint_as_float(x); }
+
+// ---- ABI 8: a k-major operand of the weight-gradient product given in the PAIR format.  The operand is [K tokens][ROWS features]; token
+// row k was split under ITS OWN scale 2^s_k (s_k = 141 - exponent of rowmax[k]), but the product reduces over the tokens, so the kernel
+// needs every element under ONE scale, the tensor's (2^s_T, s_T <= s_k).  Multiplying the fp16 halves by 2^-(s_k - s_T) is exact while the
+// result stays a normal fp16 number -- the very halves a fresh split under the tensor's scale would give -- and rounds to the fp16
+// denormal grid below that, like the fresh split does.  Two factors (2^-14 at most the first) reach down to 2^-39 of the tensor's
+// largest magnitude, the resolution of the denormal grid itself.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ inline unsigned pow2_neg_h2(int d) {               // 2^-d as two fp16 (d >= 0): normal, denormal, or 0 below 2^-24
+    const unsigned h = d <= 14 ? (unsigned)(15 - d) << 10 : (d <= 24 ? 1u << (24 - d) : 0u);
+    return h | (h << 16);
+}
+__device__ inline unsigned rescale_h2(unsigned v, unsigned f1, unsigned f2) {
+    const half2_t r = (__builtin_bit_cast(half2_t, v) * __builtin_bit_cast(half2_t, f1)) * __builtin_bit_cast(half2_t, f2);
+    return __builtin_bit_cast(unsigned, r);
+}
+// quad j = features row .. row + 3 of ONE token k = kq (the KMV coordinates): 8 bytes of HI, 8 bytes of LO, and the token's maximum
+template <int NT, int ROWS>
+__device__ inline void load_quads_pairs(const uint16_t* __restrict__ src, int ld, const unsigned* __restrict__ rowmax, int row0, int k0, int R, int Kend,
+                                        Quad (&q)[ROWS * 4 / NT]) {
+#pragma unroll
+    for (int j = 0; j < ROWS * 4 / NT; ++j) {
+        int row, kq;
+        quad_coords<NT, ROWS, false, true>(j, row, kq);
+        const int gk = k0 + kq < Kend ? k0 + kq : 0;
+        const int gr = min(row0 + row, ((R + 3) & ~3) - 4);
+        const uint16_t* p = src + (size_t)gk * ld + 32 * (gr >> 4) + (gr & 15);
+        const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 16);
+        q[j].x[0] = u2f(h.x); q[j].x[1] = u2f(h.y); q[j].x[2] = u2f(l.x); q[j].x[3] = u2f(l.y);
+        q[j].rm = rowmax[gk];
+    }
+}
+template <int NT, int ROWS, bool MASK>
+__device__ inline void store_quads_pairs(char* __restrict__ opbase, const Quad (&q)[ROWS * 4 / NT], int krem, int e_tensor) {
+    constexpr int PIECE = PieceBytes<ROWS, true>::value;
+#pragma unroll
+    for (int j = 0; j < ROWS * 4 / NT; ++j) {
+        int row, kq;
+        quad_coords<NT, ROWS, false, true>(j, row, kq);
+        const int d = max(e_tensor - (int)((q[j].rm >> 23) & 0xffu), 0), d1 = min(d, 14);
+        const unsigned f1 = pow2_neg_h2(d1), f2 = pow2_neg_h2(d - d1);
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = rescale_h2(__float_as_uint(q[j].x[e]), f1, f2);
+        if (MASK && kq >= krem) w[0] = w[1] = w[2] = w[3] = 0u;
+        char* dst = opbase + kq * (ROWS * 2) + ((((row >> 3) ^ ((kq & 3) << 2))) << 4) + ((row & 7) << 1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(w[0], w[1]);
+        *reinterpret_cast<uint2*>(dst + PIECE) = make_uint2(w[2], w[3]);
+    }
+}
+// bias gradient from a pair-format A: the elements back in fp32, (HI + LO) * 2^-s_k, summed over the tokens this thread stages
+template <int NT, int ROWS, bool MASK>
+__device__ inline void quad_rowsum_pairs(const Quad (&q)[ROWS * 4 / NT], int krem, float (&cs)[4]) {
+#pragma unroll
+    for (int j = 0; j < ROWS * 4 / NT; ++j) {
+        int row, kq;
+        quad_coords<NT, ROWS, false, true>(j, row, kq);
+        if (MASK && kq >= krem) continue;
+        const int back = (int)((q[j].rm >> 23) & 0xffu) - 141;              // -s_k
+        const half2_t h01 = __builtin_bit_cast(half2_t, __float_as_uint(q[j].x[0])), h23 = __builtin_bit_cast(half2_t, __float_as_uint(q[j].x[1]));
+        const half2_t l01 = __builtin_bit_cast(half2_t, __float_as_uint(q[j].x[2])), l23 = __builtin_bit_cast(half2_t, __float_as_uint(q[j].x[3]));
+        cs[0] += __builtin_ldexpf((float)h01[0] + (float)l01[0], back);
+        cs[1] += __builtin_ldexpf((float)h01[1] + (float)l01[1], back);
+        cs[2] += __builtin_ldexpf((float)h23[0] + (float)l23[0], back);
+        cs[3] += __builtin_ldexpf((float)h23[1] + (float)l23[1], back);
+    }
+}
 
 // split 4 consecutive-k fp32 values into NP bf16 pieces (round to nearest even; the residual r - float(piece) is exact in
 // fp32) and store each piece's 4 values as one 8-byte LDS write.  krem = valid k of this slab counted from its first column
@@ -306,7 +373,7 @@ struct KRange {
 //   (registers S) into the other stage | barrier | fragment reads of slab s+1 -> fn, one per MFMA of the last third
 // TAIL = one of the last steps of the K range: loads / stores happen only while slabs remain and the stored slab is masked to
 // the valid k; main-loop steps do both unconditionally.
-template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV, bool TAIL>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV, bool TAIL, int PSRC>
 __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict__ smem, f32x16 (&acc)[2][BN / WN / 32], int m0, int n0,
                                      const KRange& kr, int s, int wm0, int wn0, int lane, Quad (&la)[BM * 4 / NT], Quad (&lb)[BN * 4 / NT],
                                      const Quad (&sa)[BM * 4 / NT], const Quad (&sb)[BN * 4 / NT],
@@ -323,18 +390,26 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     constexpr int NFIRST = NM >= 12 ? NM * 2 / 3 : NM / 2;
     const bool do_store = !TAIL || s + 1 < kr.nsteps;
     const bool do_load = !TAIL || s + AHEAD < kr.nsteps;
+    constexpr bool PA_ = (PSRC & 1) != 0, PB_ = (PSRC & 2) != 0;      // the operand is in the pair format (wgrad layout, KMV, H3 only)
     if (do_load && !(GB_KNOCK == 3 && !TAIL)) {
-        load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
-        load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
+        if constexpr (PA_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
+        else load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
+        if constexpr (PB_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
+        else load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
     }
     __builtin_amdgcn_sched_barrier(0);
     char* nxt = smem + ((s + 1) & 1) * STAGE;
     mfma_range<MODE, TM, TN, 0, NFIRST>(fc, acc);
     if (do_store && !(GB_KNOCK == 4 && !TAIL)) {
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
-        store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF, AV>(nxt, sa, krem, sha);
-        store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF, BV>(nxt + NP * PA, sb, krem, shb);
-        if (!AK && do_cs) quad_rowsum<NT, BM, AV, TAIL>(sa, krem, cs);
+        if constexpr (PA_) store_quads_pairs<NT, BM, TAIL>(nxt, sa, krem, 141 - sha[0][0]);
+        else store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF, AV>(nxt, sa, krem, sha);
+        if constexpr (PB_) store_quads_pairs<NT, BN, TAIL>(nxt + NP * PA, sb, krem, 141 - shb[0][0]);
+        else store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF, BV>(nxt + NP * PA, sb, krem, shb);
+        if (!AK && do_cs) {
+            if constexpr (PA_) quad_rowsum_pairs<NT, BM, TAIL>(sa, krem, cs);
+            else quad_rowsum<NT, BM, AV, TAIL>(sa, krem, cs);
+        }
     }
     if (!TAIL) {
         // issue order of this phase: one MFMA, then a slice of the split arithmetic and of the LDS stores, so that the matrix
@@ -359,8 +434,10 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
 
 // one workgroup's tile; (nwg, wgid) = size of the problem's workgroup grid and this workgroup's place in it (a launch of its own:
 // gridDim / blockIdx; a grouped launch: the problem's share of the grid)
-template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV, int PSRC = 0>
 __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, int wgid) {
+    static_assert(PSRC == 0 || (MODE == H3 && KMV && !AK && !BKC), "pair-format sources: the wgrad layout of the fp16-split arithmetic only");
+    constexpr bool PA_ = (PSRC & 1) != 0, PB_ = (PSRC & 2) != 0;
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
     constexpr int NQA = BM * 4 / NT, NQB = BN * 4 / NT;
     constexpr bool AV = !AK && KMV, BV = !BKC && KMV;
@@ -417,18 +494,25 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
         Frags<NP, TM, TN> fr[2];                  // fragments of even / odd slabs
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
-            load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
-            load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
+            if constexpr (PA_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
+            else load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
+            if constexpr (PB_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
+            else load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
         }
-        store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF, AV>(smem, qa[0], kr.kend - kr.kbeg, sha);
-        store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF, BV>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, shb);
-        if (!AK && do_cs) quad_rowsum<NT, BM, AV, true>(qa[0], kr.kend - kr.kbeg, cs);
+        if constexpr (PA_) store_quads_pairs<NT, BM, true>(smem, qa[0], kr.kend - kr.kbeg, 141 - sha[0][0]);
+        else store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF, AV>(smem, qa[0], kr.kend - kr.kbeg, sha);
+        if constexpr (PB_) store_quads_pairs<NT, BN, true>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, 141 - shb[0][0]);
+        else store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF, BV>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, shb);
+        if (!AK && do_cs) {
+            if constexpr (PA_) quad_rowsum_pairs<NT, BM, true>(qa[0], kr.kend - kr.kbeg, cs);
+            else quad_rowsum<NT, BM, AV, true>(qa[0], kr.kend - kr.kbeg, cs);
+        }
         __syncthreads();
         read_frags<NP, BM, BN, TM, TN, AV, BV>(smem, wm0, wn0, lane, fr[0]);
         int s = 0;
         // step s stores slab s+1 (register set (s+1) % AHEAD) and loads slab s+AHEAD into the set slab s occupied
 #define GRAPPA_STEP(TAIL, U) \
-    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, TAIL>(d, smem, acc, m0, n0, kr, s + (U), wm0, wn0, lane, qa[U], qb[U], qa[((U) + 1) % AHEAD], \
+    pipeline_step<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, TAIL, PSRC>(d, smem, acc, m0, n0, kr, s + (U), wm0, wn0, lane, qa[U], qb[U], qa[((U) + 1) % AHEAD], \
                                                                  qb[((U) + 1) % AHEAD], fr[(U) & 1], fr[((U) + 1) & 1], cs, do_cs, sha, shb)
         // main loop: AHEAD steps per trip (the register sets rotate); never stores the last slab of the range and every load
         // it issues is for an existing slab
@@ -519,12 +603,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x_kernel(GemmParams p) {
 // together).  A wgrad alone has 8 .. 24 tiles and must cut its K (= tokens) 10 .. 32 ways to fill 256 CUs, i.e. write and re-read
 // 10 .. 32 partial tiles per output tile; sixteen of them together fill the chip with 3 .. 11 cuts each.  Problem descriptors and
 // the prefix of workgroups per problem live in device memory (copied ahead of the launch on the same stream).
-template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV, int PSRC = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16x_grouped_kernel(const GemmParams* __restrict__ ps, const int* __restrict__ wg_begin, int nprob) {
     const int wg = blockIdx.x;
     int g = 0;
     while (g + 1 < nprob && wg >= wg_begin[g + 1]) ++g;
-    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV>(ps[g], wg_begin[g + 1] - wg_begin[g], wg - wg_begin[g]);
+    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, PSRC>(ps[g], wg_begin[g + 1] - wg_begin[g], wg - wg_begin[g]);
 }
 
 template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
@@ -560,13 +644,14 @@ int launch_tile(hipStream_t st, GemmParams& p, bool vec) {
     return GRAPPA_ERR_ARG;
 }
 
-template <int MODE, bool KMV>
+// PSRC: bit 0 / bit 1 = the A / B operand of every product of the group is in the pair format (ABI 8; H3 and KMV only)
+template <int MODE, bool KMV, int PSRC = 0>
 int launch_grouped_wgrad(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs) {
     constexpr int NT = 512, BM = 256, BN = 128;
     constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (PieceBytes<BM, KMV>::value + PieceBytes<BN, KMV>::value);
     constexpr size_t staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
     constexpr size_t smem = stages > staging ? stages : staging;
-    auto kern = gemm_bf16x_grouped_kernel<NT, MODE, BM, BN, 2, false, false, false, KMV>;
+    auto kern = gemm_bf16x_grouped_kernel<NT, MODE, BM, BN, 2, false, false, false, KMV, PSRC>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -582,7 +667,16 @@ int launch_grouped_wgrad(hipStream_t st, const GemmParams* d_ps, const int* d_wg
 // one arithmetic per translation unit: GRAPPA_BF16X_MODE_FUNCS(X6, x6) defines grappa_bf16x_launch_x6 / grappa_bf16x_launch_grouped_x6
 #define GRAPPA_BF16X_MODE_FUNCS(MODE, NAME)                                                                                                  \
     int grappa_bf16x_launch_##NAME(hipStream_t st, GemmParams& p, bool vec_kcontig) { return launch_tile<MODE>(st, p, vec_kcontig); }       \
-    int grappa_bf16x_launch_grouped_##NAME(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, bool vec) { \
+    int grappa_bf16x_launch_grouped_##NAME(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, bool vec, \
+                                           int psrc) {                                                                                     \
+        if constexpr (MODE == H3) {                                                                                                        \
+            if (psrc != 0 && !vec) return GRAPPA_ERR_ARG;                                                                                  \
+            if (psrc == 1) return launch_grouped_wgrad<MODE, true, 1>(st, d_ps, d_wg_begin, nprob, total_wgs);                             \
+            if (psrc == 2) return launch_grouped_wgrad<MODE, true, 2>(st, d_ps, d_wg_begin, nprob, total_wgs);                             \
+            if (psrc == 3) return launch_grouped_wgrad<MODE, true, 3>(st, d_ps, d_wg_begin, nprob, total_wgs);                             \
+        } else if (psrc != 0) {                                                                                                            \
+            return GRAPPA_ERR_ARG;                                                                                                         \
+        }                                                                                                                                  \
         return vec ? launch_grouped_wgrad<MODE, true>(st, d_ps, d_wg_begin, nprob, total_wgs)                                              \
                    : launch_grouped_wgrad<MODE, false>(st, d_ps, d_wg_begin, nprob, total_wgs);                                            \
     }

@@ -23,7 +23,7 @@ int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool 
 int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision);                      // gemm_planes.hip
 int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p);                                      // gemm_pairs.hip
 int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* part, unsigned* out);   // amax.hip
-int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision, bool vec);   // gemm_bf16x.hip
+int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision, bool vec, int psrc);   // gemm_bf16x.hip
 
 namespace {
 
@@ -528,8 +528,17 @@ struct GroupPlan {
     int total_tickets;
 };
 
+// pair-format operand of the wgrad layout (ABI 8): [K tokens][rows] pairs, every token row under its own scale (rowmax[k]); F32_F16X3,
+// one whole-tensor scale per operand (amax_bcast), 16-byte aligned rows, rows % 32 == 0 (the pair rows carry no partial granule)
+bool pair_operand_ok(const void* q, int ld, int rows, const uint32_t* rowmax, int precision, int bcast_bit, int amax_bcast) {
+    return precision == GRAPPA_GEMM_F32_F16X3 && rowmax != nullptr && (amax_bcast & bcast_bit) != 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
+           (ld & 7) == 0 && (rows & 31) == 0 && ld >= 2 * rows;
+}
+
 bool group_desc_ok(const grappa_gemm_desc& d, int precision) {
-    if (d.a_kcontig || d.b_kcontig || d.a_planes || d.b_planes) return false;          // the wgrad layout, fp32 operands
+    if (d.a_kcontig || d.b_kcontig) return false;                                      // the wgrad layout
+    if (d.a_planes && !pair_operand_ok(d.A, d.lda, d.M, d.a_rowmax, d.precision, 1, d.amax_bcast)) return false;
+    if (d.b_planes && !pair_operand_ok(d.B, d.ldb, d.N, d.b_rowmax, d.precision, 2, d.amax_bcast)) return false;
     if (!d.A || !d.B || !d.C || d.Cp || d.C1p || d.resp || d.auxp || d.out_amax) return false;
     if (d.M <= 32 || d.N <= 32 || d.K <= 0) return false;
     if (d.precision != precision || d.precision == GRAPPA_GEMM_F32_MFMA) return false;
@@ -597,8 +606,9 @@ extern "C" size_t grappa_gemm_f32_grouped_workspace_bytes(const grappa_gemm_desc
 extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* descs, int n, void* ws, size_t ws_bytes) {
     if (!descs || n <= 0 || n > GROUP_MAX) return GRAPPA_ERR_ARG;
     const int precision = descs[0].precision;
+    const int psrc = (descs[0].a_planes ? 1 : 0) | (descs[0].b_planes ? 2 : 0);      // one operand format per group (the caller groups by it)
     for (int i = 0; i < n; ++i)
-        if (!group_desc_ok(descs[i], precision)) return GRAPPA_ERR_ARG;
+        if (!group_desc_ok(descs[i], precision) || ((descs[i].a_planes ? 1 : 0) | (descs[i].b_planes ? 2 : 0)) != psrc) return GRAPPA_ERR_ARG;
     const GroupPlan g = plan_group(descs, n);
     if (!ws || ws_bytes < g.total_bytes) return GRAPPA_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -621,6 +631,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
         vec = vec && (reinterpret_cast<uintptr_t>(d.A) & 15) == 0 && (d.lda & 3) == 0 && ((d.M + 3) & ~3) <= d.lda &&
               (reinterpret_cast<uintptr_t>(d.B) & 15) == 0 && (d.ldb & 3) == 0 && ((d.N + 3) & ~3) <= d.ldb;
     }
+    if (psrc != 0 && !vec) return GRAPPA_ERR_ARG;                                      // (fp32 partner of a pair operand must allow 16-byte row loads)
     for (int i0 = 0; i0 < n; i0 += 8) {
         const int cnt = n - i0 < 8 ? n - i0 : 8;
         for (int j = 0; j < cnt; ++j) {
@@ -662,7 +673,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
     }
     GRAPPA_LAUNCH(group_index_kernel, dim3(1), dim3(256), 0, st, ix, n, d_wg, d_blk, tickets, in_kernel ? g.total_tickets : 0);
     if (grappa_launch_status() != GRAPPA_OK) return GRAPPA_ERR_LAUNCH;
-    int rc = grappa_launch_gemm_bf16x_grouped(st, d_ps, d_wg, n, g.total_wgs, precision, vec);
+    int rc = grappa_launch_gemm_bf16x_grouped(st, d_ps, d_wg, n, g.total_wgs, precision, vec, psrc);
     if (rc != GRAPPA_OK) return rc;
     if (total_blocks > 0) {
         GRAPPA_LAUNCH(gemm_splitk_reduce_grouped_kernel, dim3(total_blocks), dim3(REDUCE_THREADS), 0, st, d_ps, d_blk, n);
@@ -679,6 +690,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     for (int np : {d->cp_nplanes, d->resp_nplanes, d->auxp_nplanes})
         if (np != 0 && np != 1 && np != 3) return GRAPPA_ERR_ARG;
     if (d->a_planes && !d->b_planes) return GRAPPA_ERR_ARG;
+    if ((d->a_planes || d->b_planes) && !d->a_kcontig && d->precision == GRAPPA_GEMM_F32_F16X3) return GRAPPA_ERR_ARG;   // ABI 8 pair operands of a weight gradient: grappa_gemm_f32_grouped only
     const bool planes = d->b_planes != 0;
     // pair format (fp16 hi / lo planes + the row maxima that define the power-of-two scale of every row): both operands, K-contiguous
     const bool pairs = planes && d->precision == GRAPPA_GEMM_F32_F16X3;

@@ -528,7 +528,59 @@ __global__ __launch_bounds__(256) void split_pairs_kernel(int R, int C, const fl
     }
 }
 
+// many matrices in ONE launch (every weight of a model, both orientations, once per optimiser step): a table of items in device memory,
+// tile_begin = prefix of 32 x 32 tiles; a workgroup finds its item by bisection
+__global__ __launch_bounds__(256) void split_pairs_batched_kernel(int count, const grappa_split_pairs_item* __restrict__ items) {
+    __shared__ uint16_t tile[2][32][33];
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile_begin <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const grappa_split_pairs_item it = items[lo];
+    const int local = (int)blockIdx.x - it.tile_begin, tiles_x = (it.C + 31) / 32;
+    const int r0 = (local / tiles_x) * 32, c0 = (local % tiles_x) * 32;
+    const int tc = threadIdx.x & 31, tr = threadIdx.x >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + tr + 8 * q, c = c0 + tc;
+        const bool ok = r < it.R && c < it.C;
+        float v = ok ? it.x[(size_t)r * it.ldx + c] : 0.f;
+        v = __builtin_ldexpf(v, ok ? amax_shift(it.amax[it.transpose ? c : r]) : 0);
+        const _Float16 hi16 = (_Float16)v;
+        const _Float16 lo16 = (_Float16)(v - (float)hi16);
+        const uint16_t hb = __builtin_bit_cast(uint16_t, hi16), lb = __builtin_bit_cast(uint16_t, lo16);
+        if (it.transpose) {
+            tile[0][tr + 8 * q][tc] = hb;
+            tile[1][tr + 8 * q][tc] = lb;
+        } else if (ok) {
+            const size_t o = pair_index(r, c, it.ldp);
+            it.pairs[o] = hb;
+            it.pairs[o + 16] = lb;
+        }
+    }
+    if (!it.transpose) return;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = c0 + tr + 8 * q, r = r0 + tc;
+        if (c < it.C && r < it.R) {
+            const size_t o = pair_index(c, r, it.ldp);
+            it.pairs[o] = tile[0][tc][tr + 8 * q];
+            it.pairs[o + 16] = tile[1][tc][tr + 8 * q];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int grappa_split_pairs_f32_batched(void* stream, int count, int total_tiles, const grappa_split_pairs_item* items) {
+    if (count < 0 || total_tiles < 0 || (count > 0 && !items)) return GRAPPA_ERR_ARG;
+    if (count == 0 || total_tiles == 0) return GRAPPA_OK;
+    GRAPPA_LAUNCH(split_pairs_batched_kernel, dim3(total_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), count, items);
+    return grappa_launch_status();
+}
 
 extern "C" int grappa_split_pairs_f32(void* stream, int R, int C, const float* x, int ldx, const uint32_t* amax, uint16_t* pairs, int ldp,
                                       int transpose) {

@@ -27,7 +27,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 7
+#define GRAPPA_ABI_VERSION 8
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -144,6 +144,14 @@ typedef struct grappa_gemm_desc {
      * operands or both in the pair format): every epilogue form of those (straight-line classes, the generic row walk with C2 / activation,
      * the split-K reduction) adds the recomputed rows; anything else is refused (GRAPPA_ERR_ARG). */
     const float* res_ln_mean; const float* res_ln_rstd; const float* res_ln_gamma; const float* res_ln_beta;
+    /* ---- ABI 8: operands of a WEIGHT-GRADIENT product (a_kcontig = b_kcontig = 0, precision F32_F16X3, grappa_gemm_f32_grouped only) in
+     * the pair format.  a_planes != 0: A is the [K tokens][M features] matrix as its producer wrote it for the forward / input-gradient
+     * products -- pairs, token row k scaled by its own maximum a_rowmax[k] (K values) -- lda in fp16 elements (>= 2 * M, % 8 == 0), M % 32
+     * == 0, 16-byte aligned; a_amax (with amax_bcast bit 0) = the maximum over the token maxima.  The kernel moves every token row onto the
+     * tensor's scale with exact fp16 multiplications by powers of two (the halves a fresh split under that scale would give, up to the
+     * rounding of fp16 denormals).  b_planes / b_rowmax / bit 1: the same for B ([K tokens][N features]).  One operand may stay fp32.
+     * All products of one grouped call must use the same formats. */
+    const uint32_t* a_rowmax; const uint32_t* b_rowmax;
 } grappa_gemm_desc;
 
 /* Largest magnitudes of an fp32 matrix x[R][C] (leading dimension ldx), as fp32 bit patterns: row_amax[r] = max_c |x[r][c]|,
@@ -178,6 +186,14 @@ int grappa_split_planes_f32(void* stream, int R, int C, const float* x, int ldx,
  * or C values when transposing: grappa_amax_f32's row_amax / col_amax).  Only the elements of X are written; the zero padding along k
  * is the caller's (allocate zeroed).  Weights are split once per optimiser step, both orientations; activations by their producers. */
 int grappa_split_pairs_f32(void* stream, int R, int C, const float* x, int ldx, const uint32_t* amax, uint16_t* pairs, int ldp, int transpose);
+/* The same for many matrices in ONE launch (the weights of a model, both orientations, once per optimiser step).  `items` lives in DEVICE
+ * memory; tile_begin = number of 32 x 32 tiles ((R + 31) / 32 * ((C + 31) / 32)) of the items before this one, total_tiles their sum;
+ * amax = the row maxima of X (transpose == 0) or its column maxima (transpose != 0: the pairs of X^T, [C][R]). */
+typedef struct grappa_split_pairs_item {
+    const float* x; const uint32_t* amax; uint16_t* pairs;
+    int R, C, ldx, ldp, transpose, tile_begin;
+} grappa_split_pairs_item;
+int grappa_split_pairs_f32_batched(void* stream, int count, int total_tiles, const grappa_split_pairs_item* items);
 
 size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);
 /* host-only: the tile (tile_m x tile_n x 32) and split-K factor the launcher will use for this shape, and the "tail": when the
