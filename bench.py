@@ -12,8 +12,11 @@ synthetic charges / coordinates / reference energies+forces, inputs resident in 
   `cpu_baseline`  the oracle's CPU restatement of the same train step on a bounded sample (rank 0, N = 1 only),
   `c3`            BASELINE configs[2] (1024 molecules of the whole pool) timed right after C2 with the same fp32-grade arithmetic,
   `c3_bf16`       the same batch in the bf16 STORAGE configuration that config names ("bf16, MFMA dense heads"): never `value`,
-  `c4_strong_n1`  BASELINE configs[3]'s 4096-molecule global batch on ONE GPU (4 chunks of 1024, gradients accumulated, one
-                  optimiser step) -- the N = 1 point of the strong-scaling curve below.
+  `scale_n1`      BASELINE configs[3]'s 4096-molecule global batch on ONE GPU (4 chunks of 1024, gradients accumulated, one
+                  optimiser step) with its own roofline -- the N = 1 point of the strong-scaling curve below,
+  `launches`      kernel launches and host enqueue time of one C2 step,
+  `b32_train`     the reference's own operating point (32 molecules x 32 conformations, training/config.py:49-52): eager and as a recorded hipGraph,
+  `predict_latency_ms`  `Grappa.predict` on one ~40-atom molecule (grappa.py:36-57): eager and through the cache of recorded forwards.
 N > 1 (default): STRONG scaling of BASELINE configs[3] (C4): ONE global batch of 4096 molecules dealt to the ranks by size
 (dist.shard_indices), loss scaled by 1/4096 on every rank, gradients summed with a two-bucket RCCL all-reduce of the flat gradient
 buffer after backward(); `--weak` switches to weak scaling of C2 (256 molecules per GPU).
@@ -486,7 +489,7 @@ def main():
         headline_graphs = job.graphs
         default_precision = be.gemm_precision_name
         for key, name, steps, bf16 in (("c3", "C3-espaloma-b1024", 5, False), ("c3_bf16", "C3-espaloma-b1024", 5, True),
-                                       ("c4_strong_n1", "C4-espaloma-b4096", 5, False)):
+                                       ("scale_n1", "C4-espaloma-b4096", 5, False)):
             try:
                 if bf16:
                     ops.set_activation_dtype("bf16")
@@ -494,11 +497,16 @@ def main():
                 j2 = Job(name, WORKLOADS[name][0], workload_molecule_ids(name, seed=0), seed=0)
                 d2, l2 = j2.timed(steps, 2)
                 extras[key] = {"value": j2.global_batch * steps / d2, "unit": "molecules/s", "ms_per_step": 1e3 * d2 / steps, "steps": steps, "warmup": 2,
-                               "scaling": "strong" if key.startswith("c4") else None, "n_gpus": 1, "gemm_precision": be.gemm_precision_name,
+                               "scaling": None, "n_gpus": 1, "gemm_precision": be.gemm_precision_name,
                                "activation_storage": "bf16" if bf16 else "f32", "final_loss": l2, "config": j2.describe()}
-                if key != "c4_strong_n1":
-                    r2, g2, _, _ = instrument(j2, 2)
-                    extras[key]["roofline"], extras[key]["roofline_gat"] = r2, g2
+                r2, g2, _, _ = instrument(j2, 2 if key != "scale_n1" else 1)
+                for k_ in ("traffic", "traffic_source"):        # PMC counters cannot be read in-process: only the headline carries a committed summary
+                    if r2.get(k_) is None:
+                        r2.pop(k_, None)
+                extras[key]["roofline"], extras[key]["roofline_gat"] = r2, g2
+                if key == "scale_n1":
+                    extras[key]["note"] = ("BASELINE configs[3]'s 4096-molecule global batch on ONE GPU (4 chunks of 1024, gradients accumulated, one optimiser "
+                                           "step): the N = 1 point of the strong-scaling curve the driver measures at N = 2, 4, 8")
                 if bf16:
                     extras[key]["note"] = ("bf16 STORAGE configuration (BASELINE configs[2]): activations and activation gradients in HBM as bf16, dense "
                                            "products straight from bf16 operands (fp32 accumulate), LayerNorm statistics / softmax / energies / forces / "
@@ -513,6 +521,94 @@ def main():
                 be.set_gemm_precision(default_precision)
                 torch.cuda.empty_cache()
         job.graphs = headline_graphs
+        # ---- launch counts and host enqueue time of one headline step: the library counts its own launches; the host time is
+        # taken with an empty queue in front of every step, so it is the time Python + the C ABI need to ISSUE the step, not to run it
+        try:
+            host_ms, launches = [], []
+            for _ in range(5):
+                sync()
+                be.lib.grappa_launch_count(1)
+                t_h = time.perf_counter()
+                job.step()
+                host_ms.append(1e3 * (time.perf_counter() - t_h))
+                sync()
+                launches.append(int(be.lib.grappa_launch_count(1)))
+            host_ms.sort()
+            extras["launches"] = {"library_kernel_launches_per_step": sorted(launches)[len(launches) // 2], "host_enqueue_ms_per_step": host_ms[len(host_ms) // 2],
+                                  "workload": job.name, "writer_head_streams": model.parameter_writer.head_streams,
+                                  "note": "kernels launched by libgrappa_hip.so per C2 train step (its own counter; torch adds ~1 fill / copy per "
+                                          "output tensor) and the wall time the host needs to issue one step into an empty queue"}
+            log(f"launches per step {extras['launches']['library_kernel_launches_per_step']}, host enqueue {extras['launches']['host_enqueue_ms_per_step']:.1f} ms")
+        except Exception as e:  # noqa: BLE001
+            extras["launches"] = {"error": repr(e)[:300]}
+        # ---- the reference's own operating point: batch 32 x 32 conformations (training/config.py:49-52), eager and as a recorded hipGraph
+        try:
+            from grappa_amd.capture import CapturedTrainStep
+            ids32 = workload_molecule_ids("C2-pubchem-b256", seed=0)[:32]
+            j32 = Job("C2-pubchem-b256", 32, ids32, seed=0)
+            d32, _ = j32.timed(20, 5)
+            sync()
+            be.lib.grappa_launch_count(1)
+            j32.step()
+            sync()
+            n32 = int(be.lib.grappa_launch_count(1))
+            cap = CapturedTrainStep(model, energy, j32.loss_fn, opt, j32.graphs[0], warmup=3)
+            for _ in range(5):
+                cap()
+            sync()
+            t_c = time.perf_counter()
+            n_rep = 50
+            for _ in range(n_rep):
+                cap()
+            sync()
+            d_c = time.perf_counter() - t_c
+            extras["b32_train"] = {"value": 32 * n_rep / d_c, "unit": "molecules/s", "ms_per_step": 1e3 * d_c / n_rep, "steps": n_rep, "warmup": 5,
+                                   "mode": "hipGraph replay (grappa_amd/capture.py CapturedTrainStep): one graph launch per train step",
+                                   "eager": {"value": 32 * 20 / d32, "ms_per_step": 1e3 * d32 / 20, "steps": 20, "warmup": 5,
+                                             "library_kernel_launches_per_step": n32},
+                                   "final_loss": float(cap.loss), "config": j32.describe(),
+                                   "note": "32 molecules x 32 conformations of the C2 molecule range, production model, train mode (dropout on: the "
+                                           "recorded step draws fresh masks per replay through the device-side salt), Adam + clip 10; the SAME resident "
+                                           "batch every step (shapes are part of a recorded graph: a loader must deliver batches of one shape to use it)"}
+            log(f"b32_train: eager {extras['b32_train']['eager']['ms_per_step']:.1f} ms/step, recorded {extras['b32_train']['ms_per_step']:.1f} ms/step "
+                f"= {extras['b32_train']['value']:.0f} molecules/s")
+            del cap, j32
+        except Exception as e:  # noqa: BLE001
+            extras["b32_train"] = {"value": None, "error": repr(e)[:400]}
+        finally:
+            torch.cuda.empty_cache()
+        # ---- Grappa.predict on ONE ~40-atom molecule (grappa.py:36-57): eager and through the cache of recorded forwards
+        try:
+            import numpy as np
+            from grappa_amd import Grappa
+            from grappa_amd.datasets import molecule_from_pool
+            mol = molecule_from_pool(int(np.argmin(np.abs(pool_atom_counts() - 40))))
+            gr = Grappa(model, device="cuda")
+            lat = {}
+            for mode in ("eager", "recorded"):
+                keep_graphs = gr._graphs
+                if mode == "eager":
+                    gr._graphs = None
+                for _ in range(4):
+                    gr.predict(mol)
+                ts = []
+                for _ in range(30):
+                    sync()
+                    t_p = time.perf_counter()
+                    gr.predict(mol)
+                    ts.append(1e3 * (time.perf_counter() - t_p))
+                ts.sort()
+                lat[mode] = {"median_ms": ts[len(ts) // 2], "min_ms": ts[0], "p90_ms": ts[int(0.9 * len(ts))]}
+                gr._graphs = keep_graphs
+            extras["predict_latency_ms"] = {"value": lat["recorded"]["median_ms"], "unit": "ms per Grappa.predict call (median of 30)", "higher_is_better": False,
+                                            "recorded": lat["recorded"], "eager": lat["eager"], "atoms": int(mol.to_dgl().num_nodes("n1")),
+                                            "note": "host-side graph preparation + copy to the device + forward + copy back + Parameters.from_dgl; "
+                                                    "`recorded`: the shape's forward replayed from the cache of hipGraphs (second and later calls on a shape)"}
+            log(f"predict: eager {lat['eager']['median_ms']:.2f} ms, recorded {lat['recorded']['median_ms']:.2f} ms")
+        except Exception as e:  # noqa: BLE001
+            extras["predict_latency_ms"] = {"value": None, "error": repr(e)[:400]}
+        finally:
+            model.train()
         # BASELINE configs[4] / SURVEY 8(d): single-graph inference latency, ONE 50,046-atom protein graph (19 x T4 lysozyme), eval mode
         try:
             from grappa_amd.datasets import protein_graph_t4

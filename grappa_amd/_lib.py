@@ -72,6 +72,8 @@ SIGNATURES = {
     "grappa_abi_version": (_i, []),
     "grappa_build_arch": (C.c_char_p, []),
     "grappa_launch_count": (C.c_longlong, [_i]),
+    "grappa_set_dropout_salt": (None, [_vp]),
+    "grappa_adam_step_dyn_f32": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _f, _vp, _f]),
     "grappa_split_planes_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _sz, _i]),
     "grappa_split_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i]),
     "grappa_split_pairs_f32_batched": (_i, [_vp, _i, _i, _vp]),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "grappa_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz]),
     "grappa_act_dropout_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i]),
     "grappa_act_dropout_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp]),
+    "grappa_act_dropout_bwd_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp, _vp, _i]),
     "grappa_add_f32": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "grappa_layernorm_fwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "grappa_layernorm_fwd_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),

@@ -141,6 +141,10 @@ class HipBackend:
         # inference (no gradient asked for): LayerNorm and the tuple attention write the A operand of the product behind them in the pair
         # format and the product reads operands split once (csrc/gemm_pairs.hip) -- same bits as the fp32-operand product of the same K cuts
         self.inference_pairs = os.environ.get("GRAPPA_INFERENCE_PAIRS", "1") not in ("0", "")
+        # training (round 4): the same producers write pairs ONLY, the dropout backward too, and the weight-gradient products read pairs
+        # (C ABI 8: token rows moved onto the tensor's scale inside the kernel) -- no fp32 copy of a normalised activation exists any more
+        self.training_pairs = os.environ.get("GRAPPA_TRAINING_PAIRS", "1") not in ("0", "")
+        self.pairs_min_rows = int(os.environ.get("GRAPPA_PAIRS_MIN_ROWS", "12288"))
         self._tails = None             # what set_tail_launches last told the library (None: the library's default)
         self._tails_pinned = False
         if os.environ.get("GRAPPA_PLAN_TAILS", "") != "":
@@ -150,6 +154,8 @@ class HipBackend:
         self._aside = []               # (side stream, items kept alive) since the last flush
         self.weight_planes = os.environ.get("GRAPPA_WEIGHT_PLANES", "0") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
+        self._wpairs = {}      # (data_ptr, rows, cols, "pairs" | "pairsT") -> [version key, pairs, weakref of the weight, epoch of last use, transposed, maxima record]
+        self._wptable = None   # (device table of grappa_split_pairs_item, count, tiles, records kept alive)
         self._wepoch = 0
         # precision "f32_f16x3": largest |element| per row / column of every operand (grappa_amax_f32).  Weights: cached until the
         # optimiser step; activations: an `Amax` record travels with the tensor through ops.py (gemm returns it, the backward
@@ -210,29 +216,85 @@ class HipBackend:
         self._wplanes[key] = (ver, planes, weakref.ref(w))
         return planes
 
-    def _pairs_of_weight(self, w: torch.Tensor) -> torch.Tensor:
-        """W (rows x cols) in the pair format, rows scaled by their own maxima (the forward orientation: out features x in features);
-        cached per weight like the planes"""
+    def _pairs_of_weight(self, w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+        """W (out features x in features) in the pair format, rows scaled by their own maxima -- the B operand of the forward products -- or
+        (transposed) W^T, rows = in features scaled by W's column maxima: the B operand of the input-gradient products.  Cached per weight
+        and orientation; after an optimiser step the first stale entry refreshes EVERY registered one in one launch
+        (grappa_split_pairs_f32_batched), like the weights' maxima."""
         R, Cc = w.shape
-        key = (w.data_ptr(), R, Cc, "pairs")
+        key = (w.data_ptr(), R, Cc, "pairsT" if transposed else "pairs")
         ver = (w._version, self._wepoch)
-        hit = self._wplanes.get(key)
+        hit = self._wpairs.get(key)
         if hit is not None and hit[2]() is not w:
             hit = None
-        if hit is not None and hit[0] == ver:
-            return hit[1]
-        pairs = hit[1] if hit is not None else torch.zeros((R, 2 * ((Cc + 31) // 32 * 32)), dtype=torch.float16, device=w.device)
-        _chk(self.lib.grappa_split_pairs_f32(self._stream(), R, Cc, w.data_ptr(), _f32_2d(w, "W", w.device), self._amax_of_weight(w).row.data_ptr(),
-                                             pairs.data_ptr(), pairs.stride(0), 0), "grappa_split_pairs_f32")
-        self._wplanes[key] = (ver, pairs, weakref.ref(w))
+        if hit is not None:
+            hit[3] = self._wepoch
+            if hit[0] == ver:
+                return hit[1]
+            self._refresh_weight_pairs()
+            if hit[0] == ver:
+                return hit[1]
+        am = self._amax_of_weight(w)
+        rows, cols = (Cc, R) if transposed else (R, Cc)
+        pairs = torch.zeros((rows, 2 * ((cols + 31) // 32 * 32)), dtype=torch.float16, device=w.device)
+        _chk(self.lib.grappa_split_pairs_f32(self._stream(), R, Cc, w.data_ptr(), _f32_2d(w, "W", w.device), (am.col if transposed else am.row).data_ptr(),
+                                             pairs.data_ptr(), pairs.stride(0), int(transposed)), "grappa_split_pairs_f32")
+        for k in [k for k, e in self._wpairs.items() if e[2]() is None]:      # entries of weights that no longer exist
+            del self._wpairs[k]
+        self._wpairs[key] = [ver, pairs, weakref.ref(w), self._wepoch, transposed, am]
+        self._wptable = None
         return pairs
 
-    def pairs_ok(self, x: torch.Tensor, width: int) -> bool:
+    def _refresh_weight_pairs(self) -> None:
+        import numpy as np
+        for k in [k for k, e in self._wpairs.items() if e[2]() is None or e[3] < self._wepoch - 1]:      # dead, or unused since the step before last
+            del self._wpairs[k]
+            self._wptable = None
+        live = [e for e in self._wpairs.values()]
+        if not live:
+            return
+        for e in live:                                  # the maxima first (one batched launch of their own when stale)
+            e[5] = self._amax_of_weight(e[2]())
+        if self._wptable is None:
+            dt = np.dtype([("x", "<u8"), ("amax", "<u8"), ("pairs", "<u8"), ("R", "<i4"), ("C", "<i4"), ("ldx", "<i4"), ("ldp", "<i4"),
+                           ("transpose", "<i4"), ("tile_begin", "<i4")])
+            tab = np.zeros(len(live), dtype=dt)
+            tiles = 0
+            for i, e in enumerate(live):
+                w, am = e[2](), e[5]
+                tab[i] = (w.data_ptr(), (am.col if e[4] else am.row).data_ptr(), e[1].data_ptr(), w.shape[0], w.shape[1], w.stride(0), e[1].stride(0),
+                          int(e[4]), tiles)
+                tiles += ((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32)
+            self._wptable = (torch.from_numpy(tab.view(np.uint8).copy()).to(live[0][1].device), len(live), tiles, [e[5] for e in live])
+        tab, n, tiles, _keep = self._wptable
+        _chk(self.lib.grappa_split_pairs_f32_batched(self._stream(), n, tiles, tab.data_ptr()), "grappa_split_pairs_f32_batched")
+        for e in live:
+            e[0] = (e[2]()._version, self._wepoch)
+
+    def to_pairs(self, x: torch.Tensor, have: "Optional[Amax]" = None) -> "Amax":
+        """an fp32 (rows, cols) tensor in the pair format by a pass of its own (producers that hold whole rows write it themselves:
+        layernorm_fwd(pairs=True), seqattn_fwd(pairs=True), act_dropout_bwd(pairs=True)): -> record with .row and .pairs"""
+        R, Cc = x.shape
+        am = self.amax(x, have, rows=True)
+        pr = torch.zeros((R, 2 * ((Cc + 31) // 32 * 32)), dtype=torch.float16, device=x.device)
+        _chk(self.lib.grappa_split_pairs_f32(self._stream(), R, Cc, x.data_ptr(), _f32_2d(x, "x", x.device), am.row.data_ptr(), pr.data_ptr(),
+                                             pr.stride(0), 0), "grappa_split_pairs_f32")
+        return Amax(row=am.row, pairs=pr)
+
+    def pairs_ok(self, x: torch.Tensor, width: int, training: bool = False) -> bool:
         """can a producer of `x` (rows of `width` columns) hand the following forward product its operand in the pair format?"""
+        if training:
+            return x.dtype == torch.float32 and self.training_pairs_ok(x.shape[0], width)
         return (self.inference_pairs and x.dtype == torch.float32 and x.shape[0] > 32 and width % 32 == 0 and self.gemm_precision_name == "f32_f16x3")
 
+    def training_pairs_ok(self, rows: int, width: int) -> bool:
+        """training with the pair format as the storage format of the products' operands: rows of this shape as pairs ONLY?  Tables with
+        fewer rows than `pairs_min_rows` stay fp32 (the GNN's 8,233 atom rows at C2: the two-workgroup pair kernel gains nothing there)"""
+        return (self.training_pairs and rows >= self.pairs_min_rows and rows > 32 and width % 32 == 0 and 32 < width <= 2048 and
+                self.gemm_precision_name == "f32_f16x3" and self.gemm_precision_bwd is None and not self.wgrad_column_maxima and self.defer_wgrads)
+
     # ------------------------------------------------------------------ row / column maxima (scales of the fp16-split products)
-    def _amax_launch(self, t: torch.Tensor, rows: bool, cols: bool):
+    def _amax_launch(self, t: torch.Tensor, rows: bool, cols: bool, row_out=None, col_out=None):
         R, Cc = t.shape
         if _AMAX_LOG is not None:                  # tools: which tensors still need a pass of their own
             import traceback
@@ -240,8 +302,8 @@ class HipBackend:
             _AMAX_LOG.append((R, Cc, rows, cols, fr[-1].lineno if fr else 0))
         dev = t.device
         ld = _f32_2d(t, "amax operand", dev)
-        row = torch.empty(R, dtype=torch.int32, device=dev) if rows else None
-        col = torch.empty(Cc, dtype=torch.int32, device=dev) if cols else None
+        row = (row_out if row_out is not None else torch.empty(R, dtype=torch.int32, device=dev)) if rows else None
+        col = (col_out if col_out is not None else torch.empty(Cc, dtype=torch.int32, device=dev)) if cols else None
         need = self.lib.grappa_amax_f32_workspace_bytes(R, Cc) if cols else 0
         ws = self._workspace_amax(need, dev) if need else None
         self._timed("amax", 0.0, 4.0 * R * Cc,
@@ -310,7 +372,14 @@ class HipBackend:
                 self._refresh_weight_amax()
                 if hit[0] == ver:
                     return hit[2]
-        am = self.amax(w, None, rows=True, cols=True)      # a new weight, or one the batched kernel cannot take: a pass of its own
+            elif hit[1] is w:
+                # a weight the batched kernel cannot take (odd width): a pass of its own INTO the arrays it already has -- the same
+                # addresses every step (a recorded hipGraph holds them) and no change to the batched kernel's table
+                self._amax_launch(w, True, True, hit[2].row, hit[2].col)
+                hit[2].tmax = None
+                hit[0] = ver
+                return hit[2]
+        am = self.amax(w, None, rows=True, cols=True)      # a new weight: a pass of its own
         batchable = Cc % 4 == 0 and Cc <= 2048 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0 and w.stride(1) == 1
         self._wamax[key] = [ver, w, am, self._wepoch, batchable]
         self._wtable = None
@@ -425,7 +494,7 @@ class HipBackend:
         br, bc = (N, K) if b_kcontig else (K, N)
         # A in the pair format (its producer wrote it: a_scales.pairs): forward layout, default arithmetic; `a` itself may then be None
         a_pairs = getattr(a_scales, "pairs", None) if a_scales is not None else None
-        if a_pairs is not None and not (a_kcontig and b_kcontig and M > 32 and N > 32 and K % 32 == 0 and precision is None
+        if a_pairs is not None and not (a_kcontig and M > 32 and N > 32 and K % 32 == 0 and precision is None and self.gemm_precision_bwd is None
                                         and self.gemm_precision_name == "f32_f16x3" and b.dtype == torch.float32 and a_colsum is None
                                         and tuple(a_pairs.shape) == (M, 2 * K)):
             if a is None:
@@ -473,11 +542,13 @@ class HipBackend:
             else:
                 a, b = self.to_f32(a), self.to_f32(b)
         if a_pairs is not None:
-            w_pairs = self._pairs_of_weight(b)
+            # forward: B = the pairs of W (rows = out features); input gradient (b_kcontig False): B = the pairs of W^T (rows = in features)
+            w_pairs = self._pairs_of_weight(b, transposed=not b_kcontig)
+            wm = self._amax_of_weight(b)
             d.A, d.lda, d.a_planes = a_pairs.data_ptr(), a_pairs.stride(0), 1
             d.B, d.ldb, d.b_planes = w_pairs.data_ptr(), w_pairs.stride(0), 1
             d.a_kcontig, d.b_kcontig = 1, 1
-            d.a_amax, d.b_amax = a_scales.row.data_ptr(), self._amax_of_weight(b).row.data_ptr()
+            d.a_amax, d.b_amax = a_scales.row.data_ptr(), (wm.row if b_kcontig else wm.col).data_ptr()
         elif planes_a is not None:
             d.A, d.lda, d.a_planes, d.a_plane_stride = planes_a.data_ptr(), planes_a.stride(0), 1, 0
             _f32_2d(planes_a, "A", dev, bf16)
@@ -618,18 +689,33 @@ class HipBackend:
         """dW += dz^T x (dz (tokens, N'), x (tokens, K'), dW (N', K')), db += column sums of dz.  fp32 products with enough rows and
         columns are queued and launched as ONE grouped grid when 16 are waiting or the backward pass ends (autograd's end-of-pass
         callback; `flush_wgrads()` is also called by the gradient reducer and the optimiser): results are those of `gemm` up to the
-        summation order of the K chunks.  Returns the `Amax` record of dz (precision "f32_f16x3") for the input-gradient product."""
-        Np, Kp, T = dz.shape[1], x.shape[1], dz.shape[0]
+        summation order of the K chunks.  Returns the `Amax` record of dz (precision "f32_f16x3") for the input-gradient product.
+        An operand whose record carries `.pairs` (its producer wrote it in the pair format, every token row under its own scale) is read
+        from there (C ABI 8) and its fp32 tensor may be None."""
+        pz, px = getattr(dz_scales, "pairs", None), getattr(x_scales, "pairs", None)
+        Np, Kp = dw.shape
+        T = (dz if dz is not None else pz).shape[0]
         prec = self.gemm_precision if self.gemm_precision_bwd is None else self.gemm_precision_bwd
-        ok = (self.defer_wgrads and dz.dtype == torch.float32 and x.dtype == torch.float32 and Np > 32 and Kp > 32 and T > 0
-              and prec != _lib.GEMM_PRECISIONS["f32"])
+        f32ok = lambda t: t is None or t.dtype == torch.float32      # noqa: E731
+        ok = (self.defer_wgrads and f32ok(dz) and f32ok(x) and Np > 32 and Kp > 32 and T > 0 and prec != _lib.GEMM_PRECISIONS["f32"])
+        pairs_ok = ok and prec == _lib.GEMM_PRECISIONS["f32_f16x3"] and not self.wgrad_column_maxima
+        if pz is not None and not (pairs_ok and Np % 32 == 0 and tuple(pz.shape) == (T, 2 * Np)):
+            pz = None
+        if px is not None and not (pairs_ok and Kp % 32 == 0 and tuple(px.shape) == (T, 2 * Kp)):
+            px = None
+        if (dz is None and pz is None) or (x is None and px is None):
+            raise ValueError("gemm_wgrad: an operand was given in the pair format only, which this product cannot read")
         if not ok:
             return self.gemm(dz, x, dw, M=Np, N=Kp, K=T, a_kcontig=False, b_kcontig=False, accumulate=True, a_colsum=db,
                              a_scales=dz_scales, b_scales=x_scales)
         dev = dw.device
-        if tuple(dw.shape) != (Np, Kp) or x.shape[0] != T or (db is not None and db.numel() != Np):
+        if (dz is not None and tuple(dz.shape) != (T, Np)) or (x is not None and tuple(x.shape) != (T, Kp)) or (db is not None and db.numel() != Np):
             raise ValueError("gemm_wgrad: shapes")
-        _f32_2d(dz, "dz", dev), _f32_2d(x, "x", dev), _f32_2d(dw, "dW", dev)
+        _f32_2d(dw, "dW", dev)
+        if pz is None:
+            _f32_2d(dz, "dz", dev)
+        if px is None:
+            _f32_2d(x, "x", dev)
         if db is not None:
             _flat(db, "db", dev)
         sdz = am = None
@@ -639,23 +725,27 @@ class HipBackend:
                 sdz = self.amax(dz, dz_scales, rows=True, cols=True)
                 am = (sdz, self.amax(x, x_scales, cols=True))
             else:
-                sdz = self.amax(dz, dz_scales, rows=True)
-                am = (sdz, self.amax(x, x_scales, rows=True))
+                sdz = dz_scales if pz is not None else self.amax(dz, dz_scales, rows=True)
+                am = (sdz, x_scales if px is not None else self.amax(x, x_scales, rows=True))
         task = self._queue_flush()                # the backward pass (autograd graph task) this product belongs to; -1 outside of one
         # one queue per backward pass and HIP stream (the writer heads run their backward passes on streams of their own): a full queue is
         # launched on the stream that filled it, what is left when the pass ends is launched together by flush_wgrads
         st = torch.cuda.current_stream()
         q = self._wq.setdefault((task, st.cuda_stream), (st, []))[1]
-        q.append((dz, x, dw, db, am))
+        q.append((dz if pz is None else None, x if px is None else None, dw, db, am, pz, px))
         if task < 0:                              # not inside a backward pass: nothing will call back
             self.flush_wgrads(-1)
             return sdz
         # a queue is launched when it is full -- or when the operands it keeps alive exceed the byte budget (at C3 / C4 sizes
         # sixteen (dz, x) pairs are tens of GB)
-        if len(q) >= _lib.GEMM_GROUP_MAX or sum(it[0].numel() + it[1].numel() for it in q) * 4 > self.wgrad_queue_bytes:
+        if len(q) >= _lib.GEMM_GROUP_MAX or sum(self._item_bytes(it) for it in q) > self.wgrad_queue_bytes:
             del self._wq[(task, st.cuda_stream)]
             self._launch_wgrad_group(q)
         return sdz
+
+    @staticmethod
+    def _item_bytes(it) -> int:
+        return sum(t.numel() * t.element_size() for t in (it[0], it[1], it[5], it[6]) if t is not None)
 
     @property
     def _wq_task(self):
@@ -779,16 +869,16 @@ class HipBackend:
         self._join_aside()                        # the gradients launched beside the pass are complete for whatever follows on this stream
 
     def _launch_wgrad_group(self, items) -> None:
-        # one grid per load style: products whose operands allow 16-byte loads along their rows (aligned, leading dimension % 4 == 0
-        # and covering round_up(columns, 4)) run the faster kernel together; an odd one (513-wide tuple features) would drag its whole
-        # group onto the dword-load kernel
+        # one grid per load style and operand format: products whose operands allow 16-byte loads along their rows (aligned, leading
+        # dimension % 4 == 0 and covering round_up(columns, 4)) run the faster kernel together; an odd one (513-wide tuple features)
+        # would drag its whole group onto the dword-load kernel
         def vec(t):
-            return t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and (t.shape[1] + 3) // 4 * 4 <= t.stride(0)
-        fast = [it for it in items if vec(it[0]) and vec(it[1])]
-        slow = [it for it in items if not (vec(it[0]) and vec(it[1]))]
-        for part in (fast, slow):
-            if part:
-                self._launch_wgrad_items(part)
+            return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and (t.shape[1] + 3) // 4 * 4 <= t.stride(0))
+        groups = {}
+        for it in items:
+            groups.setdefault(vec(it[0]) and vec(it[1]), []).append(it)        # (operand formats may mix inside a launch: C ABI 8)
+        for part in groups.values():
+            self._launch_wgrad_items(part)
 
     def _launch_wgrad_items(self, items) -> None:
         n = len(items)
@@ -798,11 +888,18 @@ class HipBackend:
         flops = nbytes = 0.0
         if not self.wgrad_column_maxima:
             self._tmax_of([r for it in items if it[4] is not None for r in it[4]], dev)
-        for d, (dz, x, dw, db, am) in zip(arr, items):
-            d.M, d.N, d.K = dz.shape[1], x.shape[1], dz.shape[0]
+        for d, (dz, x, dw, db, am, pz, px) in zip(arr, items):
+            d.M, d.N = dw.shape
+            d.K = (dz if dz is not None else pz).shape[0]
             d.a_kcontig, d.b_kcontig = 0, 0
-            d.A, d.lda = dz.data_ptr(), dz.stride(0)
-            d.B, d.ldb = x.data_ptr(), x.stride(0)
+            if pz is not None:
+                d.A, d.lda, d.a_planes, d.a_rowmax = pz.data_ptr(), pz.stride(0), 1, am[0].row.data_ptr()
+            else:
+                d.A, d.lda = dz.data_ptr(), dz.stride(0)
+            if px is not None:
+                d.B, d.ldb, d.b_planes, d.b_rowmax = px.data_ptr(), px.stride(0), 1, am[1].row.data_ptr()
+            else:
+                d.B, d.ldb = x.data_ptr(), x.stride(0)
             d.C, d.ldc = dw.data_ptr(), dw.stride(0)
             d.a_colsum = None if db is None else db.data_ptr()
             d.accumulate, d.precision = 1, prec
@@ -830,10 +927,23 @@ class HipBackend:
         _chk(self.lib.grappa_colsum_f32(self._stream(), M, N, x.data_ptr(), ldx, out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()),
              "grappa_colsum_f32")
 
-    def act_dropout_bwd(self, dy, y, drop_p, drop_seed, dz, amax=None):
-        """-> the `Amax` record (row maxima) of dz when the backward products run on fp16 pieces (amax=False: never), else None"""
-        dev = dz.device
+    def act_dropout_bwd(self, dy, y, drop_p, drop_seed, dz, amax=None, pairs=False):
+        """-> the `Amax` record (row maxima) of dz when the backward products run on fp16 pieces (amax=False: never), else None.
+        pairs=True (fp32, N % 32 == 0): the rows are written in the pair format (record's .pairs); dz may then be None"""
+        dev = dy.device
         M, N = dy.shape
+        if pairs:
+            if dy.dtype != torch.float32 or N % 32 or N > 2048 or (dz is not None and (dz.dtype != torch.float32 or tuple(dz.shape) != (M, N))) or \
+                    (y is not None and (y.dtype != torch.float32 or tuple(y.shape) != (M, N))):
+                raise ValueError("act_dropout_bwd: the pair format needs float32 rows of N % 32 == 0 (<= 2048) columns")
+            row = torch.empty(M, dtype=torch.int32, device=dev)
+            pr = torch.empty((M, 2 * N), dtype=torch.float16, device=dev)
+            if M:
+                _chk(self.lib.grappa_act_dropout_bwd_pairs_f32(self._stream(), M, N, dy.data_ptr(), _f32_2d(dy, "dy", dev), _ptr(y),
+                                                               _f32_2d(y, "y", dev) if y is not None else 0, float(drop_p), int(drop_seed) & (2 ** 64 - 1),
+                                                               _ptr(dz), _f32_2d(dz, "dz", dev) if dz is not None else 0, row.data_ptr(), pr.data_ptr(),
+                                                               pr.stride(0)), "grappa_act_dropout_bwd_pairs_f32")
+            return Amax(row=row, pairs=pr)
         if tuple(dz.shape) != (M, N) or (y is not None and tuple(y.shape) != (M, N)):
             raise ValueError("act_dropout_bwd: shapes")
         dt = _same_dtype(dy, y, dz)
@@ -1250,6 +1360,26 @@ class HipBackend:
         ws = self._workspace(self.lib.grappa_sumsq_workspace_bytes(x.numel()), dev)
         _chk(self.lib.grappa_sumsq_f32(self._stream(), x.numel(), x.data_ptr(), out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel()),
              "grappa_sumsq_f32")
+
+    def adam_step_dyn(self, p, g, m, v, lr_t, beta1, beta2, eps, weight_decay, step_t, grad_scale, sumsq, max_norm) -> None:
+        """adam_step with the learning rate (float32 tensor of one element) and the step count (int32) read from device memory"""
+        dev = p.device
+        for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+            _flat(t, n, dev)
+        _flat(lr_t, "lr", dev), _flat(step_t, "step", dev, torch.int32)
+        _chk(self.lib.grappa_adam_step_dyn_f32(self._stream(), p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr_t.data_ptr(),
+                                               float(beta1), float(beta2), float(eps), float(weight_decay), step_t.data_ptr(), float(grad_scale),
+                                               _ptr(sumsq), float(max_norm)), "grappa_adam_step_dyn_f32")
+
+    # ---- dropout salt (include/grappa_hip.h grappa_set_dropout_salt): one 64-bit word of device memory mixed into every dropout seed
+    def enable_dropout_salt(self) -> None:
+        if getattr(self, "_salt", None) is None:
+            self._salt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            self.lib.grappa_set_dropout_salt(self._salt.data_ptr())
+
+    def bump_dropout_salt(self) -> None:
+        """+1 on the device word (a kernel on the current stream: inside a capture it becomes a node of the graph)"""
+        self._salt.add_(1)
 
     def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale, sumsq, max_norm) -> None:
         dev = p.device

@@ -1,0 +1,212 @@
+"""hipGraph capture of the hot path for batches of a FIXED shape.
+
+The eager path issues ~450 kernel launches per forward pass and ~1,000 per train step from Python; at the reference's own operating
+point (batch 32, single-molecule `predict`; reference training/config.py:49-52, grappa.py:36-57) the step is bound by that host work,
+not by the GPU.  A captured step is ONE `hipGraphLaunch`: the kernels, their arguments, the cross-stream dependencies of the writer
+heads and the grouped weight gradients are recorded once (torch.cuda.CUDAGraph drives hipStreamBeginCapture; the library's kernels are
+launched on torch's capturing stream through the C ABI as always) and replayed.
+
+What makes a TRAIN step replayable although every kernel argument is frozen at capture:
+  * dropout: every seed is a constant of the graph; the library mixes a 64-bit word of DEVICE memory into them
+    (`grappa_set_dropout_salt`), and the graph's first node increments that word -- fresh masks per replay, forward and backward of one
+    replay agreeing;
+  * Adam: learning rate and step count are read from device memory (`grappa_adam_step_dyn_f32`); the graph increments the step count,
+    the host writes the learning rate between replays (`FusedAdam.lr = ...`);
+  * weights change inside the graph, so the per-weight caches (row / column maxima, pair splits) are refreshed INSIDE it: they are
+    invalidated right before capture, which puts the batched refresh kernels at the head of the recorded step.
+
+Shapes are part of the graph: a captured step serves the batch it was captured on and any batch copied into the same device tensors
+(`StaticForward.load`).  Multi-GPU steps (the RCCL all-reduce) stay eager.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from .backend import get_backend
+
+
+def _pinned_by_graph(be):
+    """everything the backend allocated OUTSIDE the capture whose address the recorded kernels hold: per-weight maxima and pair splits, their
+    device tables, the workspaces, the dropout salt.  The graph object must keep them alive (the backend's caches may drop them)."""
+    return (list(be._wamax.values()), be._wtable, list(be._wpairs.values()), be._wptable, dict(be._wplanes), dict(be._ws), getattr(be, "_salt", None),
+            dict(be._side_streams))
+
+
+def _touch_weight_caches(be) -> None:
+    """the recorded graph uses every cached per-weight entry at every replay: keep them from ageing out of the backend's tables"""
+    for e in be._wamax.values():
+        e[3] = be._wepoch
+    for e in be._wpairs.values():
+        e[3] = be._wepoch
+
+
+def _drop_outputs(g) -> None:
+    for lvl in ("n2", "n3", "n4", "n4_improper"):
+        for k in ("k", "eq"):
+            g.nodes[lvl].data.pop(k, None)
+
+
+class CapturedTrainStep:
+    """zero_grad -> GrappaModel -> Energy -> MolwiseLoss -> backward -> clip + Adam on ONE resident batch, as a hipGraph.
+
+        step = CapturedTrainStep(model, energy, loss_fn, opt, g)     # warms up (3 eager steps: these DO train) and captures
+        loss = step()                                                # one replay = one optimiser step; loss: device tensor of the graph
+
+    `opt` (optim.FusedAdam) is switched to device-side scalars (`opt.enable_dynamic()`); `opt.lr = x` between replays takes effect."""
+
+    def __init__(self, model, energy, loss_fn, opt, g, warmup: int = 3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("CapturedTrainStep needs a GPU")
+        self.model, self.energy, self.loss_fn, self.opt, self.g = model, energy, loss_fn, opt, g
+        self.be = get_backend()
+        self.be.enable_dropout_salt()
+        opt.enable_dynamic()
+        self.stream = torch.cuda.Stream(device=g.device)
+        self.stream.wait_stream(torch.cuda.current_stream(g.device))
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(int(warmup), 1)):           # on the capturing stream: workspaces and side streams are keyed by it
+                self.be.bump_dropout_salt()
+                self._eager()
+        self.stream.synchronize()
+        # (the last warm-up step's optimiser left every per-weight cache stale: the recorded step starts by refreshing them, in the graph)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.be.bump_dropout_salt()
+            self.loss = self._eager()
+        self.opt.step_count -= 1                            # (recorded, not executed: the device-side count did not move)
+        self._pinned = _pinned_by_graph(self.be)
+        torch.cuda.current_stream(g.device).wait_stream(self.stream)
+        self.replays = 0
+
+    def _eager(self):
+        self.opt.zero_grad()
+        _drop_outputs(self.g)
+        loss = self.loss_fn(self.energy(self.model(self.g)))
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def __call__(self) -> torch.Tensor:
+        self.graph.replay()
+        self.replays += 1
+        self.opt.step_count += 1                            # host mirror of the device-side counter
+        self.be.invalidate_weights()                        # the weights moved under the host-side caches' feet
+        _touch_weight_caches(self.be)
+        return self.loss
+
+
+class CapturedForward:
+    """GrappaModel forward (eval, no_grad) on ONE resident graph as a hipGraph; `load(g)` copies another graph of the same shape signature
+    into the captured tensors.  Outputs (k / eq per level) are tensors of the graph: read them before the next replay."""
+
+    def __init__(self, model, g, warmup: int = 2):
+        self.model, self.g = model, g
+        self.be = get_backend()
+        self.plan = g.plan()
+        for lvl in ("n2", "n3", "n4", "n4_improper"):       # built eagerly: their construction sorts (host-synchronising torch ops)
+            if self.plan.T[lvl]:
+                self.plan.position_tables(lvl)
+        self.stream = torch.cuda.Stream(device=g.device)
+        self.stream.wait_stream(torch.cuda.current_stream(g.device))
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for _ in range(max(int(warmup), 1)):
+                _drop_outputs(g)
+                model(g)
+        self.stream.synchronize()
+        self.weights_stamp = self._stamp()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream), torch.no_grad():
+            _drop_outputs(g)
+            model(g)
+        self._pinned = _pinned_by_graph(self.be)
+        torch.cuda.current_stream(g.device).wait_stream(self.stream)
+        self.outputs: Dict[Tuple[str, str], torch.Tensor] = {(lvl, k): g.nodes[lvl].data[k] for lvl in ("n2", "n3", "n4", "n4_improper")
+                                                            for k in ("k", "eq") if k in g.nodes[lvl].data}
+
+    def _stamp(self):
+        return (self.be._wepoch, sum(p._version for p in self.model.parameters()))
+
+    def valid(self) -> bool:
+        """the per-weight caches (maxima, pair splits) were filled OUTSIDE the graph: a graph captured before the weights changed must not be replayed"""
+        return self._stamp() == self.weights_stamp
+
+    def replay(self):
+        self.graph.replay()
+        return self.g
+
+    # ---- another graph of the same shape signature into the captured tensors
+    @staticmethod
+    def signature(g) -> tuple:
+        """everything the recorded kernels' arguments and grids depend on: node counts, edge count, the input features' shapes"""
+        return (tuple(int(g.num_nodes(nt)) for nt in ("n1", "n2", "n3", "n4", "n4_improper", "g")), int(g.num_edges()),
+                tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in g._data["n1"].items() if torch.is_tensor(v) and k != "h")))
+
+    @staticmethod
+    def _plan_tensors(plan):
+        out = {}
+        for name, val in vars(plan).items():
+            if torch.is_tensor(val):
+                out[name] = val
+            elif isinstance(val, dict):
+                for k, v in val.items():
+                    if torch.is_tensor(v):
+                        out[f"{name}.{k}"] = v
+                    elif isinstance(v, tuple):
+                        for i, t in enumerate(v):
+                            if torch.is_tensor(t):
+                                out[f"{name}.{k}.{i}"] = t
+        return out
+
+    def load(self, g_host) -> None:
+        """g_host: a MolBatch on the CPU with this graph's signature.  Its input features and its index structures (plan, position
+        tables: built on the host) are copied into the captured device tensors; nothing is allocated on the device."""
+        plan = g_host.plan()
+        for lvl in self.plan.__dict__.get("_pos_tables", {}):
+            plan.position_tables(lvl)
+        src, dst = self._plan_tensors(plan), self._plan_tensors(self.plan)
+        if set(src) != set(dst):
+            raise ValueError("load: the graph's plan has other tables than the captured one")
+        for name, t in dst.items():
+            if t.shape != src[name].shape:
+                raise ValueError(f"load: {name} has shape {tuple(src[name].shape)}, the captured graph {tuple(t.shape)}")
+            t.copy_(src[name], non_blocking=True)
+        for k, t in self.g._data["n1"].items():
+            if torch.is_tensor(t) and k != "h" and k in g_host._data["n1"]:
+                t.copy_(g_host._data["n1"][k], non_blocking=True)
+
+
+class ForwardCache:
+    """captured forwards by shape signature (`Grappa.predict`): a signature is captured the SECOND time it is seen (a one-off molecule
+    never pays for a capture), at most `max_entries` graphs are kept (least recently used out)."""
+
+    def __init__(self, model, device, max_entries: int = 16):
+        self.model, self.device, self.max_entries = model, torch.device(device), int(max_entries)
+        self.seen: Dict[tuple, int] = {}
+        self.entries: "Dict[tuple, CapturedForward]" = {}
+
+    def __call__(self, g_host):
+        """-> the parametrised graph on the CPU (k / eq written into g_host's tuple levels), or None: run the eager path"""
+        sig = CapturedForward.signature(g_host)
+        ent = self.entries.get(sig)
+        if ent is not None and not ent.valid():
+            self.entries.clear()                             # the weights changed: every recorded graph reads stale per-weight caches
+            ent = None
+        if ent is None:
+            n = self.seen.get(sig, 0) + 1
+            self.seen[sig] = n
+            if n < 2:
+                return None
+            if len(self.entries) >= self.max_entries:
+                self.entries.pop(next(iter(self.entries)))
+            ent = CapturedForward(self.model, g_host.to(self.device))
+            self.entries[sig] = ent
+            ent.replay()                                     # (recording executes nothing: the outputs are filled by the first replay)
+        else:
+            self.entries[sig] = self.entries.pop(sig)        # most recently used last
+            ent.load(g_host)
+            ent.replay()
+        for (lvl, k), t in ent.outputs.items():
+            g_host.nodes[lvl].data[k] = t.to("cpu", non_blocking=False)
+        return g_host

@@ -390,11 +390,13 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     constexpr int NFIRST = NM >= 12 ? NM * 2 / 3 : NM / 2;
     const bool do_store = !TAIL || s + 1 < kr.nsteps;
     const bool do_load = !TAIL || s + AHEAD < kr.nsteps;
-    constexpr bool PA_ = (PSRC & 1) != 0, PB_ = (PSRC & 2) != 0;      // the operand is in the pair format (wgrad layout, KMV, H3 only)
+    // the operand is in the pair format (wgrad layout, KMV, H3 only): known at compile time (PSRC 0 .. 3) or per product (PSRC 4: one grouped
+    // launch over products of mixed formats -- a uniform branch per workgroup)
+    const bool pa_ = PSRC == 4 ? d.a_planes != 0 : (PSRC & 1) != 0, pb_ = PSRC == 4 ? d.b_planes != 0 : (PSRC & 2) != 0;
     if (do_load && !(GB_KNOCK == 3 && !TAIL)) {
-        if constexpr (PA_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
+        if (pa_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
         else load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
-        if constexpr (PB_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
+        if (pb_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
         else load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -402,12 +404,12 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     mfma_range<MODE, TM, TN, 0, NFIRST>(fc, acc);
     if (do_store && !(GB_KNOCK == 4 && !TAIL)) {
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
-        if constexpr (PA_) store_quads_pairs<NT, BM, TAIL>(nxt, sa, krem, 141 - sha[0][0]);
+        if (pa_) store_quads_pairs<NT, BM, TAIL>(nxt, sa, krem, 141 - sha[0][0]);
         else store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF, AV>(nxt, sa, krem, sha);
-        if constexpr (PB_) store_quads_pairs<NT, BN, TAIL>(nxt + NP * PA, sb, krem, 141 - shb[0][0]);
+        if (pb_) store_quads_pairs<NT, BN, TAIL>(nxt + NP * PA, sb, krem, 141 - shb[0][0]);
         else store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF, BV>(nxt + NP * PA, sb, krem, shb);
         if (!AK && do_cs) {
-            if constexpr (PA_) quad_rowsum_pairs<NT, BM, TAIL>(sa, krem, cs);
+            if (pa_) quad_rowsum_pairs<NT, BM, TAIL>(sa, krem, cs);
             else quad_rowsum<NT, BM, AV, TAIL>(sa, krem, cs);
         }
     }
@@ -437,7 +439,7 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
 template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV, int PSRC = 0>
 __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, int wgid) {
     static_assert(PSRC == 0 || (MODE == H3 && KMV && !AK && !BKC), "pair-format sources: the wgrad layout of the fp16-split arithmetic only");
-    constexpr bool PA_ = (PSRC & 1) != 0, PB_ = (PSRC & 2) != 0;
+    const bool pa_ = PSRC == 4 ? p.d.a_planes != 0 : (PSRC & 1) != 0, pb_ = PSRC == 4 ? p.d.b_planes != 0 : (PSRC & 2) != 0;
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
     constexpr int NQA = BM * 4 / NT, NQB = BN * 4 / NT;
     constexpr bool AV = !AK && KMV, BV = !BKC && KMV;
@@ -494,17 +496,17 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
         Frags<NP, TM, TN> fr[2];                  // fragments of even / odd slabs
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
-            if constexpr (PA_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
+            if (pa_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
             else load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
-            if constexpr (PB_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
+            if (pb_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
             else load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
         }
-        if constexpr (PA_) store_quads_pairs<NT, BM, true>(smem, qa[0], kr.kend - kr.kbeg, 141 - sha[0][0]);
+        if (pa_) store_quads_pairs<NT, BM, true>(smem, qa[0], kr.kend - kr.kbeg, 141 - sha[0][0]);
         else store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF, AV>(smem, qa[0], kr.kend - kr.kbeg, sha);
-        if constexpr (PB_) store_quads_pairs<NT, BN, true>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, 141 - shb[0][0]);
+        if (pb_) store_quads_pairs<NT, BN, true>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, 141 - shb[0][0]);
         else store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF, BV>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, shb);
         if (!AK && do_cs) {
-            if constexpr (PA_) quad_rowsum_pairs<NT, BM, true>(qa[0], kr.kend - kr.kbeg, cs);
+            if (pa_) quad_rowsum_pairs<NT, BM, true>(qa[0], kr.kend - kr.kbeg, cs);
             else quad_rowsum<NT, BM, AV, true>(qa[0], kr.kend - kr.kbeg, cs);
         }
         __syncthreads();
@@ -674,6 +676,7 @@ int launch_grouped_wgrad(hipStream_t st, const GemmParams* d_ps, const int* d_wg
             if (psrc == 1) return launch_grouped_wgrad<MODE, true, 1>(st, d_ps, d_wg_begin, nprob, total_wgs);                             \
             if (psrc == 2) return launch_grouped_wgrad<MODE, true, 2>(st, d_ps, d_wg_begin, nprob, total_wgs);                             \
             if (psrc == 3) return launch_grouped_wgrad<MODE, true, 3>(st, d_ps, d_wg_begin, nprob, total_wgs);                             \
+            if (psrc == 4) return launch_grouped_wgrad<MODE, true, 4>(st, d_ps, d_wg_begin, nprob, total_wgs);                             \
         } else if (psrc != 0) {                                                                                                            \
             return GRAPPA_ERR_ARG;                                                                                                         \
         }                                                                                                                                  \

@@ -43,7 +43,9 @@ struct GemmParams {
     // slab; the last one to arrive sums the slabs in the fixed order s = 0, 1, ... (the same bits whichever workgroup that is) and
     // runs the epilogue.  nullptr: the host launches gemm_splitk_reduce_kernel instead (native fp32 and plane kernels)
     int* tickets;
+    const uint64_t* drop_salt;      // device word mixed into d.drop_seed (grappa_set_dropout_salt), or nullptr
 };
+__device__ inline uint64_t drop_seed_of(const GemmParams& p) { return grappa_salted(p.d.drop_seed, p.drop_salt); }
 
 // ---- plane format (include/grappa_hip.h): X = P0 + P1 + P2, three bf16 planes
 __device__ inline float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
@@ -109,7 +111,7 @@ __device__ inline float epilogue_store(const GemmParams& p, int m, int n, float 
         ldo = d.ldc2;
     }
     if (d.C1p) planes_store1(d.C1p, 0, (size_t)m * d.ldc1p + n, v, 1);
-    if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
+    if (d.drop_p > 0.0f) v = grappa_keep(drop_seed_of(p), (uint64_t)m * (uint64_t)d.N + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
     if (GRAPPA_EPI_RES_LN && d.res && d.res_ln_mean) v += grappa_ln_apply(d.res[(size_t)m * d.ldres + n], d.res_ln_mean[m], d.res_ln_rstd[m], d.res_ln_gamma[n], d.res_ln_beta[n]);
     else if (d.res) v += d.res[(size_t)m * d.ldres + n];
     else if (d.resp) v += planes_load1(d.resp, d.resp_plane_stride, (size_t)m * d.ldresp + n, d.resp_nplanes ? d.resp_nplanes : 3);
@@ -208,7 +210,7 @@ __device__ inline void tile_epilogue(const GemmParams& p, const f32x16 (&acc)[TM
                     *o = v;
                     o = c2_r + n;
                 }
-                if (d.drop_p > 0.0f) v = grappa_keep(d.drop_seed, drow + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
+                if (d.drop_p > 0.0f) v = grappa_keep(drop_seed_of(p), drow + (uint64_t)n, d.drop_p) ? v * p.drop_scale : 0.0f;
                 if (res_r) v += res_r[n];
                 if (d.accumulate) v += *o;
                 *o = v;
@@ -308,7 +310,7 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
                 if (d.drop_p > 0.0f) {
                     const uint64_t idx = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] = grappa_keep(d.drop_seed, idx + q, d.drop_p) ? x[q] * p.drop_scale : 0.0f;
+                    for (int q = 0; q < 4; ++q) x[q] = grappa_keep(drop_seed_of(p), idx + q, d.drop_p) ? x[q] * p.drop_scale : 0.0f;
                 }
                 x[0] += t[k].x; x[1] += t[k].y; x[2] += t[k].z; x[3] += t[k].w;
             }
@@ -395,7 +397,7 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, const f32x16 
                 if (d.drop_p > 0.0f) {
                     const uint64_t idx = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = grappa_keep(d.drop_seed, idx + q, d.drop_p) ? v[q] * p.drop_scale : 0.0f;
+                    for (int q = 0; q < 4; ++q) v[q] = grappa_keep(drop_seed_of(p), idx + q, d.drop_p) ? v[q] * p.drop_scale : 0.0f;
                 }
                 if (GRAPPA_EPI_RES_LN && d.res && d.res_ln_mean) {
                     const float4 t = *reinterpret_cast<const float4*>(d.res + (size_t)m * d.ldres + n);

@@ -606,9 +606,13 @@ extern "C" size_t grappa_gemm_f32_grouped_workspace_bytes(const grappa_gemm_desc
 extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* descs, int n, void* ws, size_t ws_bytes) {
     if (!descs || n <= 0 || n > GROUP_MAX) return GRAPPA_ERR_ARG;
     const int precision = descs[0].precision;
-    const int psrc = (descs[0].a_planes ? 1 : 0) | (descs[0].b_planes ? 2 : 0);      // one operand format per group (the caller groups by it)
-    for (int i = 0; i < n; ++i)
-        if (!group_desc_ok(descs[i], precision) || ((descs[i].a_planes ? 1 : 0) | (descs[i].b_planes ? 2 : 0)) != psrc) return GRAPPA_ERR_ARG;
+    // operand formats: all fp32 (psrc 0), one combination for the whole group (1 .. 3: the kernel specialised for it), or mixed (4: the
+    // kernel that reads every product's own flags -- one launch for a backward pass's products whatever their producers wrote)
+    int psrc = (descs[0].a_planes ? 1 : 0) | (descs[0].b_planes ? 2 : 0);
+    for (int i = 0; i < n; ++i) {
+        if (!group_desc_ok(descs[i], precision)) return GRAPPA_ERR_ARG;
+        if (((descs[i].a_planes ? 1 : 0) | (descs[i].b_planes ? 2 : 0)) != psrc) psrc = 4;
+    }
     const GroupPlan g = plan_group(descs, n);
     if (!ws || ws_bytes < g.total_bytes) return GRAPPA_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -650,6 +654,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
                 next_ticket += g.tiles[i];
             }
             p.drop_scale = d.drop_p > 0.0f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+            p.drop_salt = g_grappa_drop_salt;
             p.bm = 256;
             p.bn = 128;
             p.tiles_m = (d.M + 255) / 256;
@@ -732,6 +737,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool padB = d->b_kcontig || ((d->N + 3) & ~3) <= d->ldb;
     const bool vec = vecA && vecB && padA && padB;
     p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
+    p.drop_salt = g_grappa_drop_salt;
     auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
     p.vec_io = al16(d->C, d->ldc) && al16(d->C2, d->ldc2) && al16(d->pre, d->ldpre) && al16(d->res, d->ldres) && al16(d->aux, d->ldaux);
     if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_F32_F16X3) return GRAPPA_ERR_ARG;

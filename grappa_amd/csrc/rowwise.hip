@@ -321,8 +321,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const
 
 template <typename T>
 __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(int M, int N, const T* __restrict__ dy, int lddy,
-                                                              const T* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
+                                                              const T* __restrict__ y, int ldy, float p, float scale, uint64_t seed, const uint64_t* __restrict__ salt,
                                                               T* __restrict__ dz, int lddz) {
+    seed = grappa_salted(seed, salt);
     const size_t total = (size_t)M * N;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int m = (int)(i / N), n = (int)(i % N);
@@ -336,8 +337,9 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(int M, int N, cons
 // the same with 16-byte accesses: N, the leading dimensions and the base addresses are multiples of 4 floats (host-checked)
 template <typename T>
 __global__ __launch_bounds__(256) void act_dropout_bwd_vec_kernel(int M, int N, const T* __restrict__ dy, int lddy,
-                                                                  const T* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
+                                                                  const T* __restrict__ y, int ldy, float p, float scale, uint64_t seed, const uint64_t* __restrict__ salt,
                                                                   T* __restrict__ dz, int lddz) {
+    seed = grappa_salted(seed, salt);
     const int n4 = N >> 2;
     const size_t total = (size_t)M * n4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -363,8 +365,9 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_vec_kernel(int M, int N, 
 // of the F32_F16X3 products that read dz).  N <= 256 * NCH, 16-byte accesses.
 template <int NCH>
 __global__ __launch_bounds__(256) void act_dropout_bwd_rows_kernel(int M, int N, const float* __restrict__ dy, int lddy,
-                                                                   const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed,
+                                                                   const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed, const uint64_t* __restrict__ salt,
                                                                    float* __restrict__ dz, int lddz, unsigned* __restrict__ dz_amax) {
+    seed = grappa_salted(seed, salt);
     const int lane = threadIdx.x & 63;
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -397,6 +400,56 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_rows_kernel(int M, int N,
     }
 }
 
+// the same rows written in the PAIR format (dz itself optional): the A operand of the input-gradient product and an operand of the
+// weight-gradient product behind it, split once by the kernel that holds the whole row
+template <int NCH>
+__global__ __launch_bounds__(256) void act_dropout_bwd_pairs_kernel(int M, int N, const float* __restrict__ dy, int lddy,
+                                                                    const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed, const uint64_t* __restrict__ salt,
+                                                                    float* __restrict__ dz, int lddz, unsigned* __restrict__ dz_amax,
+                                                                    uint16_t* __restrict__ pairs, int ldp) {
+    seed = grappa_salted(seed, salt);
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nvec = N >> 2;
+    for (int row = wave_global; row < M; row += nwaves) {
+        unsigned am = 0u;
+        float4 keep[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nvec) {
+                v = ld4(dy + (size_t)row * lddy, c);
+                if (p > 0.f) {
+                    const uint64_t idx = (uint64_t)row * (uint64_t)N + (uint64_t)(c << 2);
+                    v.x = grappa_keep(seed, idx, p) ? v.x * scale : 0.f;
+                    v.y = grappa_keep(seed, idx + 1, p) ? v.y * scale : 0.f;
+                    v.z = grappa_keep(seed, idx + 2, p) ? v.z * scale : 0.f;
+                    v.w = grappa_keep(seed, idx + 3, p) ? v.w * scale : 0.f;
+                }
+                if (y) {
+                    const float4 t = ld4(y + (size_t)row * ldy, c);
+                    v.x *= grappa_elu_grad_from_out(t.x); v.y *= grappa_elu_grad_from_out(t.y);
+                    v.z *= grappa_elu_grad_from_out(t.z); v.w *= grappa_elu_grad_from_out(t.w);
+                }
+                if (dz) st4(dz + (size_t)row * lddz, c, v);
+                am = max(am, mag4(v));
+            }
+            keep[i] = v;
+        }
+        am = wave_umax(am);
+        const int shift = grappa_amax_shift(am);
+        uint16_t* pr = pairs + (size_t)row * ldp;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            st_pairs4_paired(pr, c, keep[i], shift, c < nvec);      // (N % 32 == 0: a lane and its partner are in range together)
+        }
+        if (lane == 0) dz_amax[row] = am;
+    }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(size_t n, const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i] + z[i];
 }
@@ -421,6 +474,33 @@ __global__ void sumsq_final_kernel(int nblocks, const float* __restrict__ part, 
 __global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
                                                    float bc1, float bc2, float grad_scale, const float* __restrict__ sumsq, float max_norm) {
+    float clip = 1.0f;
+    if (sumsq) {
+        const float norm = sqrtf(sumsq[0]) * grad_scale;
+        clip = fminf(1.0f, max_norm / (norm + 1e-6f));
+    }
+    const float gs = grad_scale * clip;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i] * gs;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+// the same with the learning rate and the step count read from device memory: a captured (hipGraph) train step replays with the values
+// the host -- or a kernel of the graph itself -- wrote last
+__global__ __launch_bounds__(256) void adam_dyn_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd,
+                                                       const int* __restrict__ step_dev, float grad_scale, const float* __restrict__ sumsq, float max_norm) {
+    const float lr = lr_dev[0];
+    const int step = step_dev[0];
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
     float clip = 1.0f;
     if (sumsq) {
         const float norm = sqrtf(sumsq[0]) * grad_scale;
@@ -542,10 +622,10 @@ int act_dropout_bwd_impl(void* stream, int M, int N, const T* dy, int lddy, cons
                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & amask) == 0;
     if (vec)
         GRAPPA_LAUNCH(act_dropout_bwd_vec_kernel<T>, dim3(grid_for((size_t)M * (N >> 2))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
+                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, g_grappa_drop_salt, dz, lddz);
     else
         GRAPPA_LAUNCH(act_dropout_bwd_kernel<T>, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz);
+                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, g_grappa_drop_salt, dz, lddz);
     return grappa_launch_status();
 }
 
@@ -688,12 +768,31 @@ extern "C" int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int blocks = (M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4;
-#define GRAPPA_ADB(NCH) GRAPPA_LAUNCH((act_dropout_bwd_rows_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, dz, lddz, dz_amax)
+#define GRAPPA_ADB(NCH) GRAPPA_LAUNCH((act_dropout_bwd_rows_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, g_grappa_drop_salt, dz, lddz, dz_amax)
     if (N <= 256) GRAPPA_ADB(1);
     else if (N <= 512) GRAPPA_ADB(2);
     else if (N <= 1024) GRAPPA_ADB(4);
     else GRAPPA_ADB(8);
 #undef GRAPPA_ADB
+    return grappa_launch_status();
+}
+extern "C" int grappa_act_dropout_bwd_pairs_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy, float drop_p,
+                                                uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, uint16_t* pairs, int ldp) {
+    if (M < 0 || N <= 0 || (N & 31) || N > 2048 || drop_p < 0.f || drop_p >= 1.f || (lddy & 3) || (dz && (lddz & 3)) || (y && (ldy & 3)) || ldp < 2 * N || (ldp & 7))
+        return GRAPPA_ERR_ARG;
+    if (M == 0) return GRAPPA_OK;
+    if (!dy || !dz_amax || !pairs) return GRAPPA_ERR_ARG;
+    if (((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(pairs)) & 15) != 0)
+        return GRAPPA_ERR_ARG;
+    const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = (M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4;
+#define GRAPPA_ADBP(NCH) GRAPPA_LAUNCH((act_dropout_bwd_pairs_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, g_grappa_drop_salt, dz, lddz, dz_amax, pairs, ldp)
+    if (N <= 256) GRAPPA_ADBP(1);
+    else if (N <= 512) GRAPPA_ADBP(2);
+    else if (N <= 1024) GRAPPA_ADBP(4);
+    else GRAPPA_ADBP(8);
+#undef GRAPPA_ADBP
     return grappa_launch_status();
 }
 extern "C" int grappa_act_dropout_bwd_bf16(void* stream, int M, int N, const uint16_t* dy, int lddy, const uint16_t* y, int ldy,
@@ -732,6 +831,19 @@ extern "C" int grappa_adam_step_f32(void* stream, size_t n, float* p, const floa
                        beta2, eps, weight_decay, bc1, bc2, grad_scale, sumsq, max_norm);
     return grappa_launch_status();
 }
+
+extern "C" int grappa_adam_step_dyn_f32(void* stream, size_t n, float* p, const float* g, float* m, float* v, const float* lr_dev, float beta1,
+                                        float beta2, float eps, float weight_decay, const int* step_dev, float grad_scale, const float* sumsq, float max_norm) {
+    if (n == 0) return GRAPPA_OK;
+    if (!p || !g || !m || !v || !lr_dev || !step_dev) return GRAPPA_ERR_ARG;
+    GRAPPA_LAUNCH(adam_dyn_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, m, v, lr_dev, beta1, beta2, eps,
+                  weight_decay, step_dev, grad_scale, sumsq, max_norm);
+    return grappa_launch_status();
+}
+
+// dropout salt (include/grappa_hip.h): one 64-bit word in device memory mixed into every dropout seed of the kernels launched afterwards
+const uint64_t* g_grappa_drop_salt = nullptr;
+extern "C" void grappa_set_dropout_salt(const uint64_t* device_word) { g_grappa_drop_salt = device_word; }
 
 extern "C" int grappa_charge_encoding_f32(void* stream, int N, const float* q, int dim, float lo, float hi, float* out, int ldo, int col0) {
     if (N < 0 || dim <= 0 || (dim & 1) || hi <= lo) return GRAPPA_ERR_ARG;

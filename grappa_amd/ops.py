@@ -126,8 +126,8 @@ def _linear_bwd_params(be, dz, x, w, b, xs=None, zs=None):
     """dW += dz^T x ; db += colsum(dz).  xs / zs: the backend's records of the largest magnitudes of x (what the forward product
     returned) and of dz (what the kernel that produced dz returned), or None; returns the record for dz, to be handed to the
     input-gradient product that follows."""
-    M, N = dz.shape
-    K = x.shape[1]
+    N, K = w.shape                                  # (dz / x may be None: the record carries the tensor in the pair format)
+    M = (dz if dz is not None else zs.pairs).shape[0]
     if M == 0:
         return zs
     want_b = b is not None and b.requires_grad
@@ -143,9 +143,18 @@ def _linear_bwd_params(be, dz, x, w, b, xs=None, zs=None):
     return zs
 
 
-def _pairs(be, x, infer) -> bool:
-    """inference on the HIP backend: may the producer of the rows `x` (or of rows of its shape) hand them on in the pair format?"""
-    return bool(infer) and hasattr(be, "pairs_ok") and x.dim() == 2 and be.pairs_ok(x, x.shape[1])
+def _pairs(be, x, lean) -> bool:
+    """HIP backend: may the producer of the rows `x` (or of rows of its shape) hand them on in the pair format?  lean: 1 = inference
+    (no gradient will be asked for), 2 = training with the pair format as the storage format of the products' operands (round 4:
+    LayerNorm, the tuple attention and the dropout backward write pairs ONLY; the weight-gradient products read them through C ABI 8)"""
+    return bool(lean) and hasattr(be, "pairs_ok") and x.dim() == 2 and be.pairs_ok(x, x.shape[1], training=lean == 2)
+
+
+def _bwd_pairs(be, M, width, *weights) -> bool:
+    """backward pass, training with pairs: may a row-wise producer of (M, width) gradient rows write them in the pair format only?  (Every
+    weight behind them must take a gradient: the bias gradient of a frozen weight would need the fp32 rows.)"""
+    f = getattr(be, "training_pairs_ok", None)
+    return f is not None and f(M, width) and all(w is None or w.requires_grad for w in weights)
 
 
 _INFERENCE = {"on": False}
@@ -158,9 +167,12 @@ def mark_mode() -> None:
     _INFERENCE["on"] = not torch.is_grad_enabled()
 
 
-def _infer(ctx) -> bool:
-    # (second condition: whatever the flag says, an input activation that asks for a gradient means a backward pass will come)
-    return _INFERENCE["on"] and not ctx.needs_input_grad[0]
+def _infer(ctx) -> int:
+    """-> 1: inference (no node will run backward); 2: training on a backend whose products read the pair format (HipBackend.training_pairs);
+    0: neither.  (Second condition of 1: whatever the flag says, an input activation that asks for a gradient means a backward pass will come.)"""
+    if _INFERENCE["on"] and not ctx.needs_input_grad[0]:
+        return 1
+    return 2 if getattr(get_backend(), "training_pairs", False) else 0
 
 
 def _ln_fwd(be, x, w, b, infer=False, need_y=True):
@@ -221,22 +233,36 @@ def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip, inf
 
 def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip, sdout=None):
     """-> (dx, record of dx's row maxima or None); sdout: the record for dout when the kernel that produced it wrote one"""
-    x, mean, rstd, xn, u, pre, sxn, su = saved
+    x, mean, rstd, xn, u, pre, sxn, su = saved          # (xn is None where the forward pass wrote the normalised rows as pairs only: sxn.pairs)
     M = x.shape[0]
     if not dout.is_contiguous():
         dout, sdout = dout.contiguous(), None
     if act2 or drop_p > 0:
-        dz2 = _new(dout.shape, dout)
-        sz = be.act_dropout_bwd(dout, pre if act2 else None, drop_p, seed, dz2)
+        if dout.dtype == F32 and _bwd_pairs(be, M, dout.shape[1], w2):
+            dz2, sz = None, be.act_dropout_bwd(dout, pre if act2 else None, drop_p, seed, None, pairs=True)      # pairs only: both products behind read them
+        else:
+            dz2 = _new(dout.shape, dout)
+            sz = be.act_dropout_bwd(dout, pre if act2 else None, drop_p, seed, dz2)
     else:
         dz2, sz = dout, sdout
     sz = _linear_bwd_params(be, dz2, u, w2, b2, su, sz)
-    dz1 = _new(u.shape, xn)                                        # (u is fp32 in front of a narrow output product, xn never)
-    _, sz = be.gemm(dz2, w2, dz1, M=M, N=u.shape[1], K=dz2.shape[1], b_kcontig=False, aux=u, a_scales=sz, out_amax=_wants_amax(be, True))   # fused ELU'(u)
+    dz1 = _new(u.shape, x)                                         # (u is fp32 in front of a narrow output product, x never)
+    _, sz = be.gemm(dz2, w2, dz1, M=M, N=u.shape[1], K=w2.shape[0], b_kcontig=False, aux=u, a_scales=sz, out_amax=_wants_amax(be, True))   # fused ELU'(u)
     sz = _linear_bwd_params(be, dz1, xn, w1, b1, sxn, sz)
-    dxn = _new(xn.shape, xn)
-    be.gemm(dz1, w1, dxn, M=M, N=xn.shape[1], K=u.shape[1], b_kcontig=False, res=dout if skip else None, a_scales=sz)
+    dxn = _new(x.shape, x)
+    be.gemm(dz1, w1, dxn, M=M, N=x.shape[1], K=u.shape[1], b_kcontig=False, res=dout if skip else None, a_scales=sz)
     return _ln_bwd(be, dxn, x, mean, rstd, norm_w, norm_b)
+
+
+def _drop_bwd(be, dy, drop_p, seed, w):
+    """dz = dropout mask of the forward pass applied to dy (no activation) -> (dz or None, record): in the pair format only where both
+    products behind it read pairs; dy itself without dropout"""
+    if drop_p <= 0:
+        return dy, None
+    if dy.dtype == F32 and _bwd_pairs(be, dy.shape[0], dy.shape[1], w):
+        return None, be.act_dropout_bwd(dy, None, drop_p, seed, None, pairs=True)
+    dz = _new(dy.shape, dy)
+    return dz, be.act_dropout_bwd(dy, None, drop_p, seed, dz)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -319,7 +345,9 @@ class AttBlockFn(Function):
         else:
             dh3, sz = _ff_bwd(be, ctx.ff_saved, dout, ln2_w, ln2_b, w1, b1, w2, b2, True, drop_p, seed2, True)
         ctx.ff_saved = None
-        if drop_p > 0:
+        if drop_p > 0 and dh3.dtype == F32 and _bwd_pairs(be, N, Fd, w_r):
+            dzr, sz = None, be.act_dropout_bwd(dh3, None, drop_p, seed1, None, pairs=True)
+        elif drop_p > 0:
             dzr = _new(dh3.shape, dh3)
             sz = be.act_dropout_bwd(dh3, None, drop_p, seed1, dzr)
         else:
@@ -331,7 +359,7 @@ class AttBlockFn(Function):
         dft = _new(ft.shape, ft)
         be.gat_bwd(plan, ft, m, alpha, dm, heads, ft.shape[1] // heads, dft)
         sz = _linear_bwd_params(be, dft, h1, w_fc, None, sh1)
-        dh1 = _new(h1.shape, h1)
+        dh1 = _new(h.shape, h)
         be.gemm(dft, w_fc, dh1, M=N, N=Fd, K=ft.shape[1], b_kcontig=False, res=dh3, a_scales=sz)        # + residual branch
         dh, _ = _ln_bwd(be, dh1, h, mean1, rstd1, ln_w, ln_b)
         _wgrads_aside(be)
@@ -437,7 +465,7 @@ def _attention(be, qkv, s, T, nheads, like, infer):
     M, Fd = qkv.shape[0], qkv.shape[1] // 3
     if not T:
         return _new((M, Fd), like), None
-    if infer and hasattr(be, "pairs_ok") and be.pairs_ok(qkv, Fd) and 32 < Fd <= 512 and M > 32:        # (the out-projection must be able to read pairs: M, N > 32)
+    if infer and hasattr(be, "pairs_ok") and be.pairs_ok(qkv, Fd, training=infer == 2) and 32 < Fd <= 512 and M > 32:        # (the out-projection must be able to read pairs: M, N > 32)
         return None, be.seqattn_fwd(qkv, s, T, nheads, None, pairs=True)
     att = _new((M, Fd), like)
     return att, be.seqattn_fwd(qkv, s, T, nheads, att)
@@ -517,19 +545,15 @@ class TransformerLayerFn(Function):
             return (torch.zeros_like(x),) + (None,) * 18
         dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
         ctx.ff_saved = None
-        if drop_p > 0:
-            dzo = _new(dx2.shape, dx2)
-            sz = be.act_dropout_bwd(dx2, None, drop_p, seed1, dzo)
-        else:
-            dzo = dx2
+        dzo, sz = _drop_bwd(be, dx2, drop_p, seed1, w_o)
         sx1, satt = ctx.scales
-        sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)
-        datt = _new(att.shape, att)
+        sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)           # (att is None where the attention wrote pairs only: satt.pairs)
+        datt = _new((M, Fd), x)
         be.gemm(dzo, w_o, datt, M=M, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)
         dqkv = _new(qkv.shape, qkv)
         sz = be.seqattn_bwd(qkv, datt, s, T, nheads, dqkv)
         sz = _linear_bwd_params(be, dqkv, x1, w_in, b_in, sx1, sz)
-        dx1 = _new(x1.shape, x1)
+        dx1 = _new(x.shape, x)
         be.gemm(dqkv, w_in, dx1, M=M, N=Fd, K=3 * Fd, b_kcontig=False, res=dx2, a_scales=sz)
         dx, _ = _ln_bwd(be, dx1, x, mean1, rstd1, n1_w, n1_b)
         return (dx,) + (None,) * 18
@@ -558,7 +582,8 @@ class ProjFirstLayerFn(Function):
         tab = _new((s * N, Fd), a)
         be.tuple_gather_fwd(a, idx_id, s, pe, tab)                 # tab[pos*N + n] = [a[n], pe[pos]]
         infer = _infer(ctx)
-        x1_tab, mean1, rstd1, sx1 = _ln_fwd(be, tab, n1_w, n1_b, infer)
+        # (training with pairs: the table's normalised rows are gathered to the tokens as the out-projection's residual, so they stay fp32)
+        x1_tab, mean1, rstd1, sx1 = _ln_fwd(be, tab, n1_w, n1_b, infer if infer == 1 else 0)
         qkv_tab = _new((s * N, 3 * Fd), tab)
         sx1 = be.gemm(x1_tab, w_in, qkv_tab, M=s * N, N=3 * Fd, K=Fd, bias=b_in, a_scales=sx1)
         M = s * T
@@ -586,17 +611,13 @@ class ProjFirstLayerFn(Function):
          w, b, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2) = ctx.saved_tensors
         s, T, N, Wp, has_pe, nheads, drop_p, seed1, seed2 = ctx.cfg
         sh, sx1, satt = ctx.scales
-        M, Fd = att.shape
+        M, Fd = qkv.shape[0], qkv.shape[1] // 3
         R = h.shape[1]
         dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
         ctx.ff_saved = None
-        if drop_p > 0:
-            dzo = _new(dx2.shape, dx2)
-            sz = be.act_dropout_bwd(dx2, None, drop_p, seed1, dzo)
-        else:
-            dzo = dx2
+        dzo, sz = _drop_bwd(be, dx2, drop_p, seed1, w_o)
         sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)
-        datt = _new(att.shape, att)
+        datt = _new((M, Fd), qkv)
         be.gemm(dzo, w_o, datt, M=M, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)
         dqkv = _new(qkv.shape, qkv)
         be.seqattn_bwd(qkv, datt, s, T, nheads, dqkv)                      # (its rows are summed into the table before any product reads them)

@@ -73,6 +73,7 @@ class FusedAdam:
     def __init__(self, flat: FlatParams, lr: float = 1.5e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  max_grad_norm: Optional[float] = 10.0):
         self.flat = flat
+        self._lr_t = self._step_t = None           # device-side learning rate / step count (enable_dynamic: captured steps)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.m = torch.zeros_like(flat.data)
         self.v = torch.zeros_like(flat.data)
@@ -81,6 +82,38 @@ class FusedAdam:
 
     def zero_grad(self):
         self.flat.zero_grad()
+
+    # ---- device-side scalars: a train step captured in a hipGraph (capture.CapturedTrainStep) freezes every kernel argument, so the
+    # learning rate and the step count of the bias corrections are read from device memory there (grappa_adam_step_dyn_f32)
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float) -> None:
+        self._lr = float(value)
+        if self._lr_t is not None:
+            self._lr_t.fill_(self._lr)
+
+    @property
+    def step_count(self) -> int:
+        return self._step_count
+
+    @step_count.setter
+    def step_count(self, value: int) -> None:
+        self._step_count = int(value)
+
+    def enable_dynamic(self) -> None:
+        if self._lr_t is None:
+            dev = self.flat.data.device
+            self._lr_t = torch.full((1,), self._lr, dtype=torch.float32, device=dev)
+            self._step_t = torch.full((1,), self._step_count, dtype=torch.int32, device=dev)
+
+    def sync_dynamic(self) -> None:
+        """host values -> device scalars (after reset_state / load_state_dict)"""
+        if self._lr_t is not None:
+            self._lr_t.fill_(self._lr)
+            self._step_t.fill_(self._step_count)
 
     def step(self, grad_scale: float = 1.0):
         be = get_backend()
@@ -91,8 +124,13 @@ class FusedAdam:
         if self.max_grad_norm is not None:
             be.sumsq(self.flat.grad, self.sumsq, accumulate=False)
             sumsq = self.sumsq
-        be.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                     self.step_count, grad_scale, sumsq, self.max_grad_norm if self.max_grad_norm is not None else 0.0)
+        if self._lr_t is not None:
+            self._step_t.add_(1)                   # (a kernel of the captured graph: the count advances with every replay)
+            be.adam_step_dyn(self.flat.data, self.flat.grad, self.m, self.v, self._lr_t, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                             self._step_t, grad_scale, sumsq, self.max_grad_norm if self.max_grad_norm is not None else 0.0)
+        else:
+            be.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                         self.step_count, grad_scale, sumsq, self.max_grad_norm if self.max_grad_norm is not None else 0.0)
         if hasattr(be, "invalidate_weight_planes"):
             be.invalidate_weight_planes()          # the kernel wrote the parameters through raw pointers: cached bf16 planes are stale
 
@@ -101,6 +139,7 @@ class FusedAdam:
         self.m.zero_()
         self.v.zero_()
         self.step_count = 0
+        self.sync_dynamic()
 
     def grad_norm(self) -> torch.Tensor:
         return torch.sqrt(self.sumsq[0])
@@ -110,3 +149,4 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count = int(sd["step"]); self.lr = float(sd.get("lr", self.lr))
+        self.sync_dynamic()

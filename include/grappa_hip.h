@@ -150,7 +150,7 @@ typedef struct grappa_gemm_desc {
      * == 0, 16-byte aligned; a_amax (with amax_bcast bit 0) = the maximum over the token maxima.  The kernel moves every token row onto the
      * tensor's scale with exact fp16 multiplications by powers of two (the halves a fresh split under that scale would give, up to the
      * rounding of fp16 denormals).  b_planes / b_rowmax / bit 1: the same for B ([K tokens][N features]).  One operand may stay fp32.
-     * All products of one grouped call must use the same formats. */
+     * The products of one grouped call may mix formats (one launch either way; a group of one combination runs the kernel specialised for it). */
     const uint32_t* a_rowmax; const uint32_t* b_rowmax;
 } grappa_gemm_desc;
 
@@ -239,6 +239,11 @@ int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int 
  * pass of their own.  A NULL array gives the plain kernel. */
 int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
                                     float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax);
+/* ABI 8: the same rows written in the PAIR format (pairs, ldp >= 2 * N fp16 elements, % 8 == 0; N % 32 == 0, N <= 2048; dz_amax = the
+ * rows' scales, required); dz (fp32) may be NULL: the products behind -- the input gradient through grappa_gemm_f32's pair operands, the
+ * weight gradient through ABI 8's -- read the pairs. */
+int grappa_act_dropout_bwd_pairs_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy, float drop_p,
+                                     uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, uint16_t* pairs, int ldp);
 
 /* y = x + z elementwise (used to merge gradient branches); y may alias x */
 int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float* y);
@@ -472,6 +477,14 @@ int grappa_sumsq_f32(void* stream, size_t n, const float* x, float* out, int acc
 int grappa_adam_step_f32(void* stream, size_t n, float* p, const float* g, float* m, float* v,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float grad_scale, const float* sumsq, float max_norm);
+/* ABI 8, for a train step captured in a hipGraph: the same update with the learning rate (lr_dev[0]) and the step count (step_dev[0] >= 1,
+ * for the bias corrections) read from DEVICE memory at execution time. */
+int grappa_adam_step_dyn_f32(void* stream, size_t n, float* p, const float* g, float* m, float* v, const float* lr_dev, float beta1, float beta2,
+                             float eps, float weight_decay, const int* step_dev, float grad_scale, const float* sumsq, float max_norm);
+/* ABI 8: dropout salt.  device_word (one uint64 in device memory, or NULL = none: the default) is read by every kernel launched AFTERWARDS
+ * that draws a dropout mask (product epilogues, grappa_act_dropout_bwd_*) and mixed into its seed: seed + word * 0x9E3779B97F4A7C15.  A
+ * captured step increments the word inside the graph, so every replay draws fresh masks while forward and backward of one replay agree. */
+void grappa_set_dropout_salt(const uint64_t* device_word);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 storage configuration (BASELINE configs[2]: "bf16, MFMA dense heads"; the reference's Lightning `precision` / its

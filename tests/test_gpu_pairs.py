@@ -99,7 +99,7 @@ def test_tuple_attention_writes_its_output_in_the_pair_format(s, T, heads, F):
 def test_inference_through_the_pair_format_equals_the_fp32_operand_path():
     """eval / no_grad: LayerNorm and the tuple attention hand their rows to the product behind them in the pair format (the default);
     GRAPPA_INFERENCE_PAIRS=0 (be.inference_pairs = False) keeps fp32 operands.  Same values: the pair kernel computes the same partial
-    products, bit for bit where both kernels cut K alike.  With gradients enabled nothing changes (the pairs are an inference path)."""
+    products, bit for bit where both kernels cut K alike.  With gradients enabled the producers write pairs only where the training configuration allows them (be.training_pairs)."""
     from grappa_amd import get_default_model_config, model_from_config
     from grappa_amd.backend import get_backend
     from grappa_amd.datasets import build_batch_from_pool
@@ -128,14 +128,18 @@ def test_inference_through_the_pair_format_equals_the_fp32_operand_path():
     for key, a in outs[True].items():
         b = outs[False][key]
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), key
-    # with gradients enabled the model does not use the pairs: the training forward is untouched
-    taken["n"] = 0
-    be.layernorm_fwd = lambda *a, **k: (taken.__setitem__("n", taken["n"] + bool(k.get("pairs"))), ln(*a, **k))[1]
-    try:
-        model(g_cpu.to("cuda"))
-    finally:
-        del be.layernorm_fwd
-    assert taken["n"] == 0
+    # with gradients enabled: pairs where the training configuration allows them (round 4: be.training_pairs, tables of >= be.pairs_min_rows
+    # rows), fp32 rows everywhere with the switch off
+    for flag in (False, True):
+        taken["n"] = 0
+        be.layernorm_fwd = lambda *a, **k: (taken.__setitem__("n", taken["n"] + bool(k.get("pairs"))), ln(*a, **k))[1]
+        be.training_pairs = flag
+        try:
+            model(g_cpu.to("cuda"))
+        finally:
+            del be.layernorm_fwd
+            be.training_pairs = True
+        assert (taken["n"] > 0) == flag, (flag, taken)
 
 
 @pytest.mark.parametrize("M,N,K,drop", [(1000, 512, 512, 0.0), (5000, 256, 512, 0.3), (257, 512, 256, 0.0), (40, 64, 64, 0.0)])
@@ -209,3 +213,116 @@ def test_inference_pair_path_on_model_variants(variant):
         be.inference_pairs = True
     for a, b in zip(outs[True], outs[False]):
         assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 5e-6 * max(float(b.abs().max()), 1e-6), variant
+
+
+@pytest.mark.parametrize("fmt", ["pz", "px", "both"])
+def test_weight_gradient_from_pair_operands(fmt):
+    """C ABI 8: the grouped weight-gradient product reads an operand that its producer wrote in the pair format (every token row under its own
+    scale) and moves the rows onto the tensor's scale with exact fp16 multiplications: the result equals the fp32-operand product -- bit
+    for bit while no element falls into the fp16 denormals under the tensor's scale, to fp32 rounding otherwise -- and so does the bias gradient"""
+    from grappa_amd.backend import Amax, get_backend
+    be = get_backend()
+    torch.manual_seed(3)
+    T, Np, Kp = 5000, 512, 256
+    for spread in (0.0, 12.0):                      # rows within one binade of each other / spread over 2^-36 .. 1 of the largest
+        dz = torch.randn(T, Np, device="cuda") * torch.exp2(-spread * 3 * torch.rand(T, 1, device="cuda"))
+        x = torch.randn(T, Kp, device="cuda") * torch.exp2(-spread * torch.rand(T, 1, device="cuda"))
+        want_w, want_b = torch.zeros(Np, Kp, device="cuda"), torch.zeros(Np, device="cuda")
+        be.gemm_wgrad(dz, x, want_w, want_b)
+        be.flush_wgrads()
+        rz, rx = be.to_pairs(dz), be.to_pairs(x)
+        got_w, got_b = torch.zeros(Np, Kp, device="cuda"), torch.zeros(Np, device="cuda")
+        be.gemm_wgrad(None if fmt in ("pz", "both") else dz, None if fmt in ("px", "both") else x, got_w, got_b,
+                      dz_scales=rz if fmt in ("pz", "both") else None, x_scales=rx if fmt in ("px", "both") else None)
+        be.flush_wgrads()
+        torch.cuda.synchronize()
+        ref = dz.double().T @ x.double()
+        scale = float(ref.abs().max())
+        err_pairs, err_f32 = float((got_w.double() - ref).abs().max()) / scale, float((want_w.double() - ref).abs().max()) / scale
+        assert err_pairs <= max(2.0 * err_f32, 2e-7), (fmt, spread, err_pairs, err_f32)
+        # (not bit for bit: a LO half that is an fp16 denormal under its row's scale is rounded once more when it moves to the tensor's)
+        assert float((got_w - want_w).abs().max()) <= 2e-7 * scale, (fmt, spread, float((got_w - want_w).abs().max()) / scale)
+        bref = dz.double().sum(0)
+        assert float((got_b.double() - bref).abs().max()) <= 2e-6 * float(bref.abs().max()), fmt
+
+
+@pytest.mark.parametrize("min_rows", [12288, 0])
+def test_training_through_the_pair_format_equals_the_fp32_operand_path(min_rows):
+    """round 4: in training LayerNorm, the tuple attention and the dropout backward write the operands of the products behind them in the pair
+    format ONLY; forward / input-gradient products read them by LDS-DMA (csrc/gemm_pairs.hip), weight-gradient products through C ABI 8.  Same
+    loss and gradients as with fp32 operands (be.training_pairs = False) to fp32 rounding, with dropout on (same counter-based masks);
+    min_rows = 0: the GNN's atom rows too"""
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    from grappa_amd.optim import FlatParams
+    import golden_utils as gu
+    be = get_backend()
+    model = model_from_config(get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").train()
+    flat = FlatParams(model)
+    g_cpu = build_batch_from_pool(list(range(100, 164)), n_confs=4, seed=3)
+    res = {}
+    keep = be.pairs_min_rows
+    try:
+        for flag in (False, True):
+            be.training_pairs, be.pairs_min_rows = flag, min_rows
+            ops.manual_seed(11)
+            flat.zero_grad()
+            g = Energy()(model(g_cpu.to("cuda")))
+            loss = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0)(g)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[flag] = (float(loss), flat.grad.clone(), g.nodes["n4"].data["k"].detach().clone(), g.nodes["n2"].data["eq"].detach().clone())
+    finally:
+        be.training_pairs, be.pairs_min_rows = True, keep
+    (l0, g0, k0, e0), (l1, g1, k1, e1) = res[False], res[True]
+    assert abs(l1 - l0) <= 1e-5 * abs(l0), (l0, l1)
+    assert float((k1 - k0).abs().max()) <= 1e-5 * float(k0.abs().max()) and float((e1 - e0).abs().max()) <= 1e-5 * float(e0.abs().max())
+    # per parameter tensor, relative to its largest gradient entry
+    for name, p in model.named_parameters():
+        a, b = flat.grad_view(p) if hasattr(flat, "grad_view") else None, None
+        break
+    worst = 0.0
+    off = 0
+    for p in model.parameters():
+        home = getattr(p, "_grappa_flat", None)
+        lo = home[1]
+        a, b = g1[lo:lo + p.numel()], g0[lo:lo + p.numel()]
+        scale = float(b.abs().max())
+        if scale > 0:
+            worst = max(worst, float((a - b).abs().max()) / scale)
+    assert worst <= 2e-5, worst
+
+
+def test_grouped_weight_gradients_of_mixed_operand_formats_in_one_launch():
+    """one grouped launch over products whose operands come as fp32 or as pairs, product by product (C ABI 8, the kernel reads each product's
+    own flags): the same results as launching every product alone in its own format"""
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    torch.manual_seed(5)
+    T = 3000
+    shapes = [(512, 512), (1536, 512), (256, 1024), (512, 256)]
+    fmts = [(True, False), (False, True), (True, True), (False, False)]
+    ops_, want = [], []
+    for (Np, Kp), (pz, px) in zip(shapes, fmts):
+        dz, x = torch.randn(T, Np, device="cuda"), torch.randn(T, Kp, device="cuda") * 3
+        rz, rx = be.to_pairs(dz), be.to_pairs(x)
+        alone = torch.zeros(Np, Kp, device="cuda")
+        be.gemm_wgrad(None if pz else dz, None if px else x, alone, None, dz_scales=rz if pz else None, x_scales=rx if px else None)
+        be.flush_wgrads()
+        want.append(alone)
+        ops_.append((dz, x, rz, rx, pz, px))
+    outs = [torch.zeros_like(w) for w in want]
+    items = []
+    for (dz, x, rz, rx, pz, px), out in zip(ops_, outs):
+        am = (rz if pz else be.amax(dz, None, rows=True), rx if px else be.amax(x, None, rows=True))
+        items.append((None if pz else dz, None if px else x, out, None, am, rz.pairs if pz else None, rx.pairs if px else None))
+    be._launch_wgrad_group(items)
+    torch.cuda.synchronize()
+    for got, w, (dz, x, *_r) in zip(outs, want, ops_):
+        ref = dz.double().T @ x.double()
+        scale = float(ref.abs().max())
+        assert float((got.double() - ref).abs().max()) <= 2e-6 * scale  # (fp32 accumulation over 3,000 tokens: measured 5e-7)
+        assert float((got - w).abs().max()) <= 2e-6 * scale          # (another K cut than alone: fp32 rounding, not bits)
