@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hi
 
 ABI_VERSION = 8
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
+GEMM_GROUP4_MAX = 4          # grappa_gemm_f32_group (forward / input-gradient products of the writer heads)
 GEMM_GROUP_MAX = 16
 GEMM_PRECISIONS = {"f32": 0, "f32_bf16x9": 1, "f32_bf16x6": 2, "bf16x3": 3, "bf16": 4, "f32_f16x3": 5}
 
@@ -36,6 +37,29 @@ class GemmDesc(C.Structure):
                 ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p),
                 # ABI 8: pair-format operands of the weight-gradient products (token maxima of the operand)
                 ("a_rowmax", C.c_void_p), ("b_rowmax", C.c_void_p)]
+
+
+class LnFwdItem(C.Structure):
+    _fields_ = [("M", C.c_int), ("W", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("y", C.c_void_p),
+                ("ldy", C.c_int), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("y_amax", C.c_void_p)]
+
+
+class LnBwdItem(C.Structure):
+    _fields_ = [("M", C.c_int), ("W", C.c_int), ("dy", C.c_void_p), ("lddy", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("dx", C.c_void_p), ("lddx", C.c_int), ("part", C.c_void_p), ("dx_amax", C.c_void_p)]
+
+
+class ActDropoutItem(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("dy", C.c_void_p), ("lddy", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("drop_p", C.c_float),
+                ("drop_seed", C.c_uint64), ("dz", C.c_void_p), ("lddz", C.c_int), ("dz_amax", C.c_void_p)]
+
+
+class SeqAttnItem(C.Structure):
+    _fields_ = [("s", C.c_int), ("T", C.c_int), ("nheads", C.c_int), ("dh", C.c_int), ("qkv", C.c_void_p), ("out", C.c_void_p), ("dout", C.c_void_p),
+                ("dqkv", C.c_void_p), ("amax", C.c_void_p)]
+
+
+ROW_BATCH_MAX = 4
 
 
 class ColsumItem(C.Structure):
@@ -89,10 +113,17 @@ SIGNATURES = {
     "grappa_gemm_f32": (_i, [_vp, C.POINTER(GemmDesc), _vp, _sz]),
     "grappa_gemm_f32_grouped_workspace_bytes": (_sz, [C.POINTER(GemmDesc), _i]),
     "grappa_gemm_f32_grouped": (_i, [_vp, C.POINTER(GemmDesc), _i, _vp, _sz]),
+    "grappa_gemm_f32_group_workspace_bytes": (_sz, [C.POINTER(GemmDesc), _i]),
+    "grappa_gemm_f32_group": (_i, [_vp, C.POINTER(GemmDesc), _i, _vp, _sz]),
     "grappa_colsum_workspace_bytes": (_sz, [_i, _i]),
     "grappa_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz]),
     "grappa_act_dropout_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i]),
     "grappa_act_dropout_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp]),
+    "grappa_layernorm_fwd_batched_f32": (_i, [_vp, C.POINTER(LnFwdItem), _i]),
+    "grappa_layernorm_bwd_batched_f32": (_i, [_vp, C.POINTER(LnBwdItem), _i]),
+    "grappa_act_dropout_bwd_batched_f32": (_i, [_vp, C.POINTER(ActDropoutItem), _i]),
+    "grappa_seqattn_fwd_batched_f32": (_i, [_vp, C.POINTER(SeqAttnItem), _i]),
+    "grappa_seqattn_bwd_batched_f32": (_i, [_vp, C.POINTER(SeqAttnItem), _i]),
     "grappa_act_dropout_bwd_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp, _vp, _i]),
     "grappa_add_f32": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "grappa_layernorm_fwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -107,6 +107,15 @@ class Amax:
         self.pairs = pairs
 
 
+class _PendingGemm:
+    """a product whose descriptor is built but not launched (HipBackend.gemm_group)"""
+    __slots__ = ("d", "shape", "flops", "nbytes", "ret", "dev", "keep", "groupable", "key")
+
+    def __init__(self, d, shape, flops, nbytes, ret, dev, keep, groupable):
+        self.d, self.shape, self.flops, self.nbytes, self.ret, self.dev, self.keep, self.groupable = d, shape, flops, nbytes, ret, dev, keep, groupable
+        self.key = (int(d.b_kcontig), int(d.a_planes), int(d.b_planes), int(d.precision))
+
+
 class HipBackend:
     name = "hip"
 
@@ -144,6 +153,8 @@ class HipBackend:
         # training (round 4): the same producers write pairs ONLY, the dropout backward too, and the weight-gradient products read pairs
         # (C ABI 8: token rows moved onto the tensor's scale inside the kernel) -- no fp32 copy of a normalised activation exists any more
         self.training_pairs = os.environ.get("GRAPPA_TRAINING_PAIRS", "1") not in ("0", "")
+        # the same product of the four writer heads as ONE launch (gemm_group); GRAPPA_GROUP_LAUNCHES=0: one by one
+        self.group_launches = os.environ.get("GRAPPA_GROUP_LAUNCHES", "1") not in ("0", "")
         self.pairs_min_rows = int(os.environ.get("GRAPPA_PAIRS_MIN_ROWS", "12288"))
         self._tails = None             # what set_tail_launches last told the library (None: the library's default)
         self._tails_pinned = False
@@ -479,7 +490,7 @@ class HipBackend:
 
     def gemm(self, a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, res=None, aux=None, pre=None, act=0,
              drop_p=0.0, drop_seed=0, accumulate=False, out2=None, a_colsum=None, precision=None, a_scales=None, b_scales=None, out_amax=False,
-             res_ln=None):
+             res_ln=None, _defer=False):
         """C = epilogue(A B^T) (include/grappa_hip.h).  Operands and epilogue tensors may be float32 or -- the bf16 storage
         configuration -- bfloat16: a bf16 A (and, for the wgrad layout, B) is read by the LDS-DMA plane kernels as a one-plane
         operand when the shape allows it, otherwise converted to fp32 first; out / out2 / res / aux are written / read in their own
@@ -671,10 +682,61 @@ class HipBackend:
         # algorithmic bytes of the fused call: both operands once, the result, and what the epilogue has to read / write beside it
         # (residual, saved activation for ELU', fp32 addend, the second output, an accumulated result's old value)
         epi = M * N * (el(res) + el(aux) + el(pre) + (el(out) if out2 is not None else 0) + (el(final) if accumulate else 0))
-        self._timed("gemm_f32", 2.0 * M * N * K, float(M * K * (4 if a_pairs is not None else el(a if planes_a is None else planes_a)) + N * K * (2 if planes_b is not None else 4)
-                                                         + M * N * el(final) + epi),
-                    lambda: self._launch_gemm(d, ws, dev, (M, N, K)))
-        return (sa, so) if out_amax else sa
+        nbytes = float(M * K * (4 if a_pairs is not None else el(a if planes_a is None else planes_a)) + N * K * (2 if planes_b is not None else 4)
+                       + M * N * el(final) + epi)
+        ret = (sa, so) if out_amax else sa
+        if _defer:                               # gemm_group: the caller launches this product together with others
+            return _PendingGemm(d, (M, N, K), 2.0 * M * N * K, nbytes, ret, dev, (a, b, out, out2, res, aux, pre, bias, a_pairs, sa, so, res_ln),
+                                groupable=big and a_kcontig and a_colsum is None and planes_a is None and (planes_b is None or a_pairs is not None)
+                                and not native and final.dtype == torch.float32)
+        self._timed("gemm_f32", 2.0 * M * N * K, nbytes, lambda: self._launch_gemm(d, ws, dev, (M, N, K)))
+        return ret
+
+    def gemm_group(self, calls):
+        """calls: [(args, kwargs)] of `gemm` -- independent products, e.g. the same product of the four writer heads -- launched as ONE grid
+        where the library can (C ABI 8 grappa_gemm_f32_group: forward or input-gradient layout, one operand format), else one by one.
+        -> the list of `gemm`'s return values.  At small batches one head's product leaves most of the chip idle for a whole tile time."""
+        pend = [self.gemm(*a, **dict(k, _defer=True)) for a, k in calls]
+        live = [p for p in pend if isinstance(p, _PendingGemm)]
+        out = [p.ret if isinstance(p, _PendingGemm) else p for p in pend]
+        i = 0
+        while i < len(live):
+            grp = [live[i]]
+            if self.group_launches and live[i].groupable:
+                for q in live[i + 1:i + _lib.GEMM_GROUP4_MAX]:
+                    if q.groupable and q.key == live[i].key:
+                        grp.append(q)
+                    else:
+                        break
+            i += len(grp)
+            if len(grp) >= 2 and self._launch_gemm_group(grp):
+                continue
+            for q in grp:
+                need = self._ws_need.get(q.shape + (self._tails,))
+                if need is None:
+                    need = self._ws_need[q.shape + (self._tails,)] = self.lib.grappa_gemm_f32_workspace_bytes(*q.shape)
+                ws = self._workspace(need, q.dev) if need else None
+                self._timed("gemm_f32", q.flops, q.nbytes, lambda q=q, ws=ws: self._launch_gemm(q.d, ws, q.dev, q.shape))
+        return out
+
+    def _launch_gemm_group(self, grp) -> bool:
+        n = len(grp)
+        arr = (_lib.GemmDesc * n)()
+        for dst, q in zip(arr, grp):
+            C.memmove(C.byref(dst), C.byref(q.d), C.sizeof(_lib.GemmDesc))
+        need = self.lib.grappa_gemm_f32_group_workspace_bytes(arr, n)
+        ws = self._workspace(need, grp[0].dev) if need else None
+        rc = [0]
+
+        def launch():
+            rc[0] = self.lib.grappa_gemm_f32_group(self._stream(), arr, n, _ptr(ws), ws.numel() if ws is not None else 0)
+        self._timed("gemm_f32", sum(q.flops for q in grp), sum(q.nbytes for q in grp), launch)
+        if rc[0] == -1:                          # GRAPPA_ERR_ARG: a combination the grouped entry does not take (nothing was launched)
+            if self._prof:
+                self._prof.pop()
+            return False
+        _chk(rc[0], "grappa_gemm_f32_group")
+        return True
 
     def _launch_gemm(self, d, ws, dev, shape) -> None:
         rc = self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0)
@@ -1027,6 +1089,125 @@ class HipBackend:
         _chk(getattr(self.lib, f"grappa_layernorm_bwd_{_sfx(x)}")(*args), "grappa_layernorm_bwd")
         return None
 
+    # ------------------------------------------------------------------ batched row-wise kernels (C ABI 8): the writer heads layer-locked
+    @staticmethod
+    def _rows_ok(*ts) -> bool:
+        return all(t is None or (t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() and t.data_ptr() % 16 == 0 and t.shape[1] % 4 == 0
+                                 and t.shape[1] <= 2048) for t in ts)
+
+    def layernorm_fwd_batched(self, xs, gammas, betas):
+        """the LayerNorms of several tensors (<= 4) in ONE launch -> [(y, mean, rstd, record of y's row maxima or None)]; None if a tensor
+        does not qualify (fp32, contiguous rows of W % 4 == 0 <= 2048 columns): the caller then goes one by one"""
+        n = len(xs)
+        if not (2 <= n <= _lib.ROW_BATCH_MAX) or not self._rows_ok(*xs) or any(x.shape[0] == 0 for x in xs):
+            return None
+        want = self.wants_amax(False)
+        arr = (_lib.LnFwdItem * n)()
+        out = []
+        for it, x, g, b in zip(arr, xs, gammas, betas):
+            M, W = x.shape
+            dev = x.device
+            _flat(g, "gamma", dev), _flat(b, "beta", dev)
+            if g.numel() != W or b.numel() != W:
+                raise ValueError("layernorm: shapes")
+            y = torch.empty_like(x)
+            mean, rstd = torch.empty(M, dtype=torch.float32, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+            row = torch.empty(M, dtype=torch.int32, device=dev) if want else None
+            it.M, it.W, it.x, it.ldx, it.gamma, it.beta, it.y, it.ldy = M, W, x.data_ptr(), x.stride(0), g.data_ptr(), b.data_ptr(), y.data_ptr(), y.stride(0)
+            it.mean, it.rstd, it.y_amax = mean.data_ptr(), rstd.data_ptr(), _ptr(row)
+            out.append((y, mean, rstd, Amax(row=row) if want else None))
+        _chk(self.lib.grappa_layernorm_fwd_batched_f32(self._stream(), arr, n), "grappa_layernorm_fwd_batched_f32")
+        return out
+
+    def layernorm_bwd_batched(self, items):
+        """items: [(dy, x, mean, rstd, gamma, dgamma, dbeta)] -> [(dx, record or None)] in ONE launch, the parameter gradients left as
+        partials for the end-of-pass reduction (inside a backward pass only); None: go one by one"""
+        n = len(items)
+        if not (2 <= n <= _lib.ROW_BATCH_MAX) or not (self.defer_wgrads and self.defer_ln):
+            return None
+        if not self._rows_ok(*[t for it in items for t in (it[0], it[1])]) or any(it[1].shape[0] == 0 for it in items):
+            return None
+        task = self._queue_flush()
+        if task < 0 or any(q[3] == it[5].data_ptr() for it in items for q in self._lnq if q[8] == task):
+            return None
+        if len({it[5].data_ptr() for it in items}) != n:
+            return None
+        want = self.wants_amax(True)
+        arr = (_lib.LnBwdItem * n)()
+        out = []
+        cur = torch.cuda.current_stream()
+        for a, (dy, x, mean, rstd, gamma, dgamma, dbeta) in zip(arr, items):
+            M, W = x.shape
+            dev = x.device
+            for t, nme, k in ((mean, "mean", M), (rstd, "rstd", M), (gamma, "gamma", W), (dgamma, "dgamma", W), (dbeta, "dbeta", W)):
+                _flat(t, nme, dev)
+                if t.numel() != k:
+                    raise ValueError(f"layernorm_bwd: {nme} length")
+            if tuple(dy.shape) != (M, W):
+                raise ValueError("layernorm_bwd: shapes")
+            dx = torch.empty_like(x)
+            ws = torch.empty(self.lib.grappa_layernorm_bwd_workspace_bytes(M, W), dtype=torch.uint8, device=dev)
+            row = torch.empty(M, dtype=torch.int32, device=dev) if want else None
+            a.M, a.W, a.dy, a.lddy, a.x, a.ldx = M, W, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+            a.mean, a.rstd, a.gamma, a.dx, a.lddx, a.part, a.dx_amax = mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dx.stride(0), ws.data_ptr(), _ptr(row)
+            self._lnq.append((ws, self.lib.grappa_layernorm_bwd_partial_rows(M), W, dgamma.data_ptr(), dbeta.data_ptr(), dgamma, dbeta, cur, task))
+            out.append((dx, Amax(row=row) if want else None))
+        _chk(self.lib.grappa_layernorm_bwd_batched_f32(self._stream(), arr, n), "grappa_layernorm_bwd_batched_f32")
+        return out
+
+    def act_dropout_bwd_batched(self, items):
+        """items: [(dy, y or None, drop_p, drop_seed)] -> [(dz, record or None)] in ONE launch; None: go one by one"""
+        n = len(items)
+        if not (2 <= n <= _lib.ROW_BATCH_MAX) or not self.wants_amax(True):
+            return None
+        if not self._rows_ok(*[t for it in items for t in (it[0], it[1])]) or any(it[0].shape[0] == 0 for it in items):
+            return None
+        arr = (_lib.ActDropoutItem * n)()
+        out = []
+        for a, (dy, y, p, seed) in zip(arr, items):
+            M, N = dy.shape
+            if y is not None and tuple(y.shape) != (M, N):
+                raise ValueError("act_dropout_bwd: shapes")
+            dz = torch.empty_like(dy)
+            row = torch.empty(M, dtype=torch.int32, device=dy.device)
+            a.M, a.N, a.dy, a.lddy, a.y, a.ldy = M, N, dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0
+            a.drop_p, a.drop_seed, a.dz, a.lddz, a.dz_amax = float(p), int(seed) & (2 ** 64 - 1), dz.data_ptr(), dz.stride(0), row.data_ptr()
+            out.append((dz, Amax(row=row)))
+        _chk(self.lib.grappa_act_dropout_bwd_batched_f32(self._stream(), arr, n), "grappa_act_dropout_bwd_batched_f32")
+        return out
+
+    def seqattn_batched(self, items, backward: bool):
+        """forward: items [(qkv, s, T, nheads)] -> [(att, record)]; backward: [(qkv, dout, s, T, nheads)] -> [(dqkv, record)]; ONE launch;
+        None: go one by one"""
+        n = len(items)
+        if not (2 <= n <= _lib.ROW_BATCH_MAX):
+            return None
+        arr = (_lib.SeqAttnItem * n)()
+        out = []
+        want = self.wants_amax(backward)
+        for a, it in zip(arr, items):
+            qkv = it[0]
+            s, T, nheads = it[-3:]
+            F = qkv.shape[1] // 3
+            if qkv.dtype != torch.float32 or not qkv.is_contiguous() or qkv.shape != (s * T, 3 * F) or F % nheads or T == 0:
+                return None
+            dev = qkv.device
+            if backward:
+                dout = it[1]
+                if dout.dtype != torch.float32 or not dout.is_contiguous() or tuple(dout.shape) != (s * T, F):
+                    return None
+                res = torch.empty_like(qkv)
+                a.dout, a.dqkv = dout.data_ptr(), res.data_ptr()
+            else:
+                res = torch.empty((s * T, F), dtype=torch.float32, device=dev)
+                a.out = res.data_ptr()
+            row = torch.empty(s * T, dtype=torch.int32, device=dev) if want else None
+            a.s, a.T, a.nheads, a.dh, a.qkv, a.amax = s, T, nheads, F // nheads, qkv.data_ptr(), _ptr(row)
+            out.append((res, Amax(row=row) if want else None))
+        fn = self.lib.grappa_seqattn_bwd_batched_f32 if backward else self.lib.grappa_seqattn_fwd_batched_f32
+        _chk(fn(self._stream(), arr, n), "grappa_seqattn_batched_f32")
+        return out
+
     # ------------------------------------------------------------------ graph
     def _csr_check(self, plan, N, dev):
         if plan.N != N or plan.indptr.device != dev or plan.indptr.dtype != torch.int32 or plan.indptr.numel() != N + 1:
@@ -1375,7 +1556,15 @@ class HipBackend:
     def enable_dropout_salt(self) -> None:
         if getattr(self, "_salt", None) is None:
             self._salt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            self._salt_off = True
+        if self._salt_off:
             self.lib.grappa_set_dropout_salt(self._salt.data_ptr())
+            self._salt_off = False
+
+    def disable_dropout_salt(self) -> None:
+        """back to the seeds as given (kernels launched afterwards; recorded graphs keep reading the word they were recorded with)"""
+        self.lib.grappa_set_dropout_salt(None)
+        self._salt_off = True
 
     def bump_dropout_salt(self) -> None:
         """+1 on the device word (a kernel on the current stream: inside a capture it becomes a node of the graph)"""

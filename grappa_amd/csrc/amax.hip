@@ -144,6 +144,23 @@ __global__ __launch_bounds__(256) void amax_combine_kernel(int M, int nseg, cons
     out[m] = v;
 }
 
+// the same for up to four products of one grouped launch (grappa_gemm_f32_group) in one launch
+struct AmaxCombine4 {
+    const unsigned* part[4];
+    unsigned* out[4];
+    int M[4], nseg[4], blk_begin[5], count;
+};
+__global__ __launch_bounds__(256) void amax_combine4_kernel(AmaxCombine4 a) {
+    int i = 0;
+    while (i + 1 < a.count && (int)blockIdx.x >= a.blk_begin[i + 1]) ++i;
+    const int m = ((int)blockIdx.x - a.blk_begin[i]) * 256 + threadIdx.x;
+    if (m >= a.M[i]) return;
+    unsigned v = 0u;
+#pragma unroll 8
+    for (int s = 0; s < a.nseg[i]; ++s) v = max(v, a.part[i][(size_t)s * a.M[i] + m]);
+    a.out[i][m] = v;
+}
+
 // BATCH_SLICES workgroups per matrix (weights: at most a few MB each; one workgroup per matrix left 100 - 200 of 256 CUs idle for 0.2 ms
 // per optimiser step), each a share of the rows; column maxima meet in LDS (ds_max_u32), then across the slices in the output array by
 // atomic maxima of the bit patterns (order-free: the same bits every run), which amax_batched_zero_kernel cleared
@@ -265,6 +282,22 @@ extern "C" int grappa_amax_reduce(void* stream, int count, const uint32_t* const
 // called by grappa_gemm_f32 (gemm_f32.hip) after a product that wrote per-segment row maxima
 int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* part, unsigned* out) {
     GRAPPA_LAUNCH(amax_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, nseg, part, out);
+    return grappa_launch_status();
+}
+
+int grappa_launch_amax_combine4(hipStream_t st, int count, const int* M, const int* nseg, const unsigned* const* part, unsigned* const* out) {
+    AmaxCombine4 a;
+    a.count = count;
+    a.blk_begin[0] = 0;
+    for (int i = 0; i < 4; ++i) {
+        a.M[i] = i < count ? M[i] : 0;
+        a.nseg[i] = i < count ? nseg[i] : 0;
+        a.part[i] = i < count ? part[i] : nullptr;
+        a.out[i] = i < count ? out[i] : nullptr;
+        a.blk_begin[i + 1] = a.blk_begin[i] + (i < count ? (M[i] + 255) / 256 : 0);
+    }
+    if (a.blk_begin[4] == 0) return GRAPPA_OK;
+    GRAPPA_LAUNCH(amax_combine4_kernel, dim3(a.blk_begin[4]), dim3(256), 0, st, a);
     return grappa_launch_status();
 }
 

@@ -6,6 +6,7 @@ using namespace grappa_gemm;
 
 #define GRAPPA_DECL(NAME)                                                                   \
     int grappa_bf16x_launch_##NAME(hipStream_t st, GemmParams& p, bool vec_kcontig);        \
+    int grappa_bf16x_launch_group4_##NAME(hipStream_t st, const GemmGroup4& g, bool b_kcontig); \
     int grappa_bf16x_launch_grouped_##NAME(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, bool vec, int psrc)
 GRAPPA_DECL(x9);
 GRAPPA_DECL(x6);
@@ -35,6 +36,19 @@ int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool 
         case GRAPPA_GEMM_BF16X3: return grappa_bf16x_launch_x3(st, p, vec_kcontig);
         case GRAPPA_GEMM_BF16: return grappa_bf16x_launch_x1(st, p, vec_kcontig);
         case GRAPPA_GEMM_F32_F16X3: return grappa_bf16x_launch_h3(st, p, vec_kcontig);
+        default: return GRAPPA_ERR_ARG;
+    }
+}
+
+
+// up to four forward / input-gradient products of one layout in one launch (grappa_gemm_f32_group), fp32 operands, tile 256 x 128
+int grappa_launch_gemm_bf16x_group4(hipStream_t st, const GemmGroup4& g, int precision, bool b_kcontig) {
+    switch (precision) {
+        case GRAPPA_GEMM_F32_BF16X9: return grappa_bf16x_launch_group4_x9(st, g, b_kcontig);
+        case GRAPPA_GEMM_F32_BF16X6: return grappa_bf16x_launch_group4_x6(st, g, b_kcontig);
+        case GRAPPA_GEMM_BF16X3: return grappa_bf16x_launch_group4_x3(st, g, b_kcontig);
+        case GRAPPA_GEMM_BF16: return grappa_bf16x_launch_group4_x1(st, g, b_kcontig);
+        case GRAPPA_GEMM_F32_F16X3: return grappa_bf16x_launch_group4_h3(st, g, b_kcontig);
         default: return GRAPPA_ERR_ARG;
     }
 }

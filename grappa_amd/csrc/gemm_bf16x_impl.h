@@ -390,13 +390,12 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     constexpr int NFIRST = NM >= 12 ? NM * 2 / 3 : NM / 2;
     const bool do_store = !TAIL || s + 1 < kr.nsteps;
     const bool do_load = !TAIL || s + AHEAD < kr.nsteps;
-    // the operand is in the pair format (wgrad layout, KMV, H3 only): known at compile time (PSRC 0 .. 3) or per product (PSRC 4: one grouped
-    // launch over products of mixed formats -- a uniform branch per workgroup)
-    const bool pa_ = PSRC == 4 ? d.a_planes != 0 : (PSRC & 1) != 0, pb_ = PSRC == 4 ? d.b_planes != 0 : (PSRC & 2) != 0;
+    // the operand is in the pair format (wgrad layout, KMV, H3 only)
+    constexpr bool pa_ = (PSRC & 1) != 0, pb_ = (PSRC & 2) != 0;
     if (do_load && !(GB_KNOCK == 3 && !TAIL)) {
-        if (pa_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
+        if constexpr (pa_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
         else load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(s + AHEAD), d.M, kr.kend, la);
-        if (pb_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
+        if constexpr (pb_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
         else load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(s + AHEAD), d.N, kr.kend, lb);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -404,12 +403,12 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     mfma_range<MODE, TM, TN, 0, NFIRST>(fc, acc);
     if (do_store && !(GB_KNOCK == 4 && !TAIL)) {
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
-        if (pa_) store_quads_pairs<NT, BM, TAIL>(nxt, sa, krem, 141 - sha[0][0]);
+        if constexpr (pa_) store_quads_pairs<NT, BM, TAIL>(nxt, sa, krem, 141 - sha[0][0]);
         else store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF, AV>(nxt, sa, krem, sha);
-        if (pb_) store_quads_pairs<NT, BN, TAIL>(nxt + NP * PA, sb, krem, 141 - shb[0][0]);
+        if constexpr (pb_) store_quads_pairs<NT, BN, TAIL>(nxt + NP * PA, sb, krem, 141 - shb[0][0]);
         else store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF, BV>(nxt + NP * PA, sb, krem, shb);
         if (!AK && do_cs) {
-            if (pa_) quad_rowsum_pairs<NT, BM, TAIL>(sa, krem, cs);
+            if constexpr (pa_) quad_rowsum_pairs<NT, BM, TAIL>(sa, krem, cs);
             else quad_rowsum<NT, BM, AV, TAIL>(sa, krem, cs);
         }
     }
@@ -439,7 +438,8 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
 template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV, int PSRC = 0>
 __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, int wgid) {
     static_assert(PSRC == 0 || (MODE == H3 && KMV && !AK && !BKC), "pair-format sources: the wgrad layout of the fp16-split arithmetic only");
-    const bool pa_ = PSRC == 4 ? p.d.a_planes != 0 : (PSRC & 1) != 0, pb_ = PSRC == 4 ? p.d.b_planes != 0 : (PSRC & 2) != 0;
+    static_assert(PSRC >= 0 && PSRC <= 3, "PSRC 4 (formats per product) is resolved by the grouped kernel");
+    constexpr bool pa_ = (PSRC & 1) != 0, pb_ = (PSRC & 2) != 0;
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
     constexpr int NQA = BM * 4 / NT, NQB = BN * 4 / NT;
     constexpr bool AV = !AK && KMV, BV = !BKC && KMV;
@@ -496,17 +496,17 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
         Frags<NP, TM, TN> fr[2];                  // fragments of even / odd slabs
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
-            if (pa_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
+            if constexpr (pa_) load_quads_pairs<NT, BM>(reinterpret_cast<const uint16_t*>(d.A), d.lda, d.a_rowmax, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
             else load_quads<NT, BM, AK, VEC, AV>(d.A, d.lda, m0, kr.k_of(u < nsteps ? u : 0), d.M, kr.kend, qa[u]);
-            if (pb_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
+            if constexpr (pb_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
             else load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
         }
-        if (pa_) store_quads_pairs<NT, BM, true>(smem, qa[0], kr.kend - kr.kbeg, 141 - sha[0][0]);
+        if constexpr (pa_) store_quads_pairs<NT, BM, true>(smem, qa[0], kr.kend - kr.kbeg, 141 - sha[0][0]);
         else store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF, AV>(smem, qa[0], kr.kend - kr.kbeg, sha);
-        if (pb_) store_quads_pairs<NT, BN, true>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, 141 - shb[0][0]);
+        if constexpr (pb_) store_quads_pairs<NT, BN, true>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, 141 - shb[0][0]);
         else store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF, BV>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, shb);
         if (!AK && do_cs) {
-            if (pa_) quad_rowsum_pairs<NT, BM, true>(qa[0], kr.kend - kr.kbeg, cs);
+            if constexpr (pa_) quad_rowsum_pairs<NT, BM, true>(qa[0], kr.kend - kr.kbeg, cs);
             else quad_rowsum<NT, BM, AV, true>(qa[0], kr.kend - kr.kbeg, cs);
         }
         __syncthreads();
@@ -610,7 +610,42 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x_grouped_kernel(const GemmPar
     const int wg = blockIdx.x;
     int g = 0;
     while (g + 1 < nprob && wg >= wg_begin[g + 1]) ++g;
-    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, PSRC>(ps[g], wg_begin[g + 1] - wg_begin[g], wg - wg_begin[g]);
+    if constexpr (PSRC == 4) {
+        // products of mixed operand formats in one launch: every workgroup runs the body SPECIALISED for its product's formats (one uniform
+        // branch per workgroup; a body that decides per load measured 13 % slower: the pinned MFMA / VALU interleave assumes one instruction mix)
+        const int f = (ps[g].d.a_planes ? 1 : 0) | (ps[g].d.b_planes ? 2 : 0);
+        const int nwg = wg_begin[g + 1] - wg_begin[g], id = wg - wg_begin[g];
+        if (f == 0) gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, 0>(ps[g], nwg, id);
+        else if (f == 1) gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, 1>(ps[g], nwg, id);
+        else if (f == 2) gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, 2>(ps[g], nwg, id);
+        else gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, 3>(ps[g], nwg, id);
+    } else {
+        gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV, PSRC>(ps[g], wg_begin[g + 1] - wg_begin[g], wg - wg_begin[g]);
+    }
+}
+
+// the same product of up to four independent problems (the four writer heads) in one grid: at small batches one head's product leaves
+// most of the chip idle for a whole tile time (batch 32: 44 .. 176 workgroups on 256 CUs)
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16x_group4_kernel(GemmGroup4 g) {
+    const int i = group4_find(g, blockIdx.x);
+    gemm_bf16x_body<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV>(g.p[i], g.wg_begin[i + 1] - g.wg_begin[i], blockIdx.x - g.wg_begin[i]);
+}
+
+template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
+int launch_group4_mode(hipStream_t st, const GemmGroup4& g) {
+    constexpr size_t stages = 2 * (size_t)Pieces<MODE>::NP * (PieceBytes<BM, !AK && KMV>::value + PieceBytes<BN, !BKC && KMV>::value);
+    constexpr size_t staging = (NT / 64) * (size_t)EPI_WAVE_BYTES;
+    constexpr size_t smem = stages > staging ? stages : staging;
+    auto kern = gemm_bf16x_group4_kernel<NT, MODE, BM, BN, WN, AK, BKC, VEC, KMV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return GRAPPA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    GRAPPA_LAUNCH(kern, dim3(g.wg_begin[g.count]), dim3(NT), smem, st, g);
+    return grappa_launch_status();
 }
 
 template <int NT, int MODE, int BM, int BN, int WN, bool AK, bool BKC, bool VEC, bool KMV>
@@ -667,8 +702,16 @@ int launch_grouped_wgrad(hipStream_t st, const GemmParams* d_ps, const int* d_wg
 }  // namespace
 
 // one arithmetic per translation unit: GRAPPA_BF16X_MODE_FUNCS(X6, x6) defines grappa_bf16x_launch_x6 / grappa_bf16x_launch_grouped_x6
+// forward (b_kcontig) or input-gradient layout, 16-byte loads, tile 256 x 128
+template <int MODE>
+int launch_group4(hipStream_t st, const GemmGroup4& g, bool b_kcontig) {
+    if (b_kcontig) return launch_group4_mode<512, MODE, 256, 128, 2, true, true, true, false>(st, g);
+    return launch_group4_mode<512, MODE, 256, 128, 2, true, false, true, true>(st, g);
+}
+
 #define GRAPPA_BF16X_MODE_FUNCS(MODE, NAME)                                                                                                  \
     int grappa_bf16x_launch_##NAME(hipStream_t st, GemmParams& p, bool vec_kcontig) { return launch_tile<MODE>(st, p, vec_kcontig); }       \
+    int grappa_bf16x_launch_group4_##NAME(hipStream_t st, const GemmGroup4& g, bool b_kcontig) { return launch_group4<MODE>(st, g, b_kcontig); } \
     int grappa_bf16x_launch_grouped_##NAME(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, bool vec, \
                                            int psrc) {                                                                                     \
         if constexpr (MODE == H3) {                                                                                                        \

@@ -45,6 +45,19 @@ struct GemmParams {
     int* tickets;
     const uint64_t* drop_salt;      // device word mixed into d.drop_seed (grappa_set_dropout_salt), or nullptr
 };
+// several independent forward / input-gradient products in ONE launch (grappa_gemm_f32_group: the same product of the four writer heads):
+// descriptors and the prefix of workgroups per product travel as the kernel's argument
+constexpr int GEMM_GROUP4_MAX = 4;
+struct GemmGroup4 {
+    GemmParams p[GEMM_GROUP4_MAX];
+    int wg_begin[GEMM_GROUP4_MAX + 1];
+    int count;
+};
+__device__ inline int group4_find(const GemmGroup4& g, int wg) {
+    int i = 0;
+    while (i + 1 < g.count && wg >= g.wg_begin[i + 1]) ++i;
+    return i;
+}
 __device__ inline uint64_t drop_seed_of(const GemmParams& p) { return grappa_salted(p.d.drop_seed, p.drop_salt); }
 
 // ---- plane format (include/grappa_hip.h): X = P0 + P1 + P2, three bf16 planes

@@ -23,6 +23,9 @@ int grappa_launch_gemm_bf16x(hipStream_t st, GemmParams& p, int precision, bool 
 int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision);                      // gemm_planes.hip
 int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p);                                      // gemm_pairs.hip
 int grappa_launch_amax_combine(hipStream_t st, int M, int nseg, const unsigned* part, unsigned* out);   // amax.hip
+int grappa_launch_gemm_bf16x_group4(hipStream_t st, const GemmGroup4& g, int precision, bool b_kcontig);   // gemm_bf16x.hip
+int grappa_launch_gemm_pairs_group4(hipStream_t st, const GemmGroup4& g);                                  // gemm_pairs.hip
+int grappa_launch_amax_combine4(hipStream_t st, int count, const int* M, const int* nseg, const unsigned* const* part, unsigned* const* out);   // amax.hip
 int grappa_launch_gemm_bf16x_grouped(hipStream_t st, const GemmParams* d_ps, const int* d_wg_begin, int nprob, int total_wgs, int precision, bool vec, int psrc);   // gemm_bf16x.hip
 
 namespace {
@@ -452,6 +455,23 @@ int dispatch(hipStream_t st, GemmParams& p, int cfg, bool vec) {
     return dispatch_cfg<AK, BKC, false>(st, p, cfg);
 }
 
+
+// the straight-line row epilogues (gemm_common.h epilogue_band_fast): one output tensor, whole float4s, no pre-activation addend
+int choose_epi_class(const grappa_gemm_desc& d, bool vec_io, bool bf16x) {
+    if (!(bf16x && (d.N & 3) == 0 && !d.C2 && !d.C1p && !d.pre && !d.accumulate)) return 0;
+    const bool f32_only = vec_io && d.C && !d.Cp && !d.resp && !d.auxp;
+    const bool bf16_only = d.Cp && !d.C && !d.res && !d.aux && d.cp_nplanes == 1 && (!d.resp || d.resp_nplanes == 1) &&
+                           (!d.auxp || d.auxp_nplanes == 1);
+    static const int fast_mask = getenv("GRAPPA_EPI_FAST") ? atoi(getenv("GRAPPA_EPI_FAST")) : 3;      // tuning only: bit 0 fp32, bit 1 bf16 classes
+    if (!((f32_only && (fast_mask & 1)) || (bf16_only && (fast_mask & 2)))) return 0;
+    const bool has_aux = d.aux || d.auxp, has_res = d.res || d.resp;
+    int cls;
+    if (has_aux) cls = (!d.bias && d.act == GRAPPA_ACT_NONE && d.drop_p == 0.0f) ? 4 : 0;
+    else if (d.act == GRAPPA_ACT_ELU) cls = (d.drop_p == 0.0f && !has_res) ? 2 : 0;
+    else cls = (d.drop_p > 0.0f || has_res) ? 3 : 1;
+    if (cls == 3 && d.res_ln_mean) cls = f32_only ? 5 : 0;             // the residual recomputed from the rows before their LayerNorm
+    return cls == 0 ? 0 : cls + (bf16_only ? 8 : 0);
+}
 }  // namespace
 
 // per-segment row maxima of OUT (d.out_amax): M x ceil(N / 32) words at most (32 columns = the narrowest wavefront share of a tile row),
@@ -800,22 +820,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     p.amax_part = nullptr;
     p.amax_seg = p.bm == 256 ? 64 : 32;                     // 256 x 128 tile: wavefronts of 64 columns; 128 x 128: of 32
     // the straight-line row epilogues (gemm_common.h epilogue_band_fast): one fp32 output, whole float4s, no pre-activation addend
-    p.epi_class = 0;
-    if (bf16x && (d->N & 3) == 0 && !d->C2 && !d->C1p && !d->pre && !d->accumulate) {
-        const bool f32_only = p.vec_io && d->C && !d->Cp && !d->resp && !d->auxp;
-        const bool bf16_only = d->Cp && !d->C && !d->res && !d->aux && d->cp_nplanes == 1 && (!d->resp || d->resp_nplanes == 1) &&
-                               (!d->auxp || d->auxp_nplanes == 1);
-        static const int fast_mask = getenv("GRAPPA_EPI_FAST") ? atoi(getenv("GRAPPA_EPI_FAST")) : 3;      // tuning only: bit 0 fp32, bit 1 bf16 classes
-        if ((f32_only && (fast_mask & 1)) || (bf16_only && (fast_mask & 2))) {
-            const bool has_aux = d->aux || d->auxp, has_res = d->res || d->resp;
-            int cls;
-            if (has_aux) cls = (!d->bias && d->act == GRAPPA_ACT_NONE && d->drop_p == 0.0f) ? 4 : 0;
-            else if (d->act == GRAPPA_ACT_ELU) cls = (d->drop_p == 0.0f && !has_res) ? 2 : 0;
-            else cls = (d->drop_p > 0.0f || has_res) ? 3 : 1;
-            if (cls == 3 && d->res_ln_mean) cls = f32_only ? 5 : 0;             // the residual recomputed from the rows before their LayerNorm
-            p.epi_class = cls == 0 ? 0 : cls + (bf16_only ? 8 : 0);
-        }
-    }
+    p.epi_class = choose_epi_class(*d, p.vec_io != 0, bf16x);
     if (amax_fused) {
         if (!ws || ws_bytes < need + amax_part_bytes(d->M, d->N)) return GRAPPA_ERR_WORKSPACE;
         p.amax_part = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + need);
@@ -827,6 +832,105 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     if (rc == GRAPPA_OK && d->out_amax && !amax_fused) {
         const float* o = d->C2 ? d->C2 : d->C;
         rc = grappa_amax_f32(stream, d->M, d->N, o, d->C2 ? d->ldc2 : d->ldc, d->out_amax, nullptr, nullptr, 0);
+    }
+    return rc;
+}
+
+
+// ------------------------------------------------------------------------------------------------ grouped forward / input-gradient products
+// Up to four independent products of ONE layout and operand format in one launch: the same product of the four writer heads.  Each
+// keeps its own epilogue (class, bias, residual, dropout seed, row maxima); no split-K (these products have K <= 2048), tile 256 x 128.
+namespace {
+bool group4_desc_ok(const grappa_gemm_desc& d, const grappa_gemm_desc& first) {
+    if (!d.A || !d.B || !d.C || d.Cp || d.C1p || d.resp || d.auxp || d.a_colsum) return false;
+    if (d.M <= 32 || d.N <= 32 || d.K <= 0 || !d.a_kcontig) return false;
+    if (d.precision != first.precision || d.precision == GRAPPA_GEMM_F32_MFMA || d.b_kcontig != first.b_kcontig) return false;
+    if ((d.a_planes != 0) != (first.a_planes != 0) || (d.b_planes != 0) != (first.b_planes != 0)) return false;
+    if (d.drop_p < 0.0f || d.drop_p >= 1.0f) return false;
+    const bool pairs = d.a_planes && d.b_planes;
+    if ((d.a_planes || d.b_planes) && !(pairs && d.precision == GRAPPA_GEMM_F32_F16X3 && d.b_kcontig && !d.amax_bcast)) return false;
+    if (d.precision == GRAPPA_GEMM_F32_F16X3 && (!d.a_amax || !d.b_amax)) return false;
+    if (pairs) {
+        const int kpad = (d.K + 31) / 32 * 32;
+        auto ok = [](const void* q, int ld, int cols) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 7) == 0 && ld >= cols; };
+        if (!ok(d.A, d.lda, 2 * kpad) || !ok(d.B, d.ldb, 2 * kpad)) return false;
+        if ((size_t)d.M * d.lda * 2 >= (1ull << 32) || (size_t)d.N * d.ldb * 2 >= (1ull << 32)) return false;
+    } else {
+        // 16-byte loads: K-contiguous operands along k (K % 4 == 0), the row-contiguous weight of the input gradient along its rows
+        const bool vecA = (reinterpret_cast<uintptr_t>(d.A) & 15) == 0 && (d.lda & 3) == 0 && (d.K & 3) == 0;
+        const bool vecB = (reinterpret_cast<uintptr_t>(d.B) & 15) == 0 && (d.ldb & 3) == 0 && (!d.b_kcontig || (d.K & 3) == 0);
+        const bool padB = d.b_kcontig || ((d.N + 3) & ~3) <= d.ldb;
+        if (!(vecA && vecB && padB)) return false;
+    }
+    if (d.res_ln_mean && (!d.res || !d.res_ln_rstd || !d.res_ln_gamma || !d.res_ln_beta || (d.N & 3) || d.aux ||
+                          ((reinterpret_cast<uintptr_t>(d.res_ln_gamma) | reinterpret_cast<uintptr_t>(d.res_ln_beta)) & 15) != 0))
+        return false;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t grappa_gemm_f32_group_workspace_bytes(const grappa_gemm_desc* descs, int n) {
+    if (!descs || n <= 0 || n > GEMM_GROUP4_MAX) return 0;
+    size_t need = 0;
+    for (int i = 0; i < n; ++i)
+        if (descs[i].out_amax) need += (amax_part_bytes(descs[i].M, descs[i].N) + 255) / 256 * 256;
+    return need;
+}
+
+extern "C" int grappa_gemm_f32_group(void* stream, const grappa_gemm_desc* descs, int n, void* ws, size_t ws_bytes) {
+    if (!descs || n <= 0 || n > GEMM_GROUP4_MAX) return GRAPPA_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!group4_desc_ok(descs[i], descs[0])) return GRAPPA_ERR_ARG;
+    if (ws_bytes < grappa_gemm_f32_group_workspace_bytes(descs, n) || (ws_bytes > 0 && !ws)) return GRAPPA_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
+    GemmGroup4 g;
+    g.count = n;
+    g.wg_begin[0] = 0;
+    char* part = reinterpret_cast<char*>(ws);
+    for (int i = 0; i < n; ++i) {
+        const grappa_gemm_desc& d = descs[i];
+        GemmParams& p = g.p[i];
+        p.d = d;
+        p.bm = 256;
+        p.bn = 128;
+        p.tiles_m = (d.M + 255) / 256;
+        p.tiles_n = (d.N + 127) / 128;
+        p.tile_begin = 0;
+        p.ntiles_launch = p.tiles_m * p.tiles_n;
+        p.nsplit = 1;
+        p.k_per_split = (d.K + BK - 1) / BK * BK;
+        p.slab = nullptr;
+        p.cs_slab = nullptr;
+        p.tickets = nullptr;
+        p.drop_scale = d.drop_p > 0.0f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+        p.drop_salt = g_grappa_drop_salt;
+        p.vec_io = al16(d.C, d.ldc) && al16(d.C2, d.ldc2) && al16(d.pre, d.ldpre) && al16(d.res, d.ldres) && al16(d.aux, d.ldaux);
+        p.epi_class = choose_epi_class(d, p.vec_io != 0, true);
+        p.amax_seg = 64;
+        p.amax_part = nullptr;
+        if (d.out_amax) {
+            p.amax_part = reinterpret_cast<unsigned*>(part);
+            part += (amax_part_bytes(d.M, d.N) + 255) / 256 * 256;
+        }
+        g.wg_begin[i + 1] = g.wg_begin[i] + p.ntiles_launch;
+    }
+    for (int i = n; i < GEMM_GROUP4_MAX; ++i) g.wg_begin[i + 1] = g.wg_begin[n];
+    int rc = (descs[0].a_planes && descs[0].b_planes) ? grappa_launch_gemm_pairs_group4(st, g)
+                                                      : grappa_launch_gemm_bf16x_group4(st, g, descs[0].precision, descs[0].b_kcontig != 0);
+    if (rc == GRAPPA_OK) {                       // the row maxima of every product that asked for them: one combine launch
+        int cnt = 0, Ms[4], segs[4];
+        const unsigned* parts[4];
+        unsigned* outs[4];
+        for (int i = 0; i < n; ++i)
+            if (descs[i].out_amax) {
+                Ms[cnt] = descs[i].M;
+                segs[cnt] = (descs[i].N + 63) / 64;
+                parts[cnt] = g.p[i].amax_part;
+                outs[cnt] = descs[i].out_amax;
+                ++cnt;
+            }
+        if (cnt) rc = grappa_launch_amax_combine4(st, cnt, Ms, segs, parts, outs);
     }
     return rc;
 }

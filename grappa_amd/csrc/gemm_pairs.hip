@@ -113,12 +113,12 @@ __device__ inline void qmfma(const QFrags& f, f32x16 (&acc)[QTM][QTN]) {
 }
 
 template <int QBN>
-__global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_pairs_body(const GemmParams& p, int nwg, int wgid) {
     using S = QShape<QBN>;
     constexpr int QSTAGE = S::STAGE, QPIECES = S::PIECES;
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
-    const TileCoord tc = map_workgroup(p);
+    const TileCoord tc = map_logical(p, nwg, wgid);
     const int split = tc.split, tile_local = tc.tile_local;
     const int m0 = tc.tile_m * QBM, n0 = tc.tile_n * QBN;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -246,6 +246,16 @@ __global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_kernel(GemmPara
     }
 #pragma unroll
     for (int i = 0; i < QTM; ++i) epilogue_band<QBM, QBN, QTN>(p, acc[i], wave_buf, m0, n0, mb + 32 * i, n, lane, b4, split, tile_local, p.vec_io != 0);
+}
+
+template <int QBN>
+__global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_kernel(GemmParams p) { gemm_pairs_body<QBN>(p, gridDim.x, blockIdx.x); }
+
+// up to four independent pair-format products (the same product of the four writer heads) in one grid
+template <int QBN>
+__global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_group4_kernel(GemmGroup4 g) {
+    const int i = group4_find(g, blockIdx.x);
+    gemm_pairs_body<QBN>(g.p[i], g.wg_begin[i + 1] - g.wg_begin[i], blockIdx.x - g.wg_begin[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -590,6 +600,22 @@ extern "C" int grappa_split_pairs_f32(void* stream, int R, int C, const float* x
     if (!x || !amax || !pairs || ldx < C || ldp < 2 * ((kk + 15) / 16 * 16)) return GRAPPA_ERR_ARG;
     GRAPPA_LAUNCH(split_pairs_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), R, C, x, ldx,
                        amax, pairs, ldp, transpose);
+    return grappa_launch_status();
+}
+
+// called by grappa_gemm_f32_group: pair-format products, tile 256 x 128, two workgroups per CU
+int grappa_launch_gemm_pairs_group4(hipStream_t st, const GemmGroup4& g) {
+    using S = QShape<128>;
+    constexpr size_t ring = (size_t)QNSTAGE * S::STAGE, staging = S::NW * (size_t)EPI_WAVE_BYTES;
+    constexpr size_t smem = ring > staging ? ring : staging;
+    auto kern = gemm_pairs_group4_kernel<128>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return GRAPPA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    GRAPPA_LAUNCH(kern, dim3(g.wg_begin[g.count]), dim3(S::NT), smem, st, g);
     return grappa_launch_status();
 }
 

@@ -22,13 +22,13 @@ __device__ inline unsigned wave_umax(unsigned v) {
 // NCH = float4 chunks per lane (row width <= 256 * NCH): the row lives in registers, so the chunk count is a template parameter --
 // sized for the widest row (8 chunks) every width would carry ~130 live registers and run at 3 wavefronts per SIMD
 template <int NCH, bool STORE_STATS, typename T>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const T* __restrict__ x, int ldx,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            T* __restrict__ y, int ldy, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out, unsigned* __restrict__ y_amax) {
+__device__ __forceinline__ void layernorm_fwd_body(int M, int W, const T* __restrict__ x, int ldx,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   T* __restrict__ y, int ldy, float* __restrict__ mean_out,
+                                                   float* __restrict__ rstd_out, unsigned* __restrict__ y_amax, int vblock, int vnblocks) {
     const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int wave_global = (vblock * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (vnblocks * blockDim.x) >> 6;
     const int nvec = W >> 2;
     // one row per wavefront and trip.  (Two rows per trip measured 20 % faster on the widest tables, but that kernel is the one
     // that returned deviating rows when several queues ran this library's kernels at once -- DESIGN.md section 6 -- so it is not used.)
@@ -81,6 +81,30 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const 
             if (lane == 0) y_amax[row] = am;
         }
     }
+}
+
+template <int NCH, bool STORE_STATS, typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int M, int W, const T* __restrict__ x, int ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ y, int ldy, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, unsigned* __restrict__ y_amax) {
+    layernorm_fwd_body<NCH, STORE_STATS, T>(M, W, x, ldx, gamma, beta, y, ldy, mean_out, rstd_out, y_amax, blockIdx.x, gridDim.x);
+}
+
+// several LayerNorms in ONE launch (the same LayerNorm of the four writer heads, layer-locked: ops.MultiTransformerLayerFn): every item has
+// its own rows, width, gamma / beta; a workgroup finds its item by the prefix of workgroups
+struct LnFwdBatch {
+    grappa_ln_fwd_item it[GRAPPA_ROW_BATCH_MAX];
+    int blk_begin[GRAPPA_ROW_BATCH_MAX + 1];
+    int count;
+};
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_batched_kernel(LnFwdBatch b) {
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.blk_begin[i + 1]) ++i;
+    const grappa_ln_fwd_item& t = b.it[i];
+    layernorm_fwd_body<NCH, true, float>(t.M, t.W, t.x, t.ldx, t.gamma, t.beta, t.y, t.ldy, t.mean, t.rstd, t.y_amax, (int)blockIdx.x - b.blk_begin[i],
+                                         b.blk_begin[i + 1] - b.blk_begin[i]);
 }
 
 // The same rows also written in the PAIR format (fp16 hi / lo halves scaled by the row's largest magnitude, common.h st_pairs4): the A
@@ -154,15 +178,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_pairs_kernel(int M, int W, 
 
 // dx per row; per-block partial dgamma/dbeta into part[block][2][W]
 template <int NCH, typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const T* __restrict__ dy, int lddy,
-                                                            const T* __restrict__ x, int ldx, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                            T* __restrict__ dx, int lddx, float* __restrict__ part,
-                                                            unsigned* __restrict__ dx_amax) {
+__device__ __forceinline__ void layernorm_bwd_body(int M, int W, const T* __restrict__ dy, int lddy,
+                                                   const T* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                   T* __restrict__ dx, int lddx, float* __restrict__ part,
+                                                   unsigned* __restrict__ dx_amax, int vblock, int vnblocks) {
     extern __shared__ float red[];   // [4 waves][2][W]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_global = blockIdx.x * 4 + wave;
-    const int nwaves = gridDim.x * 4;
+    const int wave_global = vblock * 4 + wave;
+    const int nwaves = vnblocks * 4;
     const int nvec = W >> 2;
     float4 dg[NCH], db[NCH];
 #pragma unroll
@@ -225,8 +249,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[(size_t)(w * 2 + which) * W + col];
-        part[((size_t)blockIdx.x * 2 + which) * W + col] = s;
+        part[((size_t)vblock * 2 + which) * W + col] = s;
     }
+}
+
+template <int NCH, typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const T* __restrict__ dy, int lddy,
+                                                            const T* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            T* __restrict__ dx, int lddx, float* __restrict__ part,
+                                                            unsigned* __restrict__ dx_amax) {
+    layernorm_bwd_body<NCH, T>(M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax, blockIdx.x, gridDim.x);
+}
+
+struct LnBwdBatch {
+    grappa_ln_bwd_item it[GRAPPA_ROW_BATCH_MAX];
+    int blk_begin[GRAPPA_ROW_BATCH_MAX + 1];
+    int count;
+};
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_batched_kernel(LnBwdBatch b) {
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.blk_begin[i + 1]) ++i;
+    const grappa_ln_bwd_item& t = b.it[i];
+    layernorm_bwd_body<NCH, float>(t.M, t.W, t.dy, t.lddy, t.x, t.ldx, t.mean, t.rstd, t.gamma, t.dx, t.lddx, t.part, t.dx_amax,
+                                   (int)blockIdx.x - b.blk_begin[i], b.blk_begin[i + 1] - b.blk_begin[i]);
 }
 
 // out[g*out_stride + j] (+)= sum over rows b in group g of part[b*stride + j]   (grid.y = number of groups)
@@ -364,13 +411,13 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_vec_kernel(int M, int N, 
 // the same, one wavefront per row (as LayerNorm), so that the row's largest |dz| falls out of a wavefront reduction (dz_amax: the scale
 // of the F32_F16X3 products that read dz).  N <= 256 * NCH, 16-byte accesses.
 template <int NCH>
-__global__ __launch_bounds__(256) void act_dropout_bwd_rows_kernel(int M, int N, const float* __restrict__ dy, int lddy,
-                                                                   const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed, const uint64_t* __restrict__ salt,
-                                                                   float* __restrict__ dz, int lddz, unsigned* __restrict__ dz_amax) {
+__device__ __forceinline__ void act_dropout_bwd_rows_body(int M, int N, const float* __restrict__ dy, int lddy,
+                                                          const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed, const uint64_t* __restrict__ salt,
+                                                          float* __restrict__ dz, int lddz, unsigned* __restrict__ dz_amax, int vblock, int vnblocks) {
     seed = grappa_salted(seed, salt);
     const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int wave_global = (vblock * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (vnblocks * blockDim.x) >> 6;
     const int nvec = N >> 2;
     for (int row = wave_global; row < M; row += nwaves) {
         unsigned am = 0u;
@@ -398,6 +445,27 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_rows_kernel(int M, int N,
         am = wave_umax(am);
         if (lane == 0) dz_amax[row] = am;
     }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void act_dropout_bwd_rows_kernel(int M, int N, const float* __restrict__ dy, int lddy,
+                                                                   const float* __restrict__ y, int ldy, float p, float scale, uint64_t seed, const uint64_t* __restrict__ salt,
+                                                                   float* __restrict__ dz, int lddz, unsigned* __restrict__ dz_amax) {
+    act_dropout_bwd_rows_body<NCH>(M, N, dy, lddy, y, ldy, p, scale, seed, salt, dz, lddz, dz_amax, blockIdx.x, gridDim.x);
+}
+
+struct ActDropBatch {
+    grappa_act_dropout_item it[GRAPPA_ROW_BATCH_MAX];
+    int blk_begin[GRAPPA_ROW_BATCH_MAX + 1];
+    int count;
+};
+template <int NCH>
+__global__ __launch_bounds__(256) void act_dropout_bwd_batched_kernel(ActDropBatch b, const uint64_t* __restrict__ salt) {
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.blk_begin[i + 1]) ++i;
+    const grappa_act_dropout_item& t = b.it[i];
+    act_dropout_bwd_rows_body<NCH>(t.M, t.N, t.dy, t.lddy, t.y, t.ldy, t.drop_p, t.drop_p > 0.f ? 1.0f / (1.0f - t.drop_p) : 1.0f, t.drop_seed, salt, t.dz, t.lddz,
+                                   t.dz_amax, (int)blockIdx.x - b.blk_begin[i], b.blk_begin[i + 1] - b.blk_begin[i]);
 }
 
 // the same rows written in the PAIR format (dz itself optional): the A operand of the input-gradient product and an operand of the
@@ -776,6 +844,94 @@ extern "C" int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const
 #undef GRAPPA_ADB
     return grappa_launch_status();
 }
+// ---- batched row-wise kernels (C ABI 8): the same kernel of up to GRAPPA_ROW_BATCH_MAX independent tensors in one launch
+namespace {
+template <typename Item>
+bool row_items_ok(const Item* items, int count) { return items && count > 0 && count <= GRAPPA_ROW_BATCH_MAX; }
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+}  // namespace
+
+extern "C" int grappa_layernorm_fwd_batched_f32(void* stream, const grappa_ln_fwd_item* items, int count) {
+    if (!row_items_ok(items, count)) return GRAPPA_ERR_ARG;
+    LnFwdBatch b;
+    b.count = count;
+    b.blk_begin[0] = 0;
+    int wmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const grappa_ln_fwd_item& t = items[i];
+        if (t.M < 0 || t.W <= 0 || (t.W & 3) || t.W > 2048 || (t.ldx & 3) || (t.ldy & 3)) return GRAPPA_ERR_ARG;
+        if (t.M > 0 && (!t.x || !t.gamma || !t.beta || !t.y || !t.mean || !t.rstd || !al16(t.x) || !al16(t.y) || !al16(t.gamma) || !al16(t.beta))) return GRAPPA_ERR_ARG;
+        b.it[i] = t;
+        const int blocks = t.W <= 1024 ? ((t.M + 3) / 4 > 2048 ? 2048 : (t.M + 3) / 4) : ln_blocks(t.M);
+        b.blk_begin[i + 1] = b.blk_begin[i] + (t.M > 0 ? blocks : 0);
+        wmax = t.W > wmax ? t.W : wmax;
+    }
+    for (int i = count; i < GRAPPA_ROW_BATCH_MAX; ++i) b.blk_begin[i + 1] = b.blk_begin[count];
+    if (b.blk_begin[count] == 0) return GRAPPA_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define GRAPPA_LNB(NCH) GRAPPA_LAUNCH((layernorm_fwd_batched_kernel<NCH>), dim3(b.blk_begin[count]), dim3(256), 0, st, b)
+    if (wmax <= 256) GRAPPA_LNB(1);
+    else if (wmax <= 512) GRAPPA_LNB(2);
+    else if (wmax <= 1024) GRAPPA_LNB(4);
+    else GRAPPA_LNB(8);
+#undef GRAPPA_LNB
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_layernorm_bwd_batched_f32(void* stream, const grappa_ln_bwd_item* items, int count) {
+    if (!row_items_ok(items, count)) return GRAPPA_ERR_ARG;
+    LnBwdBatch b;
+    b.count = count;
+    b.blk_begin[0] = 0;
+    int wmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const grappa_ln_bwd_item& t = items[i];
+        if (t.M < 0 || t.W <= 0 || (t.W & 3) || t.W > 2048 || (t.ldx & 3) || (t.lddy & 3) || (t.lddx & 3)) return GRAPPA_ERR_ARG;
+        if (t.M > 0 && (!t.dy || !t.x || !t.mean || !t.rstd || !t.gamma || !t.dx || !t.part || !al16(t.dy) || !al16(t.x) || !al16(t.dx) || !al16(t.gamma)))
+            return GRAPPA_ERR_ARG;
+        b.it[i] = t;
+        b.blk_begin[i + 1] = b.blk_begin[i] + (t.M > 0 ? ln_blocks(t.M) : 0);          // = grappa_layernorm_bwd_partial_rows(M) rows of partials
+        wmax = t.W > wmax ? t.W : wmax;
+    }
+    for (int i = count; i < GRAPPA_ROW_BATCH_MAX; ++i) b.blk_begin[i + 1] = b.blk_begin[count];
+    if (b.blk_begin[count] == 0) return GRAPPA_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t smem = (size_t)4 * 2 * wmax * sizeof(float);
+#define GRAPPA_LNBB(NCH) GRAPPA_LAUNCH((layernorm_bwd_batched_kernel<NCH>), dim3(b.blk_begin[count]), dim3(256), smem, st, b)
+    if (wmax <= 256) GRAPPA_LNBB(1);
+    else if (wmax <= 512) GRAPPA_LNBB(2);
+    else if (wmax <= 1024) GRAPPA_LNBB(4);
+    else GRAPPA_LNBB(8);
+#undef GRAPPA_LNBB
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_act_dropout_bwd_batched_f32(void* stream, const grappa_act_dropout_item* items, int count) {
+    if (!row_items_ok(items, count)) return GRAPPA_ERR_ARG;
+    ActDropBatch b;
+    b.count = count;
+    b.blk_begin[0] = 0;
+    int nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const grappa_act_dropout_item& t = items[i];
+        if (t.M < 0 || t.N <= 0 || (t.N & 3) || t.N > 2048 || (t.lddy & 3) || (t.lddz & 3) || (t.y && (t.ldy & 3)) || t.drop_p < 0.f || t.drop_p >= 1.f) return GRAPPA_ERR_ARG;
+        if (t.M > 0 && (!t.dy || !t.dz || !t.dz_amax || !al16(t.dy) || !al16(t.dz) || !al16(t.y))) return GRAPPA_ERR_ARG;
+        b.it[i] = t;
+        b.blk_begin[i + 1] = b.blk_begin[i] + (t.M > 0 ? ((t.M + 3) / 4 > 2048 ? 2048 : (t.M + 3) / 4) : 0);
+        nmax = t.N > nmax ? t.N : nmax;
+    }
+    for (int i = count; i < GRAPPA_ROW_BATCH_MAX; ++i) b.blk_begin[i + 1] = b.blk_begin[count];
+    if (b.blk_begin[count] == 0) return GRAPPA_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define GRAPPA_ADBB(NCH) GRAPPA_LAUNCH((act_dropout_bwd_batched_kernel<NCH>), dim3(b.blk_begin[count]), dim3(256), 0, st, b, g_grappa_drop_salt)
+    if (nmax <= 256) GRAPPA_ADBB(1);
+    else if (nmax <= 512) GRAPPA_ADBB(2);
+    else if (nmax <= 1024) GRAPPA_ADBB(4);
+    else GRAPPA_ADBB(8);
+#undef GRAPPA_ADBB
+    return grappa_launch_status();
+}
+
 extern "C" int grappa_act_dropout_bwd_pairs_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy, float drop_p,
                                                 uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, uint16_t* pairs, int ldp) {
     if (M < 0 || N <= 0 || (N & 31) || N > 2048 || drop_p < 0.f || drop_p >= 1.f || (lddy & 3) || (dz && (lddz & 3)) || (y && (ldy & 3)) || ldp < 2 * N || (ldp & 7))

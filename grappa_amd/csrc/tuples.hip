@@ -72,10 +72,10 @@ __device__ inline unsigned wave_umax(unsigned v) {
 
 // row_amax (optional): largest |out| of each of the tuple's S token rows
 template <int S, typename TE>
-__global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, TE* __restrict__ out,
-                                                          unsigned* __restrict__ row_amax) {
+__device__ __forceinline__ void seqattn_fwd_body(int T, int F, int dh, const TE* __restrict__ qkv, TE* __restrict__ out,
+                                                 unsigned* __restrict__ row_amax, int vblock) {
     const int lane = threadIdx.x & 63;
-    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int t = (vblock * blockDim.x + threadIdx.x) >> 6;
     if (t >= T) return;
     const int nvec = F >> 2, lph = dh >> 2;
     const float scale = 1.0f / sqrtf((float)dh);
@@ -126,6 +126,31 @@ __global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, 
             const unsigned m = wave_umax(am[i]);
             if (lane == 0) row_amax[(size_t)i * T + t] = m;
         }
+    }
+}
+
+template <int S, typename TE>
+__global__ __launch_bounds__(256) void seqattn_fwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, TE* __restrict__ out,
+                                                          unsigned* __restrict__ row_amax) {
+    seqattn_fwd_body<S, TE>(T, F, dh, qkv, out, row_amax, blockIdx.x);
+}
+
+// the attention of several heads (different s, T) in ONE launch: C ABI 8 grappa_seqattn_fwd_batched_f32 / _bwd_
+struct SeqAttnBatch {
+    grappa_seqattn_item it[GRAPPA_ROW_BATCH_MAX];
+    int blk_begin[GRAPPA_ROW_BATCH_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void seqattn_fwd_batched_kernel(SeqAttnBatch b) {
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.blk_begin[i + 1]) ++i;
+    const grappa_seqattn_item& t = b.it[i];
+    const int vb = (int)blockIdx.x - b.blk_begin[i], F = t.nheads * t.dh;
+    switch (t.s) {
+        case 1: seqattn_fwd_body<1, float>(t.T, F, t.dh, t.qkv, t.out, t.amax, vb); break;
+        case 2: seqattn_fwd_body<2, float>(t.T, F, t.dh, t.qkv, t.out, t.amax, vb); break;
+        case 3: seqattn_fwd_body<3, float>(t.T, F, t.dh, t.qkv, t.out, t.amax, vb); break;
+        default: seqattn_fwd_body<4, float>(t.T, F, t.dh, t.qkv, t.out, t.amax, vb); break;
     }
 }
 
@@ -195,10 +220,10 @@ __global__ __launch_bounds__(256) void seqattn_fwd_pairs_kernel(int T, int F, in
 }
 
 template <int S, typename TE>
-__global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, const TE* __restrict__ dout,
-                                                          TE* __restrict__ dqkv, unsigned* __restrict__ row_amax) {
+__device__ __forceinline__ void seqattn_bwd_body(int T, int F, int dh, const TE* __restrict__ qkv, const TE* __restrict__ dout,
+                                                 TE* __restrict__ dqkv, unsigned* __restrict__ row_amax, int vblock) {
     const int lane = threadIdx.x & 63;
-    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int t = (vblock * blockDim.x + threadIdx.x) >> 6;
     if (t >= T) return;
     const int nvec = F >> 2, lph = dh >> 2;
     const float scale = 1.0f / sqrtf((float)dh);
@@ -269,6 +294,24 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, 
     }
 }
 
+template <int S, typename TE>
+__global__ __launch_bounds__(256) void seqattn_bwd_kernel(int T, int F, int dh, const TE* __restrict__ qkv, const TE* __restrict__ dout,
+                                                          TE* __restrict__ dqkv, unsigned* __restrict__ row_amax) {
+    seqattn_bwd_body<S, TE>(T, F, dh, qkv, dout, dqkv, row_amax, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void seqattn_bwd_batched_kernel(SeqAttnBatch b) {
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.blk_begin[i + 1]) ++i;
+    const grappa_seqattn_item& t = b.it[i];
+    const int vb = (int)blockIdx.x - b.blk_begin[i], F = t.nheads * t.dh;
+    switch (t.s) {
+        case 1: seqattn_bwd_body<1, float>(t.T, F, t.dh, t.qkv, t.dout, t.dqkv, t.amax, vb); break;
+        case 2: seqattn_bwd_body<2, float>(t.T, F, t.dh, t.qkv, t.dout, t.dqkv, t.amax, vb); break;
+        case 3: seqattn_bwd_body<3, float>(t.T, F, t.dh, t.qkv, t.dout, t.dqkv, t.amax, vb); break;
+        default: seqattn_bwd_body<4, float>(t.T, F, t.dh, t.qkv, t.dout, t.dqkv, t.amax, vb); break;
+    }
+}
 
 // ---- the same with E elements per lane (E = 8: 16-byte accesses of bf16 rows, see Chunk<E> in common.h)
 template <int S, int E, typename TE>
@@ -688,6 +731,41 @@ extern "C" int grappa_tuple_gather_bwd_bf16(void* stream, int N, int W, const in
                                             uint16_t* da, int ldda, int has_pe, int accumulate) {
     return tuple_gather_bwd_impl<grappa_bf16_t, grappa_bf16_t>(stream, N, W, inv_ptr, inv_rows, dx, lddx, da, ldda, has_pe, accumulate);
 }
+namespace {
+int seqattn_batch(const grappa_seqattn_item* items, int count, bool bwd, SeqAttnBatch& b) {
+    if (!items || count <= 0 || count > GRAPPA_ROW_BATCH_MAX) return GRAPPA_ERR_ARG;
+    b.count = count;
+    b.blk_begin[0] = 0;
+    for (int i = 0; i < count; ++i) {
+        const grappa_seqattn_item& t = items[i];
+        if (t.s < 1 || t.s > 4 || t.T < 0 || t.nheads <= 0 || t.dh <= 0 || (t.dh & 3) || !pow2(t.dh / 4) || t.dh / 4 > 64 || t.nheads * t.dh > 1024) return GRAPPA_ERR_ARG;
+        if (t.T > 0) {
+            if (!t.qkv || !aligned_el<float>(t.qkv)) return GRAPPA_ERR_ARG;
+            if (bwd ? (!t.dout || !t.dqkv || !aligned_el<float>(t.dout) || !aligned_el<float>(t.dqkv)) : (!t.out || !aligned_el<float>(t.out))) return GRAPPA_ERR_ARG;
+        }
+        b.it[i] = t;
+        b.blk_begin[i + 1] = b.blk_begin[i] + (t.T + 3) / 4;
+    }
+    for (int i = count; i < GRAPPA_ROW_BATCH_MAX; ++i) b.blk_begin[i + 1] = b.blk_begin[count];
+    return GRAPPA_OK;
+}
+}  // namespace
+
+extern "C" int grappa_seqattn_fwd_batched_f32(void* stream, const grappa_seqattn_item* items, int count) {
+    SeqAttnBatch b;
+    const int rc = seqattn_batch(items, count, false, b);
+    if (rc != GRAPPA_OK || b.blk_begin[count] == 0) return rc;
+    GRAPPA_LAUNCH(seqattn_fwd_batched_kernel, dim3(b.blk_begin[count]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    return grappa_launch_status();
+}
+extern "C" int grappa_seqattn_bwd_batched_f32(void* stream, const grappa_seqattn_item* items, int count) {
+    SeqAttnBatch b;
+    const int rc = seqattn_batch(items, count, true, b);
+    if (rc != GRAPPA_OK || b.blk_begin[count] == 0) return rc;
+    GRAPPA_LAUNCH(seqattn_bwd_batched_kernel, dim3(b.blk_begin[count]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    return grappa_launch_status();
+}
+
 extern "C" int grappa_seqattn_fwd_f32(void* stream, int s, int T, int nheads, int dh, const float* qkv, float* out) {
     return seqattn_fwd_impl<float>(stream, s, T, nheads, dh, qkv, out);
 }

@@ -309,6 +309,37 @@ class _WriterBase(nn.Module):
     def _consts(self) -> torch.Tensor:
         raise NotImplementedError
 
+    def _tokens(self, g):
+        """atom embeddings -> tokens, through the first transformer layer where that runs on (atom, position) rows:
+        (x (s*T, F), T, transformer layers still to run)"""
+        plan = g.plan()
+        lvl = self.level
+        h = g.nodes["n1"].data["h"]
+        model = self._model()
+        T, N = plan.T[lvl], plan.N
+        pe = None
+        layers = []
+        if model.grappa_transformer is not None:
+            layers = list(model.grappa_transformer.transformer)
+            if model.grappa_transformer.positional_encoding is not None:
+                pe = model.grappa_transformer.positional_encoding.reshape(-1).contiguous()
+        lin = self.rep_projector.mlp[0]
+        if ops.FIRST_LAYER_ON_ATOM_ROWS and layers and T > 0 and 4 * N <= 3 * T:
+            l0 = layers[0]
+            p = l0.p if l0.training else 0.0
+            s1, s2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+            ops.mark_mode()
+            x = ops.ProjFirstLayerFn.apply(h, lin.weight, lin.bias, plan.position_tables(lvl), self.s, T, pe, ops.act_dtype(), l0.num_heads, p, s1, s2,
+                                           *_wb(getattr(l0, "norm1", None)), l0.attn.in_proj_weight, l0.attn.in_proj_bias,
+                                           l0.attn.out_proj.weight, l0.attn.out_proj.bias, *l0.ff.params())
+            return x, T, layers[1:]
+        x = ops.ProjGatherFn.apply(h, lin.weight, lin.bias, plan.idx32[lvl], plan.inv_ptr[lvl], plan.inv_rows[lvl], self.s, pe, ops.act_dtype())
+        return x, T, layers
+
+    def _write(self, g, o, T):
+        """the output map of the symmetrised features o -> k (, eq) in the graph (the tail of forward)"""
+        raise NotImplementedError
+
     def _symmetrised(self, g):
         """atom embeddings -> tokens -> transformer -> symmetriser: (o (P*T, out_feats), T)"""
         plan = g.plan()
@@ -358,12 +389,15 @@ class WriteBondParameters(_WriterBase):
         return torch.stack([self.to_eq.mean_over_std, self.to_eq.std, self.to_eq.min_, self.to_k.mean_over_std, self.to_k.std,
                             self.to_k.min_]).float().contiguous()
 
-    def forward(self, g):
-        o, T = self._symmetrised(g)
+    def _write(self, g, o, T):
         k, eq = ops.ParamOutFn.apply(o, 0, T, 2, 0, False, 0.0, self._consts())
         g.nodes["n2"].data["eq" + self.suffix] = eq
         g.nodes["n2"].data["k" + self.suffix] = k           # harmonic_gate has no effect on the outputs (reference quirk Q3)
         return g
+
+    def forward(self, g):
+        o, T = self._symmetrised(g)
+        return self._write(g, o, T)
 
 
 class WriteAngleParameters(_WriterBase):
@@ -389,14 +423,17 @@ class WriteAngleParameters(_WriterBase):
         z = torch.zeros((), dtype=torch.float32, device=self.to_k.std.device)
         return torch.stack([self.to_eq.std_over_max, self.to_eq.max, z, self.to_k.mean_over_std, self.to_k.std, self.to_k.min_]).float().contiguous()
 
-    def forward(self, g):
-        if "n3" not in g.ntypes:
-            return g
-        o, T = self._symmetrised(g)
+    def _write(self, g, o, T):
         k, eq = ops.ParamOutFn.apply(o, 1, T, 2, 0, False, 0.0, self._consts())
         g.nodes["n3"].data["eq" + self.suffix] = eq
         g.nodes["n3"].data["k" + self.suffix] = k
         return g
+
+    def forward(self, g):
+        if "n3" not in g.ntypes:
+            return g
+        o, T = self._symmetrised(g)
+        return self._write(g, o, T)
 
 
 class WriteTorsionParameters(_WriterBase):
@@ -445,14 +482,17 @@ class WriteTorsionParameters(_WriterBase):
     def _consts(self):
         return torch.cat([self.k_std.reshape(-1), self.k_mean.reshape(-1)]).float().contiguous()
 
+    def _write(self, g, o, T):
+        k = ops.ParamOutFn.apply(o, 2, T, self._P, self._n_per, self.gated, self.cutoff_value, self._consts())
+        g.nodes[self.level].data["k" + self.suffix] = k
+        return g
+
     def forward(self, g):
         lvl = self.level
         if lvl not in g.ntypes:
             return g
         o, T = self._symmetrised(g)
-        k = ops.ParamOutFn.apply(o, 2, T, self._P, self._n_per, self.gated, self.cutoff_value, self._consts())
-        g.nodes[lvl].data["k" + self.suffix] = k
-        return g
+        return self._write(g, o, T)
 
 
 class WriteParameters(nn.Module):
@@ -487,6 +527,12 @@ class WriteParameters(nn.Module):
         # (ops.SplitHeadsFn), so no torch arithmetic kernel runs on a side stream.
         self.head_streams = int(os.environ.get("GRAPPA_HEAD_STREAMS", "4"))
         self._streams = None
+        # round 4: the heads LAYER-LOCKED on one stream -- every product of a transformer / symmetriser layer is ONE grouped launch over the
+        # heads (ops.MultiTransformerLayerFn, backend.gemm_group): what the four streams approximated, without their launch count.
+        # GRAPPA_MERGED_HEADS: "auto" (default) = when a head's tokens would not fill the chip by themselves (fewer than
+        # `merged_heads_max_tokens` tokens in the largest head), "1" always, "0" never
+        self.merged_heads = os.environ.get("GRAPPA_MERGED_HEADS", "auto")
+        self.merged_heads_max_tokens = int(os.environ.get("GRAPPA_MERGED_HEADS_MAX_TOKENS", "40000"))
 
     def _writers_largest_first(self):
         return [self.proper_writer, self.angle_writer, self.improper_writer, self.bond_writer]
@@ -497,6 +543,8 @@ class WriteParameters(nn.Module):
         # every head reads an alias of h of its own, so that its gradient of h arrives alone at the node that adds the four
         aliases = ops.SplitHeadsFn.apply(h, len(writers)) if (torch.is_grad_enabled() and h.requires_grad) else (h,) * len(writers)
         try:
+            if self._use_merged(g, h):
+                return self._forward_merged(g, writers, aliases)
             if self.head_streams <= 1 or not h.is_cuda:
                 for w, a in zip(writers, aliases):          # same host order (hence dropout seeds) as the multi-stream path
                     g.nodes["n1"].data["h"] = a
@@ -522,6 +570,69 @@ class WriteParameters(nn.Module):
             return g
         finally:
             g.nodes["n1"].data["h"] = h
+
+
+def _use_merged(self, g, h) -> bool:
+    if self.merged_heads in ("0", "") or ops.act_dtype() is not None:
+        return False
+    if self.merged_heads == "1":
+        return True
+    plan = g.plan()
+    return h.is_cuda and max(w.s * plan.T[w.level] for w in self._writers_largest_first()) < self.merged_heads_max_tokens
+
+
+def _forward_merged(self, g, writers, aliases):
+    """the heads layer-locked: tokens head by head, then transformer layer li of every head that still has one as ONE node, the symmetrisers
+    as one node, the output maps head by head.  Dropout seeds are drawn in the order of the head-by-head path (same masks)."""
+    plan = g.plan()
+    st = []
+    for w, a in zip(writers, aliases):
+        if w.level not in g.ntypes:
+            continue
+        if plan.T[w.level] == 0:                                # an empty level: the head-by-head path (zero-row tensors, no launches)
+            g.nodes["n1"].data["h"] = a
+            g = w(g)
+            continue
+        g.nodes["n1"].data["h"] = a
+        x, T, left = w._tokens(g)
+        model = w._model()
+        nl = len(model.grappa_transformer.transformer) if model.grappa_transformer is not None else 0
+        seeds = []
+        for layer in left:
+            p = layer.p if layer.training else 0.0
+            seeds.append((p,) + ((ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)))
+        st.append(dict(w=w, x=x, T=T, left=left, first=nl - len(left), seeds=seeds, model=model))
+    depth = max((s_["first"] + len(s_["left"]) for s_ in st), default=0)
+    for li in range(depth):
+        act = [s_ for s_ in st if s_["first"] <= li < s_["first"] + len(s_["left"])]
+        if not act:
+            continue
+        cfgs, flat = [], []
+        for s_ in act:
+            layer = s_["left"][li - s_["first"]]
+            p, s1, s2 = s_["seeds"][li - s_["first"]]
+            cfgs.append((s_["w"].s, s_["T"], layer.num_heads, p, s1, s2))
+            flat += [s_["x"], *_wb(getattr(layer, "norm1", None)), layer.attn.in_proj_weight, layer.attn.in_proj_bias, layer.attn.out_proj.weight,
+                     layer.attn.out_proj.bias, *layer.ff.params()]
+        ops.mark_mode()
+        outs = ops.MultiTransformerLayerFn.apply(tuple(cfgs), *flat)
+        for s_, o in zip(act, outs):
+            s_["x"] = o
+    if st:
+        cfgs, flat = [], []
+        for s_ in st:
+            sym = s_["model"].symmetriser
+            cfgs.append((s_["w"].s, s_["T"], sym._perm_list, len(sym.mlp)))
+            flat += [s_["x"]] + [t for ff in sym.mlp for t in ff.params()]
+        ops.mark_mode()
+        outs = ops.MultiSymmetriserFn.apply(tuple(cfgs), *flat)
+        for s_, o in zip(st, outs):
+            g = s_["w"]._write(g, o, s_["T"])
+    return g
+
+
+WriteParameters._use_merged = _use_merged
+WriteParameters._forward_merged = _forward_merged
 
 
 class GrappaModel(nn.Module):

@@ -801,3 +801,299 @@ class MolwiseLossFn(Function):
             return t if one else t * gl
 
         return (None, None, sc(gE), sc(gG)) + tuple(sc(g) for g in gps)
+
+
+# ------------------------------------------------------------------------------------------------
+# The writer heads layer-locked (round 4).  The four heads (bond / angle / proper / improper) have the same architecture and read the
+# same atom embedding; head by head, each of their products leaves most of the chip idle at small batches (batch 32: 44 .. 176
+# workgroups of one tile time each on 256 CUs) and costs a launch.  Here one autograd node runs ONE transformer layer (or the
+# symmetrisers) of all heads: row-wise kernels head by head, every product of the layer as ONE grouped launch (backend.gemm_group).
+# Same arithmetic per head as TransformerLayerFn / SymmetriserFn above (same kernels, same K cuts: the same bits).
+def _gemm_group(be, calls):
+    f = getattr(be, "gemm_group", None)
+    if f is None or len(calls) < 2:
+        return [be.gemm(*a, **k) for a, k in calls]
+    return f(calls)
+
+
+def _ln_fwd_multi(be, xs, ws, bs, infer, need_y):
+    """_ln_fwd for several heads: one batched launch where the backend has it and no head writes the pair format"""
+    f = getattr(be, "layernorm_fwd_batched", None)
+    if f is not None and len(xs) >= 2 and all(w is not None for w in ws) and not any(_pairs(be, x, infer) for x in xs):
+        r = f(xs, ws, bs)
+        if r is not None:
+            return r
+    return [_ln_fwd(be, x, w, b, infer, need_y=ny) for x, w, b, ny in zip(xs, ws, bs, need_y)]
+
+
+def _ln_bwd_multi(be, dys, xs, means, rstds, ws, bs):
+    f = getattr(be, "layernorm_bwd_batched", None)
+    if f is not None and len(xs) >= 2 and all(w is not None and w.requires_grad and b.requires_grad for w, b in zip(ws, bs)):
+        r = f([(dy, x, m, r_, w, _pgrad(w), _pgrad(b)) for dy, x, m, r_, w, b in zip(dys, xs, means, rstds, ws, bs)])
+        if r is not None:
+            return r
+    return [_ln_bwd(be, dy, x, m, r_, w, b) for dy, x, m, r_, w, b in zip(dys, xs, means, rstds, ws, bs)]
+
+
+def _drop_bwd_multi(be, dys, drops, ws, ys=None):
+    """dropout (and ELU') backward of several heads -> [(dz or None, record)]; ys: the saved ELU outputs (act2) or None"""
+    n = len(dys)
+    ys = ys or [None] * n
+    f = getattr(be, "act_dropout_bwd_batched", None)
+    plain = all((p > 0 or y is not None) for (p, _s), y in zip(drops, ys)) and not any(dy.dtype == F32 and _bwd_pairs(be, dy.shape[0], dy.shape[1], w) for dy, w in zip(dys, ws))
+    if f is not None and n >= 2 and plain:
+        r = f([(dy, y, p, sd) for dy, y, (p, sd) in zip(dys, ys, drops)])
+        if r is not None:
+            return r
+    out = []
+    for dy, (p, sd), w, y in zip(dys, drops, ws, ys):
+        if p <= 0 and y is None:
+            out.append((dy, None))
+        elif dy.dtype == F32 and _bwd_pairs(be, dy.shape[0], dy.shape[1], w):
+            out.append((None, be.act_dropout_bwd(dy, y, p, sd, None, pairs=True)))
+        else:
+            dz = _new(dy.shape, dy)
+            out.append((dz, be.act_dropout_bwd(dy, y, p, sd, dz)))
+    return out
+
+
+def _attention_multi(be, qkvs, cfgs, likes, infer):
+    """_attention for several heads (cfgs: (s, T, nheads)): one batched launch unless a head writes the pair format"""
+    f = getattr(be, "seqattn_batched", None)
+    def wants_pairs(qkv):
+        Fd = qkv.shape[1] // 3
+        return infer and hasattr(be, "pairs_ok") and be.pairs_ok(qkv, Fd, training=infer == 2) and 32 < Fd <= 512 and qkv.shape[0] > 32
+    if f is not None and len(qkvs) >= 2 and not any(wants_pairs(q) for q in qkvs):
+        r = f([(q, s, T, nh) for q, (s, T, nh) in zip(qkvs, cfgs)], False)
+        if r is not None:
+            return r
+    return [_attention(be, q, s, T, nh, like, infer) for q, (s, T, nh), like in zip(qkvs, cfgs, likes)]
+
+
+def _attention_bwd_multi(be, qkvs, datts, cfgs):
+    f = getattr(be, "seqattn_batched", None)
+    if f is not None and len(qkvs) >= 2:
+        r = f([(q, d, s, T, nh) for q, d, (s, T, nh) in zip(qkvs, datts, cfgs)], True)
+        if r is not None:
+            return r
+    out = []
+    for q, d, (s, T, nh) in zip(qkvs, datts, cfgs):
+        dqkv = _new(q.shape, q)
+        out.append((dqkv, be.seqattn_bwd(q, d, s, T, nh, dqkv)))
+    return out
+
+
+def _ff_fwd_multi(be, xs, params, act2, drops, skip, infer):
+    """_ff_fwd for several heads at once: xs [x], params [(norm_w, norm_b, w1, b1, w2, b2)], drops [(drop_p, seed)], skip [bool] -> ([out], [saved])"""
+    n = len(xs)
+    pre1, calls1 = [], []
+    leans = []
+    for x, (norm_w, norm_b, w1, b1, w2, b2), sk in zip(xs, params, skip):
+        leans.append(_pairs(be, x, infer) and norm_w is not None and w1.shape[0] > 32 and x.shape[0] > 32 and (not sk or not w2.shape[0] <= 32))
+    lns = _ln_fwd_multi(be, xs, [p[0] for p in params], [p[1] for p in params], infer, [not l for l in leans])
+    for x, (norm_w, norm_b, w1, b1, w2, b2), sk, (xn, mean, rstd, sxn) in zip(xs, params, skip, lns):
+        M, Hd, Nout = x.shape[0], w1.shape[0], w2.shape[0]
+        narrow = Nout <= 32
+        u = _new((M, Hd), x, F32 if narrow else None)
+        pre1.append((xn, mean, rstd, u, narrow))
+        calls1.append(((xn, w1, u), dict(M=M, N=Hd, K=x.shape[1], bias=b1, act=ELU, a_scales=sxn, out_amax=_wants_amax(be, False))))
+    r1 = _gemm_group(be, calls1)
+    outs, saved, calls2 = [], [], []
+    for i in range(n):
+        x, (norm_w, norm_b, w1, b1, w2, b2), (drop_p, seed) = xs[i], params[i], drops[i]
+        xn, mean, rstd, u, narrow = pre1[i]
+        sxn, su = r1[i]
+        M, Hd, Nout = x.shape[0], w1.shape[0], w2.shape[0]
+        out = _new((M, Nout), x, F32 if narrow else None)
+        ln_res = (mean, rstd, norm_w, norm_b) if (skip[i] and xn is None) else None
+        pre = None
+        if act2:
+            pre = _new((M, Nout), x)
+            kw = dict(res=x, res_ln=ln_res) if ln_res else dict(res=xn if skip[i] else None)
+            calls2.append(((u, w2, pre), dict(M=M, N=Nout, K=Hd, bias=b2, act=ELU, drop_p=drop_p, drop_seed=seed, out2=out, a_scales=su, **kw)))
+        elif ln_res:
+            calls2.append(((u, w2, out), dict(M=M, N=Nout, K=Hd, bias=b2, drop_p=drop_p, drop_seed=seed, res=x, res_ln=ln_res, a_scales=su)))
+        else:
+            calls2.append(((u, w2, out), dict(M=M, N=Nout, K=Hd, bias=b2, drop_p=drop_p, drop_seed=seed, res=xn if skip[i] else None, a_scales=su)))
+        outs.append(out)
+        saved.append([x, mean, rstd, xn, u, pre, sxn, None])
+    r2 = _gemm_group(be, calls2)
+    for sv, su in zip(saved, r2):
+        sv[7] = su
+    return outs, [tuple(sv) for sv in saved]
+
+
+def _ff_bwd_multi(be, saved, douts, params, act2, drops, skip, sdouts=None):
+    """_ff_bwd for several heads at once -> ([dx], [record of dx or None])"""
+    n = len(saved)
+    sdouts = sdouts or [None] * n
+    dz2s, szs, calls = [], [], []
+    douts, sdouts = list(douts), list(sdouts)
+    for i in range(n):
+        if not douts[i].is_contiguous():
+            douts[i], sdouts[i] = douts[i].contiguous(), None
+    dzs = _drop_bwd_multi(be, douts, drops, [p[4] for p in params], [sv[5] for sv in saved] if act2 else None)
+    for i in range(n):
+        x, mean, rstd, xn, u, pre, sxn, su = saved[i]
+        norm_w, norm_b, w1, b1, w2, b2 = params[i]
+        M = x.shape[0]
+        dz2, sz = dzs[i]
+        if dz2 is douts[i]:                      # (no dropout, no activation: the incoming gradient itself, with its producer's record)
+            sz = sdouts[i]
+        sz = _linear_bwd_params(be, dz2, u, w2, b2, su, sz)
+        dz1 = _new(u.shape, x)
+        dz2s.append(dz1)
+        calls.append(((dz2, w2, dz1), dict(M=M, N=u.shape[1], K=w2.shape[0], b_kcontig=False, aux=u, a_scales=sz, out_amax=_wants_amax(be, True))))
+    r = _gemm_group(be, calls)
+    calls, dxns = [], []
+    for i in range(n):
+        x, mean, rstd, xn, u, pre, sxn, su = saved[i]
+        norm_w, norm_b, w1, b1, w2, b2 = params[i]
+        dz1 = dz2s[i]
+        sz = _linear_bwd_params(be, dz1, xn, w1, b1, sxn, r[i][1])
+        dxn = _new(x.shape, x)
+        dxns.append(dxn)
+        calls.append(((dz1, w1, dxn), dict(M=x.shape[0], N=x.shape[1], K=u.shape[1], b_kcontig=False, res=douts[i] if skip[i] else None, a_scales=sz)))
+    _gemm_group(be, calls)
+    out = _ln_bwd_multi(be, dxns, [sv[0] for sv in saved], [sv[1] for sv in saved], [sv[2] for sv in saved], [p[0] for p in params], [p[1] for p in params])
+    return [o[0] for o in out], [o[1] for o in out]
+
+
+_NP_LAYER = 13        # tensors per head of MultiTransformerLayerFn: x, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2
+
+
+class MultiTransformerLayerFn(Function):
+    """TransformerLayerFn for several heads at once.  cfgs: per head (s, T, nheads, drop_p, seed1, seed2); tensors: _NP_LAYER per head."""
+
+    @staticmethod
+    def forward(ctx, cfgs, *t):
+        be = get_backend()
+        n = len(cfgs)
+        heads = [t[_NP_LAYER * i:_NP_LAYER * (i + 1)] for i in range(n)]
+        infer = 1 if (_INFERENCE["on"] and not any(ctx.needs_input_grad[1 + _NP_LAYER * i] for i in range(n))) else \
+            (2 if getattr(be, "training_pairs", False) else 0)
+        xs = [_c(h[0]) for h in heads]
+        st, calls = [], []
+        leans = [_pairs(be, x, infer) and h[1] is not None and x.shape[0] > 32 and x.shape[1] > 32 for x, h in zip(xs, heads)]
+        lns = _ln_fwd_multi(be, xs, [h[1] for h in heads], [h[2] for h in heads], infer, [not l for l in leans])
+        for x, (_, n1_w, n1_b, w_in, b_in, *_r), (x1, mean1, rstd1, sx1) in zip(xs, heads, lns):
+            M, Fd = x.shape
+            qkv = _new((M, 3 * Fd), x)
+            st.append([x1, mean1, rstd1, qkv])
+            calls.append(((x1, w_in, qkv), dict(M=M, N=3 * Fd, K=Fd, bias=b_in, a_scales=sx1)))
+        sx1s = _gemm_group(be, calls)
+        calls, x2s, atts = [], [], []
+        att_r = _attention_multi(be, [q[3] for q in st], [(c[0], c[1], c[2]) for c in cfgs], xs, infer)
+        for i, (x, hp) in enumerate(zip(xs, heads)):
+            s, T, nheads, drop_p, seed1, seed2 = cfgs[i]
+            _, n1_w, n1_b, w_in, b_in, w_o, b_o = hp[:7]
+            x1, mean1, rstd1, qkv = st[i]
+            M, Fd = x.shape
+            att, satt = att_r[i]
+            x2 = _new((M, Fd), x)
+            kw = dict(res=x, res_ln=(mean1, rstd1, n1_w, n1_b)) if x1 is None else dict(res=x1)
+            calls.append(((att, w_o, x2), dict(M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, a_scales=satt, **kw)))
+            x2s.append(x2)
+            atts.append(att)
+        satts = _gemm_group(be, calls)
+        outs, ff_saved = _ff_fwd_multi(be, x2s, [hp[7:13] for hp in heads], False, [(c[3], c[5]) for c in cfgs], [True] * n, infer)
+        ctx.cfgs, ctx.scales, ctx.ff_saved, ctx.n = cfgs, list(zip(sx1s, satts)), ff_saved, n
+        flat = []
+        for i in range(n):
+            flat += [xs[i], st[i][1], st[i][2], st[i][0], st[i][3], atts[i]] + list(heads[i][1:])
+        ctx.save_for_backward(*flat)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        be = get_backend()
+        n, cfgs = ctx.n, ctx.cfgs
+        sv = ctx.saved_tensors
+        per = 6 + (_NP_LAYER - 1)
+        H = [sv[per * i:per * (i + 1)] for i in range(n)]
+        params = [h[6 + 6:6 + 12] for h in H]                       # nf_w, nf_b, w1, b1, w2, b2
+        dx2s, szs = _ff_bwd_multi(be, ctx.ff_saved, douts, params, False, [(c[3], c[5]) for c in cfgs], [True] * n)
+        ctx.ff_saved = None
+        calls, datts = [], []
+        dzos = _drop_bwd_multi(be, dx2s, [(c[3], c[4]) for c in cfgs], [H[i][10] for i in range(n)])
+        for i in range(n):
+            x, mean1, rstd1, x1, qkv, att, n1_w, n1_b, w_in, b_in, w_o, b_o = H[i][:12]
+            s, T, nheads, drop_p, seed1, seed2 = cfgs[i]
+            M, Fd = x.shape
+            dzo, sz = dzos[i]
+            sz = sz if drop_p > 0 else szs[i]
+            sx1, satt = ctx.scales[i]
+            sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)
+            datt = _new((M, Fd), x)
+            datts.append(datt)
+            calls.append(((dzo, w_o, datt), dict(M=M, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)))
+        _gemm_group(be, calls)
+        calls, dx1s = [], []
+        dq = _attention_bwd_multi(be, [H[i][4] for i in range(n)], datts, [(c[0], c[1], c[2]) for c in cfgs])
+        for i in range(n):
+            x, mean1, rstd1, x1, qkv, att, n1_w, n1_b, w_in, b_in, w_o, b_o = H[i][:12]
+            s, T, nheads, drop_p, seed1, seed2 = cfgs[i]
+            M, Fd = x.shape
+            dqkv, sz = dq[i]
+            sz = _linear_bwd_params(be, dqkv, x1, w_in, b_in, ctx.scales[i][0], sz)
+            dx1 = _new(x.shape, x)
+            dx1s.append(dx1)
+            calls.append(((dqkv, w_in, dx1), dict(M=M, N=Fd, K=3 * Fd, b_kcontig=False, res=dx2s[i], a_scales=sz)))
+        _gemm_group(be, calls)
+        grads = [None]
+        dxs = _ln_bwd_multi(be, dx1s, [H[i][0] for i in range(n)], [H[i][1] for i in range(n)], [H[i][2] for i in range(n)],
+                            [H[i][6] for i in range(n)], [H[i][7] for i in range(n)])
+        for i in range(n):
+            grads += [dxs[i][0]] + [None] * (_NP_LAYER - 1)
+        return tuple(grads)
+
+
+class MultiSymmetriserFn(Function):
+    """SymmetriserFn for several heads at once.  cfgs: per head (s, T, perms, n_layers); tensors: per head x followed by 6 per layer."""
+
+    @staticmethod
+    def forward(ctx, cfgs, *t):
+        be = get_backend()
+        n = len(cfgs)
+        heads, pos, xpos = [], 0, []
+        for (s, T, perms, nl) in cfgs:
+            xpos.append(pos)
+            heads.append((t[pos], [t[pos + 1 + 6 * i:pos + 7 + 6 * i] for i in range(nl)]))
+            pos += 1 + 6 * nl
+        infer = 1 if (_INFERENCE["on"] and not any(ctx.needs_input_grad[1 + p] for p in xpos)) else (2 if getattr(be, "training_pairs", False) else 0)
+        cur, saved = [], [[] for _ in range(n)]
+        for (s, T, perms, nl), (x, layers) in zip(cfgs, heads):
+            x = _c(x)
+            z = _new((len(perms) * T, s * x.shape[1]), x)
+            be.perm_concat_fwd(x, s, T, perms, z)
+            cur.append(z)
+        for li in range(max(c[3] for c in cfgs)):
+            act = [i for i in range(n) if li < cfgs[i][3]]
+            outs, sv = _ff_fwd_multi(be, [cur[i] for i in act], [heads[i][1][li] for i in act], False, [(0.0, 0)] * len(act),
+                                     [(li != 0) and (li != cfgs[i][3] - 1) for i in act], infer)
+            for j, i in enumerate(act):
+                cur[i] = outs[j]
+                saved[i].append(sv[j])
+        ctx.cfgs, ctx.saved_layers, ctx.layers = cfgs, saved, [h[1] for h in heads]
+        ctx.xmeta = [(tuple(h[0].shape), h[0].dtype) for h in heads]
+        return tuple(cur)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        be = get_backend()
+        cfgs, n = ctx.cfgs, len(ctx.cfgs)
+        g, sg = [_c(d) for d in douts], [None] * n
+        for li in reversed(range(max(c[3] for c in cfgs))):
+            act = [i for i in range(n) if li < cfgs[i][3]]
+            dxs, sdx = _ff_bwd_multi(be, [ctx.saved_layers[i][li] for i in act], [g[i] for i in act], [ctx.layers[i][li] for i in act], False,
+                                     [(0.0, 0)] * len(act), [(li != 0) and (li != cfgs[i][3] - 1) for i in act], [sg[i] for i in act])
+            for j, i in enumerate(act):
+                g[i], sg[i] = dxs[j], sdx[j]
+        ctx.saved_layers = None
+        grads = [None]
+        for i, (s, T, perms, nl) in enumerate(cfgs):
+            shape, dtype = ctx.xmeta[i]
+            dx = torch.empty(shape, dtype=dtype, device=g[i].device)
+            be.perm_concat_bwd(g[i], s, T, perms, dx)
+            grads += [dx] + [None] * (6 * nl)
+        return tuple(grads)

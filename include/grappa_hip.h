@@ -35,7 +35,9 @@ const char* grappa_build_arch(void);
 long long grappa_launch_count(int reset);
 
 /* ------------------------------------------------------------------------------------------------
- * Dense blocks (fp32 MFMA v_mfma_f32_32x32x2_f32).  C = epilogue(opA(A) * opB(B)).
+ * Dense blocks.  C = epilogue(opA(A) * opB(B)); the arithmetic of the product is grappa_gemm_desc.precision (below): the engine's default is
+ * F32_F16X3 (fp32 operands as two fp16 pieces, three partial products on v_mfma_f32_32x32x16_f16), the native fp32 matrix instruction
+ * (v_mfma_f32_32x32x2_f32) serves products with M or N <= 32 and precision F32_MFMA.
  *   A(m,k) = a_kcontig ? A[m*lda + k] : A[k*lda + m]
  *   B(n,k) = b_kcontig ? B[n*ldb + k] : B[k*ldb + n]
  *   forward  Y = X W^T      : a_kcontig=1 (X[M,K]),  b_kcontig=1 (W[N,K])   nn.Linear
@@ -59,7 +61,7 @@ long long grappa_launch_count(int reset);
 #define GRAPPA_ACT_ELU 1
 
 /* Arithmetic of the product (grappa_gemm_desc.precision).  Inputs, outputs, epilogue and accumulation are fp32 in every mode.
- *   F32_MFMA    native fp32 matrix instruction (default; 157 TFLOP/s peak)
+ *   F32_MFMA    native fp32 matrix instruction (157 TFLOP/s peak; the value 0 of a zeroed descriptor -- the Python engine asks for F32_F16X3)
  *   F32_BF16X9  each fp32 operand split exactly into 3 bf16 pieces, all 9 partial products on the bf16 matrix cores: every
  *               partial product is exact, the result differs from an fp32 FMA chain only by accumulation order
  *   F32_BF16X6  the 6 largest partial products (drops terms <= 2^-24 |a||b|): fp32-grade, ~2 ulp per product
@@ -224,6 +226,13 @@ int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws
 #define GRAPPA_GEMM_GROUP_MAX 16
 size_t grappa_gemm_f32_grouped_workspace_bytes(const grappa_gemm_desc* descs, int n);
 int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* descs, int n, void* ws, size_t ws_bytes);
+/* ABI 8: up to 4 FORWARD or INPUT-GRADIENT products in ONE launch -- the same product of the four writer heads (bond / angle / proper /
+ * improper), which at small batches leaves most of the chip idle when launched head by head.  All descriptors: a_kcontig = 1, one
+ * b_kcontig, one precision (not F32_MFMA), operands all fp32 or all in the pair format (both operands, b_kcontig = 1), M, N > 32, fp32 C
+ * (no bf16 tensors, no a_colsum), operands that allow 16-byte loads; every product keeps its own epilogue (bias, activation, dropout,
+ * residual incl. res_ln_*, C2, out_amax).  No split-K.  Anything else: GRAPPA_ERR_ARG (launch the products one by one). */
+size_t grappa_gemm_f32_group_workspace_bytes(const grappa_gemm_desc* descs, int n);
+int grappa_gemm_f32_group(void* stream, const grappa_gemm_desc* descs, int n, void* ws, size_t ws_bytes);
 
 /* out[n] (+)= sum_m x[m*ldx + n]   (bias gradients) */
 size_t grappa_colsum_workspace_bytes(int M, int N);
@@ -239,6 +248,29 @@ int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int 
  * pass of their own.  A NULL array gives the plain kernel. */
 int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
                                     float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax);
+/* ---- ABI 8: batched row-wise kernels.  The writer heads run layer-locked (one autograd node per transformer layer over all heads): their
+ * products go out as one grouped launch (grappa_gemm_f32_group) and their row-wise kernels as ONE launch over up to
+ * GRAPPA_ROW_BATCH_MAX independent tensors.  Same arithmetic per tensor as the single-tensor entry points (fp32, row maxima written). */
+#define GRAPPA_ROW_BATCH_MAX 4
+typedef struct grappa_ln_fwd_item {          /* = grappa_layernorm_fwd_amax_f32's arguments; y_amax may be NULL */
+    int M, W; const float* x; int ldx; const float* gamma; const float* beta; float* y; int ldy; float* mean; float* rstd; uint32_t* y_amax;
+} grappa_ln_fwd_item;
+int grappa_layernorm_fwd_batched_f32(void* stream, const grappa_ln_fwd_item* items, int count);
+typedef struct grappa_ln_bwd_item {          /* grappa_layernorm_bwd_amax_f32 with accumulate = 2: `part` receives grappa_layernorm_bwd_partial_rows(M)
+                                              * rows of [dgamma | dbeta] partials (2 W floats each) for grappa_colsum_partials_batched; dx_amax may be NULL */
+    int M, W; const float* dy; int lddy; const float* x; int ldx; const float* mean; const float* rstd; const float* gamma; float* dx; int lddx;
+    float* part; uint32_t* dx_amax;
+} grappa_ln_bwd_item;
+int grappa_layernorm_bwd_batched_f32(void* stream, const grappa_ln_bwd_item* items, int count);
+typedef struct grappa_act_dropout_item {     /* = grappa_act_dropout_bwd_amax_f32's arguments (N % 4 == 0, N <= 2048, 16-byte aligned rows); y may be NULL */
+    int M, N; const float* dy; int lddy; const float* y; int ldy; float drop_p; uint64_t drop_seed; float* dz; int lddz; uint32_t* dz_amax;
+} grappa_act_dropout_item;
+int grappa_act_dropout_bwd_batched_f32(void* stream, const grappa_act_dropout_item* items, int count);
+typedef struct grappa_seqattn_item {         /* = grappa_seqattn_fwd_amax_f32 / grappa_seqattn_bwd_amax_f32's arguments; amax may be NULL */
+    int s, T, nheads, dh; const float* qkv; float* out; const float* dout; float* dqkv; uint32_t* amax;
+} grappa_seqattn_item;
+int grappa_seqattn_fwd_batched_f32(void* stream, const grappa_seqattn_item* items, int count);      /* uses qkv, out, amax (of out) */
+int grappa_seqattn_bwd_batched_f32(void* stream, const grappa_seqattn_item* items, int count);      /* uses qkv, dout, dqkv, amax (of dqkv) */
 /* ABI 8: the same rows written in the PAIR format (pairs, ldp >= 2 * N fp16 elements, % 8 == 0; N % 32 == 0, N <= 2048; dz_amax = the
  * rows' scales, required); dz (fp32) may be NULL: the products behind -- the input gradient through grappa_gemm_f32's pair operands, the
  * weight gradient through ABI 8's -- read the pairs. */
