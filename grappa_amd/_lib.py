@@ -36,7 +36,8 @@ class GemmDesc(C.Structure):
                 # ABI 7: residual = LayerNorm(res) recomputed by the epilogue
                 ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p),
                 # ABI 8: pair-format operands of the weight-gradient products (token maxima of the operand)
-                ("a_rowmax", C.c_void_p), ("b_rowmax", C.c_void_p)]
+                ("a_rowmax", C.c_void_p), ("b_rowmax", C.c_void_p),
+                ("out_amax_parts", C.c_void_p), ("a_amax_nseg", C.c_int)]
 
 
 class LnFwdItem(C.Structure):
@@ -105,6 +106,7 @@ SIGNATURES = {
     "grappa_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz]),
     "grappa_amax_f32_batched": (_i, [_vp, _i, _vp]),
     "grappa_amax_reduce": (_i, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _vp]),
+    "grappa_amax_combine": (_i, [_vp, _i, _i, _vp, _vp]),
     "grappa_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
     "grappa_gemm_f32_plan": (_i, [_i, _i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "grappa_gemm_f32_set_plan_override": (None, [_i, _i, _i]),

@@ -98,10 +98,13 @@ class Amax:
     """largest magnitudes of a 2-d fp32 tensor as int32 tensors of fp32 bit patterns: per row (activations: written by the kernel
     that produced the tensor, or by one pass of grappa_amax_f32), per column (weights), and of the whole tensor (`tmax`, one value:
     max over the rows, for the weight-gradient products whose reduction runs over the rows)"""
-    __slots__ = ("row", "col", "tmax", "pairs")
+    __slots__ = ("row", "col", "tmax", "pairs", "parts", "nseg")
 
-    def __init__(self, row=None, col=None, tmax=None, pairs=None):
+    def __init__(self, row=None, col=None, tmax=None, pairs=None, parts=None, nseg=0):
         self.row, self.col, self.tmax = row, col, tmax
+        # the row maxima as the per-segment partials a product's epilogue wrote (C ABI 8 out_amax_parts: nseg arrays of `rows` values): the
+        # products that read the tensor take the maximum over the segments themselves, nothing launches a combine
+        self.parts, self.nseg = parts, nseg
         # the tensor itself in the PAIR format (include/grappa_hip.h ABI 5; (rows, 2 * round_up(cols, 32)) float16), written by its
         # producer beside -- or instead of -- the fp32 tensor: a product that gets this record as a_scales reads the pairs
         self.pairs = pairs
@@ -155,6 +158,11 @@ class HipBackend:
         self.training_pairs = os.environ.get("GRAPPA_TRAINING_PAIRS", "1") not in ("0", "")
         # the same product of the four writer heads as ONE launch (gemm_group); GRAPPA_GROUP_LAUNCHES=0: one by one
         self.group_launches = os.environ.get("GRAPPA_GROUP_LAUNCHES", "1") not in ("0", "")
+        # opt-in (GRAPPA_AMAX_PARTS=1): the row maxima of a product's output stay the per-segment partials its epilogue writes and the
+        # products that read the tensor combine them (C ABI 8 out_amax_parts / a_amax_nseg: 62 combine launches per C2 step gone).  Measured
+        # SLOWER: 37.4 against 35.9 ms per C2 step -- every workgroup of the consumer re-reads 16 partials per row in its prologue and
+        # epilogue, which costs more than the one small launch it replaces (profiles/r4_amax_parts_ab.txt) -- hence not the default
+        self.amax_parts = os.environ.get("GRAPPA_AMAX_PARTS", "0") not in ("0", "")
         self.pairs_min_rows = int(os.environ.get("GRAPPA_PAIRS_MIN_ROWS", "12288"))
         self._tails = None             # what set_tail_launches last told the library (None: the library's default)
         self._tails_pinned = False
@@ -334,7 +342,10 @@ class HipBackend:
         """`have` completed by the maxima asked for (one pass over t for missing row / column maxima; the whole-tensor maximum is
         a reduction of the row maxima)"""
         am = have if have is not None else Amax()
-        need_r, need_c = (rows or tmax) and am.row is None, cols and am.col is None
+        if rows and am.row is None and am.parts is not None:           # a consumer that wants one array: combine the partials (one small launch)
+            am.row = torch.empty(t.shape[0], dtype=torch.int32, device=t.device)
+            _chk(self.lib.grappa_amax_combine(self._stream(), t.shape[0], am.nseg, am.parts.data_ptr(), am.row.data_ptr()), "grappa_amax_combine")
+        need_r, need_c = (rows or tmax) and am.row is None and am.parts is None, cols and am.col is None
         if need_r or need_c:
             r, c = self._amax_launch(t, need_r, need_c)
             am.row = r if need_r else am.row
@@ -350,9 +361,10 @@ class HipBackend:
             return
         n = len(todo)
         out = torch.empty(n, dtype=torch.int32, device=dev)
-        ptrs = (C.c_void_p * n)(*[r.row.data_ptr() for r in todo])
-        lens = (C.c_int * n)(*[r.row.numel() for r in todo])
-        self._timed("amax", 0.0, 4.0 * sum(r.row.numel() for r in todo),
+        src = [r.row if r.row is not None else r.parts for r in todo]       # (the maximum over all partials is the tensor's too)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+        lens = (C.c_int * n)(*[t.numel() for t in src])
+        self._timed("amax", 0.0, 4.0 * sum(t.numel() for t in src),
                     lambda: _chk(self.lib.grappa_amax_reduce(self._stream(), n, ptrs, lens, out.data_ptr()), "grappa_amax_reduce"))
         for i, r in enumerate(todo):
             r.tmax = out[i:i + 1]
@@ -657,10 +669,17 @@ class HipBackend:
         elif d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] and big and planes_a is None and planes_b is None:
             # power-of-two scales of both operands from their largest magnitudes along the reduced dimension
             if a_kcontig:
-                sa = self.amax(a, a_scales, rows=True)
                 wm = self._amax_of_weight(b)
-                am, bm = sa.row, (wm.row if b_kcontig else wm.col)
-                if am.numel() != M or bm.numel() != N:
+                bm = wm.row if b_kcontig else wm.col
+                if a_scales is not None and a_scales.row is None and a_scales.parts is not None and a_scales.parts.numel() == a_scales.nseg * M:
+                    sa, am = a_scales, a_scales.parts              # the producer's partials: this product combines them (a_amax_nseg)
+                    d.a_amax_nseg = a_scales.nseg
+                else:
+                    sa = self.amax(a, a_scales, rows=True)
+                    am = sa.row
+                    if am.numel() != M:
+                        raise ValueError("gemm: operand maxima do not match the operands")
+                if bm.numel() != N:
                     raise ValueError("gemm: operand maxima do not match the operands")
             elif self.wgrad_column_maxima:
                 sa = self.amax(a, a_scales, cols=True)
@@ -672,8 +691,13 @@ class HipBackend:
                 d.amax_bcast = 3
             d.a_amax, d.b_amax = am.data_ptr(), bm.data_ptr()
         if out_amax is True and final.dtype == torch.float32:          # (out_amax == "pair": the caller only wants the pair returned)
-            so = Amax(row=torch.empty(M, dtype=torch.int32, device=dev))
-            d.out_amax = so.row.data_ptr()
+            if self.amax_parts and big and not native and planes_a is None and (planes_b is None or a_pairs is not None):
+                nseg = (N + 31) // 32
+                so = Amax(parts=torch.empty(nseg * M, dtype=torch.int32, device=dev), nseg=nseg)
+                d.out_amax_parts = so.parts.data_ptr()
+            else:
+                so = Amax(row=torch.empty(M, dtype=torch.int32, device=dev))
+                d.out_amax = so.row.data_ptr()
         need = self._ws_need.get((M, N, K, self._tails))
         if need is None:                         # (the query plans the product for every kernel family: 5 - 10 us, the same answer per shape)
             need = self._ws_need[(M, N, K, self._tails)] = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
@@ -787,8 +811,9 @@ class HipBackend:
                 sdz = self.amax(dz, dz_scales, rows=True, cols=True)
                 am = (sdz, self.amax(x, x_scales, cols=True))
             else:
-                sdz = dz_scales if pz is not None else self.amax(dz, dz_scales, rows=True)
-                am = (sdz, x_scales if px is not None else self.amax(x, x_scales, rows=True))
+                has = lambda r: r is not None and (r.row is not None or r.parts is not None)      # noqa: E731
+                sdz = dz_scales if (pz is not None or has(dz_scales)) else self.amax(dz, dz_scales, rows=True)
+                am = (sdz, x_scales if (px is not None or has(x_scales)) else self.amax(x, x_scales, rows=True))
         task = self._queue_flush()                # the backward pass (autograd graph task) this product belongs to; -1 outside of one
         # one queue per backward pass and HIP stream (the writer heads run their backward passes on streams of their own): a full queue is
         # launched on the stream that filled it, what is left when the pass ends is launched together by flush_wgrads

@@ -117,6 +117,7 @@ class CapturedForward:
         for lvl in ("n2", "n3", "n4", "n4_improper"):       # built eagerly: their construction sorts (host-synchronising torch ops)
             if self.plan.T[lvl]:
                 self.plan.position_tables(lvl)
+        self._rehome_inputs()
         self.stream = torch.cuda.Stream(device=g.device)
         self.stream.wait_stream(torch.cuda.current_stream(g.device))
         with torch.cuda.stream(self.stream), torch.no_grad():
@@ -129,10 +130,13 @@ class CapturedForward:
         with torch.cuda.graph(self.graph, stream=self.stream), torch.no_grad():
             _drop_outputs(g)
             model(g)
+            self.outputs: Dict[Tuple[str, str], torch.Tensor] = {(lvl, k): g.nodes[lvl].data[k] for lvl in ("n2", "n3", "n4", "n4_improper")
+                                                                for k in ("k", "eq") if k in g.nodes[lvl].data}
+            # every output behind one another in ONE buffer (a node of the graph): one copy back to the host instead of six
+            self.out_flat = torch.cat([t.reshape(-1).float() for t in self.outputs.values()]) if self.outputs else None
         self._pinned = _pinned_by_graph(self.be)
         torch.cuda.current_stream(g.device).wait_stream(self.stream)
-        self.outputs: Dict[Tuple[str, str], torch.Tensor] = {(lvl, k): g.nodes[lvl].data[k] for lvl in ("n2", "n3", "n4", "n4_improper")
-                                                            for k in ("k", "eq") if k in g.nodes[lvl].data}
+        self.out_host = torch.empty(self.out_flat.shape, dtype=torch.float32).pin_memory() if self.out_flat is not None else None
 
     def _stamp(self):
         return (self.be._wepoch, sum(p._version for p in self.model.parameters()))
@@ -168,22 +172,72 @@ class CapturedForward:
                                 out[f"{name}.{k}.{i}"] = t
         return out
 
+    # ---- the inputs of the recorded graph live in ONE device buffer (every plan table and input feature is a view of it), mirrored by
+    # one pinned host buffer: loading another graph of the same signature is a few dozen small host copies and ONE transfer
+    def _input_slots(self, plan, g):
+        slots = dict(self._plan_tensors(plan))
+        for k, t in g._data["n1"].items():
+            if torch.is_tensor(t) and k != "h":
+                slots["n1." + k] = t
+        return slots
+
+    def _rehome_inputs(self) -> None:
+        slots = self._input_slots(self.plan, self.g)
+        self._layout, off = {}, 0
+        for name, t in slots.items():
+            nbytes = t.numel() * t.element_size()
+            self._layout[name] = (off, nbytes, t.dtype, tuple(t.shape))
+            off += (nbytes + 15) // 16 * 16
+        self._in_dev = torch.zeros(max(off, 16), dtype=torch.uint8, device=self.g.device)
+        self._in_host = torch.zeros(max(off, 16), dtype=torch.uint8).pin_memory()
+        views = {}
+        for name, (o, nbytes, dtype, shape) in self._layout.items():
+            v = self._in_dev[o:o + nbytes].view(dtype).view(shape)
+            v.copy_(slots[name])
+            views[name] = v
+        # the plan's attributes and the graph's features now point into the buffer
+        for name, v in views.items():
+            parts = name.split(".")
+            if parts[0] == "n1":
+                self.g._data["n1"][name[3:]] = v
+            elif len(parts) == 1:
+                setattr(self.plan, name, v)
+            elif len(parts) == 2:
+                getattr(self.plan, parts[0])[parts[1]] = v
+            else:
+                d = getattr(self.plan, parts[0])
+                tup = list(d[parts[1]])
+                tup[int(parts[2])] = v
+                d[parts[1]] = tuple(tup)
+
     def load(self, g_host) -> None:
         """g_host: a MolBatch on the CPU with this graph's signature.  Its input features and its index structures (plan, position
-        tables: built on the host) are copied into the captured device tensors; nothing is allocated on the device."""
+        tables: built on the host) are laid out in the pinned mirror of the input buffer and sent in ONE transfer; nothing is allocated
+        on the device."""
         plan = g_host.plan()
         for lvl in self.plan.__dict__.get("_pos_tables", {}):
             plan.position_tables(lvl)
-        src, dst = self._plan_tensors(plan), self._plan_tensors(self.plan)
-        if set(src) != set(dst):
-            raise ValueError("load: the graph's plan has other tables than the captured one")
-        for name, t in dst.items():
-            if t.shape != src[name].shape:
-                raise ValueError(f"load: {name} has shape {tuple(src[name].shape)}, the captured graph {tuple(t.shape)}")
-            t.copy_(src[name], non_blocking=True)
-        for k, t in self.g._data["n1"].items():
-            if torch.is_tensor(t) and k != "h" and k in g_host._data["n1"]:
-                t.copy_(g_host._data["n1"][k], non_blocking=True)
+        src = self._input_slots(plan, g_host)
+        if set(src) != set(self._layout):
+            raise ValueError("load: the graph has other input tables than the captured one")
+        for name, (o, nbytes, dtype, shape) in self._layout.items():
+            t = src[name]
+            if tuple(t.shape) != shape or t.dtype != dtype:
+                raise ValueError(f"load: {name} is {t.dtype} {tuple(t.shape)}, the captured graph holds {dtype} {shape}")
+            self._in_host[o:o + nbytes].view(dtype).view(shape).copy_(t)
+        self._in_dev.copy_(self._in_host, non_blocking=True)
+
+    def read_outputs(self, g_host) -> None:
+        """k / eq of every level from the graph's output buffer (one transfer) into g_host's node data"""
+        if self.out_flat is None:
+            return
+        self.out_host.copy_(self.out_flat, non_blocking=True)
+        torch.cuda.current_stream(self.out_flat.device).synchronize()
+        off = 0
+        for (lvl, k), t in self.outputs.items():
+            n = t.numel()
+            g_host.nodes[lvl].data[k] = self.out_host[off:off + n].view(t.shape).clone()
+            off += n
 
 
 class ForwardCache:
@@ -216,6 +270,5 @@ class ForwardCache:
             self.entries[sig] = self.entries.pop(sig)        # most recently used last
             ent.load(g_host)
             ent.replay()
-        for (lvl, k), t in ent.outputs.items():
-            g_host.nodes[lvl].data[k] = t.to("cpu", non_blocking=False)
+        ent.read_outputs(g_host)
         return g_host

@@ -301,6 +301,13 @@ int grappa_launch_amax_combine4(hipStream_t st, int count, const int* M, const i
     return grappa_launch_status();
 }
 
+extern "C" int grappa_amax_combine(void* stream, int M, int nseg, const uint32_t* parts, uint32_t* out) {
+    if (M < 0 || nseg <= 0) return GRAPPA_ERR_ARG;
+    if (M == 0) return GRAPPA_OK;
+    if (!parts || !out) return GRAPPA_ERR_ARG;
+    return grappa_launch_amax_combine(reinterpret_cast<hipStream_t>(stream), M, nseg, parts, out);
+}
+
 extern "C" int grappa_amax_f32_batched(void* stream, int count, const grappa_amax_item* descs) {
     if (count < 0 || (count > 0 && !descs)) return GRAPPA_ERR_ARG;
     if (count == 0) return GRAPPA_OK;

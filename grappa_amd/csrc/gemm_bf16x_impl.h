@@ -60,6 +60,13 @@ template <int MODE> struct Pieces {
 // (zero / denormal rows: 2^141, still finite after scaling; Inf / NaN rows stay Inf / NaN)
 __device__ inline int amax_shift(unsigned bits) { return 141 - (int)((bits >> 23) & 0xffu); }
 
+// largest magnitude of row m of A: one array, or the maximum over the per-segment partials its producer left (grappa_gemm_desc.a_amax_nseg)
+__device__ inline unsigned a_row_amax(const grappa_gemm_desc& d, int m) {
+    unsigned v = d.a_amax[m];
+    for (int s = 1; s < d.a_amax_nseg; ++s) v = max(v, d.a_amax[(size_t)s * d.M + m]);
+    return v;
+}
+
 struct Quad { float x[4]; unsigned rm; };      // rm: pair-format sources only (the token row's largest magnitude); dead otherwise
 
 // slab element (row, kq..kq+3) owned by this thread for quad slot j of an operand with ROWS rows.
@@ -478,7 +485,7 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
         quad_coords<NT, BM, AK, AV>(j, row, kq);
 #pragma unroll
         for (int e = 0; e < (AV ? 4 : 1); ++e)
-            sha[j][e] = Pieces<MODE>::HALF ? amax_shift(d.a_amax[(d.amax_bcast & 1) ? 0 : min(m0 + row + e, d.M - 1)]) : 0;
+            sha[j][e] = Pieces<MODE>::HALF ? amax_shift((d.amax_bcast & 1) ? d.a_amax[0] : a_row_amax(d, min(m0 + row + e, d.M - 1))) : 0;
     }
 #pragma unroll
     for (int j = 0; j < NQB; ++j) {
@@ -557,7 +564,7 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
         // undo the row scales: accumulator element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, wn0 + 32 j + 8 (e / 4) + 4 lh + e % 4)
         int ea[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) ea[i] = amax_shift(d.a_amax[(d.amax_bcast & 1) ? 0 : min(m0 + wm0 + i * 32 + lr, d.M - 1)]);
+        for (int i = 0; i < TM; ++i) ea[i] = amax_shift((d.amax_bcast & 1) ? d.a_amax[0] : a_row_amax(d, min(m0 + wm0 + i * 32 + lr, d.M - 1)));
         const bool b_rows = (d.amax_bcast & 2) == 0 && (reinterpret_cast<uintptr_t>(d.b_amax) & 15) == 0;
         const int eb_all = (d.amax_bcast & 2) ? amax_shift(d.b_amax[0]) : 0;
 #pragma unroll

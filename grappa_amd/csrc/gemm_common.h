@@ -30,8 +30,7 @@ struct GemmParams {
     int ntiles_launch;
     int bm, bn;            // tile shape (for the reduce kernel)
     int vec_io;            // every epilogue tensor is 16-byte aligned with a leading dimension % 4 == 0 (float4 epilogue)
-    // d.out_amax: row maxima of OUT are first written per column segment (amax_seg columns wide: one wavefront's share of a tile
-    // row), amax_part[seg * M + m] -- plain stores, no atomics (device-scope atomics cost more than the whole pass they replace) --
+    // d.out_amax: row maxima of OUT are first written per column segment (amax_seg = 32 columns wide), amax_part[seg * M + m] -- plain stores, no atomics (device-scope atomics cost more than the whole pass they replace) --
     // and combined by amax_combine_kernel after the product's launches
     unsigned* amax_part;
     int amax_seg;
@@ -343,9 +342,9 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
             }
             if (!BF && p.amax_part) {
                 unsigned am = ok ? max(max(mag_bits(x[0]), mag_bits(x[1])), max(mag_bits(x[2]), mag_bits(x[3]))) : 0u;
-                am = group_umax<TN == 2 ? 16 : 8>(am);
-                const int nseg0 = n - rc4;
-                if ((lane & (TN == 2 ? 15 : 7)) == 0 && m < d.M && nseg0 < d.N) p.amax_part[(size_t)(nseg0 / p.amax_seg) * d.M + m] = am;
+                am = group_umax<8>(am);                              // segments of 32 columns (8 lanes x 4), whatever the tile: the consumer
+                const int nseg0 = n - ((lane & 7) << 2);             // of the partials need not know which tile wrote them
+                if ((lane & 7) == 0 && m < d.M && nseg0 < d.N) p.amax_part[(size_t)(nseg0 / p.amax_seg) * d.M + m] = am;
             }
         }
     }
@@ -438,11 +437,11 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, const f32x16 
             }
         }
         if (p.amax_part && p.nsplit == 1) {
-            // the 16 (TN == 2) or 8 lanes that hold one row segment combine; segment-major layout: the 4 / 8 rows of a trip are
-            // consecutive words, the 32 rows of the band one 128-byte line
-            am = group_umax<TN == 2 ? 16 : 8>(am);
-            const int nseg0 = n - rc4;                       // first column of this wavefront's segment
-            if ((lane & (TN == 2 ? 15 : 7)) == 0 && m < d.M && nseg0 < d.N) p.amax_part[(size_t)(nseg0 / p.amax_seg) * d.M + m] = am;
+            // the 8 lanes that hold 32 columns of a row combine; segment-major layout: the 4 / 8 rows of a trip are consecutive words,
+            // the 32 rows of the band one 128-byte line
+            am = group_umax<8>(am);
+            const int nseg0 = n - ((lane & 7) << 2);         // first column of this lane group's segment
+            if ((lane & 7) == 0 && m < d.M && nseg0 < d.N) p.amax_part[(size_t)(nseg0 / p.amax_seg) * d.M + m] = am;
         }
     }
 }

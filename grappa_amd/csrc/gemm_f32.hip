@@ -683,7 +683,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
             p.ntiles_launch = g.tiles[i];
             p.vec_io = al16(d.C, d.ldc) && al16(d.C2, d.ldc2) && al16(d.pre, d.ldpre) && al16(d.res, d.ldres) && al16(d.aux, d.ldaux);
             p.amax_part = nullptr;
-            p.amax_seg = 64;
+            p.amax_seg = 32;
             p.epi_class = 0;
             ix.wg_begin[i + 1] = ix.wg_begin[i] + g.tiles[i] * g.nsplit[i];
             int blocks = 0;
@@ -815,20 +815,24 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     int rc = GRAPPA_OK;
     // row maxima of OUT: the row-epilogue kernels and the split-K reduction leave per-segment maxima behind the slabs (plain stores),
     // one small launch combines them; the native fp32 kernel (tiny or non-default products) leaves them to one pass over its output
-    const bool amax_fused = d->out_amax && bf16x;
+    const bool amax_fused = (d->out_amax || d->out_amax_parts) && bf16x;
+    if (d->out_amax_parts && (!bf16x || d->out_amax)) return GRAPPA_ERR_ARG;          // partials: the split kernels' epilogue only, instead of out_amax
+    if (d->a_amax_nseg > 1 && (!d->a_kcontig || planes || !bf16x || (d->amax_bcast & 1))) return GRAPPA_ERR_ARG;   // a consumer of partials: fp32 A of the split kernels
     if (d->out_amax && !amax_fused && !d->C) return GRAPPA_ERR_ARG;
     p.amax_part = nullptr;
-    p.amax_seg = p.bm == 256 ? 64 : 32;                     // 256 x 128 tile: wavefronts of 64 columns; 128 x 128: of 32
+    p.amax_seg = 32;                                        // segments of 32 columns whatever the tile (ABI 8: the consumer may combine them)
     // the straight-line row epilogues (gemm_common.h epilogue_band_fast): one fp32 output, whole float4s, no pre-activation addend
     p.epi_class = choose_epi_class(*d, p.vec_io != 0, bf16x);
-    if (amax_fused) {
+    if (amax_fused && d->out_amax_parts) {
+        p.amax_part = d->out_amax_parts;         // the caller's array: the consumer combines
+    } else if (amax_fused) {
         if (!ws || ws_bytes < need + amax_part_bytes(d->M, d->N)) return GRAPPA_ERR_WORKSPACE;
         p.amax_part = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + need);
     }
     if (pl.main_tiles > 0) rc = launch(0, pl.main_tiles, pl.nsplit, pl.k_per_split);
     if (rc == GRAPPA_OK && pl.tail_nsplit > 1 && pl.main_tiles < tiles)
         rc = launch(pl.main_tiles, tiles - pl.main_tiles, pl.tail_nsplit, pl.tail_k_per_split);
-    if (rc == GRAPPA_OK && amax_fused) rc = grappa_launch_amax_combine(st, d->M, (d->N + p.amax_seg - 1) / p.amax_seg, p.amax_part, d->out_amax);
+    if (rc == GRAPPA_OK && amax_fused && !d->out_amax_parts) rc = grappa_launch_amax_combine(st, d->M, (d->N + p.amax_seg - 1) / p.amax_seg, p.amax_part, d->out_amax);
     if (rc == GRAPPA_OK && d->out_amax && !amax_fused) {
         const float* o = d->C2 ? d->C2 : d->C;
         rc = grappa_amax_f32(stream, d->M, d->N, o, d->C2 ? d->ldc2 : d->ldc, d->out_amax, nullptr, nullptr, 0);
@@ -862,6 +866,8 @@ bool group4_desc_ok(const grappa_gemm_desc& d, const grappa_gemm_desc& first) {
         const bool padB = d.b_kcontig || ((d.N + 3) & ~3) <= d.ldb;
         if (!(vecA && vecB && padB)) return false;
     }
+    if (d.out_amax_parts && d.out_amax) return false;
+    if (d.a_amax_nseg > 1 && (d.a_planes || (d.amax_bcast & 1))) return false;
     if (d.res_ln_mean && (!d.res || !d.res_ln_rstd || !d.res_ln_gamma || !d.res_ln_beta || (d.N & 3) || d.aux ||
                           ((reinterpret_cast<uintptr_t>(d.res_ln_gamma) | reinterpret_cast<uintptr_t>(d.res_ln_beta)) & 15) != 0))
         return false;
@@ -873,7 +879,7 @@ extern "C" size_t grappa_gemm_f32_group_workspace_bytes(const grappa_gemm_desc* 
     if (!descs || n <= 0 || n > GEMM_GROUP4_MAX) return 0;
     size_t need = 0;
     for (int i = 0; i < n; ++i)
-        if (descs[i].out_amax) need += (amax_part_bytes(descs[i].M, descs[i].N) + 255) / 256 * 256;
+        if (descs[i].out_amax && !descs[i].out_amax_parts) need += (amax_part_bytes(descs[i].M, descs[i].N) + 255) / 256 * 256;
     return need;
 }
 
@@ -907,9 +913,11 @@ extern "C" int grappa_gemm_f32_group(void* stream, const grappa_gemm_desc* descs
         p.drop_salt = g_grappa_drop_salt;
         p.vec_io = al16(d.C, d.ldc) && al16(d.C2, d.ldc2) && al16(d.pre, d.ldpre) && al16(d.res, d.ldres) && al16(d.aux, d.ldaux);
         p.epi_class = choose_epi_class(d, p.vec_io != 0, true);
-        p.amax_seg = 64;
+        p.amax_seg = 32;
         p.amax_part = nullptr;
-        if (d.out_amax) {
+        if (d.out_amax_parts) {
+            p.amax_part = d.out_amax_parts;
+        } else if (d.out_amax) {
             p.amax_part = reinterpret_cast<unsigned*>(part);
             part += (amax_part_bytes(d.M, d.N) + 255) / 256 * 256;
         }
@@ -923,9 +931,9 @@ extern "C" int grappa_gemm_f32_group(void* stream, const grappa_gemm_desc* descs
         const unsigned* parts[4];
         unsigned* outs[4];
         for (int i = 0; i < n; ++i)
-            if (descs[i].out_amax) {
+            if (descs[i].out_amax && !descs[i].out_amax_parts) {
                 Ms[cnt] = descs[i].M;
-                segs[cnt] = (descs[i].N + 63) / 64;
+                segs[cnt] = (descs[i].N + 31) / 32;
                 parts[cnt] = g.p[i].amax_part;
                 outs[cnt] = descs[i].out_amax;
                 ++cnt;

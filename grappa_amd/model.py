@@ -529,9 +529,12 @@ class WriteParameters(nn.Module):
         self._streams = None
         # round 4: the heads LAYER-LOCKED on one stream -- every product of a transformer / symmetriser layer is ONE grouped launch over the
         # heads (ops.MultiTransformerLayerFn, backend.gemm_group): what the four streams approximated, without their launch count.
-        # GRAPPA_MERGED_HEADS: "auto" (default) = when a head's tokens would not fill the chip by themselves (fewer than
-        # `merged_heads_max_tokens` tokens in the largest head), "1" always, "0" never
-        self.merged_heads = os.environ.get("GRAPPA_MERGED_HEADS", "auto")
+        # GRAPPA_MERGED_HEADS: "0" (default) never, "1" always, "auto" = when a head's tokens would not fill the chip by themselves (fewer
+        # than `merged_heads_max_tokens` tokens in the largest head).  Measured (round 4): the layer-locked heads cut
+        # the launches per batch-32 step from 681 to 487 and the products' time on one queue by 6 %, but lose to four streams on the wall
+        # clock in every regime tried -- C2 37.2 against 35.8 ms, batch 32 eager 18.4 against 16.4 ms (the Python that builds the grouped
+        # calls costs more than the launches it saves), recorded 9.5 against 9.0 ms, recorded predict 3.5 against 3.0 ms -- hence opt-in
+        self.merged_heads = os.environ.get("GRAPPA_MERGED_HEADS", "0")
         self.merged_heads_max_tokens = int(os.environ.get("GRAPPA_MERGED_HEADS_MAX_TOKENS", "40000"))
 
     def _writers_largest_first(self):

@@ -154,6 +154,12 @@ typedef struct grappa_gemm_desc {
      * rounding of fp16 denormals).  b_planes / b_rowmax / bit 1: the same for B ([K tokens][N features]).  One operand may stay fp32.
      * The products of one grouped call may mix formats (one launch either way; a group of one combination runs the kernel specialised for it). */
     const uint32_t* a_rowmax; const uint32_t* b_rowmax;
+    /* ---- ABI 8: row maxima of OUT left as the per-segment partials the epilogue writes anyway, combined by the CONSUMER.
+     * out_amax_parts != NULL (instead of out_amax; the split kernels only: M, N > 32, precision other than F32_MFMA): receives
+     * nseg = ceil(N / 32) arrays of M maxima, parts[seg * M + m].  A following product whose A operand is OUT (forward / input-gradient
+     * layout, fp32 operands) passes a_amax = parts and a_amax_nseg = nseg and takes the maximum over the segments itself;
+     * grappa_amax_reduce over all nseg * M values gives the whole-tensor maximum of a weight-gradient product. */
+    uint32_t* out_amax_parts; int a_amax_nseg;
 } grappa_gemm_desc;
 
 /* Largest magnitudes of an fp32 matrix x[R][C] (leading dimension ldx), as fp32 bit patterns: row_amax[r] = max_c |x[r][c]|,
@@ -175,6 +181,9 @@ int grappa_amax_f32_batched(void* stream, int count, const grappa_amax_item* des
 /* out[b] = max_i in[b][i], i < n[b], for `count` arrays in one launch per 32 (bit patterns of magnitudes: unsigned order): whole-tensor
  * maxima from row maxima.  `in` and `n` are HOST arrays (of device pointers / lengths). */
 int grappa_amax_reduce(void* stream, int count, const uint32_t* const* in, const int* n, uint32_t* out);
+/* out[m] = max over seg of parts[seg * M + m]: the row maxima from a product's per-segment partials (grappa_gemm_desc.out_amax_parts), for a
+ * consumer that needs them as one array */
+int grappa_amax_combine(void* stream, int M, int nseg, const uint32_t* parts, uint32_t* out);
 
 /* fp32 X[R][C] -> plane format: planes[p][r][c] (transpose == 0) or planes[p][c][r] (transpose != 0), p = 0..2, leading
  * dimension ldp, `plane_stride` elements between planes.  Only the R x C (C x R) block is written: padding the GEMM relies on

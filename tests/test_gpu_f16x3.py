@@ -105,7 +105,8 @@ def test_seqattn_row_maxima(hip, s, T, heads):
                                             (20, 16, 64, 1, 1, "plain"), (2600, 512, 4096, 1, 1, "plain")])
 def test_gemm_writes_output_row_maxima(hip, M, N, K, ak, bk, kw, precision):
     """out_amax: row maxima of the FINAL output (after bias / ELU / dropout / residual), from the row epilogue, the split-K reduction
-    (tail launches) and -- native kernel -- the pass that follows it"""
+    (tail launches) and -- native kernel -- the pass that follows it; both ways of delivering them (one array; the epilogue's partials
+    combined by the consumer, C ABI 8)"""
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).cuda()
     B = (torch.randn((N, K) if bk else (K, N), generator=g) / math.sqrt(K)).cuda()
@@ -117,7 +118,27 @@ def test_gemm_writes_output_row_maxima(hip, M, N, K, ak, bk, kw, precision):
         extra = dict(aux=torch.randn(M, N, generator=g).cuda())
     _, so = hip.gemm(A, B, out, M=M, N=N, K=K, a_kcontig=True, b_kcontig=bool(bk), precision=precision, out_amax=True, **extra)
     torch.cuda.synchronize()
-    assert so is not None and torch.equal(so.row, row_bits(out)), f"{precision} {M}x{N}x{K}"
+    assert so is not None
+    if precision == "f32_f16x3" and M > 32 and N > 32:
+        # the partials, and a product that consumes them (a_amax_nseg) against one that gets the combined array: the same bits
+        keep = hip.amax_parts
+        hip.amax_parts = True
+        try:
+            out_p = torch.empty_like(out)
+            _, sp = hip.gemm(A, B, out_p, M=M, N=N, K=K, a_kcontig=True, b_kcontig=bool(bk), precision=precision, out_amax=True, **extra)
+        finally:
+            hip.amax_parts = keep
+        assert sp.row is None and sp.parts is not None and torch.equal(out_p, out)
+        W2 = (torch.randn(64, N, generator=g) / math.sqrt(N)).cuda()
+        y_parts, y_row = torch.empty(M, 64, device="cuda"), torch.empty(M, 64, device="cuda")
+        hip.gemm(out_p, W2, y_parts, M=M, N=64, K=N, a_scales=sp)
+        assert torch.equal(hip.amax(out_p, sp, rows=True).row, row_bits(out))
+        hip.gemm(out, W2, y_row, M=M, N=64, K=N, a_scales=so if so.row is not None else None)
+        torch.cuda.synchronize()
+        assert torch.equal(y_parts, y_row)
+    if so.row is None:                           # GRAPPA_AMAX_PARTS=1: the partials of the epilogue, combined on request
+        so = hip.amax(out, so, rows=True)
+    assert torch.equal(so.row, row_bits(out)), f"{precision} {M}x{N}x{K}"
 
 
 def _rowrel(out, exact):

@@ -59,8 +59,7 @@ def main():
         ent.replay()
         torch.cuda.synchronize()
         e = time.perf_counter()
-        for (lvl, k), tt in ent.outputs.items():
-            g.nodes[lvl].data[k] = tt.to("cpu")
+        ent.read_outputs(g)
         f = time.perf_counter()
         Parameters.from_dgl(g)
         h = time.perf_counter()
