@@ -164,6 +164,9 @@ class HipBackend:
         # epilogue, which costs more than the one small launch it replaces (profiles/r4_amax_parts_ab.txt) -- hence not the default
         self.amax_parts = os.environ.get("GRAPPA_AMAX_PARTS", "0") not in ("0", "")
         self.pairs_min_rows = int(os.environ.get("GRAPPA_PAIRS_MIN_ROWS", "12288"))
+        # the dropout backward writing ITS rows (gradients) as pairs too: the input-gradient products behind gain (pair kernel), the weight-
+        # gradient products lose a little (a pair-format A operand costs 3 - 5 %, a pair-format B operand gains 9 %: tools/wgrad_pairs_bench.py)
+        self.backward_pairs = os.environ.get("GRAPPA_BACKWARD_PAIRS", "1") not in ("0", "")
         self._tails = None             # what set_tail_launches last told the library (None: the library's default)
         self._tails_pinned = False
         if os.environ.get("GRAPPA_PLAN_TAILS", "") != "":

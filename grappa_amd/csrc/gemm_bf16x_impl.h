@@ -138,7 +138,10 @@ __device__ inline unsigned rescale_h2(unsigned v, unsigned f1, unsigned f2) {
     const half2_t r = (__builtin_bit_cast(half2_t, v) * __builtin_bit_cast(half2_t, f1)) * __builtin_bit_cast(half2_t, f2);
     return __builtin_bit_cast(unsigned, r);
 }
-// quad j = features row .. row + 3 of ONE token k = kq (the KMV coordinates): 8 bytes of HI, 8 bytes of LO, and the token's maximum
+// "quad" j of a pair-format source = ONE 16-byte chunk of one token row k = kq (the KMV coordinates: chunk c = row / 4): a token's row
+// segment is a sequence of 64-byte granules [8 HI | 8 HI | 8 LO | 8 LO] of 16 features, so chunk c holds ONE piece (c & 2: LO) of the 8
+// features 16 (c / 4) + 8 (c & 1) .. + 7 -- the 64 lanes of a wavefront read 1 KB of one token row in one instruction (the fp32 path's
+// access pattern; 8-byte HI / LO loads per 4 features measured 10 % slower than the fp32-operand kernel) -- plus the token's maximum
 template <int NT, int ROWS>
 __device__ inline void load_quads_pairs(const uint16_t* __restrict__ src, int ld, const unsigned* __restrict__ rowmax, int row0, int k0, int R, int Kend,
                                         Quad (&q)[ROWS * 4 / NT]) {
@@ -146,50 +149,48 @@ __device__ inline void load_quads_pairs(const uint16_t* __restrict__ src, int ld
     for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
         quad_coords<NT, ROWS, false, true>(j, row, kq);
+        const int c = row >> 2;
         const int gk = k0 + kq < Kend ? k0 + kq : 0;
-        const int gr = min(row0 + row, ((R + 3) & ~3) - 4);
-        const uint16_t* p = src + (size_t)gk * ld + 32 * (gr >> 4) + (gr & 15);
-        const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 16);
-        q[j].x[0] = u2f(h.x); q[j].x[1] = u2f(h.y); q[j].x[2] = u2f(l.x); q[j].x[3] = u2f(l.y);
+        const int gran = min((row0 >> 4) + (c >> 2), (R >> 4) - 1);               // granules beyond the operand's rows are clamped (never stored)
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)gk * ld + 32 * gran + 8 * (c & 3));
+        q[j].x[0] = u2f(v.x); q[j].x[1] = u2f(v.y); q[j].x[2] = u2f(v.z); q[j].x[3] = u2f(v.w);
         q[j].rm = rowmax[gk];
     }
 }
+// do_cs (the A operand of the tile_n == 0 workgroups): the bias gradient rides on the rescaled halves -- cs[0 .. 7] += this thread's piece of
+// its 8 features UNDER THE TENSOR'S SCALE, one v_dot2_f32_f16 per element (HI and LO sums and the scale 2^-s_T meet in the reduction behind
+// the main loop).  (Converting every half back to fp32 under its row's scale -- 3 vector instructions per element on a quarter of the
+// workgroups -- made the whole launch 11 % slower than the fp32-operand kernel: the grid waits for its slowest workgroups.)
 template <int NT, int ROWS, bool MASK>
-__device__ inline void store_quads_pairs(char* __restrict__ opbase, const Quad (&q)[ROWS * 4 / NT], int krem, int e_tensor) {
+__device__ inline void store_quads_pairs(char* __restrict__ opbase, const Quad (&q)[ROWS * 4 / NT], int krem, int e_tensor, bool do_cs, float (&cs)[8]) {
     constexpr int PIECE = PieceBytes<ROWS, true>::value;
+    half2_t one_zero, zero_one;
+    one_zero[0] = (_Float16)1.0f; one_zero[1] = (_Float16)0.0f;
+    zero_one[0] = (_Float16)0.0f; zero_one[1] = (_Float16)1.0f;
 #pragma unroll
     for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
         quad_coords<NT, ROWS, false, true>(j, row, kq);
+        const int c = row >> 2, piece = (c >> 1) & 1, row8 = 16 * (c >> 2) + 8 * (c & 1);
         const int d = max(e_tensor - (int)((q[j].rm >> 23) & 0xffu), 0), d1 = min(d, 14);
         const unsigned f1 = pow2_neg_h2(d1), f2 = pow2_neg_h2(d - d1);
         unsigned w[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = rescale_h2(__float_as_uint(q[j].x[e]), f1, f2);
         if (MASK && kq >= krem) w[0] = w[1] = w[2] = w[3] = 0u;
-        char* dst = opbase + kq * (ROWS * 2) + ((((row >> 3) ^ ((kq & 3) << 2))) << 4) + ((row & 7) << 1);
-        *reinterpret_cast<uint2*>(dst) = make_uint2(w[0], w[1]);
-        *reinterpret_cast<uint2*>(dst + PIECE) = make_uint2(w[2], w[3]);
-    }
-}
-// bias gradient from a pair-format A: the elements back in fp32, (HI + LO) * 2^-s_k, summed over the tokens this thread stages
-template <int NT, int ROWS, bool MASK>
-__device__ inline void quad_rowsum_pairs(const Quad (&q)[ROWS * 4 / NT], int krem, float (&cs)[4]) {
+        if (do_cs) {
 #pragma unroll
-    for (int j = 0; j < ROWS * 4 / NT; ++j) {
-        int row, kq;
-        quad_coords<NT, ROWS, false, true>(j, row, kq);
-        if (MASK && kq >= krem) continue;
-        const int back = (int)((q[j].rm >> 23) & 0xffu) - 141;              // -s_k
-        const half2_t h01 = __builtin_bit_cast(half2_t, __float_as_uint(q[j].x[0])), h23 = __builtin_bit_cast(half2_t, __float_as_uint(q[j].x[1]));
-        const half2_t l01 = __builtin_bit_cast(half2_t, __float_as_uint(q[j].x[2])), l23 = __builtin_bit_cast(half2_t, __float_as_uint(q[j].x[3]));
-        cs[0] += __builtin_ldexpf((float)h01[0] + (float)l01[0], back);
-        cs[1] += __builtin_ldexpf((float)h01[1] + (float)l01[1], back);
-        cs[2] += __builtin_ldexpf((float)h23[0] + (float)l23[0], back);
-        cs[3] += __builtin_ldexpf((float)h23[1] + (float)l23[1], back);
+            for (int e = 0; e < 4; ++e) {
+                const half2_t h = __builtin_bit_cast(half2_t, w[e]);
+                cs[2 * e] = __builtin_amdgcn_fdot2(h, one_zero, cs[2 * e], false);
+                cs[2 * e + 1] = __builtin_amdgcn_fdot2(h, zero_one, cs[2 * e + 1], false);
+            }
+        }
+        // [k][row] with the 16-byte chunk (8 rows) swizzled by the k-row, as store_quads: one 16-byte write
+        char* dst = opbase + piece * PIECE + kq * (ROWS * 2) + ((((row8 >> 3) ^ ((kq & 3) << 2))) << 4);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
-
 // split 4 consecutive-k fp32 values into NP bf16 pieces (round to nearest even; the residual r - float(piece) is exact in
 // fp32) and store each piece's 4 values as one 8-byte LDS write.  krem = valid k of this slab counted from its first column
 // (MASK: a slab at the end of a K range, whose tail is zero-filled here).
@@ -251,7 +252,7 @@ __device__ inline void store_quads(char* __restrict__ opbase, const Quad (&q)[RO
 // bias gradient: sum over k of A(row, k) for the rows a thread stages.  Row-contiguous A, dword loads: one row per thread (cs[0]);
 // KMV: four consecutive rows per thread (cs[0..3])
 template <int NT, int ROWS, bool KMV, bool MASK>
-__device__ inline void quad_rowsum(const Quad (&q)[ROWS * 4 / NT], int krem, float (&cs)[4]) {
+__device__ inline void quad_rowsum(const Quad (&q)[ROWS * 4 / NT], int krem, float (&cs)[8]) {
 #pragma unroll
     for (int j = 0; j < ROWS * 4 / NT; ++j) {
         int row, kq;
@@ -385,7 +386,7 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
                                      const KRange& kr, int s, int wm0, int wn0, int lane, Quad (&la)[BM * 4 / NT], Quad (&lb)[BN * 4 / NT],
                                      const Quad (&sa)[BM * 4 / NT], const Quad (&sb)[BN * 4 / NT],
                                      const Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fc, Frags<Pieces<MODE>::NP, 2, BN / WN / 32>& fn,
-                                     float (&cs)[4], bool do_cs, const int (&sha)[BM * 4 / NT][(!AK && KMV) ? 4 : 1],
+                                     float (&cs)[8], bool do_cs, const int (&sha)[BM * 4 / NT][(!AK && KMV) ? 4 : 1],
                                      const int (&shb)[BN * 4 / NT][(!BKC && KMV) ? 4 : 1]) {
     constexpr int NP = Pieces<MODE>::NP, TM = 2, TN = BN / WN / 32;
     constexpr bool AV = !AK && KMV, BV = !BKC && KMV;          // row-contiguous operands read by 16-byte loads along their rows
@@ -410,13 +411,12 @@ __device__ inline void pipeline_step(const grappa_gemm_desc& d, char* __restrict
     mfma_range<MODE, TM, TN, 0, NFIRST>(fc, acc);
     if (do_store && !(GB_KNOCK == 4 && !TAIL)) {
         const int krem = TAIL ? kr.kend - kr.k_of(s + 1) : SK;
-        if constexpr (pa_) store_quads_pairs<NT, BM, TAIL>(nxt, sa, krem, 141 - sha[0][0]);
+        if constexpr (pa_) store_quads_pairs<NT, BM, TAIL>(nxt, sa, krem, 141 - sha[0][0], !AK && do_cs, cs);
         else store_quads<NT, NP, BM, AK, TAIL, Pieces<MODE>::HALF, AV>(nxt, sa, krem, sha);
-        if constexpr (pb_) store_quads_pairs<NT, BN, TAIL>(nxt + NP * PA, sb, krem, 141 - shb[0][0]);
+        if constexpr (pb_) store_quads_pairs<NT, BN, TAIL>(nxt + NP * PA, sb, krem, 141 - shb[0][0], false, cs);
         else store_quads<NT, NP, BN, BKC, TAIL, Pieces<MODE>::HALF, BV>(nxt + NP * PA, sb, krem, shb);
         if (!AK && do_cs) {
-            if constexpr (pa_) quad_rowsum_pairs<NT, BM, TAIL>(sa, krem, cs);
-            else quad_rowsum<NT, BM, AV, TAIL>(sa, krem, cs);
+            if constexpr (!pa_) quad_rowsum<NT, BM, AV, TAIL>(sa, krem, cs);
         }
     }
     if (!TAIL) {
@@ -496,7 +496,7 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
             shb[j][e] = Pieces<MODE>::HALF ? amax_shift(d.b_amax[(d.amax_bcast & 2) ? 0 : min(n0 + row + e, d.N - 1)]) : 0;
     }
     const bool do_cs = !AK && d.a_colsum != nullptr && tile_n == 0;
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};      // sums over k of A(row, k) for the row (KMV: the four rows) this thread stages -- the same for all its quads
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // sums over k of A(row, k) for the row (KMV: the four rows; pair format: the eight rows of one piece) this thread stages -- the same for all its quads
     if (nsteps > 0) {
         static_assert(AHEAD % 2 == 0, "the fragment sets alternate with the slabs");
         Quad qa[AHEAD][NQA], qb[AHEAD][NQB];      // register sets: slab t lives in set t % AHEAD from its load to its split
@@ -508,13 +508,12 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
             if constexpr (pb_) load_quads_pairs<NT, BN>(reinterpret_cast<const uint16_t*>(d.B), d.ldb, d.b_rowmax, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
             else load_quads<NT, BN, BKC, VEC, BV>(d.B, d.ldb, n0, kr.k_of(u < nsteps ? u : 0), d.N, kr.kend, qb[u]);
         }
-        if constexpr (pa_) store_quads_pairs<NT, BM, true>(smem, qa[0], kr.kend - kr.kbeg, 141 - sha[0][0]);
+        if constexpr (pa_) store_quads_pairs<NT, BM, true>(smem, qa[0], kr.kend - kr.kbeg, 141 - sha[0][0], !AK && do_cs, cs);
         else store_quads<NT, NP, BM, AK, true, Pieces<MODE>::HALF, AV>(smem, qa[0], kr.kend - kr.kbeg, sha);
-        if constexpr (pb_) store_quads_pairs<NT, BN, true>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, 141 - shb[0][0]);
+        if constexpr (pb_) store_quads_pairs<NT, BN, true>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, 141 - shb[0][0], false, cs);
         else store_quads<NT, NP, BN, BKC, true, Pieces<MODE>::HALF, BV>(smem + NP * PA, qb[0], kr.kend - kr.kbeg, shb);
         if (!AK && do_cs) {
-            if constexpr (pa_) quad_rowsum_pairs<NT, BM, true>(qa[0], kr.kend - kr.kbeg, cs);
-            else quad_rowsum<NT, BM, AV, true>(qa[0], kr.kend - kr.kbeg, cs);
+            if constexpr (!pa_) quad_rowsum<NT, BM, AV, true>(qa[0], kr.kend - kr.kbeg, cs);
         }
         __syncthreads();
         read_frags<NP, BM, BN, TM, TN, AV, BV>(smem, wm0, wn0, lane, fr[0]);
@@ -540,7 +539,13 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
     if (!AK && do_cs) {
         __syncthreads();                                     // every wavefront is past its last fragment read
         float* red = reinterpret_cast<float*>(smem);
-        if (AV) {
+        if constexpr (pa_) {
+            // thread t staged ONE piece of rows 16 (c / 4) + 8 (c & 1) .. + 7, c = t % (BM / 4), for the tokens of its k group t / (BM / 4):
+            // red[2 * group + piece][row]
+            const int c = threadIdx.x % (BM / 4), grp = threadIdx.x / (BM / 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(grp * 2 + ((c >> 1) & 1)) * BM + 16 * (c >> 2) + 8 * (c & 1) + e] = cs[e];
+        } else if (AV) {
             // thread t staged rows 4 (t % 64) .. + 3 (k = t / 64 and t / 64 + 8): red[t / 64][row]
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[(threadIdx.x / (BM / 4)) * BM + ((threadIdx.x % (BM / 4)) << 2) + e] = cs[e];
@@ -550,9 +555,10 @@ __device__ __forceinline__ void gemm_bf16x_body(const GemmParams& p, int nwg, in
         __syncthreads();
         if (threadIdx.x < BM) {
             float sum = 0.f;
-            constexpr int NG = AV ? NT / (BM / 4) : NT / BM;
+            constexpr int NG = pa_ ? 2 * (NT / (BM / 4)) : (AV ? NT / (BM / 4) : NT / BM);
 #pragma unroll
             for (int t = 0; t < NG; ++t) sum += red[threadIdx.x + t * BM];
+            if constexpr (pa_) sum = __builtin_ldexpf(sum, -sha[0][0]);          // the halves were summed under the tensor's scale 2^s_T
             const int m = m0 + threadIdx.x;
             if (m < d.M) {
                 if (p.nsplit > 1) p.cs_slab[(size_t)split * d.M + m] = sum;

@@ -154,7 +154,7 @@ def _bwd_pairs(be, M, width, *weights) -> bool:
     """backward pass, training with pairs: may a row-wise producer of (M, width) gradient rows write them in the pair format only?  (Every
     weight behind them must take a gradient: the bias gradient of a frozen weight would need the fp32 rows.)"""
     f = getattr(be, "training_pairs_ok", None)
-    return f is not None and f(M, width) and all(w is None or w.requires_grad for w in weights)
+    return f is not None and getattr(be, "backward_pairs", True) and f(M, width) and all(w is None or w.requires_grad for w in weights)
 
 
 _INFERENCE = {"on": False}
