@@ -166,7 +166,9 @@ class HipBackend:
         self.pairs_min_rows = int(os.environ.get("GRAPPA_PAIRS_MIN_ROWS", "12288"))
         # the dropout backward writing ITS rows (gradients) as pairs too: the input-gradient products behind gain (pair kernel), the weight-
         # gradient products lose a little (a pair-format A operand costs 3 - 5 %, a pair-format B operand gains 9 %: tools/wgrad_pairs_bench.py)
-        self.backward_pairs = os.environ.get("GRAPPA_BACKWARD_PAIRS", "1") not in ("0", "")
+        # Measured on the C2 step: 34.9 ms with the forward producers' pairs only, 35.0 - 35.1 with the backward producers' too, 35.35 without
+        # pairs (profiles/r4_backward_pairs_ab.txt) -- hence off by default
+        self.backward_pairs = os.environ.get("GRAPPA_BACKWARD_PAIRS", "0") not in ("0", "")
         self._tails = None             # what set_tail_launches last told the library (None: the library's default)
         self._tails_pinned = False
         if os.environ.get("GRAPPA_PLAN_TAILS", "") != "":
