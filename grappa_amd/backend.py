@@ -173,6 +173,7 @@ class HipBackend:
         self._tails_pinned = False
         if os.environ.get("GRAPPA_PLAN_TAILS", "") != "":
             self.pin_tail_launches(os.environ["GRAPPA_PLAN_TAILS"] != "0")
+        self.gnn_tails = os.environ.get("GRAPPA_GNN_TAILS", "0") not in ("0", "")      # tuning: tail launches for the GNN's products while the heads run without
         self.wgrads_aside = os.environ.get("GRAPPA_WGRADS_ASIDE", "1") not in ("0", "")      # tuning: 0 = every queued product waits for the end of the pass
         self._side_streams = {}        # (device, caller's stream handle) -> the side stream of launch_wgrads_aside
         self._aside = []               # (side stream, items kept alive) since the last flush

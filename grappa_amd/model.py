@@ -677,8 +677,13 @@ class GrappaModel(nn.Module):
             # ONE plan setting for every product of the call, the GNN's included, chosen before the first of them (flipping it
             # in front of the heads planned the first call's GNN differently from every later call's).  Several streams busy: a product's
             # partial last round overlaps with another head's kernels, its split-K tail launch is a loss
-            be.set_tail_launches(not (self.parameter_writer.head_streams > 1 and plan.device.type == "cuda"))
+            multi = self.parameter_writer.head_streams > 1 and plan.device.type == "cuda"
+            # (opt-in GRAPPA_GNN_TAILS=1: the GNN runs alone on the chip -- forward and backward -- so ITS products keep their tail launches;
+            # the setting is per PHASE and the same in every call: the backward pass switches at ops.SplitHeadsFn)
+            be.set_tail_launches(True if (multi and getattr(be, "gnn_tails", False)) else not multi)
         g = self.gnn(g)
+        if hasattr(be, "set_tail_launches") and getattr(be, "gnn_tails", False):
+            be.set_tail_launches(not (self.parameter_writer.head_streams > 1 and plan.device.type == "cuda"))
         h = g.nodes["n1"].data["h"]
         if self.on_heads_backward_done is not None and h.requires_grad:
             # fires when the gradient of the atom embedding is complete = every writer head has finished its backward pass

@@ -447,6 +447,8 @@ class SplitHeadsFn(Function):
     @staticmethod
     def backward(ctx, *gs):
         be = get_backend()
+        if getattr(be, "gnn_tails", False):
+            be.set_tail_launches(True)               # the GNN's backward pass has the chip to itself (model.GrappaModel.forward switches back)
         _wgrads_aside(be, all_streams=True)          # every head is done: what they left queued runs beside the GNN's backward pass
         gs = [_c(g) for g in gs if g is not None]
         if not gs:

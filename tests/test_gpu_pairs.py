@@ -246,12 +246,12 @@ def test_weight_gradient_from_pair_operands(fmt):
         assert float((got_b.double() - bref).abs().max()) <= 2e-6 * float(bref.abs().max()), fmt
 
 
-@pytest.mark.parametrize("min_rows", [12288, 0])
-def test_training_through_the_pair_format_equals_the_fp32_operand_path(min_rows):
-    """round 4: in training LayerNorm, the tuple attention and the dropout backward write the operands of the products behind them in the pair
-    format ONLY; forward / input-gradient products read them by LDS-DMA (csrc/gemm_pairs.hip), weight-gradient products through C ABI 8.  Same
-    loss and gradients as with fp32 operands (be.training_pairs = False) to fp32 rounding, with dropout on (same counter-based masks);
-    min_rows = 0: the GNN's atom rows too"""
+@pytest.mark.parametrize("min_rows,bwd", [(12288, False), (0, True), (12288, True)])
+def test_training_through_the_pair_format_equals_the_fp32_operand_path(min_rows, bwd):
+    """round 4: in training LayerNorm and the tuple attention (bwd: the dropout backward too, GRAPPA_BACKWARD_PAIRS) write the operands of the
+    products behind them in the pair format ONLY; forward / input-gradient products read them by LDS-DMA (csrc/gemm_pairs.hip), weight-gradient
+    products through C ABI 8.  Same loss and gradients as with fp32 operands (be.training_pairs = False) to fp32 rounding, with dropout on (same
+    counter-based masks); min_rows = 0: the GNN's atom rows too"""
     from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
     from grappa_amd.backend import get_backend
     from grappa_amd.datasets import build_batch_from_pool
@@ -264,10 +264,10 @@ def test_training_through_the_pair_format_equals_the_fp32_operand_path(min_rows)
     flat = FlatParams(model)
     g_cpu = build_batch_from_pool(list(range(100, 164)), n_confs=4, seed=3)
     res = {}
-    keep = be.pairs_min_rows
+    keep, keep_bwd = be.pairs_min_rows, be.backward_pairs
     try:
         for flag in (False, True):
-            be.training_pairs, be.pairs_min_rows = flag, min_rows
+            be.training_pairs, be.pairs_min_rows, be.backward_pairs = flag, min_rows, bwd
             ops.manual_seed(11)
             flat.zero_grad()
             g = Energy()(model(g_cpu.to("cuda")))
@@ -276,7 +276,7 @@ def test_training_through_the_pair_format_equals_the_fp32_operand_path(min_rows)
             torch.cuda.synchronize()
             res[flag] = (float(loss), flat.grad.clone(), g.nodes["n4"].data["k"].detach().clone(), g.nodes["n2"].data["eq"].detach().clone())
     finally:
-        be.training_pairs, be.pairs_min_rows = True, keep
+        be.training_pairs, be.pairs_min_rows, be.backward_pairs = True, keep, keep_bwd
     (l0, g0, k0, e0), (l1, g1, k1, e1) = res[False], res[True]
     assert abs(l1 - l0) <= 1e-5 * abs(l0), (l0, l1)
     assert float((k1 - k0).abs().max()) <= 1e-5 * float(k0.abs().max()) and float((e1 - e0).abs().max()) <= 1e-5 * float(e0.abs().max())
