@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrappa_host.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -17,6 +17,8 @@ SIGNATURES = {
     "grappa_topo_enumerate": (C.c_int, [C.c_int, _i32p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _i64, _i64]),
     "grappa_degree_encoding": (C.c_int, [C.c_int, C.c_int, _i32p, _f32p]),
     "grappa_ring_encoding": (C.c_int, [C.c_int, C.c_int, _i32p, _f32p]),
+    "grappa_plan_build": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, _i32p, C.POINTER(C.c_void_p), _i32p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 _lib = None
 
@@ -78,3 +80,32 @@ def ring_encoding(n_atoms: int, bonds) -> np.ndarray:
     if rc != 0:
         raise RuntimeError(f"grappa_ring_encoding failed with status {rc}")
     return enc
+
+
+def plan_build(N: int, src: np.ndarray, dst: np.ndarray, idx_levels):
+    """index plan of a batched graph (include/grappa_host.h grappa_plan_build).  src / dst: int64 (E,); idx_levels: four int32 (T_l, arity)
+    arrays (bond, angle, proper, improper).  -> dict of int32 arrays + max_degree; raises like grappa_amd.batch.BatchPlan"""
+    lib = load()
+    src = np.ascontiguousarray(src, dtype=np.int64)
+    dst = np.ascontiguousarray(dst, dtype=np.int64)
+    E = int(src.shape[0])
+    arity = (2, 3, 4, 4)
+    idx = [np.ascontiguousarray(a, dtype=np.int32).reshape(-1, s) for a, s in zip(idx_levels, arity)]
+    T = np.array([a.shape[0] for a in idx], dtype=np.int32)
+    out = {"indptr": np.empty(N + 1, np.int32), "indices": np.empty(E, np.int32), "rev": np.empty(E, np.int32), "inc_ptr": np.empty(N + 1, np.int32),
+           "inc_code": np.empty(int(sum(s * t for s, t in zip(arity, T))), np.int32)}
+    inv_ptr = [np.empty(N + 1, np.int32) for _ in range(4)]
+    inv_rows = [np.empty(s * int(t), np.int32) for s, t in zip(arity, T)]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+    arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])      # noqa: E731
+    maxdeg, detail = C.c_int32(0), C.c_int32(0)
+    rc = lib.grappa_plan_build(int(N), E, vp(src), vp(dst), T, arr(idx), out["indptr"], vp(out["indices"]), vp(out["rev"]), arr(inv_ptr), arr(inv_rows),
+                               out["inc_ptr"], vp(out["inc_code"]), C.byref(maxdeg), C.byref(detail))
+    if rc != 0:
+        if detail.value == 1:
+            raise ValueError("MolBatch: the n1 graph must contain both directions of every bond")
+        if detail.value == 2:
+            raise RuntimeError("There are 0-in-degree nodes in the graph (every atom must be bonded)")
+        raise RuntimeError(f"grappa_plan_build failed with status {rc}")
+    out["inv_ptr"], out["inv_rows"], out["max_degree"] = inv_ptr, inv_rows, int(maxdeg.value)
+    return out

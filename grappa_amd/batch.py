@@ -55,67 +55,117 @@ class BatchPlan:
         N = g.num_nodes("n1")
         src, dst = g._src.cpu().numpy().astype(np.int64), g._dst.cpu().numpy().astype(np.int64)
         E = len(src)
-        # CSR by destination, neighbours ascending by source id (deterministic)
-        order = np.lexsort((src, dst))
-        s_sorted, d_sorted = src[order], dst[order]
-        indptr = np.zeros(N + 1, dtype=np.int64)
-        np.add.at(indptr, d_sorted + 1, 1)
-        indptr = np.cumsum(indptr)
-        # reverse edge slot: edge (u -> v) stored in v's list; its reverse (v -> u) is in u's list
-        key = d_sorted * max(N, 1) + s_sorted          # sorted ascending by construction
-        rkey = s_sorted * max(N, 1) + d_sorted
-        rev = np.searchsorted(key, rkey)
-        if E and not (np.all(rev < E) and np.all(key[np.minimum(rev, E - 1)] == rkey)):
-            raise ValueError("MolBatch: the n1 graph must contain both directions of every bond")
-        if N and np.any(np.diff(indptr) == 0):
-            raise RuntimeError("There are 0-in-degree nodes in the graph (every atom must be bonded)")
-        self.N, self.E = N, E
-        self.indptr = torch.from_numpy(indptr.astype(np.int32)).to(dev)
-        self.indices = torch.from_numpy(s_sorted.astype(np.int32)).to(dev)
-        self.rev = torch.from_numpy(rev.astype(np.int32)).to(dev)
-        self.max_degree = int(np.max(np.diff(indptr))) if N else 0
-
-        self.B = g.num_nodes("g")
-        self.atom_molptr = torch.from_numpy(_cum(g._bnn["n1"])).to(dev)
-        self.idx32: Dict[str, torch.Tensor] = {}
-        self.mol_ptr: Dict[str, torch.Tensor] = {}
-        self.T: Dict[str, int] = {}
-        self.inv_ptr: Dict[str, torch.Tensor] = {}
-        self.inv_rows: Dict[str, torch.Tensor] = {}
-        inc_atom, inc_code = [], []
-        for li, lvl in enumerate(TUPLE_LEVELS):
+        idx_np = []
+        for lvl in TUPLE_LEVELS:
             s = LEVEL_ARITY[lvl]
             idx = g._data[lvl]["idxs"].detach().cpu().numpy().astype(np.int64).reshape(-1, s)
-            T = idx.shape[0]
-            if T and (idx.min() < 0 or idx.max() >= N):
+            if idx.shape[0] and (idx.min() < 0 or idx.max() >= N):
                 raise AssertionError(
                     f"Encountered idxs up to {idx.max()} at the level g.nodes[{lvl}].data[\"idxs\"], "
                     f"but there are only {N} atom-level-nodes in the graph")
-            self.T[lvl] = T
-            self.idx32[lvl] = torch.from_numpy(idx.astype(np.int32)).to(dev)
-            self.mol_ptr[lvl] = torch.from_numpy(_cum(g._bnn[lvl])).to(dev)
-            # inverse incidence: atom -> rows (pos*T + t) of the (s, T, F) token table
-            atoms = idx.T.reshape(-1)                      # row r = pos*T + t  <->  atoms[r]
-            rows = np.argsort(atoms, kind="stable")
-            ptr = np.zeros(N + 1, dtype=np.int64)
-            np.add.at(ptr, atoms + 1, 1)
-            self.inv_ptr[lvl] = torch.from_numpy(np.cumsum(ptr).astype(np.int32)).to(dev)
-            self.inv_rows[lvl] = torch.from_numpy(rows.astype(np.int32)).to(dev)
-            # packed incidence for the force kernel: code = (tuple << 4) | (level << 2) | pos
-            pos = np.repeat(np.arange(s, dtype=np.int64), T)
-            t = np.tile(np.arange(T, dtype=np.int64), s)
-            inc_atom.append(atoms)
-            inc_code.append((t << 4) | (li << 2) | pos)
-        inc_atom = np.concatenate(inc_atom) if inc_atom else np.zeros(0, np.int64)
-        inc_code = np.concatenate(inc_code) if inc_code else np.zeros(0, np.int64)
-        o = np.argsort(inc_atom, kind="stable")
-        ptr = np.zeros(N + 1, dtype=np.int64)
-        np.add.at(ptr, inc_atom + 1, 1)
-        if len(inc_code) and inc_code.max() >= 2 ** 31:
-            raise ValueError("too many tuples for the packed int32 incidence code")
-        self.inc_ptr = torch.from_numpy(np.cumsum(ptr).astype(np.int32)).to(dev)
-        self.inc_code = torch.from_numpy(inc_code[o].astype(np.int32)).to(dev)
+            idx_np.append(idx.astype(np.int32))
+        arrays = _plan_arrays_native(N, src, dst, idx_np) if _NATIVE_PLAN else None
+        if arrays is None:
+            arrays = _plan_arrays_numpy(N, src, dst, idx_np)
+        self.N, self.E = N, E
+        self.max_degree = arrays.pop("max_degree")
+        self.B = g.num_nodes("g")
+        arrays["atom_molptr"] = _cum(g._bnn["n1"])
+        for lvl, idx in zip(TUPLE_LEVELS, idx_np):
+            arrays[f"idx32.{lvl}"] = idx
+            arrays[f"mol_ptr.{lvl}"] = _cum(g._bnn[lvl])
+        # ONE transfer: every table is a 16-byte aligned view of one flat int32 buffer (a 40-atom molecule's plan was 25 copies of a few
+        # hundred bytes each)
+        off, layout = 0, {}
+        for name, a in arrays.items():
+            layout[name] = (off, a.size, a.shape)
+            off += (a.size + 3) // 4 * 4
+        flat = np.zeros(max(off, 4), dtype=np.int32)
+        for name, a in arrays.items():
+            o, n, _ = layout[name]
+            flat[o:o + n] = a.reshape(-1)
+        flat_t = torch.from_numpy(flat).to(dev)
+        view = {name: flat_t[o:o + n].view(shape) for name, (o, n, shape) in layout.items()}
+        self.indptr, self.indices, self.rev = view["indptr"], view["indices"], view["rev"]
+        self.atom_molptr = view["atom_molptr"]
+        self.T: Dict[str, int] = {lvl: int(idx.shape[0]) for lvl, idx in zip(TUPLE_LEVELS, idx_np)}
+        self.idx32 = {lvl: view[f"idx32.{lvl}"] for lvl in TUPLE_LEVELS}
+        self.mol_ptr = {lvl: view[f"mol_ptr.{lvl}"] for lvl in TUPLE_LEVELS}
+        self.inv_ptr = {lvl: view[f"inv_ptr.{lvl}"] for lvl in TUPLE_LEVELS}
+        self.inv_rows = {lvl: view[f"inv_rows.{lvl}"] for lvl in TUPLE_LEVELS}
+        self.inc_ptr, self.inc_code = view["inc_ptr"], view["inc_code"]
         self.device = dev
+        self._idx_host = dict(zip(TUPLE_LEVELS, idx_np))      # (position_tables builds its tables from these on the host: no device sync)
+
+
+import os as _os
+
+_NATIVE_PLAN = _os.environ.get("GRAPPA_HOST_PLAN", "1") not in ("0", "")
+
+
+def _plan_arrays_native(N, src, dst, idx_np):
+    """the index structures from libgrappa_host.so (include/grappa_host.h grappa_plan_build); None if the library is not built"""
+    try:
+        from . import _hostlib
+        out = _hostlib.plan_build(N, src, dst, idx_np)
+    except (OSError, RuntimeError) as e:
+        if "0-in-degree" in str(e) or "grappa_plan_build failed" in str(e):
+            raise
+        return None
+    arrays = {"indptr": out["indptr"], "indices": out["indices"], "rev": out["rev"], "max_degree": out["max_degree"]}
+    for li, lvl in enumerate(TUPLE_LEVELS):
+        arrays[f"inv_ptr.{lvl}"] = out["inv_ptr"][li]
+        arrays[f"inv_rows.{lvl}"] = out["inv_rows"][li]
+    arrays["inc_ptr"], arrays["inc_code"] = out["inc_ptr"], out["inc_code"]
+    return arrays
+
+
+def _plan_arrays_numpy(N, src, dst, idx_np):
+    """the same in numpy (GRAPPA_HOST_PLAN=0, or the host library missing): the definition the native builder is tested against"""
+    E = len(src)
+    # CSR by destination, neighbours ascending by source id (deterministic)
+    order = np.lexsort((src, dst))
+    s_sorted, d_sorted = src[order], dst[order]
+    indptr = np.zeros(N + 1, dtype=np.int64)
+    np.add.at(indptr, d_sorted + 1, 1)
+    indptr = np.cumsum(indptr)
+    # reverse edge slot: edge (u -> v) stored in v's list; its reverse (v -> u) is in u's list
+    key = d_sorted * max(N, 1) + s_sorted          # sorted ascending by construction
+    rkey = s_sorted * max(N, 1) + d_sorted
+    rev = np.searchsorted(key, rkey)
+    if E and not (np.all(rev < E) and np.all(key[np.minimum(rev, E - 1)] == rkey)):
+        raise ValueError("MolBatch: the n1 graph must contain both directions of every bond")
+    if N and np.any(np.diff(indptr) == 0):
+        raise RuntimeError("There are 0-in-degree nodes in the graph (every atom must be bonded)")
+    arrays = {"indptr": indptr.astype(np.int32), "indices": s_sorted.astype(np.int32), "rev": rev.astype(np.int32),
+              "max_degree": int(np.max(np.diff(indptr))) if N else 0}
+    inc_atom, inc_code = [], []
+    for li, (lvl, idx) in enumerate(zip(TUPLE_LEVELS, idx_np)):
+        s = LEVEL_ARITY[lvl]
+        idx = idx.astype(np.int64)
+        T = idx.shape[0]
+        # inverse incidence: atom -> rows (pos*T + t) of the (s, T, F) token table
+        atoms = idx.T.reshape(-1)                      # row r = pos*T + t  <->  atoms[r]
+        rows = np.argsort(atoms, kind="stable")
+        ptr = np.zeros(N + 1, dtype=np.int64)
+        np.add.at(ptr, atoms + 1, 1)
+        arrays[f"inv_ptr.{lvl}"] = np.cumsum(ptr).astype(np.int32)
+        arrays[f"inv_rows.{lvl}"] = rows.astype(np.int32)
+        # packed incidence for the force kernel: code = (tuple << 4) | (level << 2) | pos
+        pos = np.repeat(np.arange(s, dtype=np.int64), T)
+        t = np.tile(np.arange(T, dtype=np.int64), s)
+        inc_atom.append(atoms)
+        inc_code.append((t << 4) | (li << 2) | pos)
+    inc_atom = np.concatenate(inc_atom) if inc_atom else np.zeros(0, np.int64)
+    inc_code = np.concatenate(inc_code) if inc_code else np.zeros(0, np.int64)
+    o = np.argsort(inc_atom, kind="stable")
+    ptr = np.zeros(N + 1, dtype=np.int64)
+    np.add.at(ptr, inc_atom + 1, 1)
+    if len(inc_code) and inc_code.max() >= 2 ** 31:
+        raise ValueError("too many tuples for the packed int32 incidence code")
+    arrays["inc_ptr"] = np.cumsum(ptr).astype(np.int32)
+    arrays["inc_code"] = inc_code[o].astype(np.int32)
+    return arrays
 
 
 def _plan_position_tables(self, lvl: str):
@@ -137,6 +187,27 @@ def _position_tables(plan: "BatchPlan", lvl: str):
       invtab_ptr / invtab_rows: table row <- token rows pos*T + t (ascending) -- its inverse"""
     s, N, T = LEVEL_ARITY[lvl], plan.N, plan.T[lvl]
     dev = plan.idx32[lvl].device
+    host = getattr(plan, "_idx_host", None)
+    if host is not None:
+        # the plan was built on the host: six numpy expressions and ONE transfer instead of a dozen torch kernels (and bincount's sync)
+        idx = host[lvl].astype(np.int64)
+        pos = np.arange(s, dtype=np.int64)
+        idx_tab = idx + pos.reshape(1, s) * N
+        key = idx_tab.T.reshape(-1)
+        parts = [np.repeat(np.arange(N, dtype=np.int64), s),                                  # idx_id (N, s)
+                 np.arange(N + 1, dtype=np.int64) * s,                                          # invid_ptr
+                 (pos.reshape(1, s) * N + np.arange(N, dtype=np.int64).reshape(N, 1)).reshape(-1),   # invid_rows
+                 idx_tab.reshape(-1),                                                           # idx_tab (T, s)
+                 np.concatenate(([0], np.cumsum(np.bincount(key, minlength=s * N)))),           # invtab_ptr
+                 np.argsort(key, kind="stable")]                                                # invtab_rows
+        sizes = [p.size for p in parts]
+        offs = np.concatenate(([0], np.cumsum([(n + 3) // 4 * 4 for n in sizes])))
+        flat = np.zeros(max(int(offs[-1]), 4), dtype=np.int32)
+        for p, o in zip(parts, offs):
+            flat[o:o + p.size] = p
+        ft = torch.from_numpy(flat).to(dev)
+        v = [ft[o:o + n] for o, n in zip(offs, sizes)]
+        return v[0].view(N, s), v[1], v[2], v[3].view(T, s), v[4], v[5]
     i32 = dict(dtype=torch.int32, device=dev)
     pos = torch.arange(s, **i32)
     idx_id = torch.arange(N, **i32).view(N, 1).expand(N, s).contiguous()

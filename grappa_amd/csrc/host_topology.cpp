@@ -62,7 +62,7 @@ struct Cycle {
 
 }  // namespace
 
-extern "C" int grappa_host_abi_version(void) { return 1; }
+extern "C" int grappa_host_abi_version(void) { return 2; }
 
 extern "C" int grappa_topo_enumerate(int n_bonds, const int32_t* bonds, int32_t* angles, int64_t cap_angles, int32_t* propers,
                                      int64_t cap_propers, int64_t* n_angles, int64_t* n_propers) {
@@ -288,6 +288,95 @@ extern "C" int grappa_ring_encoding(int n_atoms, int n_bonds, const int32_t* bon
                 if (t >= 0) basis.emplace(t, std::move(r));
             }
             i = j;
+        }
+    }
+    return OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ index plan of a batched graph
+// grappa_amd/batch.py BatchPlan in O(E + sum s T) counting sorts instead of ~60 numpy calls (0.4 ms for one 40-atom molecule: a seventh of
+// a recorded Grappa.predict call).  Same arrays, element for element (tests/test_host_plan.py).
+extern "C" int grappa_plan_build(int N, int64_t E, const int64_t* src, const int64_t* dst, const int32_t* T, const int32_t* const* idx,
+                                 int32_t* indptr, int32_t* indices, int32_t* rev, int32_t* const* inv_ptr, int32_t* const* inv_rows,
+                                 int32_t* inc_ptr, int32_t* inc_code, int32_t* max_degree, int32_t* status_detail) {
+    static const int ARITY[4] = {2, 3, 4, 4};
+    if (N < 0 || E < 0 || (E > 0 && (!src || !dst)) || !T || !idx || !indptr || !inv_ptr || !inv_rows || !inc_ptr || !max_degree) return ERR_ARG;
+    if (status_detail) *status_detail = 0;
+    // ---- CSR by destination, neighbours ascending by source id, duplicates in input order (= numpy's lexsort((src, dst)))
+    for (int i = 0; i <= N; ++i) indptr[i] = 0;
+    for (int64_t e = 0; e < E; ++e) {
+        if (src[e] < 0 || src[e] >= N || dst[e] < 0 || dst[e] >= N) return ERR_ARG;
+        ++indptr[dst[e] + 1];
+    }
+    for (int i = 0; i < N; ++i) indptr[i + 1] += indptr[i];
+    std::vector<int64_t> order((size_t)E);
+    {
+        // stable counting sort by src, then by dst: the result is ordered by (dst, src) with ties in input order
+        std::vector<int64_t> cnt((size_t)N + 1, 0), tmp((size_t)E);
+        for (int64_t e = 0; e < E; ++e) ++cnt[src[e] + 1];
+        for (int i = 0; i < N; ++i) cnt[i + 1] += cnt[i];
+        for (int64_t e = 0; e < E; ++e) tmp[cnt[src[e]]++] = e;
+        std::vector<int64_t> pos(indptr, indptr + N);
+        for (int64_t k = 0; k < E; ++k) {
+            const int64_t e = tmp[k];
+            order[pos[dst[e]]++] = e;
+        }
+    }
+    for (int64_t k = 0; k < E; ++k) indices[k] = (int32_t)src[order[k]];
+    // reverse edge slot: edge k = (u -> v) lies in v's list; its reverse (v -> u) is the FIRST entry with source v in u's list
+    for (int64_t k = 0; k < E; ++k) {
+        const int64_t u = src[order[k]], v = dst[order[k]];
+        const int32_t* lo = indices + indptr[u];
+        const int32_t* hi = indices + indptr[u + 1];
+        const int32_t* it = std::lower_bound(lo, hi, (int32_t)v);
+        if (it == hi || *it != (int32_t)v) {
+            if (status_detail) *status_detail = 1;           // the graph does not hold both directions of a bond
+            return ERR_ARG;
+        }
+        rev[k] = (int32_t)(it - indices);
+    }
+    int maxdeg = 0;
+    for (int i = 0; i < N; ++i) {
+        const int d = indptr[i + 1] - indptr[i];
+        if (d == 0) {
+            if (status_detail) *status_detail = 2;           // a 0-in-degree node
+            return ERR_ARG;
+        }
+        maxdeg = d > maxdeg ? d : maxdeg;
+    }
+    *max_degree = maxdeg;
+    // ---- per level: inverse incidence atom -> token rows (pos * T + t), rows ascending (a stable sort of the rows by atom)
+    int64_t total = 0;
+    for (int l = 0; l < 4; ++l) total += (int64_t)ARITY[l] * T[l];
+    for (int i = 0; i <= N; ++i) inc_ptr[i] = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int s = ARITY[l], Tl = T[l];
+        int32_t* ptr = inv_ptr[l];
+        for (int i = 0; i <= N; ++i) ptr[i] = 0;
+        for (int t = 0; t < Tl; ++t)
+            for (int p = 0; p < s; ++p) {
+                const int a = idx[l][(size_t)t * s + p];
+                if (a < 0 || a >= N) return ERR_ARG;
+                ++ptr[a + 1];
+                ++inc_ptr[a + 1];
+            }
+        for (int i = 0; i < N; ++i) ptr[i + 1] += ptr[i];
+        std::vector<int32_t> pos(ptr, ptr + N);
+        for (int p = 0; p < s; ++p)
+            for (int t = 0; t < Tl; ++t) inv_rows[l][pos[idx[l][(size_t)t * s + p]]++] = p * Tl + t;
+    }
+    // ---- packed incidence of the force kernel: code = (tuple << 4) | (level << 2) | pos, grouped by atom, inside an atom in the order
+    // level, position, tuple (the stable sort of the concatenated lists)
+    for (int i = 0; i < N; ++i) inc_ptr[i + 1] += inc_ptr[i];
+    if (total > 0) {
+        if (!inc_code) return ERR_ARG;
+        std::vector<int32_t> pos(inc_ptr, inc_ptr + N);
+        for (int l = 0; l < 4; ++l) {
+            const int s = ARITY[l], Tl = T[l];
+            if (Tl > 0 && (((int64_t)(Tl - 1) << 4) | 15) >= (int64_t(1) << 31)) return ERR_ARG;
+            for (int p = 0; p < s; ++p)
+                for (int t = 0; t < Tl; ++t) inc_code[pos[idx[l][(size_t)t * s + p]]++] = (int32_t)(((int64_t)t << 4) | (l << 2) | p);
         }
     }
     return OK;

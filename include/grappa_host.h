@@ -38,6 +38,15 @@ int grappa_degree_encoding(int n_atoms, int n_bonds, const int32_t* bonds, float
  * RDKit's symmetrised SSSR on the ring systems of organic molecules (grappa_amd/featurize.py states the same definition). */
 int grappa_ring_encoding(int n_atoms, int n_bonds, const int32_t* bonds, float* enc);
 
+/* Index plan of a (batched) molecular graph -- what grappa_amd/batch.py BatchPlan holds for the kernels: CSR by destination with
+ * neighbours ascending (indptr [N+1], indices [E]), the slot of every edge's reverse edge (rev [E]), per tuple level l = bond, angle,
+ * proper, improper (arity 2, 3, 4, 4; idx[l] = [T[l]][arity] atom indices) the inverse incidence atom -> token rows pos * T + t
+ * (inv_ptr[l] [N+1], inv_rows[l] [arity * T[l]]), and the packed incidence of the force kernel (inc_ptr [N+1], inc_code: (t << 4) |
+ * (l << 2) | pos).  status_detail (optional): 1 = a bond is stored in one direction only, 2 = an atom without bonds. */
+int grappa_plan_build(int N, int64_t E, const int64_t* src, const int64_t* dst, const int32_t* T, const int32_t* const* idx,
+                      int32_t* indptr, int32_t* indices, int32_t* rev, int32_t* const* inv_ptr, int32_t* const* inv_rows,
+                      int32_t* inc_ptr, int32_t* inc_code, int32_t* max_degree, int32_t* status_detail);
+
 #ifdef __cplusplus
 }
 #endif

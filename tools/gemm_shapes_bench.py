@@ -28,7 +28,7 @@ def record_shapes():
     orig = be.gemm
 
     def rec(a, b, out, *, M, N, K, a_kcontig=True, b_kcontig=True, **kw):
-        shapes[(M, N, K, int(a_kcontig), int(b_kcontig), a.stride(0) if a.dim() == 2 and a.shape[0] > 1 else 0,
+        shapes[(M, N, K, int(a_kcontig), int(b_kcontig), (a.stride(0) if a.dim() == 2 and a.shape[0] > 1 else 0) if a is not None else K,
                 b.stride(0) if b.shape[0] > 1 else 0, out.stride(0) if out.shape[0] > 1 else 0)] += 1
         return orig(a, b, out, M=M, N=N, K=K, a_kcontig=a_kcontig, b_kcontig=b_kcontig, **kw)
 
@@ -36,7 +36,12 @@ def record_shapes():
     model = model_from_config(get_default_model_config())
     model.load_state_dict(gu.keyed_state_dict(model))
     model = model.to(DEV).train()
-    g = build_workload(WORKLOAD, seed=0).to(DEV)
+    n_mols = int(os.environ.get("GRAPPA_TUNE_MOLECULES", "0"))
+    if n_mols:                               # the first molecules of the workload only (e.g. 32: the reference's own batch size)
+        from grappa_amd.datasets import build_batch_from_pool, workload_molecule_ids
+        g = build_batch_from_pool(workload_molecule_ids(WORKLOAD, seed=0)[:n_mols], n_confs=32, seed=0).to(DEV)
+    else:
+        g = build_workload(WORKLOAD, seed=0).to(DEV)
     loss = MolwiseLoss(param_weight=0.0)(Energy()(model(g)))
     loss.backward()
     if DEV == "cuda":
