@@ -17,6 +17,7 @@ SIGNATURES = {
     "grappa_topo_enumerate": (C.c_int, [C.c_int, _i32p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _i64, _i64]),
     "grappa_degree_encoding": (C.c_int, [C.c_int, C.c_int, _i32p, _f32p]),
     "grappa_ring_encoding": (C.c_int, [C.c_int, C.c_int, _i32p, _f32p]),
+    "grappa_components": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, _i32p]),
     "grappa_plan_build": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, _i32p, C.POINTER(C.c_void_p), _i32p, C.c_void_p, C.c_void_p,
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
@@ -109,3 +110,15 @@ def plan_build(N: int, src: np.ndarray, dst: np.ndarray, idx_levels):
         raise RuntimeError(f"grappa_plan_build failed with status {rc}")
     out["inv_ptr"], out["inv_rows"], out["max_degree"] = inv_ptr, inv_rows, int(maxdeg.value)
     return out
+
+
+def components(n: int, src: np.ndarray, dst: np.ndarray) -> np.ndarray:
+    """label[a] = smallest atom index of a's connected component (include/grappa_host.h grappa_components)"""
+    lib = load()
+    src = np.ascontiguousarray(src, dtype=np.int64)
+    dst = np.ascontiguousarray(dst, dtype=np.int64)
+    label = np.empty(n, dtype=np.int32)
+    rc = lib.grappa_components(int(n), int(src.shape[0]), src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), label)
+    if rc != 0:
+        raise RuntimeError(f"grappa_components failed with status {rc}")
+    return label

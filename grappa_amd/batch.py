@@ -439,19 +439,24 @@ def check_disconnected_graphs(g: MolBatch, print_information: bool = True) -> No
     """Water guard of `Grappa.predict` (reference utils/dgl_utils.py:210-236): raise if a
     connected component has exactly three atoms with elements {H, O}."""
     n = g.num_nodes("n1")
-    parent = np.arange(n)
+    src, dst = g._src.cpu().numpy(), g._dst.cpu().numpy()
+    try:                                              # connected components natively: the Python union-find was 0.2 - 0.45 ms of a 3 ms predict
+        from . import _hostlib
+        roots = _hostlib.components(n, src, dst)
+    except (OSError, RuntimeError):
+        parent = np.arange(n)
 
-    def find(a):
-        while parent[a] != a:
-            parent[a] = parent[parent[a]]
-            a = parent[a]
-        return a
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
 
-    for a, b in zip(g._src.cpu().numpy().tolist(), g._dst.cpu().numpy().tolist()):
-        ra, rb = find(a), find(b)
-        if ra != rb:
-            parent[ra] = rb
-    roots = np.array([find(a) for a in range(n)])
+        for a, b in zip(src.tolist(), dst.tolist()):
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                parent[ra] = rb
+        roots = np.array([find(a) for a in range(n)])
     comps, counts = np.unique(roots, return_counts=True)
     if print_information and len(comps) > 1:
         print(f"Found {len(comps)} disconnected subgraphs of lengths {counts[:3].tolist()}...")

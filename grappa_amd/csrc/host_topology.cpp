@@ -381,3 +381,25 @@ extern "C" int grappa_plan_build(int N, int64_t E, const int64_t* src, const int
     }
     return OK;
 }
+
+
+// connected components of an undirected graph given as directed edges: label[a] = smallest atom index of a's component
+extern "C" int grappa_components(int N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* label) {
+    if (N < 0 || E < 0 || (E > 0 && (!src || !dst)) || (N > 0 && !label)) return ERR_ARG;
+    std::vector<int32_t> parent((size_t)N);
+    for (int i = 0; i < N; ++i) parent[i] = i;
+    auto find = [&](int a) {
+        while (parent[a] != a) {
+            parent[a] = parent[parent[a]];
+            a = parent[a];
+        }
+        return a;
+    };
+    for (int64_t e = 0; e < E; ++e) {
+        if (src[e] < 0 || src[e] >= N || dst[e] < 0 || dst[e] >= N) return ERR_ARG;
+        const int ra = find((int)src[e]), rb = find((int)dst[e]);
+        if (ra != rb) parent[ra > rb ? ra : rb] = ra > rb ? rb : ra;          // the smaller index stays the root
+    }
+    for (int i = 0; i < N; ++i) label[i] = find(i);
+    return OK;
+}

@@ -103,10 +103,23 @@ class Molecule:
         `n1` carries 'ids' (= self.atoms); the tuple levels carry 'idxs' (positions in self.atoms)."""
         assert max_element > 0, f"max_element must be larger than 0 but is {max_element}"
         assert not any(x is None for x in (self.angles, self.propers)), "angles and propers must not be None"
-        idx = {a: i for i, a in enumerate(self.atoms)}
+        ids_arr = np.asarray(self.atoms, dtype=np.int64)
+        identity = ids_arr.size == 0 or (ids_arr[0] == 0 and ids_arr[-1] == ids_arr.size - 1 and bool(np.all(np.diff(ids_arr) == 1)))
+        if not identity:
+            order = np.argsort(ids_arr, kind="stable")
+            sorted_ids = ids_arr[order]
 
         def table(rows, s):
-            return np.array([[idx[x] for x in r] for r in rows], dtype=np.int64).reshape(-1, s)
+            """atom ids -> positions in self.atoms (vectorised: the id list is 0 .. n-1 for most molecules)"""
+            t = np.asarray(rows, dtype=np.int64).reshape(-1, s)
+            if identity or t.size == 0:
+                if t.size and (t.min() < 0 or t.max() >= ids_arr.size):
+                    raise KeyError(int(t.max() if t.max() >= ids_arr.size else t.min()))
+                return t
+            pos = np.searchsorted(sorted_ids, t)
+            if np.any(pos >= sorted_ids.size) or np.any(sorted_ids[np.minimum(pos, sorted_ids.size - 1)] != t):
+                raise KeyError(int(t[(pos >= sorted_ids.size) | (sorted_ids[np.minimum(pos, sorted_ids.size - 1)] != t)][0]))
+            return order[pos]
 
         idxs = {"n2": table(self.bonds, 2), "n3": table(self.angles, 3), "n4": table(self.propers, 4),
                 "n4_improper": table(self.impropers, 4)}

@@ -47,6 +47,10 @@ int grappa_plan_build(int N, int64_t E, const int64_t* src, const int64_t* dst, 
                       int32_t* indptr, int32_t* indices, int32_t* rev, int32_t* const* inv_ptr, int32_t* const* inv_rows,
                       int32_t* inc_ptr, int32_t* inc_code, int32_t* max_degree, int32_t* status_detail);
 
+/* Connected components of the bond graph (directed edge list, both directions or one): label[a] = smallest atom index of a's component.
+ * The water guard of Grappa.predict (reference utils/dgl_utils.py:210-236) walks them. */
+int grappa_components(int N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* label);
+
 #ifdef __cplusplus
 }
 #endif
