@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hip.so")   # override: kernel A/B builds (tools/)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
 GEMM_GROUP4_MAX = 4          # grappa_gemm_f32_group (forward / input-gradient products of the writer heads)
 GEMM_GROUP_MAX = 16
@@ -136,6 +136,7 @@ SIGNATURES = {
     "grappa_colsum_partials_batched": (_i, [_vp, C.POINTER(ColsumItem), _i]),
     "grappa_layernorm_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
     "grappa_layernorm_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "grappa_layernorm_bwd_drop_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _f, _u64, _vp, _i, _vp]),
     "grappa_gat_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "grappa_gat_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "grappa_neighbor_mean_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i]),

@@ -163,6 +163,9 @@ class HipBackend:
         # SLOWER: 37.4 against 35.9 ms per C2 step -- every workgroup of the consumer re-reads 16 partials per row in its prologue and
         # epilogue, which costs more than the one small launch it replaces (profiles/r4_amax_parts_ab.txt) -- hence not the default
         self.amax_parts = os.environ.get("GRAPPA_AMAX_PARTS", "0") not in ("0", "")
+        # the dropout backward of a layer's two dropouts written by the LayerNorm backward that produces their input (C ABI 9): 30 of the
+        # 40 act_dropout_bwd launches of a C2 step gone with the read of the gradient they made.  GRAPPA_FUSE_LN_DROP=0: launches of their own
+        self.fuse_ln_drop = os.environ.get("GRAPPA_FUSE_LN_DROP", "1") not in ("0", "")
         self.pairs_min_rows = int(os.environ.get("GRAPPA_PAIRS_MIN_ROWS", "12288"))
         # the dropout backward writing ITS rows (gradients) as pairs too: the input-gradient products behind gain (pair kernel), the weight-
         # gradient products lose a little (a pair-format A operand costs 3 - 5 %, a pair-format B operand gains 9 %: tools/wgrad_pairs_bench.py)
@@ -1091,7 +1094,9 @@ class HipBackend:
         _chk(getattr(self.lib, f"grappa_layernorm_fwd_{_sfx(x)}")(*args), "grappa_layernorm_fwd")
         return None
 
-    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True, amax=None):
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True, amax=None, drop=None):
+        """drop=(p, seed): ALSO -> dz = the dropout backward (that mask, 1 / (1 - p)) of dx with its row maxima, written by the same
+        launch (C ABI 9); the return value is then (record of dx, dz, record of dz).  `drop_fusable(x)` says when."""
         dev = dx.device
         M, W = x.shape
         for t, n, k in ((mean, "mean", M), (rstd, "rstd", M), (gamma, "gamma", W), (dgamma, "dgamma", W), (dbeta, "dbeta", W)):
@@ -1114,11 +1119,25 @@ class HipBackend:
         if defer:
             self._lnq.append((ws, self.lib.grappa_layernorm_bwd_partial_rows(M), W, dgamma.data_ptr(), dbeta.data_ptr(), dgamma, dbeta,
                               torch.cuda.current_stream(), task))
+        if drop is not None:
+            p, seed = drop
+            if not self.drop_fusable(x) or not (0.0 < p < 1.0):
+                raise ValueError("layernorm_bwd: drop needs fp32 rows and the fp16-split arithmetic (drop_fusable)")
+            dz = torch.empty_like(dx)
+            zrow = torch.empty(M, dtype=torch.int32, device=dev)
+            _chk(self.lib.grappa_layernorm_bwd_drop_f32(*args, _ptr(row), float(p), int(seed) & (2 ** 64 - 1), dz.data_ptr(), dz.stride(0), zrow.data_ptr()),
+                 "grappa_layernorm_bwd_drop_f32")
+            return (Amax(row=row) if row is not None else None), dz, Amax(row=zrow)
         if row is not None:
             _chk(self.lib.grappa_layernorm_bwd_amax_f32(*args, row.data_ptr()), "grappa_layernorm_bwd_amax_f32")
             return Amax(row=row)
         _chk(getattr(self.lib, f"grappa_layernorm_bwd_{_sfx(x)}")(*args), "grappa_layernorm_bwd")
         return None
+
+    def drop_fusable(self, x) -> bool:
+        """may the LayerNorm backward over rows like x write the dropout backward of its result too (layernorm_bwd drop=)?"""
+        return (self.fuse_ln_drop and not self.backward_pairs and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and x.is_contiguous()
+                and self.wants_amax(True))
 
     # ------------------------------------------------------------------ batched row-wise kernels (C ABI 8): the writer heads layer-locked
     @staticmethod

@@ -176,13 +176,24 @@ __global__ __launch_bounds__(256) void layernorm_fwd_pairs_kernel(int M, int W, 
     }
 }
 
+// the dropout backward of the tensor the LayerNorm's input came out of, applied to dx while the row is in registers: dz = mask * dx / (1 - p)
+// and dz's row maxima (what act_dropout_bwd_rows_kernel would compute from dx in a launch of its own)
+struct LnBwdDrop {
+    float p, scale;
+    uint64_t seed;
+    const uint64_t* salt;
+    float* dz;
+    int lddz;
+    unsigned* dz_amax;
+};
+
 // dx per row; per-block partial dgamma/dbeta into part[block][2][W]
-template <int NCH, typename T>
+template <int NCH, typename T, bool DROP = false>
 __device__ __forceinline__ void layernorm_bwd_body(int M, int W, const T* __restrict__ dy, int lddy,
                                                    const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                    T* __restrict__ dx, int lddx, float* __restrict__ part,
-                                                   unsigned* __restrict__ dx_amax, int vblock, int vnblocks) {
+                                                   unsigned* __restrict__ dx_amax, int vblock, int vnblocks, const LnBwdDrop dr = LnBwdDrop{}) {
     extern __shared__ float red[];   // [4 waves][2][W]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_global = vblock * 4 + wave;
@@ -194,6 +205,8 @@ __device__ __forceinline__ void layernorm_bwd_body(int M, int W, const T* __rest
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    uint64_t seed_ = 0;
+    if constexpr (DROP) seed_ = grappa_salted(dr.seed, dr.salt);
     for (int row = wave_global; row < M; row += nwaves) {
         const T* xr = x + (size_t)row * ldx;
         const T* dyr = dy + (size_t)row * lddy;
@@ -215,7 +228,7 @@ __device__ __forceinline__ void layernorm_bwd_body(int M, int W, const T* __rest
         }
         const float m1 = wave_sum(s1) / (float)W, m2 = wave_sum(s2) / (float)W;
         T* dxr = dx + (size_t)row * lddx;
-        unsigned am = 0u;
+        unsigned am = 0u, amz = 0u;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
@@ -227,11 +240,25 @@ __device__ __forceinline__ void layernorm_bwd_body(int M, int W, const T* __rest
                 o.w = rs * (g[i].w - m1 - xh[i].w * m2);
                 st4(dxr, c, o);
                 am = max(am, mag4(o));
+                if constexpr (DROP) {
+                    const uint64_t idx = (uint64_t)row * (uint64_t)W + (uint64_t)(c << 2);
+                    float4 v;
+                    v.x = grappa_keep(seed_, idx, dr.p) ? o.x * dr.scale : 0.f;
+                    v.y = grappa_keep(seed_, idx + 1, dr.p) ? o.y * dr.scale : 0.f;
+                    v.z = grappa_keep(seed_, idx + 2, dr.p) ? o.z * dr.scale : 0.f;
+                    v.w = grappa_keep(seed_, idx + 3, dr.p) ? o.w * dr.scale : 0.f;
+                    *reinterpret_cast<float4*>(dr.dz + (size_t)row * dr.lddz + (c << 2)) = v;
+                    amz = max(amz, mag4(v));
+                }
             }
         }
         if (dx_amax) {
             am = wave_umax(am);
             if (lane == 0) dx_amax[row] = am;
+        }
+        if constexpr (DROP) {
+            amz = wave_umax(amz);
+            if (lane == 0) dr.dz_amax[row] = amz;
         }
     }
     // block reduction of the per-wave partials (fixed order -> reproducible)
@@ -260,6 +287,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int M, int W, const 
                                                             T* __restrict__ dx, int lddx, float* __restrict__ part,
                                                             unsigned* __restrict__ dx_amax) {
     layernorm_bwd_body<NCH, T>(M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax, blockIdx.x, gridDim.x);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_drop_kernel(int M, int W, const float* __restrict__ dy, int lddy,
+                                                                 const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                 float* __restrict__ dx, int lddx, float* __restrict__ part,
+                                                                 unsigned* __restrict__ dx_amax, LnBwdDrop dr) {
+    layernorm_bwd_body<NCH, float, true>(M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax, blockIdx.x, gridDim.x, dr);
 }
 
 struct LnBwdBatch {
@@ -652,8 +688,11 @@ int layernorm_fwd_impl(void* stream, int M, int W, const T* x, int ldx, const fl
 template <typename T>
 int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const T* x, int ldx, const float* mean, const float* rstd,
                        const float* gamma, T* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
-                       unsigned* dx_amax = nullptr) {
+                       unsigned* dx_amax = nullptr, const LnBwdDrop* drop = nullptr) {
     if (M < 0 || W <= 0 || (W & 3) || W > 2048 || (ldx & 3) || (lddy & 3) || (lddx & 3)) return GRAPPA_ERR_ARG;
+    if (drop && (sizeof(T) != 4 || !drop->dz || !drop->dz_amax || (drop->lddz & 3) || drop->lddz < W || (reinterpret_cast<uintptr_t>(drop->dz) & 15) ||
+                 !(drop->p > 0.f) || drop->p >= 1.f))
+        return GRAPPA_ERR_ARG;
     if (M == 0) return GRAPPA_OK;
     if (!dy || !x || !mean || !rstd || !gamma || !dx || (accumulate != 2 && (!dgamma || !dbeta))) return GRAPPA_ERR_ARG;
     const uintptr_t amask = sizeof(T) == 4 ? 15 : 7;
@@ -666,7 +705,16 @@ int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const 
     float* part = reinterpret_cast<float*>(ws);
     float* scratch = part + (size_t)blocks * 2 * W;
     const size_t smem = (size_t)4 * 2 * W * sizeof(float);
-#define GRAPPA_LN_BWD(NCH) GRAPPA_LAUNCH((layernorm_bwd_kernel<NCH, T>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax)
+#define GRAPPA_LN_BWD(NCH)                                                                                                                     \
+    do {                                                                                                                                       \
+        if constexpr (sizeof(T) == 4) {                                                                                                        \
+            if (drop) {                                                                                                                        \
+                GRAPPA_LAUNCH((layernorm_bwd_drop_kernel<NCH>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax, *drop); \
+                break;                                                                                                                         \
+            }                                                                                                                                  \
+        }                                                                                                                                      \
+        GRAPPA_LAUNCH((layernorm_bwd_kernel<NCH, T>), dim3(blocks), dim3(256), smem, st, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, part, dx_amax); \
+    } while (0)
     if (W <= 256) GRAPPA_LN_BWD(1);
     else if (W <= 512) GRAPPA_LN_BWD(2);
     else if (W <= 1024) GRAPPA_LN_BWD(4);
@@ -788,6 +836,13 @@ extern "C" int grappa_layernorm_bwd_amax_f32(void* stream, int M, int W, const f
                                              const float* mean, const float* rstd, const float* gamma, float* dx, int lddx,
                                              float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, uint32_t* dx_amax) {
     return layernorm_bwd_impl<float>(stream, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, accumulate, ws, ws_bytes, dx_amax);
+}
+extern "C" int grappa_layernorm_bwd_drop_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
+                                             const float* mean, const float* rstd, const float* gamma, float* dx, int lddx,
+                                             float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, uint32_t* dx_amax,
+                                             float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax) {
+    const LnBwdDrop dr{drop_p, drop_p > 0.f && drop_p < 1.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_seed, g_grappa_drop_salt, dz, lddz, dz_amax};
+    return layernorm_bwd_impl<float>(stream, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, accumulate, ws, ws_bytes, dx_amax, &dr);
 }
 extern "C" int grappa_layernorm_bwd_bf16(void* stream, int M, int W, const uint16_t* dy, int lddy, const uint16_t* x, int ldx,
                                          const float* mean, const float* rstd, const float* gamma, uint16_t* dx, int lddx,

@@ -190,8 +190,10 @@ def _ln_fwd(be, x, w, b, infer=False, need_y=True):
     return y, mean, rstd, sy
 
 
-def _ln_bwd(be, dy, x, mean, rstd, w, b):
-    """-> (dx, the backend's record of dx's row maxima or None)"""
+def _ln_bwd(be, dy, x, mean, rstd, w, b, drop=None):
+    """-> (dx, the backend's record of dx's row maxima or None).  drop = (p, seed) of the dropout whose backward reads dx next: where the
+    backend can, the same launch writes that too and dx carries it as dx._grappa_masked = (dz, record of dz, p, seed) -- `_masked_grad`
+    picks it up, in this Function's backward or in the one of the layer in front"""
     if w is None:                                   # layer_norm=False
         return dy, None
     dx = _new(x.shape, x)
@@ -200,8 +202,20 @@ def _ln_bwd(be, dy, x, mean, rstd, w, b):
     # a frozen affine pair still needs somewhere to put the reductions the kernel produces
     dw = _pgrad(w) if w.requires_grad else torch.zeros_like(w)
     db = _pgrad(b) if b.requires_grad else torch.zeros_like(b)
+    if drop is not None and drop[0] > 0 and getattr(be, "drop_fusable", None) is not None and be.drop_fusable(x):
+        sdx, dz, sz = be.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, db, accumulate=True, drop=drop)
+        dx._grappa_masked = (dz, sz, float(drop[0]), int(drop[1]))
+        return dx, sdx
     sdx = be.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, db, accumulate=True)
     return dx, sdx
+
+
+def _masked_grad(dy, drop_p, seed):
+    """the dropout backward of dy if the kernel that produced dy wrote it already (see _ln_bwd) -> (dz, record) or None"""
+    m = getattr(dy, "_grappa_masked", None)
+    if m is None or m[2] != float(drop_p) or m[3] != int(seed) or m[0].shape != dy.shape:
+        return None
+    return m[0], m[1]
 
 
 def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip, infer=False):
@@ -231,13 +245,17 @@ def _ff_fwd(be, x, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip, inf
     return out, (x, mean, rstd, xn, u, pre, sxn, su)
 
 
-def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip, sdout=None):
-    """-> (dx, record of dx's row maxima or None); sdout: the record for dout when the kernel that produced it wrote one"""
+def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed, skip, sdout=None, then_drop=None):
+    """-> (dx, record of dx's row maxima or None); sdout: the record for dout when the kernel that produced it wrote one; then_drop: (p, seed)
+    of the dropout whose backward reads dx next (_ln_bwd)"""
     x, mean, rstd, xn, u, pre, sxn, su = saved          # (xn is None where the forward pass wrote the normalised rows as pairs only: sxn.pairs)
     M = x.shape[0]
     if not dout.is_contiguous():
         dout, sdout = dout.contiguous(), None
-    if act2 or drop_p > 0:
+    ready = _masked_grad(dout, drop_p, seed) if (drop_p > 0 and not act2) else None
+    if ready is not None:
+        dz2, sz = ready
+    elif act2 or drop_p > 0:
         if dout.dtype == F32 and _bwd_pairs(be, M, dout.shape[1], w2):
             dz2, sz = None, be.act_dropout_bwd(dout, pre if act2 else None, drop_p, seed, None, pairs=True)      # pairs only: both products behind read them
         else:
@@ -251,7 +269,7 @@ def _ff_bwd(be, saved, dout, norm_w, norm_b, w1, b1, w2, b2, act2, drop_p, seed,
     sz = _linear_bwd_params(be, dz1, xn, w1, b1, sxn, sz)
     dxn = _new(x.shape, x)
     be.gemm(dz1, w1, dxn, M=M, N=x.shape[1], K=u.shape[1], b_kcontig=False, res=dout if skip else None, a_scales=sz)
-    return _ln_bwd(be, dxn, x, mean, rstd, norm_w, norm_b)
+    return _ln_bwd(be, dxn, x, mean, rstd, norm_w, norm_b, drop=then_drop)
 
 
 def _drop_bwd(be, dy, drop_p, seed, w):
@@ -259,6 +277,9 @@ def _drop_bwd(be, dy, drop_p, seed, w):
     products behind it read pairs; dy itself without dropout"""
     if drop_p <= 0:
         return dy, None
+    ready = _masked_grad(dy, drop_p, seed)
+    if ready is not None:
+        return ready
     if dy.dtype == F32 and _bwd_pairs(be, dy.shape[0], dy.shape[1], w):
         return None, be.act_dropout_bwd(dy, None, drop_p, seed, None, pairs=True)
     dz = _new(dy.shape, dy)
@@ -518,6 +539,7 @@ class TransformerLayerFn(Function):
     @staticmethod
     def forward(ctx, x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2):
         be = get_backend()
+        ctx.up_drop = getattr(x, "_grappa_drop", None)       # (p, seed) of the dropout that produced x: the layer in front (see below)
         x = _c(x)
         M, Fd = x.shape
         infer = _infer(ctx)
@@ -535,6 +557,9 @@ class TransformerLayerFn(Function):
         ctx.cfg, ctx.scales = (s, T, nheads, drop_p, seed1, seed2), (sx1, satt)
         ctx.ff_saved = ff_saved
         ctx.save_for_backward(x, mean1, rstd1, x1, qkv, att, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)
+        if drop_p > 0:
+            # the layer behind reads this: its LayerNorm backward then writes the backward of THIS layer's last dropout with its result
+            out._grappa_drop = (drop_p, seed2)
         return out
 
     @staticmethod
@@ -545,7 +570,7 @@ class TransformerLayerFn(Function):
         M, Fd = x.shape
         if M == 0:
             return (torch.zeros_like(x),) + (None,) * 18
-        dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True, then_drop=(drop_p, seed1))
         ctx.ff_saved = None
         dzo, sz = _drop_bwd(be, dx2, drop_p, seed1, w_o)
         sx1, satt = ctx.scales
@@ -557,7 +582,7 @@ class TransformerLayerFn(Function):
         sz = _linear_bwd_params(be, dqkv, x1, w_in, b_in, sx1, sz)
         dx1 = _new(x.shape, x)
         be.gemm(dqkv, w_in, dx1, M=M, N=Fd, K=3 * Fd, b_kcontig=False, res=dx2, a_scales=sz)
-        dx, _ = _ln_bwd(be, dx1, x, mean1, rstd1, n1_w, n1_b)
+        dx, _ = _ln_bwd(be, dx1, x, mean1, rstd1, n1_w, n1_b, drop=ctx.up_drop)
         return (dx,) + (None,) * 18
 
 
@@ -604,6 +629,8 @@ class ProjFirstLayerFn(Function):
         ctx.ff_saved = ff_saved
         ctx.save_for_backward(h, a, tab, mean1, rstd1, x1_tab, qkv, att, invid_ptr, invid_rows, invtab_ptr, invtab_rows,
                               w, b, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)
+        if drop_p > 0:
+            out._grappa_drop = (drop_p, seed2)            # (TransformerLayerFn.forward)
         return out
 
     @staticmethod
@@ -615,7 +642,7 @@ class ProjFirstLayerFn(Function):
         sh, sx1, satt = ctx.scales
         M, Fd = qkv.shape[0], qkv.shape[1] // 3
         R = h.shape[1]
-        dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True)
+        dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True, then_drop=(drop_p, seed1))
         ctx.ff_saved = None
         dzo, sz = _drop_bwd(be, dx2, drop_p, seed1, w_o)
         sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)

@@ -27,7 +27,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 8
+#define GRAPPA_ABI_VERSION 9
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -328,6 +328,16 @@ int grappa_layernorm_bwd_amax_f32(void* stream, int M, int W, const float* dy, i
                                   const float* mean, const float* rstd, const float* gamma,
                                   float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
                                   void* ws, size_t ws_bytes, uint32_t* dx_amax);
+/* ABI 9: the same with the dropout backward of the tensor this LayerNorm read fused in -- the reference's layers are
+ * y = LN(x) + drop(f(LN(x))) chains (perm_equiv_transformer.py:127-151), so the gradient a LayerNorm backward produces is what the dropout
+ * of the layer in front masks next: dz[r][c] = keep(drop_seed, r * W + c) ? dx[r][c] / (1 - drop_p) : 0 (the mask of grappa_act_dropout_bwd_f32
+ * on an [M x W] tensor) and dz's row maxima, written while the row is in registers instead of by a launch of its own.  0 < drop_p < 1;
+ * dx_amax may be NULL */
+int grappa_layernorm_bwd_drop_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
+                                  const float* mean, const float* rstd, const float* gamma,
+                                  float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                                  void* ws, size_t ws_bytes, uint32_t* dx_amax,
+                                  float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph attention message passing (DGL DotGatConv, graph_attention.py:249/:283 -> DGL u_dot_v +
