@@ -1,50 +1,56 @@
-"""tools/timeline_gaps.py TRACE.csv -- from a rocprofv3 --kernel-trace CSV of bench.py: per train step (delimited by adam_kernel) the
-wall time, the union of kernel-busy time, the idle time, the idle time by the kernel that FOLLOWS the gap, and the time with >= 2
-kernels in flight.  Says how much of a step is launch gaps / host stalls rather than kernels."""
+"""How busy is the GPU inside a train step?  Reads a rocprofv3 --kernel-trace CSV (Start_Timestamp / End_Timestamp per dispatch) and prints,
+for the steady-state part (after the first `skip` fraction of the dispatches): span, union of the kernels' intervals (time with at least one
+kernel running), idle time (gaps), sum of the kernel durations, time with >= 2 / >= 3 kernels in flight, and the longest gaps with the kernels
+either side of them.
+    python tools/timeline_gaps.py <kernel_trace.csv> [skip_fraction=0.4]"""
 import csv
 import sys
-from collections import defaultdict
 
-rows = []
-with open(sys.argv[1]) as f:
-    for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
-rows.sort()
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
-print(f"{len(rows)} kernels, {len(adam)} steps")
-for s in range(max(1, len(adam) - 3), len(adam)):
-    lo, hi = adam[s - 1] + 1, adam[s] + 1
-    seg = rows[lo:hi]
-    t0, t1 = rows[adam[s - 1]][1], rows[adam[s]][1]
-    busy = 0
-    multi = 0
-    gaps = defaultdict(float)
-    ngaps = defaultdict(int)
-    cur_end = t0
-    events = []
-    for a, b, n in seg:
-        events.append((a, 1))
-        events.append((b, -1))
-        if a > cur_end:
-            key = n.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
-            gaps[key] += a - cur_end
-            ngaps[key] += 1
-        cur_end = max(cur_end, b)
-    events.sort()
+
+def main():
+    path = sys.argv[1]
+    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
+    rows.sort()
+    rows = rows[int(len(rows) * skip):]
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    ev = []
+    for s, e, _n, _q in rows:
+        ev.append((s, 1))
+        ev.append((e, -1))
+    ev.sort()
+    busy = {1: 0, 2: 0, 3: 0, 4: 0}
     depth, last = 0, t0
-    for t, d in events:
-        if depth >= 1:
-            busy += t - last
-        if depth >= 2:
-            multi += t - last
+    for t, d in ev:
+        for k in busy:
+            if depth >= k:
+                busy[k] += t - last
         depth += d
         last = t
-    wall = t1 - t0
-    print(f"step {s}: wall {wall / 1e6:.2f} ms, {len(seg)} kernels, busy {busy / 1e6:.2f}, idle {(wall - busy) / 1e6:.2f}, >=2 in flight {multi / 1e6:.2f}, "
-          f"sum of kernel durations {sum(b - a for a, b, _ in seg) / 1e6:.2f}")
-    top = sorted(gaps.items(), key=lambda kv: -kv[1])[:12]
-    for k, v in top:
-        print(f"    idle before {k:60s} {v / 1e3:8.1f} us in {ngaps[k]:4d} gaps")
-    big = sorted(((a - e, n) for (a, _, n), e in zip(seg[1:], [max(x[1] for x in seg[:i + 1]) for i in range(len(seg) - 1)])), reverse=True)[:8] if len(seg) < 4000 else []
-    for g, n in big:
-        print(f"    gap {g / 1e3:7.1f} us before {n[:80]}")
+    span = t1 - t0
+    ksum = sum(e - s for s, e, _n, _q in rows)
+    print(f"dispatches {len(rows)}, queues {len(set(r[3] for r in rows))}, span {span / 1e6:.2f} ms, kernel-duration sum {ksum / 1e6:.2f} ms "
+          f"({ksum / span:.2f} x span)")
+    print(f"at least 1 kernel in flight {busy[1] / 1e6:.2f} ms ({100 * busy[1] / span:.1f} %), idle {(span - busy[1]) / 1e6:.2f} ms; "
+          f">= 2 in flight {100 * busy[2] / span:.1f} %, >= 3 {100 * busy[3] / span:.1f} %, >= 4 {100 * busy[4] / span:.1f} %")
+    # gaps: between the end of everything so far and the next start
+    gaps = []
+    end = rows[0][1]
+    prev = rows[0][2]
+    for s, e, n, _q in rows[1:]:
+        if s > end:
+            gaps.append((s - end, prev, n))
+        if e > end:
+            end, prev = e, n
+    gaps.sort(reverse=True)
+    print(f"gaps: {len(gaps)}, total {sum(g[0] for g in gaps) / 1e6:.2f} ms; > 20 us: {sum(1 for g in gaps if g[0] > 20000)} "
+          f"({sum(g[0] for g in gaps if g[0] > 20000) / 1e6:.2f} ms)")
+    for g, a, b in gaps[:12]:
+        print(f"  {g / 1e3:8.1f} us  after {a[:70]}  before {b[:70]}")
+
+
+if __name__ == "__main__":
+    main()
