@@ -561,7 +561,15 @@ __global__ __launch_bounds__(256) void add_kernel(size_t n, const float* __restr
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(size_t n, const float* __restrict__ x, float* __restrict__ part) {
     __shared__ float red[4];
     float s = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
+    // 16-byte loads, four partial sums per thread (one dword per thread and trip read the 163 MB gradient buffer at 2.4 TB/s)
+    const size_t n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n >> 2 : 0;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w * v.w;
+    }
+    s = (s0 + s1) + (s2 + s3);
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
