@@ -139,7 +139,10 @@ class CapturedForward:
         self.out_host = torch.empty(self.out_flat.shape, dtype=torch.float32).pin_memory() if self.out_flat is not None else None
 
     def _stamp(self):
-        return (self.be._wepoch, sum(p._version for p in self.model.parameters()))
+        ps = self.__dict__.get("_params")
+        if ps is None:                                       # (walking the module tree costs 0.25 ms of a 2.7 ms predict: once)
+            ps = self._params = list(self.model.parameters())
+        return (self.be._wepoch, sum(p._version for p in ps))
 
     def valid(self) -> bool:
         """the per-weight caches (maxima, pair splits) were filled OUTSIDE the graph: a graph captured before the weights changed must not be replayed"""
@@ -190,6 +193,7 @@ class CapturedForward:
             off += (nbytes + 15) // 16 * 16
         self._in_dev = torch.zeros(max(off, 16), dtype=torch.uint8, device=self.g.device)
         self._in_host = torch.zeros(max(off, 16), dtype=torch.uint8).pin_memory()
+        self._host_views = {name: self._in_host[o:o + nbytes].view(dtype).view(shape) for name, (o, nbytes, dtype, shape) in self._layout.items()}
         views = {}
         for name, (o, nbytes, dtype, shape) in self._layout.items():
             v = self._in_dev[o:o + nbytes].view(dtype).view(shape)
@@ -224,7 +228,7 @@ class CapturedForward:
             t = src[name]
             if tuple(t.shape) != shape or t.dtype != dtype:
                 raise ValueError(f"load: {name} is {t.dtype} {tuple(t.shape)}, the captured graph holds {dtype} {shape}")
-            self._in_host[o:o + nbytes].view(dtype).view(shape).copy_(t)
+            self._host_views[name].copy_(t)
         self._in_dev.copy_(self._in_host, non_blocking=True)
 
     def read_outputs(self, g_host) -> None:

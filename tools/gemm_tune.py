@@ -49,8 +49,8 @@ def main():
         model_plan = tuple(x.value for x in v)
         t_model = timeit(be, A, B, Cm, M, N, K, ak, bk, mode)
         best = (t_model, "model")
-        max_split = max(1, K // 256)
-        splits = sorted({s for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64) if s <= max_split})
+        max_split = max(1, K // 32)            # (GRAPPA_PLAN_MIN_KSTEPS=1, the default since round 4: K ranges down to one slab)
+        splits = sorted({s for s in (1, 2, 3, 4, 5, 7, 9, 12, 15, 19, 24, 30, 38, 48, 60) if s <= max_split})
         for cfg in cfgs:
             for ns in splits:
                 for tail in ((0, 1) if ns == 1 else (0,)):
