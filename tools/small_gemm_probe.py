@@ -1,6 +1,6 @@
-"""GPU: where do the ~20 us of a small dense product go?  Times the default product (f32_f16x3, fp32 operands) through the backend for small
-M over K = 16 .. 512 (the K = 16 time is the fixed cost: launch, prologue, epilogue, split-K reduction launch if the plan cuts K), back to
-back on one stream (HIP events around 200 launches), with and without the row-maxima output, with split-K forced off.
+"""GPU: what does a small dense product cost on the DEVICE?  100 identical launches of the default product (f32_f16x3, fp32 operands)
+recorded in a hipGraph and replayed: device time per product including its split-K reduction launch, free of the host's ~12 us per call.
+Over M (one molecule ... a batch of 32), K (16: the fixed cost of a launch) and forced K cuts.
     python tools/small_gemm_probe.py"""
 import os
 import sys
@@ -15,39 +15,56 @@ def main():
     from grappa_amd.backend import get_backend
     be = get_backend()
     lib = be.lib
+    st = torch.cuda.Stream()
 
-    def t(f, n=200):
-        for _ in range(10):
-            f()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        lib.grappa_launch_count(1)
-        e0.record()
-        for _ in range(n):
-            f()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / n, lib.grappa_launch_count(1) / n
+    def replay_us(f, n=100):
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                f()
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(n):
+                    f()
+            g.replay()
+            st.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(5):
+                g.replay()
+            e1.record(st)
+            st.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (5 * n)
 
-    print("us per product (library launches per product)")
-    for M in (40, 160, 1062, 2228, 5546):
-        for N in (512, 1536):
-            row = []
-            for K in (16, 64, 128, 256, 512, 2048):
-                A = torch.randn(M, K, device="cuda")
-                W = torch.randn(N, K, device="cuda")
-                Cc = torch.empty(M, N, device="cuda")
-                b = torch.randn(N, device="cuda")
+    print("device us per product, 100 dependent-free launches back to back in a hipGraph (plan: tile, K cuts)")
+    v = [__import__("ctypes").c_int() for _ in range(5)]
+    import ctypes as C
+    for M in (40, 160, 1062, 5546):
+        for N, K in ((512, 16), (512, 128), (512, 512), (1536, 512), (2048, 512), (512, 2048)):
+            A = torch.randn(M, K, device="cuda")
+            W = torch.randn(N, K, device="cuda")
+            Cc = torch.empty(M, N, device="cuda")
+            b = torch.randn(N, device="cuda")
+            with torch.cuda.stream(st):
                 sa = be.amax(A, rows=True)
-                us, nl = t(lambda: be.gemm(A, W, Cc, M=M, N=N, K=K, bias=b, a_scales=sa))
-                us2, nl2 = t(lambda: be.gemm(A, W, Cc, M=M, N=N, K=K, bias=b, a_scales=sa, out_amax=True))
-                row.append(f"K={K}: {us:5.1f} ({nl:.1f}) +amax {us2:5.1f} ({nl2:.1f})")
-            print(f"M={M:5d} N={N:4d}  " + " | ".join(row))
-    # an empty-ish kernel for scale: the library's add of two small vectors
+            row = []
+            for ns in (0, 1, 2, 4, 7, 15):
+                lib.grappa_gemm_f32_set_plan_override(-1, ns, -1)
+                lib.grappa_gemm_f32_plan(M, N, K, 5, *[C.byref(x) for x in v])
+                if ns and v[2].value != ns:
+                    continue
+                try:
+                    us = replay_us(lambda: be.gemm(A, W, Cc, M=M, N=N, K=K, bias=b, a_scales=sa))
+                except Exception as e:
+                    row.append(f"ns{ns}: {type(e).__name__}")
+                    continue
+                row.append(f"{'model' if ns == 0 else 'ns' + str(ns)} ({v[0].value}x{v[1].value} ns{v[2].value}): {us:5.1f}")
+            lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+            print(f"M={M:5d} N={N:4d} K={K:4d}  " + " | ".join(row))
     x = torch.randn(1024, device="cuda")
     y = torch.empty_like(x)
-    us, _ = t(lambda: lib.grappa_add_f32(torch.cuda.current_stream().cuda_stream, 1024, x.data_ptr(), x.data_ptr(), y.data_ptr()))
-    print(f"grappa_add_f32 on 1024 floats: {us:.1f} us per launch (launch floor)")
+    us = replay_us(lambda: lib.grappa_add_f32(st.cuda_stream, 1024, x.data_ptr(), x.data_ptr(), y.data_ptr()))
+    print(f"grappa_add_f32 on 1024 floats: {us:.1f} us per launch in the graph (launch floor)")
 
 
 if __name__ == "__main__":
