@@ -343,14 +343,20 @@ struct CostModel {
     double grid(int c, long wgs, int kps) const {
         const int conc = CFG_CONC[c];
         const long ncu = plan_cus();
-        const double t = (double)CFG_BM[c] * CFG_BN[c] * (kps + k0[c]) / rate[c];
+        double t = (double)CFG_BM[c] * CFG_BN[c] * (kps + k0[c]) / rate[c];
+        // a 128 x 128 workgroup of the fp16-split kernel on an otherwise idle chip: 5.0 us + 0.334 us per 16 columns of K measured
+        // (profiles/r4_small_gemm_probe.txt) = 50 (k + 240) cycles; the loaded chip's 80 (k + 128) as the grid fills it
+        if (c == 5 && wgs < ncu) {
+            const double lone = 50.0 * (kps + 240.0);
+            t = lone + (t - lone) * ((double)wgs / (double)ncu);
+        }
         if (wgs <= ncu * conc) {
             const double per_cu = (double)((wgs + ncu - 1) / ncu);
             return per_cu * t * (per_cu < 2 && conc > 1 ? 1.3 : 1.0);   // a lone workgroup of a multi-resident tile cannot hide its barrier bubbles
         }
         return (double)((wgs + ncu * conc - 1) / (ncu * conc)) * conc * t;
     }
-    static double splitk(int nsplit, double elems) { return 12000.0 + nsplit * elems / 200.0; }   // two launches + slab write / reduce
+    static double splitk(int nsplit, double elems) { return 14000.0 + nsplit * elems / 200.0; }   // two launches + slab write / reduce (the reduction launch alone: 5.4 us)
 };
 
 int pairs_cfg() {
