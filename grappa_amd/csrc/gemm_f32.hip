@@ -293,10 +293,10 @@ struct Plan {
 
 // cfg 0: 128x128, 1: 64x64, 2: 128x32, 3: 32x128, 4: 128x64
 // cfg 5, 6: the 128x128 and 256x128 tiles of the bf16-split kernel (gemm_bf16x_impl.h), one 512-thread workgroup per CU
-constexpr int NCFG = 8;                 // cfg 7: the 256 x 256 tile of the pair-format kernel (GRAPPA_PAIRS_TILE=256)
-constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256, 256};
-constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128, 256};
-constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1, 1};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
+constexpr int NCFG = 9;                 // cfg 7: the 256 x 256 tile of the pair-format kernel (GRAPPA_PAIRS_TILE=256); cfg 8: its 128 x 128 tile (both operands pairs)
+constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256, 256, 128};
+constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128, 256, 128};
+constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1, 1, 2};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
 
 // split-K summed by a launch of gemm_splitk_reduce_kernel behind the product (default) or inside the product's own launch by the last
 // workgroup of each tile (GRAPPA_SPLITK_IN_KERNEL=1 / grappa_gemm_f32_set_splitk_reduce_launch(0)).  Same bits; the second is the
@@ -338,8 +338,8 @@ bool plan_tails() {
 
 struct CostModel {
     // MACs per cycle per CU sustained in the main loop, and the per-tile prologue + epilogue expressed in columns of K
-    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0, 450.0};
-    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0, 200.0};
+    const double rate[NCFG] = {128.0, 90.0, 70.0, 70.0, 119.0, 205.0, 307.0, 450.0, 230.0};
+    const double k0[NCFG] = {96.0, 96.0, 96.0, 96.0, 96.0, 128.0, 160.0, 200.0, 160.0};
     double grid(int c, long wgs, int kps) const {
         const int conc = CFG_CONC[c];
         const long ncu = plan_cus();
@@ -348,6 +348,11 @@ struct CostModel {
         // (profiles/r4_small_gemm_probe.txt) = 50 (k + 240) cycles; the loaded chip's 80 (k + 128) as the grid fills it
         if (c == 5 && wgs < ncu) {
             const double lone = 50.0 * (kps + 240.0);
+            t = lone + (t - lone) * ((double)wgs / (double)ncu);
+        }
+        // the pair kernel's 128 x 128 tile alone on a CU: its 12 MFMAs per wavefront and slab (0.16 us) + DMA turn-round, ~0.2 us per slab
+        if (c == 8 && wgs < ncu) {
+            const double lone = 30.0 * (kps + 400.0);
             t = lone + (t - lone) * ((double)wgs / (double)ncu);
         }
         if (wgs <= ncu * conc) {
@@ -364,7 +369,7 @@ int pairs_cfg() {
     return t == 256 ? 7 : 6;
 }
 
-Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false) {
+Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false, bool pairs_small = false) {
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
@@ -384,8 +389,9 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
     for (int c = 0; c < NCFG; ++c) {
         if (g_override.cfg >= 0 && c != g_override.cfg && !planes) continue;
         if (bf16x != (c >= 5)) continue;
-        if (planes && c != (pairs ? pairs_cfg() : 6)) continue;      // the plane-format kernels have one tile shape each
-        if (!planes && c == 7) continue;
+        // the plane-format kernels have one tile shape each; the pair kernel (both operands pairs) also a 128 x 128 one
+        if (planes && c != (pairs ? pairs_cfg() : 6) && !(pairs_small && c == 8)) continue;
+        if (!planes && (c == 7 || c == 8)) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
         if (c == 3 && M > 32) continue;
@@ -499,6 +505,8 @@ extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
         if (e > a) a = e;
         const size_t f = plan_workspace_floats(make_plan(M, N, K, true, true, true, true), M, N);
         if (f > a) a = f;
+        const size_t g = plan_workspace_floats(make_plan(M, N, K, true, true, true, true, true), M, N);
+        if (g > a) a = g;
     }
     return a * sizeof(float) + amax_part_bytes(M, N);
 }
@@ -783,7 +791,8 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             return GRAPPA_ERR_ARG;
         if (pairs && !d->a_planes) return GRAPPA_ERR_ARG;               // (the weight-pairs kernel has its own epilogue dispatch)
     }
-    Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes, pairs);
+    static const bool small_tile = !(getenv("GRAPPA_PAIRS_SMALL_TILE") && atoi(getenv("GRAPPA_PAIRS_SMALL_TILE")) == 0);
+    Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && g_override.cfg < 0);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
     if (need > 0 && (!ws || ws_bytes < need)) return GRAPPA_ERR_WORKSPACE;

@@ -40,14 +40,18 @@ namespace {
 constexpr int QBM = 256, QSLAB = 16, QNSTAGE = 3;
 constexpr int QROWB = 64;                       // bytes of a row in a stage: 16 k x (hi, lo)
 constexpr int QA_BYTES = QBM * QROWB;           // 16 KB
-constexpr int QTM = 4, QTN = 2;                 // 32 x 32 accumulators per wavefront (128 x 64)
+constexpr int QTN = 2;                          // 32 x 32 accumulator columns per wavefront (64); rows: QShape::TM blocks
 // two shapes: BN = 128 on 256 threads (24 KB stages, TWO workgroups per CU: the default) and BN = 256 on 512 threads (32 KB stages, one
 // workgroup per CU, 21 instead of 32 operand bytes per MFMA-cycle: GRAPPA_PAIRS_TILE=256)
-template <int BN> struct QShape {
+// a third shape since round 4: BM = 128 (BN = 128, 4 wavefronts of 64 x 64, 16 KB stages): products of a few hundred to a few thousand rows
+// (one molecule, a batch of 32) are a handful of workgroups whose time is the padded tile's MFMAs on ONE CU -- half the tile, half the time
+template <int BN, int BM = QBM> struct QShape {
     static constexpr int NT = BN * 2;                               // 4 or 8 wavefronts, two rows of them
     static constexpr int NW = NT / 64, NWN = BN / 64;
-    static constexpr int STAGE = (QBM + BN) * QROWB;
-    static constexpr int A_PIECES = (QBM / 16) / NW, B_PIECES = (BN / 16) / NW;      // 1 KB pieces (16 rows) per wavefront and slab
+    static constexpr int TM = BM / 64;                              // 32-row accumulator blocks per wavefront (its rows: BM / 2)
+    static constexpr int A_BYTES = BM * QROWB;
+    static constexpr int STAGE = (BM + BN) * QROWB;
+    static constexpr int A_PIECES = (BM / 16) / NW, B_PIECES = (BN / 16) / NW;      // 1 KB pieces (16 rows) per wavefront and slab
     static constexpr int PIECES = A_PIECES + B_PIECES;
 };
 
@@ -60,11 +64,11 @@ __device__ inline void glds16(const char* g, char* lds_wave_base) {
 // per-lane source offsets (bytes, without the slab's uniform part) of a wavefront's pieces.  A piece = 16 rows x 64 B: lane -> (row =
 // lane >> 2, physical chunk = lane & 3); logical chunk (0, 1: hi k 0..7, 8..15; 2, 3: lo) = physical ^ ((row >> 2) & 3), so that the 16
 // lanes of a ds_read_b128 group (rows r..r+3, r+12.., r+20..) hit 16 distinct 16-byte slots of the 256-byte bank row
-template <int BN> struct QLaneSrc { unsigned a[QShape<BN>::A_PIECES], b[QShape<BN>::B_PIECES]; };
-template <int BN>
-__device__ inline QLaneSrc<BN> qlane_sources(const grappa_gemm_desc& d, int m0, int n0, int wave, int lane) {
-    using S = QShape<BN>;
-    QLaneSrc<BN> s;
+template <int BN, int BM = QBM> struct QLaneSrc { unsigned a[QShape<BN, BM>::A_PIECES], b[QShape<BN, BM>::B_PIECES]; };
+template <int BN, int BM = QBM>
+__device__ inline QLaneSrc<BN, BM> qlane_sources(const grappa_gemm_desc& d, int m0, int n0, int wave, int lane) {
+    using S = QShape<BN, BM>;
+    QLaneSrc<BN, BM> s;
     const int rin = lane >> 2, c = (lane & 3) ^ ((lane >> 4) & 3);
 #pragma unroll
     for (int q = 0; q < S::A_PIECES; ++q) s.a[q] = ((unsigned)min(m0 + (wave + S::NW * q) * 16 + rin, d.M - 1) * (unsigned)d.lda + 8u * c) * 2u;
@@ -73,37 +77,39 @@ __device__ inline QLaneSrc<BN> qlane_sources(const grappa_gemm_desc& d, int m0, 
     return s;
 }
 
-template <int BN>
-__device__ inline void qissue_slab(const char* __restrict__ A, const char* __restrict__ B, size_t k_bytes, const QLaneSrc<BN>& s, char* __restrict__ stage,
+template <int BN, int BM = QBM>
+__device__ inline void qissue_slab(const char* __restrict__ A, const char* __restrict__ B, size_t k_bytes, const QLaneSrc<BN, BM>& s, char* __restrict__ stage,
                                    int wave) {
-    using S = QShape<BN>;
+    using S = QShape<BN, BM>;
 #pragma unroll
     for (int q = 0; q < S::A_PIECES; ++q) glds16(A + k_bytes + s.a[q], stage + (wave + S::NW * q) * 1024);
 #pragma unroll
-    for (int q = 0; q < S::B_PIECES; ++q) glds16(B + k_bytes + s.b[q], stage + QA_BYTES + (wave + S::NW * q) * 1024);
+    for (int q = 0; q < S::B_PIECES; ++q) glds16(B + k_bytes + s.b[q], stage + S::A_BYTES + (wave + S::NW * q) * 1024);
 }
 
-struct QFrags { f16x8 a[QTM][2], b[QTN][2]; };      // [32-row block][hi / lo]
+template <int TM> struct QFrags { f16x8 a[TM][2], b[QTN][2]; };      // [32-row block][hi / lo]
 
-// fragments of a staged slab: 12 ds_read_b128.  off[p] = lr * 64 + ((2 p + lh) ^ swizzle(lr)) * 16
-__device__ inline void qread_frags(const char* __restrict__ stage, const unsigned (&off)[2], int wm0, int wn0, QFrags& f) {
+// fragments of a staged slab: 12 (8: TM = 2) ds_read_b128.  off[p] = lr * 64 + ((2 p + lh) ^ swizzle(lr)) * 16
+template <int TM>
+__device__ inline void qread_frags(const char* __restrict__ stage, int a_bytes, const unsigned (&off)[2], int wm0, int wn0, QFrags<TM>& f) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int j = 0; j < QTN; ++j) f.b[j][p] = *reinterpret_cast<const f16x8*>(stage + QA_BYTES + (wn0 + j * 32) * QROWB + off[p]);
+        for (int j = 0; j < QTN; ++j) f.b[j][p] = *reinterpret_cast<const f16x8*>(stage + a_bytes + (wn0 + j * 32) * QROWB + off[p]);
 #pragma unroll
-        for (int i = 0; i < QTM; ++i) f.a[i][p] = *reinterpret_cast<const f16x8*>(stage + (wm0 + i * 32) * QROWB + off[p]);
+        for (int i = 0; i < TM; ++i) f.a[i][p] = *reinterpret_cast<const f16x8*>(stage + (wm0 + i * 32) * QROWB + off[p]);
     }
 }
 
-// the 24 MFMAs of a slab: hi*lo, lo*hi, hi*hi (smallest first), the accumulators innermost.  B fragment first: the accumulator holds
+// the 24 (12) MFMAs of a slab: hi*lo, lo*hi, hi*hi (smallest first), the accumulators innermost.  B fragment first: the accumulator holds
 // the transposed tile (4 consecutive n per lane: the row epilogue)
-__device__ inline void qmfma(const QFrags& f, f32x16 (&acc)[QTM][QTN]) {
+template <int TM>
+__device__ inline void qmfma(const QFrags<TM>& f, f32x16 (&acc)[TM][QTN]) {
 #pragma unroll
     for (int pr = 0; pr < 3; ++pr) {
         const int pa = pr == 1 ? 1 : 0, pb = pr == 0 ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < QTM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < QTN; ++j) {
                 if (GQ_KNOCK == 2) asm volatile("" ::"v"(f.b[j][pb]), "v"(f.a[i][pa]));
@@ -112,25 +118,27 @@ __device__ inline void qmfma(const QFrags& f, f32x16 (&acc)[QTM][QTN]) {
     }
 }
 
-template <int QBN>
-__device__ __forceinline__ void gemm_pairs_body(const GemmParams& p, int nwg, int wgid) {
-    using S = QShape<QBN>;
+template <int QBN, int QBMt>
+struct PairsBody {
+static __device__ __forceinline__ void run(const GemmParams& p, int nwg, int wgid) {
+    using S = QShape<QBN, QBMt>;
+    constexpr int TM = S::TM;
     constexpr int QSTAGE = S::STAGE, QPIECES = S::PIECES;
     extern __shared__ char smem[];
     const grappa_gemm_desc& d = p.d;
     const TileCoord tc = map_logical(p, nwg, wgid);
     const int split = tc.split, tile_local = tc.tile_local;
-    const int m0 = tc.tile_m * QBM, n0 = tc.tile_n * QBN;
+    const int m0 = tc.tile_m * QBMt, n0 = tc.tile_n * QBN;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wm0 = (wave / S::NWN) * 128, wn0 = (wave % S::NWN) * 64;
+    const int wm0 = (wave / S::NWN) * (QBMt / 2), wn0 = (wave % S::NWN) * 64;
     const int lr = lane & 31, lh = lane >> 5;
     const int kbeg = split * p.k_per_split;
     const int kend = min(d.K, kbeg + p.k_per_split);
     const int nslab = (kend - kbeg + QSLAB - 1) / QSLAB;      // the rows are zero beyond K up to the next multiple of 32
 
-    f32x16 acc[QTM][QTN];
+    f32x16 acc[TM][QTN];
 #pragma unroll
-    for (int i = 0; i < QTM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < QTN; ++j)
 #pragma unroll
@@ -140,20 +148,20 @@ __device__ __forceinline__ void gemm_pairs_body(const GemmParams& p, int nwg, in
         const char* A = reinterpret_cast<const char*>(d.A);
         const char* B = reinterpret_cast<const char*>(d.B);
         const size_t kb0 = (size_t)kbeg * 4;                  // 16 k = 64 bytes of a row
-        const QLaneSrc<QBN> src = qlane_sources<QBN>(d, m0, n0, wave, lane);
+        const QLaneSrc<QBN, QBMt> src = qlane_sources<QBN, QBMt>(d, m0, n0, wave, lane);
         const unsigned swz = (lr >> 2) & 3;
         const unsigned off[2] = {lr * QROWB + ((lh ^ swz) << 4), lr * QROWB + (((2 + lh) ^ swz) << 4)};
-        QFrags f0, f1;
+        QFrags<TM> f0, f1;
 
 #pragma unroll
         for (int u = 0; u < QNSTAGE; ++u)
-            if (u < nslab) qissue_slab<QBN>(A, B, kb0 + (size_t)u * QROWB, src, smem + u * QSTAGE, wave);
+            if (u < nslab) qissue_slab<QBN, QBMt>(A, B, kb0 + (size_t)u * QROWB, src, smem + u * QSTAGE, wave);
         if (nslab >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QPIECES) : "memory");
         else if (nslab == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        qread_frags(smem, off, wm0, wn0, f0);
+        qread_frags<TM>(smem, S::A_BYTES, off, wm0, wn0, f0);
         int st = 0;                                          // t % 3
         // one slab: FC holds slab T's fragments; FN receives those of slab T + 1
 #define GQ_STEP(T, FC, FN)                                                                                                             \
@@ -167,10 +175,10 @@ __device__ __forceinline__ void gemm_pairs_body(const GemmParams& p, int nwg, in
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
             __builtin_amdgcn_s_barrier();                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            if ((T) + QNSTAGE < nslab && GQ_KNOCK != 1) qissue_slab<QBN>(A, B, kb0 + (size_t)((T) + QNSTAGE) * QROWB, src, cur_, wave); \
-            qread_frags(smem + st * QSTAGE, off, wm0, wn0, FN);                                                                        \
+            if ((T) + QNSTAGE < nslab && GQ_KNOCK != 1) qissue_slab<QBN, QBMt>(A, B, kb0 + (size_t)((T) + QNSTAGE) * QROWB, src, cur_, wave); \
+            qread_frags<TM>(smem + st * QSTAGE, S::A_BYTES, off, wm0, wn0, FN);                                                                        \
         }                                                                                                                              \
-        qmfma(FC, acc);                                                                                                                \
+        qmfma<TM>(FC, acc);                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                                             \
     } while (0)
         int t = 0;
@@ -184,9 +192,9 @@ __device__ __forceinline__ void gemm_pairs_body(const GemmParams& p, int nwg, in
 
     // undo the row scales: accumulator element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, wn0 + 32 j + 8 (e / 4) + 4 lh + e % 4)
     {
-        int ea[QTM];
+        int ea[TM];
 #pragma unroll
-        for (int i = 0; i < QTM; ++i) ea[i] = amax_shift(d.a_amax[min(m0 + wm0 + i * 32 + lr, d.M - 1)]);
+        for (int i = 0; i < TM; ++i) ea[i] = amax_shift(d.a_amax[min(m0 + wm0 + i * 32 + lr, d.M - 1)]);
         const bool b_vec = (reinterpret_cast<uintptr_t>(d.b_amax) & 15) == 0;
 #pragma unroll
         for (int j = 0; j < QTN; ++j)
@@ -204,13 +212,13 @@ __device__ __forceinline__ void gemm_pairs_body(const GemmParams& p, int nwg, in
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int i = 0; i < QTM; ++i) acc[i][j][4 * g + q] = __builtin_ldexpf(acc[i][j][4 * g + q], -(ea[i] + eb[q]));
+                    for (int i = 0; i < TM; ++i) acc[i][j][4 * g + q] = __builtin_ldexpf(acc[i][j][4 * g + q], -(ea[i] + eb[q]));
             }
     }
     __syncthreads();                                         // the ring is dead: reuse as epilogue staging
     if (GQ_KNOCK == 3) {
 #pragma unroll
-        for (int i = 0; i < QTM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < QTN; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
@@ -228,7 +236,7 @@ __device__ __forceinline__ void gemm_pairs_body(const GemmParams& p, int nwg, in
     const int mb = m0 + wm0;
     if (p.epi_class != 0 && p.nsplit == 1) {
 #define GQ_FAST(CLS, T)                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < QTM; ++i) epilogue_band_fast<QTN, CLS, T, 4>(p, acc[i], wave_buf, mb + 32 * i, n, lane, b4); \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) epilogue_band_fast<QTN, CLS, T, 4>(p, acc[i], wave_buf, mb + 32 * i, n, lane, b4); \
     break
         switch (p.epi_class) {
             case 1: GQ_FAST(1, float);
@@ -245,17 +253,19 @@ __device__ __forceinline__ void gemm_pairs_body(const GemmParams& p, int nwg, in
         return;
     }
 #pragma unroll
-    for (int i = 0; i < QTM; ++i) epilogue_band<QBM, QBN, QTN>(p, acc[i], wave_buf, m0, n0, mb + 32 * i, n, lane, b4, split, tile_local, p.vec_io != 0);
+    for (int i = 0; i < TM; ++i) epilogue_band<QBMt, QBN, QTN>(p, acc[i], wave_buf, m0, n0, mb + 32 * i, n, lane, b4, split, tile_local, p.vec_io != 0);
 }
+};
 
 template <int QBN>
-__global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_kernel(GemmParams p) { gemm_pairs_body<QBN>(p, gridDim.x, blockIdx.x); }
+__global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_kernel(GemmParams p) { PairsBody<QBN, QBM>::run(p, gridDim.x, blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void gemm_pairs_small_kernel(GemmParams p) { PairsBody<128, 128>::run(p, gridDim.x, blockIdx.x); }
 
 // up to four independent pair-format products (the same product of the four writer heads) in one grid
 template <int QBN>
 __global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_group4_kernel(GemmGroup4 g) {
     const int i = group4_find(g, blockIdx.x);
-    gemm_pairs_body<QBN>(g.p[i], g.wg_begin[i + 1] - g.wg_begin[i], blockIdx.x - g.wg_begin[i]);
+    PairsBody<QBN, QBM>::run(g.p[i], g.wg_begin[i + 1] - g.wg_begin[i], blockIdx.x - g.wg_begin[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -498,6 +508,21 @@ int launch_pairs(hipStream_t st, GemmParams& p) {
     return grappa_launch_status();
 }
 
+int launch_pairs_small(hipStream_t st, GemmParams& p) {
+    using S = QShape<128, 128>;
+    constexpr size_t ring = (size_t)QNSTAGE * S::STAGE, staging = S::NW * (size_t)EPI_WAVE_BYTES;
+    constexpr size_t smem = ring > staging ? ring : staging;
+    auto kern = gemm_pairs_small_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return GRAPPA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    GRAPPA_LAUNCH(kern, dim3(p.ntiles_launch * p.nsplit), dim3(S::NT), smem, st, p);
+    return grappa_launch_status();
+}
+
 // fp32 X[R][C] -> pair format; one 32 x 32 tile per 256-thread workgroup, through LDS when transposing.  amax: bit patterns of the
 // largest magnitude of every OUTPUT row (R values, or C values when transposing)
 __device__ inline size_t pair_index(size_t row, int k, int ldo) { return row * ldo + 32 * (k >> 4) + (k & 15); }
@@ -622,5 +647,6 @@ int grappa_launch_gemm_pairs_group4(hipStream_t st, const GemmGroup4& g) {
 // called by grappa_gemm_f32 (gemm_f32.hip) when both operands are in the pair format (precision F32_F16X3); tile 256 x 128
 int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p) {
     if (!p.d.a_planes) return launch_wpairs(st, p);          // fp32 A, weight pairs
+    if (p.bm == 128) return launch_pairs_small(st, p);
     return p.bn == 256 ? launch_pairs<256>(st, p) : launch_pairs<128>(st, p);
 }

@@ -100,16 +100,19 @@ def check(M, N, K, gen, dgrad=False, scale_rows=False, **epi):
     o_split = torch.full((M, N), float("nan"), device=dev)
     gemm(ap, bp, o_pairs, M, N, K, am_a, am_b, True, **kw)
     gemm(A, W, o_split, M, N, K, am_a, am_b, False, b_kcontig=not dgrad, **kw)
-    if K % 16 == 0:                         # fp32 A + weight pairs: the same bits as the all-pairs product (same tile, same K cuts)
+    o_wp = None
+    if K % 16 == 0:                         # fp32 A + weight pairs: the same bits as the all-pairs product where their K cuts agree
         o_wp = torch.full((M, N), float("nan"), device=dev)
         gemm(A, bp, o_wp, M, N, K, am_a, am_b, "b", **kw)
-        torch.cuda.synchronize()
-        assert torch.equal(o_wp, o_pairs), ("weight-pairs kernel differs from the pair kernel", float((o_wp - o_pairs).abs().max()))
     torch.cuda.synchronize()
     scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
     e_pairs = ((o_pairs.double() - ref).abs() / scale).max().item()
     e_split = ((o_split.double() - ref).abs() / scale).max().item()
     same = torch.equal(o_pairs, o_split)
+    if o_wp is not None:
+        e_wp = ((o_wp.double() - ref).abs() / scale).max().item()
+        assert e_wp < 3e-6, ("weight-pairs kernel", e_wp)
+        same = same and torch.equal(o_wp, o_pairs)
     print(f"  M={M:6d} N={N:5d} K={K:5d} dgrad={int(dgrad)} rows_scaled={int(scale_rows)} epi={sorted(epi)}: pairs err {e_pairs:.2e}  split err {e_split:.2e}  "
           f"bit-identical {same}")
     assert e_pairs < 3e-6, e_pairs
