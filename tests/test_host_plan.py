@@ -49,3 +49,42 @@ def test_malformed_graphs_raise_as_before():
     bad._data["n3"]["idxs"][0, 0] = 10 ** 6
     with pytest.raises(AssertionError, match="Encountered idxs"):
         bad.plan()
+
+
+def test_native_connected_components_against_union_find():
+    """grappa_components (the water guard of Grappa.predict): label = smallest atom index of the component, on random forests with extra
+    edges, isolated atoms, one direction or both; out-of-range atoms are refused"""
+    from grappa_amd import _hostlib
+    rng = np.random.default_rng(0)
+    for n, e in [(1, 0), (5, 0), (40, 39), (200, 150), (1000, 1400)]:
+        src = rng.integers(0, n, size=e).astype(np.int64)
+        dst = rng.integers(0, n, size=e).astype(np.int64)
+        if e and e % 2 == 0:                                  # both directions, as MolBatch stores them
+            src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])
+        parent = list(range(n))
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+        for a, b in zip(src.tolist(), dst.tolist()):
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+        want = np.array([find(i) for i in range(n)], dtype=np.int32)
+        # (the smallest index of a component is its root under "the smaller index stays the root")
+        got = _hostlib.components(n, src, dst)
+        assert got.dtype == np.int32 and np.array_equal(got, want), (n, e)
+    with pytest.raises(RuntimeError):
+        _hostlib.components(3, np.array([0, 5]), np.array([1, 2]))
+
+
+def test_water_guard_still_fires_through_the_native_components():
+    from grappa_amd.molecule import Molecule
+    # two waters in one graph: disconnected, every component {H, O} only
+    mol = Molecule(atoms=[1, 2, 3, 4, 5, 6], bonds=[(1, 2), (1, 3), (4, 5), (4, 6)], impropers=[], atomic_numbers=[8, 1, 1, 8, 1, 1],
+                   partial_charges=[-0.8, 0.4, 0.4, -0.8, 0.4, 0.4])
+    g = mol.to_dgl(max_element=53, exclude_feats=[])
+    with pytest.raises(Exception):
+        B.check_disconnected_graphs(g)
