@@ -382,7 +382,9 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
     // the shortest K range of a split: one slab of BK (GRAPPA_PLAN_MIN_KSTEPS=8: rounds 1-3' limit of eight): the model may cut K = 512 sixteen ways instead of
     // two (small products -- one molecule, a batch of 32 -- are a few workgroups that each take in their whole K range at a CU's ~30 GB/s)
     static const int min_ksteps = [] { const char* e = getenv("GRAPPA_PLAN_MIN_KSTEPS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
-    int max_split = K >= 2 * min_ksteps * BK ? K / (min_ksteps * BK) : 1;
+    // (the bf16 plane kernels keep the limit of eight: their configuration's parity sits at its 2e-2 tolerance and moves with the K cuts)
+    const int mk = (planes && !pairs) ? 8 : min_ksteps;
+    int max_split = K >= 2 * mk * BK ? K / (mk * BK) : 1;
     if (max_split > 64) max_split = 64;
     int max_tail_split = K >= 8 * BK ? K / (4 * BK) : 1;      // the tail may be cut finer than a full split-K GEMM
     if (max_tail_split > 64) max_tail_split = 64;
