@@ -50,6 +50,34 @@ def main():
           f"({sum(g[0] for g in gaps if g[0] > 20000) / 1e6:.2f} ms)")
     for g, a, b in gaps[:12]:
         print(f"  {g / 1e3:8.1f} us  after {a[:70]}  before {b[:70]}")
+    # time during which exactly ONE kernel is in flight, by kernel: what a chain of dependent launches waits for; and the idle time in front
+    # of a kernel (launch latency of a dependent node), by the kernel that ends the gap
+    alone, before = {}, {}
+    ev2 = []
+    for i, (s_, e_, n_, _q) in enumerate(rows):
+        ev2.append((s_, 1, i))
+        ev2.append((e_, -1, i))
+    ev2.sort()
+    live, last = set(), t0
+    for t, d, i in ev2:
+        if len(live) == 1:
+            n_ = rows[next(iter(live))][2]
+            alone[n_] = alone.get(n_, 0) + (t - last)
+        elif len(live) == 0 and d == 1 and t > last:
+            n_ = rows[i][2]
+            before[n_] = before.get(n_, 0) + (t - last)
+        if d == 1:
+            live.add(i)
+        else:
+            live.discard(i)
+        last = t
+    tot_alone = sum(alone.values())
+    print(f"exactly one kernel in flight: {tot_alone / 1e6:.2f} ms ({100 * tot_alone / span:.1f} % of the span), by kernel:")
+    for n_, v in sorted(alone.items(), key=lambda kv: -kv[1])[:25]:
+        print(f"  {v / 1e6:8.2f} ms {100 * v / span:5.1f} %  {n_[:110]}")
+    print("idle time in front of a kernel, by kernel:")
+    for n_, v in sorted(before.items(), key=lambda kv: -kv[1])[:12]:
+        print(f"  {v / 1e6:8.2f} ms  {n_[:110]}")
 
 
 if __name__ == "__main__":
