@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrappa_host.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -18,6 +18,7 @@ SIGNATURES = {
     "grappa_degree_encoding": (C.c_int, [C.c_int, C.c_int, _i32p, _f32p]),
     "grappa_ring_encoding": (C.c_int, [C.c_int, C.c_int, _i32p, _f32p]),
     "grappa_components": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, _i32p]),
+    "grappa_position_tables": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong]),
     "grappa_plan_build": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, _i32p, C.POINTER(C.c_void_p), _i32p, C.c_void_p, C.c_void_p,
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
@@ -122,3 +123,23 @@ def components(n: int, src: np.ndarray, dst: np.ndarray) -> np.ndarray:
     if rc != 0:
         raise RuntimeError(f"grappa_components failed with status {rc}")
     return label
+
+
+def position_tables(N: int, idx: np.ndarray):
+    """flat int32 array + (offset, size) of its six parts (include/grappa_host.h grappa_position_tables); idx: (T, s) int32"""
+    lib = load()
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    T, s = idx.shape
+    need = lib.grappa_position_tables(int(N), int(T), int(s), idx.ctypes.data_as(C.c_void_p), None, 0)
+    if need < 0:
+        raise RuntimeError(f"grappa_position_tables failed with status {need}")
+    flat = np.empty(int(need), dtype=np.int32)
+    rc = lib.grappa_position_tables(int(N), int(T), int(s), idx.ctypes.data_as(C.c_void_p), flat.ctypes.data_as(C.c_void_p), int(need))
+    if rc < 0:
+        raise RuntimeError(f"grappa_position_tables failed with status {rc}")
+    sizes = [N * s, N + 1, N * s, T * s, s * N + 1, s * T]
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += (n + 3) // 4 * 4
+    return flat, list(zip(offs, sizes))

@@ -62,7 +62,7 @@ struct Cycle {
 
 }  // namespace
 
-extern "C" int grappa_host_abi_version(void) { return 2; }
+extern "C" int grappa_host_abi_version(void) { return 3; }
 
 extern "C" int grappa_topo_enumerate(int n_bonds, const int32_t* bonds, int32_t* angles, int64_t cap_angles, int32_t* propers,
                                      int64_t cap_propers, int64_t* n_angles, int64_t* n_propers) {
@@ -402,4 +402,45 @@ extern "C" int grappa_components(int N, int64_t E, const int64_t* src, const int
     }
     for (int i = 0; i < N; ++i) label[i] = find(i);
     return OK;
+}
+
+
+// index tables of the (atom, position) formulation of a writer's first layer (grappa_amd/batch.py _position_tables), one flat int32 array:
+//   idx_id (N x s) | invid_ptr (N + 1) | invid_rows (N s) | idx_tab (T x s) | invtab_ptr (s N + 1) | invtab_rows (s T)
+// every part starting at the next multiple of 4 elements; returns the number of elements written (or needed, if out == NULL), < 0 on error
+extern "C" long long grappa_position_tables(int N, int T, int s, const int32_t* idx, int32_t* out, long long out_len) {
+    if (N < 0 || T < 0 || s < 1 || s > 4 || (T > 0 && !idx)) return ERR_ARG;
+    const long long sizes[6] = {(long long)N * s, (long long)N + 1, (long long)N * s, (long long)T * s, (long long)s * N + 1, (long long)s * T};
+    long long offs[7];
+    offs[0] = 0;
+    for (int i = 0; i < 6; ++i) offs[i + 1] = offs[i] + (sizes[i] + 3) / 4 * 4;
+    const long long need = offs[6] > 4 ? offs[6] : 4;
+    if (!out) return need;
+    if (out_len < need) return ERR_ARG;
+    for (long long i = 0; i < need; ++i) out[i] = 0;
+    int32_t* idx_id = out + offs[0];
+    int32_t* invid_ptr = out + offs[1];
+    int32_t* invid_rows = out + offs[2];
+    int32_t* idx_tab = out + offs[3];
+    int32_t* invtab_ptr = out + offs[4];
+    int32_t* invtab_rows = out + offs[5];
+    for (int n = 0; n < N; ++n)
+        for (int p = 0; p < s; ++p) {
+            idx_id[(long long)n * s + p] = n;
+            invid_rows[(long long)n * s + p] = p * N + n;
+        }
+    for (int n = 0; n <= N; ++n) invid_ptr[n] = n * s;
+    for (long long t = 0; t < T; ++t)
+        for (int p = 0; p < s; ++p) {
+            const int32_t a = idx[t * s + p];
+            if (a < 0 || a >= N) return ERR_ARG;
+            const int32_t row = p * N + a;
+            idx_tab[t * s + p] = row;
+            ++invtab_ptr[row + 1];
+        }
+    for (long long r = 0; r < (long long)s * N; ++r) invtab_ptr[r + 1] += invtab_ptr[r];
+    std::vector<int32_t> fill(invtab_ptr, invtab_ptr + (long long)s * N);
+    for (int p = 0; p < s; ++p)                                   // token rows pos * T + t in ascending order: a stable sort by table row
+        for (long long t = 0; t < T; ++t) invtab_rows[fill[idx_tab[t * s + p]]++] = (int32_t)(p * (long long)T + t);
+    return need;
 }

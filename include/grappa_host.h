@@ -51,6 +51,12 @@ int grappa_plan_build(int N, int64_t E, const int64_t* src, const int64_t* dst, 
  * The water guard of Grappa.predict (reference utils/dgl_utils.py:210-236) walks them. */
 int grappa_components(int N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* label);
 
+/* Index tables of the (atom, position) formulation of a writer's first layer (reference models/interaction_parameters.py:155-180 run once
+ * per (atom, position) instead of once per token; grappa_amd/batch.py _position_tables), s = arity of the level (2..4), idx = T x s atom indices.
+ * One flat array: idx_id (N x s) | invid_ptr (N + 1) | invid_rows (N s) | idx_tab (T x s) | invtab_ptr (s N + 1) | invtab_rows (s T), each
+ * part at the next multiple of 4 elements.  Returns the elements written (out == NULL: needed), < 0 on error. */
+long long grappa_position_tables(int N, int T, int s, const int32_t* idx, int32_t* out, long long out_len);
+
 #ifdef __cplusplus
 }
 #endif

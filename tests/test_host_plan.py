@@ -88,3 +88,25 @@ def test_water_guard_still_fires_through_the_native_components():
     g = mol.to_dgl(max_element=53, exclude_feats=[])
     with pytest.raises(Exception):
         B.check_disconnected_graphs(g)
+
+
+@pytest.mark.parametrize("ids", [[0], [17], [3, 50, 900]])
+def test_native_position_tables_equal_the_numpy_definition(ids, monkeypatch):
+    """grappa_position_tables against batch._position_tables' numpy expressions, level by level (incl. an empty level)"""
+    g = build_batch_from_pool(ids, n_confs=1, seed=0) if len(ids) > 1 else molecule_from_pool(ids[0]).to_dgl()
+    got = {lvl: g.plan().position_tables(lvl) for lvl in B.TUPLE_LEVELS}
+    monkeypatch.setenv("GRAPPA_HOST_PLAN", "numpy")
+    g2 = build_batch_from_pool(ids, n_confs=1, seed=0) if len(ids) > 1 else molecule_from_pool(ids[0]).to_dgl()
+    want = {lvl: g2.plan().position_tables(lvl) for lvl in B.TUPLE_LEVELS}
+    for lvl in B.TUPLE_LEVELS:
+        assert len(got[lvl]) == len(want[lvl]) == 6
+        for a, b in zip(got[lvl], want[lvl]):
+            assert a.dtype == b.dtype == torch.int32 and a.shape == b.shape and torch.equal(a, b), lvl
+
+
+def test_native_position_tables_refuse_bad_indices():
+    from grappa_amd import _hostlib
+    with pytest.raises(RuntimeError):
+        _hostlib.position_tables(3, np.array([[0, 7]], dtype=np.int32))
+    flat, parts = _hostlib.position_tables(4, np.zeros((0, 3), dtype=np.int32))         # an empty level
+    assert [n for _o, n in parts] == [12, 5, 12, 0, 13, 0] and flat.dtype == np.int32

@@ -22,7 +22,7 @@ def test_host_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_hostlib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert sorted(_hostlib.SIGNATURES) == names and _hostlib.load().grappa_host_abi_version() == _hostlib.ABI_VERSION == 2
+    assert sorted(_hostlib.SIGNATURES) == names and _hostlib.load().grappa_host_abi_version() == _hostlib.ABI_VERSION == 3
 
 
 def test_tuple_enumeration_matches_reference_rows_and_order():
