@@ -473,18 +473,23 @@ def tiny_config(**opts):
     return cfg
 
 
-def make_variants_golden():
+def make_variants_golden(only=None):
     """constructor / Energy variants of the reference that had no reference-generated fixture (VERDICT r3 missing #2):
     wrong_symmetry=True (models/interaction_parameters.py:502-507: six permutations of the improper tokens, positional code [0,0,1,0]),
     harmonic_gate=True (:257-264, :352-360: a third output column per bond / angle that the written k ignores), n_periodicity_proper=3
     (experiments/train-grappa-1.2.1/grappa_config.yaml:98-99) and Energy(offset_torsion=True) (models/energy.py:79) end to end,
-    i.e. with the loss and every parameter gradient behind it."""
+    i.e. with the loss and every parameter gradient behind it.  Round 4, second batch: positional_encoding=False (:166-176, no position code on
+    the tokens) with two input features only and a non-default torsion_cutoff -- three more options without a fixture of their own.
+    `only`: write that file alone."""
     mols = build_inputs(pick_small(4, 9, 22, start=60), n_confs=4, seed=31, charge_model="amber99")
     lk = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=1e-3, proper_regularisation=1e-3, improper_regularisation=1e-3)
     for name, opts, ek in (("ref_tiny_wrongsym.npz", dict(wrong_symmetry=True), None),
                            ("ref_tiny_harmonic_gate.npz", dict(harmonic_gate=True), None),
                            ("ref_tiny_nper3.npz", dict(n_periodicity_proper=3, gated_torsion=True), None),
-                           ("ref_tiny_offset_torsion.npz", dict(), dict(offset_torsion=True))):
+                           ("ref_tiny_offset_torsion.npz", dict(), dict(offset_torsion=True)),
+                           ("ref_tiny_nopos.npz", dict(positional_encoding=False, in_feat_name=["atomic_number", "partial_charge"], torsion_cutoff=1e-2), None)):
+        if only and name != only:
+            continue
         cfg = tiny_config(**opts)
         out, sd, g = run_reference(cfg, mols, 4, loss_kwargs=lk, energy_kwargs=ek)
         extra = {"loss_kwargs_keys": np.array(list(lk.keys())), "loss_kwargs_vals": np.array(list(lk.values())),
@@ -544,7 +549,7 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "options":
         make_options_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "variants":
-        make_variants_golden()
+        make_variants_golden(sys.argv[2] if len(sys.argv) > 2 else None)
     elif len(sys.argv) > 1 and sys.argv[1] == "eval":
         make_eval_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "tuples":

@@ -37,7 +37,7 @@ def _check_graph(g, out, loss):
                                                  ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False),
                                                  ("ref_small_learnstats.npz", 5, False),     # last three: layer_norm=False / self_interaction=False / learnable_statistics=True
                                                  ("ref_tiny_wrongsym.npz", 4, True), ("ref_tiny_harmonic_gate.npz", 4, True),
-                                                 ("ref_tiny_nper3.npz", 4, True), ("ref_tiny_offset_torsion.npz", 4, True)])     # wrong_symmetry / harmonic_gate / n_periodicity_proper=3 / Energy(offset_torsion=True)
+                                                 ("ref_tiny_nper3.npz", 4, True), ("ref_tiny_offset_torsion.npz", 4, True), ("ref_tiny_nopos.npz", 4, True)])     # wrong_symmetry / harmonic_gate / n_periodicity_proper=3 / Energy(offset_torsion=True)
 def test_small_configs_against_reference_goldens(name, n_confs, refs):
     from grappa_amd import Energy, GrappaModel, MolwiseLoss
     _assert_loaded()

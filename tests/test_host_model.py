@@ -32,7 +32,7 @@ def _run(fx_name, n_confs, refs):
                                                  ("ref_small_nonorm.npz", 5, False), ("ref_small_nosi.npz", 5, False),
                                                  ("ref_small_learnstats.npz", 5, False),     # last three: layer_norm=False / self_interaction=False / learnable_statistics=True
                                                  ("ref_tiny_wrongsym.npz", 4, True), ("ref_tiny_harmonic_gate.npz", 4, True),
-                                                 ("ref_tiny_nper3.npz", 4, True), ("ref_tiny_offset_torsion.npz", 4, True)])     # wrong_symmetry / harmonic_gate / n_periodicity_proper=3 / Energy(offset_torsion=True)
+                                                 ("ref_tiny_nper3.npz", 4, True), ("ref_tiny_offset_torsion.npz", 4, True), ("ref_tiny_nopos.npz", 4, True)])     # wrong_symmetry / harmonic_gate / n_periodicity_proper=3 / Energy(offset_torsion=True)
 def test_product_host_path_matches_reference(ref_backend, name, n_confs, refs):
     fx, g, loss, model = _run(name, n_confs, refs)
     out = gu.outputs_of(fx)

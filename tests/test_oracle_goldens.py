@@ -46,7 +46,7 @@ def _check_outputs(out, g, loss, scaled=False):
 # ref_tiny_*: the reference's wrong_symmetry=True / harmonic_gate=True / n_periodicity_proper=3 (gated) / Energy(offset_torsion=True)
 @pytest.mark.parametrize("name,n_confs,refs", [("ref_small_att.npz", 4, True), ("ref_small_conv.npz", 5, False),
                                                  ("ref_tiny_wrongsym.npz", 4, True), ("ref_tiny_harmonic_gate.npz", 4, True),
-                                                 ("ref_tiny_nper3.npz", 4, True), ("ref_tiny_offset_torsion.npz", 4, True)])
+                                                 ("ref_tiny_nper3.npz", 4, True), ("ref_tiny_offset_torsion.npz", 4, True), ("ref_tiny_nopos.npz", 4, True)])
 def test_small_config_matches_reference(name, n_confs, refs):
     fx, g, loss, model = _run(name, n_confs, refs)
     out = gu.outputs_of(fx)
