@@ -275,7 +275,10 @@ class HipBackend:
 
     def _refresh_weight_pairs(self) -> None:
         import numpy as np
-        for k in [k for k, e in self._wpairs.items() if e[2]() is None or e[3] < self._wepoch - 1]:      # dead, or unused since the step before last
+        # (never while a hipGraph is being recorded: a changed table is a host-to-device copy, which a capture cannot hold; what would have
+        # aged out is refreshed once more instead)
+        ageing = not torch.cuda.is_current_stream_capturing()
+        for k in [k for k, e in self._wpairs.items() if e[2]() is None or (ageing and e[3] < self._wepoch - 1)]:      # dead, or unused since the step before last
             del self._wpairs[k]
             self._wptable = None
         live = [e for e in self._wpairs.values()]
@@ -419,10 +422,12 @@ class HipBackend:
 
     def _refresh_weight_amax(self) -> None:
         import numpy as np
-        # weights not used since the step before last leave the table (dead models of a test session, frozen heads, ...)
-        for k in [k for k, e in self._wamax.items() if e[3] < self._wepoch - 1]:
-            del self._wamax[k]
-            self._wtable = None
+        # weights not used since the step before last leave the table (dead models of a test session, frozen heads, ...) -- not while a
+        # hipGraph is being recorded (see _refresh_weight_pairs)
+        if not torch.cuda.is_current_stream_capturing():
+            for k in [k for k, e in self._wamax.items() if e[3] < self._wepoch - 1]:
+                del self._wamax[k]
+                self._wtable = None
         live = [e for e in self._wamax.values() if e[4]]
         if not live:
             return

@@ -110,8 +110,12 @@ class CapturedForward:
     """GrappaModel forward (eval, no_grad) on ONE resident graph as a hipGraph; `load(g)` copies another graph of the same shape signature
     into the captured tensors.  Outputs (k / eq per level) are tensors of the graph: read them before the next replay."""
 
-    def __init__(self, model, g, warmup: int = 2):
+    def __init__(self, model, g, warmup: int = 2, refresh_weights: bool = False):
+        """refresh_weights: the per-weight caches (row / column maxima, pair splits) are rebuilt INSIDE the graph at every replay (as in
+        CapturedTrainStep), so the graph stays valid while the weights change between replays (predict calls interleaved with training);
+        costs the two batched refresh launches per replay, hence only where the weights were seen to change (ForwardCache)"""
         self.model, self.g = model, g
+        self.refresh_weights = bool(refresh_weights)
         self.be = get_backend()
         self.plan = g.plan()
         for lvl in ("n2", "n3", "n4", "n4_improper"):       # built eagerly: their construction sorts (host-synchronising torch ops)
@@ -121,10 +125,16 @@ class CapturedForward:
         self.stream = torch.cuda.Stream(device=g.device)
         self.stream.wait_stream(torch.cuda.current_stream(g.device))
         with torch.cuda.stream(self.stream), torch.no_grad():
-            for _ in range(max(int(warmup), 1)):
+            for _ in range(max(int(warmup), 3 if self.refresh_weights else 1)):
+                if self.refresh_weights:
+                    # (three epochs of eager refreshes: weights of other models age out of the backend's tables and the tables are rebuilt NOW --
+                    # a rebuild is a host-to-device copy, which a capture cannot hold)
+                    self.be.invalidate_weights()
                 _drop_outputs(g)
                 model(g)
         self.stream.synchronize()
+        if self.refresh_weights:
+            self.be.invalidate_weights()                     # every per-weight cache is stale now: the recorded forward starts by refreshing them
         self.weights_stamp = self._stamp()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream), torch.no_grad():
@@ -145,11 +155,14 @@ class CapturedForward:
         return (self.be._wepoch, sum(p._version for p in ps))
 
     def valid(self) -> bool:
-        """the per-weight caches (maxima, pair splits) were filled OUTSIDE the graph: a graph captured before the weights changed must not be replayed"""
-        return self._stamp() == self.weights_stamp
+        """the per-weight caches (maxima, pair splits) were filled OUTSIDE the graph: a graph captured before the weights changed must not be
+        replayed -- unless it refreshes them itself (refresh_weights)"""
+        return self.refresh_weights or self._stamp() == self.weights_stamp
 
     def replay(self):
         self.graph.replay()
+        if self.refresh_weights:
+            _touch_weight_caches(self.be)
         return self.g
 
     # ---- another graph of the same shape signature into the captured tensors
@@ -252,13 +265,16 @@ class ForwardCache:
         self.model, self.device, self.max_entries = model, torch.device(device), int(max_entries)
         self.seen: Dict[tuple, int] = {}
         self.entries: "Dict[tuple, CapturedForward]" = {}
+        self.refresh_weights = False                         # set once the weights were seen to change between two calls
 
     def __call__(self, g_host):
         """-> the parametrised graph on the CPU (k / eq written into g_host's tuple levels), or None: run the eager path"""
         sig = CapturedForward.signature(g_host)
         ent = self.entries.get(sig)
         if ent is not None and not ent.valid():
-            self.entries.clear()                             # the weights changed: every recorded graph reads stale per-weight caches
+            # the weights changed: every graph recorded so far reads stale per-weight caches.  From now on the graphs refresh them themselves
+            self.entries.clear()
+            self.refresh_weights = True
             ent = None
         if ent is None:
             n = self.seen.get(sig, 0) + 1
@@ -267,7 +283,7 @@ class ForwardCache:
                 return None
             if len(self.entries) >= self.max_entries:
                 self.entries.pop(next(iter(self.entries)))
-            ent = CapturedForward(self.model, g_host.to(self.device))
+            ent = CapturedForward(self.model, g_host.to(self.device), refresh_weights=self.refresh_weights)
             self.entries[sig] = ent
             ent.replay()                                     # (recording executes nothing: the outputs are filled by the first replay)
         else:
