@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--strong-global-batch", type=int, default=0, help="strong scaling of this many molecules of the workload's molecule range (default at N > 1: 4096 of C4)")
     ap.add_argument("--chunk", type=int, default=1024, help="molecules per forward/backward pass of a rank (larger shards are accumulated over chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shape-table", default="", help="append a per-shape account of the dense products of every instrumented job to this file "
+                    "(shape, layout, operand format, launches and kernel time per step, TFLOP/s, fraction of the ceiling, share of the products' time)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the C3 and C4-on-one-GPU timings that follow the headline measurement")
     ap.add_argument("--gemm-precision", default=None, help="arithmetic of the dense products (default: the backend's, f32_f16x3)")
     ap.add_argument("--act-dtype", default="f32", choices=["f32", "bf16"], help="bf16: the bf16 STORAGE configuration for the main job (profiling / "
@@ -359,6 +361,36 @@ def main():
                       "8(d)'s per-token count (`tflop_per_step`) is ~5 % larger because the first layer of the proper and angle writers runs its "
                       "LayerNorm + QKV product on (atom, position) rows (`achieved_with_algorithmic_credit` = that count over the same time)")
 
+    def write_shape_table(path, title, details, steps):
+        """per-shape account of the products of an instrumented pass (one queue: a launch's HIP-event time is its kernel's own).  A grouped
+        launch's time is shared among its products by their FLOPs."""
+        import collections
+        acc = collections.OrderedDict()
+        total_ms = 0.0
+        for fam, det, ms, fl, _by in details:
+            if fam != "gemm_f32" or not det:
+                continue
+            total_ms += ms
+            fsum = sum(2.0 * d["M"] * d["N"] * d["K"] for d in det) or 1.0
+            for d in det:
+                f = 2.0 * d["M"] * d["N"] * d["K"]
+                key = (d["layout"], d["M"], d["N"], d["K"], d["fmt"], d["epi"], len(det) > 1)
+                a = acc.setdefault(key, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += ms * f / fsum
+                a[2] += f
+        kname, nprod = GEMM_KERNELS[getattr(be, "gemm_precision_name", "f32")]
+        peak = (PEAK_F32_MFMA_TFLOPS if nprod == 0 else PEAK_BF16_MFMA_TFLOPS / nprod) if ops.act_dtype() is None else PEAK_BF16_MFMA_TFLOPS
+        with open(path, "a") as fh:
+            fh.write(f"# {title}: dense products of {steps} instrumented step(s) on ONE queue, HIP events around every launch; ceiling {peak:.1f} TFLOP/s; "
+                     f"products {total_ms / steps:.2f} ms per step\n")
+            fh.write("# layout      M      N      K  operands epilogue grouped  launches/step  us/launch   ms/step  TFLOP/s   frac  share  tiles(256x128)/256 CUs\n")
+            for (lay, M, N, K, fmt, epi, grouped), (n, ms, fl) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+                tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                tiles = ((M + 255) // 256) * ((N + 127) // 128)
+                fh.write(f"  {lay:6s} {M:6d} {N:6d} {K:6d}  {fmt:7s}  {epi:7s} {'yes' if grouped else 'no ':3s}   {n / steps:10.1f}  {1e3 * ms / n:9.1f}  {ms / steps:8.3f}  {tf:7.1f}  {tf / peak:5.3f}  "
+                         f"{100 * ms / total_ms:5.1f}  {tiles / 256:6.2f}\n")
+
     def instrument(j, steps):
         """instrumented repetition of a job's steps: HIP events around every GEMM / GAT launch on the launch stream (ONE stream:
         GRAPPA_HEAD_STREAMS=1 and GRAPPA_WGRADS_ASIDE=0 semantics; profiles/ rocprof runs use the same settings) and around the gradient all-reduce
@@ -382,6 +414,8 @@ def main():
             j.step()
         prof = be.stop_profile() if on_gpu else {}
         dtp = time.perf_counter() - t1
+        if on_gpu and args.shape_table:
+            write_shape_table(args.shape_table, j.name + (" bf16 storage" if ops.act_dtype() is not None else ""), be.last_profile_details, steps)
         ar_ms = sum((ev[0].elapsed_time(ev[1]) if on_gpu else ev) for ev in j.allreduce_events) / max(len(j.allreduce_events), 1)
         # with the overlap on: how long before finish() the heads' bucket left (the collective had that long to run beside the GNN's backward pass)
         leads = [te[1].elapsed_time(ev[0]) for ev in j.allreduce_events if on_gpu for te in ev[2] if te[0] == "heads_sent"]

@@ -453,9 +453,13 @@ class HipBackend:
         the kernels run on (torch's current stream)."""
         torch.cuda.synchronize()
         out = {}
-        for name, fl, by, e0, e1 in self._prof or []:
+        self.last_profile_details = details = []      # (family, detail, ms, flops, bytes) per launch: tools/step_gemm_table.py
+        for name, fl, by, e0, e1, detail in self._prof or []:
             n, ms, f, b = out.get(name, (0, 0.0, 0.0, 0.0))
-            out[name] = (n + 1, ms + (e0.elapsed_time(e1) if e0 is not None else 0.0), f + fl, b + by)
+            t = e0.elapsed_time(e1) if e0 is not None else 0.0
+            out[name] = (n + 1, ms + t, f + fl, b + by)
+            if detail is not None:
+                details.append((name, detail, t, fl, by))
         self._prof = None
         return out
 
@@ -463,9 +467,9 @@ class HipBackend:
         """profiling only: algorithmic work (SURVEY 8(d) counts per token) that a formulation did not have to launch -- e.g. the first
         writer layer's products on (atom, position) rows instead of tokens -- recorded under its own family, without time"""
         if self._prof is not None:
-            self._prof.append((name, float(flops), 0.0, None, None))
+            self._prof.append((name, float(flops), 0.0, None, None, None))
 
-    def _timed(self, name, flops, nbytes, launch) -> None:
+    def _timed(self, name, flops, nbytes, launch, detail=None) -> None:
         if self._prof is None:
             launch()
             return
@@ -473,7 +477,18 @@ class HipBackend:
         e0.record()
         launch()
         e1.record()
-        self._prof.append((name, float(flops), float(nbytes), e0, e1))
+        self._prof.append((name, float(flops), float(nbytes), e0, e1, detail() if callable(detail) else detail))
+
+    @staticmethod
+    def _gemm_detail(d) -> dict:
+        """profiling only: what a product launch was (shape, layout, operand formats, epilogue) -- read back from its descriptor"""
+        lay = "fwd" if d.a_kcontig and d.b_kcontig else ("dgrad" if d.a_kcontig else "wgrad")
+        fmt = ("pairs" if d.a_planes and d.b_planes and d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] else
+               "wpairs" if d.b_planes and not d.a_planes and d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] else
+               "planes" if d.a_planes or d.b_planes else "f32")
+        epi = "".join(c for c, on in (("b", d.bias), ("e", d.act), ("x", d.aux or d.auxp), ("d", d.drop_p > 0), ("r", d.res or d.resp), ("2", d.C2 or d.C1p),
+                                      ("p", d.pre), ("+", d.accumulate), ("m", d.out_amax or d.out_amax_parts), ("c", d.a_colsum)) if on)
+        return {"M": d.M, "N": d.N, "K": d.K, "layout": lay, "fmt": fmt, "epi": epi or "-"}
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -727,7 +742,7 @@ class HipBackend:
             return _PendingGemm(d, (M, N, K), 2.0 * M * N * K, nbytes, ret, dev, (a, b, out, out2, res, aux, pre, bias, a_pairs, sa, so, res_ln),
                                 groupable=big and a_kcontig and a_colsum is None and planes_a is None and (planes_b is None or a_pairs is not None)
                                 and not native and final.dtype == torch.float32)
-        self._timed("gemm_f32", 2.0 * M * N * K, nbytes, lambda: self._launch_gemm(d, ws, dev, (M, N, K)))
+        self._timed("gemm_f32", 2.0 * M * N * K, nbytes, lambda: self._launch_gemm(d, ws, dev, (M, N, K)), lambda: [self._gemm_detail(d)])
         return ret
 
     def gemm_group(self, calls):
@@ -754,7 +769,7 @@ class HipBackend:
                 if need is None:
                     need = self._ws_need[q.shape + (self._tails,)] = self.lib.grappa_gemm_f32_workspace_bytes(*q.shape)
                 ws = self._workspace(need, q.dev) if need else None
-                self._timed("gemm_f32", q.flops, q.nbytes, lambda q=q, ws=ws: self._launch_gemm(q.d, ws, q.dev, q.shape))
+                self._timed("gemm_f32", q.flops, q.nbytes, lambda q=q, ws=ws: self._launch_gemm(q.d, ws, q.dev, q.shape), lambda q=q: [self._gemm_detail(q.d)])
         return out
 
     def _launch_gemm_group(self, grp) -> bool:
@@ -768,7 +783,7 @@ class HipBackend:
 
         def launch():
             rc[0] = self.lib.grappa_gemm_f32_group(self._stream(), arr, n, _ptr(ws), ws.numel() if ws is not None else 0)
-        self._timed("gemm_f32", sum(q.flops for q in grp), sum(q.nbytes for q in grp), launch)
+        self._timed("gemm_f32", sum(q.flops for q in grp), sum(q.nbytes for q in grp), launch, lambda: [self._gemm_detail(q.d) for q in grp])
         if rc[0] == -1:                          # GRAPPA_ERR_ARG: a combination the grouped entry does not take (nothing was launched)
             if self._prof:
                 self._prof.pop()
@@ -1014,7 +1029,8 @@ class HipBackend:
         need = self.lib.grappa_gemm_f32_grouped_workspace_bytes(arr, n)
         ws = self._workspace(need, dev)
         self._timed("gemm_f32", flops, nbytes,
-                    lambda: _chk(self.lib.grappa_gemm_f32_grouped(self._stream(), arr, n, ws.data_ptr(), ws.numel()), "grappa_gemm_f32_grouped"))
+                    lambda: _chk(self.lib.grappa_gemm_f32_grouped(self._stream(), arr, n, ws.data_ptr(), ws.numel()), "grappa_gemm_f32_grouped"),
+                    lambda: [self._gemm_detail(d) for d in arr])
 
     def colsum(self, x, out, accumulate=False) -> None:
         dev = out.device

@@ -250,7 +250,7 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;     // private staging region pe
 //   CLS 1: v + bias            2: elu(v + bias)            3: drop(v + bias) + res (drop_p may be 0, res may be NULL)
 //   CLS 4: v * elu'(aux) (+ res)
 //   CLS 5: drop(v + bias) + LayerNorm(res) (fp32 only: grappa_gemm_desc.res_ln_*, the residual recomputed from the rows before normalisation)
-template <int TN, int CLS, typename T, int HB>
+template <int TN, int CLS, typename T, int HB, int LD = EPI_LD>
 __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f32x16 (&acc_i)[TN], float* __restrict__ wave_buf, int mband, int n, int lane,
                                                    const float4& b4) {
     const grappa_gemm_desc& d = p.d;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(wave_buf + lr * EPI_LD + j * 32 + 8 * g + 4 * lh) =
+            *reinterpret_cast<float4*>(wave_buf + lr * LD + j * 32 + 8 * g + 4 * lh) =
                 make_float4(acc_i[j][4 * g], acc_i[j][4 * g + 1], acc_i[j][4 * g + 2], acc_i[j][4 * g + 3]);
     const bool col_ok = n < d.N;
     const int mfirst = mband + rrow;
@@ -286,7 +286,7 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
 #pragma unroll
         for (int k = 0; k < HB; ++k) {
             const int it = h * HB + k, m = mfirst + it * ROWS_PER_IT;
-            v[k] = *reinterpret_cast<const float4*>(wave_buf + (it * ROWS_PER_IT + rrow) * EPI_LD + rc4);
+            v[k] = *reinterpret_cast<const float4*>(wave_buf + (it * ROWS_PER_IT + rrow) * LD + rc4);
             t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             r4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (GB_NT_STORE >= 2 && !BF) {
@@ -351,7 +351,7 @@ __device__ __forceinline__ void epilogue_band_fast(const GemmParams& p, const f3
 }
 
 // one 32-row band (accumulator row i of the wavefront's TM x TN grid)
-template <int BM, int BN, int TN>
+template <int BM, int BN, int TN, int LD = EPI_LD>
 __device__ __forceinline__ void epilogue_band(const GemmParams& p, const f32x16 (&acc_i)[TN], float* __restrict__ wave_buf, int m0, int n0, int mband,
                                      int n, int lane, const float4& b4, int split, int tile_local, bool vec_io) {
     const grappa_gemm_desc& d = p.d;
@@ -363,11 +363,11 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, const f32x16 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(wave_buf + lr * EPI_LD + j * 32 + 8 * g + 4 * lh) =
+            *reinterpret_cast<float4*>(wave_buf + lr * LD + j * 32 + 8 * g + 4 * lh) =
                 make_float4(acc_i[j][4 * g], acc_i[j][4 * g + 1], acc_i[j][4 * g + 2], acc_i[j][4 * g + 3]);
     for (int it = 0; it < NIT; ++it) {
         const int row = it * ROWS_PER_IT + rrow;
-        const float4 v4 = *reinterpret_cast<const float4*>(wave_buf + row * EPI_LD + rc4);
+        const float4 v4 = *reinterpret_cast<const float4*>(wave_buf + row * LD + rc4);
         const int m = mband + row;
         unsigned am = 0u;                                    // largest |OUT(m, n .. n+3)| of this lane (d.out_amax)
         if (m < d.M && n < d.N) {
