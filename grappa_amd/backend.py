@@ -172,6 +172,11 @@ class HipBackend:
         # Measured on the C2 step: 34.9 ms with the forward producers' pairs only, 35.0 - 35.1 with the backward producers' too, 35.35 without
         # pairs (profiles/r4_backward_pairs_ab.txt) -- hence off by default
         self.backward_pairs = os.environ.get("GRAPPA_BACKWARD_PAIRS", "0") not in ("0", "")
+        # round 5: forward / input-gradient products whose A operand reaches them as fp32 rows (the second product of a feed-forward, every
+        # input-gradient product) read the WEIGHT from its pairs and split A's fragments in registers (csrc/gemm_wpairs_il.hip: the pinned
+        # pipeline, two workgroups per CU) where that beats the fp32-operand kernel: tables of at least `wpairs_min_rows` rows (on the C2 shapes
+        # 1.08 - 1.12 x at >= 28 k rows, slower than the 512-thread kernel on one round of tiles: profiles/r5_pairs_lab_v4.txt)
+        self.weight_pairs_min_rows = int(os.environ.get("GRAPPA_WPAIRS_MIN_ROWS", "24000"))
         self._tails = None             # what set_tail_launches last told the library (None: the library's default)
         self._tails_pinned = False
         if os.environ.get("GRAPPA_PLAN_TAILS", "") != "":
@@ -482,7 +487,7 @@ class HipBackend:
     @staticmethod
     def _gemm_detail(d) -> dict:
         """profiling only: what a product launch was (shape, layout, operand formats, epilogue) -- read back from its descriptor"""
-        lay = "fwd" if d.a_kcontig and d.b_kcontig else ("dgrad" if d.a_kcontig else "wgrad")
+        lay = getattr(d, "_layout", None) or ("fwd" if d.a_kcontig and d.b_kcontig else ("dgrad" if d.a_kcontig else "wgrad"))
         fmt = ("pairs" if d.a_planes and d.b_planes and d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] else
                "wpairs" if d.b_planes and not d.a_planes and d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] else
                "planes" if d.a_planes or d.b_planes else "f32")
@@ -542,6 +547,7 @@ class HipBackend:
         dev = out.device
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
+        d._layout = "fwd" if a_kcontig and b_kcontig else ("dgrad" if a_kcontig else "wgrad")      # (profiling only: pair operands turn every layout into k-contiguous rows)
         ar, ac = (M, K) if a_kcontig else (K, M)
         br, bc = (N, K) if b_kcontig else (K, N)
         # A in the pair format (its producer wrote it: a_scales.pairs): forward layout, default arithmetic; `a` itself may then be None
@@ -593,6 +599,11 @@ class HipBackend:
                 d.precision = _lib.GEMM_PRECISIONS["bf16"]
             else:
                 a, b = self.to_f32(a), self.to_f32(b)
+        # fp32 A + the weight's pairs ("weight pairs": the library splits A's fragments in registers)
+        w_only = (a_pairs is None and planes_a is None and planes_b is None and a_kcontig and big and M >= self.weight_pairs_min_rows
+                  and d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] and precision is None and self.gemm_precision_bwd is None and K % 32 == 0
+                  and a.dtype == torch.float32 and b.dtype == torch.float32 and b.requires_grad and a_colsum is None
+                  and a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and a.stride(1) == 1 and getattr(a_scales, "parts", None) is None)
         if a_pairs is not None:
             # forward: B = the pairs of W (rows = out features); input gradient (b_kcontig False): B = the pairs of W^T (rows = in features)
             w_pairs = self._pairs_of_weight(b, transposed=not b_kcontig)
@@ -601,12 +612,22 @@ class HipBackend:
             d.B, d.ldb, d.b_planes = w_pairs.data_ptr(), w_pairs.stride(0), 1
             d.a_kcontig, d.b_kcontig = 1, 1
             d.a_amax, d.b_amax = a_scales.row.data_ptr(), (wm.row if b_kcontig else wm.col).data_ptr()
+        elif w_only:
+            w_pairs = self._pairs_of_weight(b, transposed=not b_kcontig)
+            wm = self._amax_of_weight(b)
+            sa_w = self.amax(a, a_scales, rows=True)
+            if sa_w.row.numel() != M:
+                raise ValueError("gemm: operand maxima do not match the operands")
+            d.A, d.lda = a.data_ptr(), _f32_2d(a, "A", dev)
+            d.B, d.ldb, d.b_planes = w_pairs.data_ptr(), w_pairs.stride(0), 1
+            d.a_kcontig, d.b_kcontig = 1, 1
+            d.a_amax, d.b_amax = sa_w.row.data_ptr(), (wm.row if b_kcontig else wm.col).data_ptr()
         elif planes_a is not None:
             d.A, d.lda, d.a_planes, d.a_plane_stride = planes_a.data_ptr(), planes_a.stride(0), 1, 0
             _f32_2d(planes_a, "A", dev, bf16)
         else:
             d.A, d.lda = a.data_ptr(), _f32_2d(a, "A", dev)
-        if a_pairs is not None:
+        if a_pairs is not None or w_only:
             pass
         elif planes_b is not None and planes_b.dim() == 3:                           # weight planes (3, rows_pad, cols_pad)
             d.B, d.ldb, d.b_planes, d.b_plane_stride = planes_b.data_ptr(), planes_b.stride(1), 1, planes_b.stride(0)
@@ -618,7 +639,7 @@ class HipBackend:
             d.B, d.ldb = b.data_ptr(), _f32_2d(b, "B", dev)
             d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
         # ---- the native fp32 kernel (precision "f32", or M / N <= 32) has no bf16 epilogue: run it on fp32 copies (tiny or non-default)
-        native = planes_a is None and a_pairs is None and (not big or d.precision == _lib.GEMM_PRECISIONS["f32"])
+        native = planes_a is None and a_pairs is None and not w_only and (not big or d.precision == _lib.GEMM_PRECISIONS["f32"])
         if native and any(t is not None and t.dtype == bf16 for t in (out, out2, res, aux)):
             f = lambda t: None if t is None else (self.to_f32(t) if t.dtype == bf16 else t)      # noqa: E731
             o32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out.dtype == bf16 else out
@@ -695,6 +716,8 @@ class HipBackend:
         sa = so = None
         if a_pairs is not None:
             sa = a_scales
+        elif w_only:
+            sa = sa_w
         elif d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] and big and planes_a is None and planes_b is None:
             # power-of-two scales of both operands from their largest magnitudes along the reduced dimension
             if a_kcontig:

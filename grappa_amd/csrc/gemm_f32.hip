@@ -791,7 +791,6 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
         if (!bf16x || !d->res || !d->res_ln_rstd || !d->res_ln_gamma || !d->res_ln_beta || (d->N & 3) ||
             ((reinterpret_cast<uintptr_t>(d->res_ln_gamma) | reinterpret_cast<uintptr_t>(d->res_ln_beta)) & 15) != 0 || (planes && !pairs))
             return GRAPPA_ERR_ARG;
-        if (pairs && !d->a_planes) return GRAPPA_ERR_ARG;               // (the weight-pairs kernel has its own epilogue dispatch)
     }
     static const bool small_tile = !(getenv("GRAPPA_PAIRS_SMALL_TILE") && atoi(getenv("GRAPPA_PAIRS_SMALL_TILE")) == 0);
     Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && g_override.cfg < 0);

@@ -30,6 +30,8 @@
 using namespace grappa_gemm;
 
 int grappa_launch_gemm_pairs_persist(hipStream_t st, GemmParams& p);      // gemm_pairs_persist.hip
+int grappa_launch_gemm_pairs_il(hipStream_t st, GemmParams& p);           // gemm_pairs_il.hip
+int grappa_launch_gemm_wpairs_il(hipStream_t st, GemmParams& p);          // gemm_wpairs_il.hip
 
 #include "gemm_pairs_impl.h"
 
@@ -52,6 +54,11 @@ static __device__ __forceinline__ void run(const GemmParams& p, int nwg, int wgi
     const int kbeg = split * p.k_per_split;
     const int kend = min(d.K, kbeg + p.k_per_split);
     const int nslab = (kend - kbeg + QSLAB - 1) / QSLAB;      // the rows are zero beyond K up to the next multiple of 32
+#if GQ_STAMP
+    unsigned long long q_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q_wait = 0, q_ta = 0, q_tb = 0;
+    q_t[0] = __builtin_amdgcn_s_memrealtime();
+    q_t[1] = __builtin_amdgcn_s_memtime();
+#endif
 
     f32x16 acc[TM][QTN];
 #pragma unroll
@@ -78,6 +85,9 @@ static __device__ __forceinline__ void run(const GemmParams& p, int nwg, int wgi
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#if GQ_STAMP
+        q_t[2] = __builtin_amdgcn_s_memtime();
+#endif
         qread_frags<TM>(smem, S::A_BYTES, off, wm0, wn0, f0);
         int st = 0;                                          // t % 3
         // one slab: FC holds slab T's fragments; FN receives those of slab T + 1
@@ -86,18 +96,27 @@ static __device__ __forceinline__ void run(const GemmParams& p, int nwg, int wgi
         char* cur_ = smem + st * QSTAGE;                                                                                               \
         st = st == QNSTAGE - 1 ? 0 : st + 1;                                                                                           \
         if ((T) + 1 < nslab) {                                                                                                         \
+            GQ_STAMP_A                                                                                                                 \
             /* this wavefront's pieces of slab T+1 have landed (slab T+2 may stay in flight) and its reads of slab T are in registers; */ \
             /* behind the barrier that holds for every wavefront: stage `cur_` is free, slab T+1 is readable */                          \
             if ((T) + 2 < nslab) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(QPIECES) : "memory");                             \
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
             __builtin_amdgcn_s_barrier();                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            GQ_STAMP_B                                                                                                                 \
             if ((T) + QNSTAGE < nslab && GQ_KNOCK != 1) qissue_slab<QBN, QBMt>(A, B, kb0 + (size_t)((T) + QNSTAGE) * QROWB, src, cur_, wave); \
             qread_frags<TM>(smem + st * QSTAGE, S::A_BYTES, off, wm0, wn0, FN);                                                                        \
         }                                                                                                                              \
         qmfma<TM>(FC, acc);                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                                             \
     } while (0)
+#if GQ_STAMP
+#define GQ_STAMP_A q_wait += q_tb - q_ta; q_ta = __builtin_amdgcn_s_memtime();
+#define GQ_STAMP_B q_tb = __builtin_amdgcn_s_memtime();
+#else
+#define GQ_STAMP_A
+#define GQ_STAMP_B
+#endif
         int t = 0;
         for (; t + 1 < nslab; t += 2) {
             GQ_STEP(t, f0, f1);
@@ -105,7 +124,13 @@ static __device__ __forceinline__ void run(const GemmParams& p, int nwg, int wgi
         }
         if (t < nslab) GQ_STEP(t, f0, f1);
 #undef GQ_STEP
+#if GQ_STAMP
+        q_wait += q_tb - q_ta;
+#endif
     }
+#if GQ_STAMP
+    q_t[3] = __builtin_amdgcn_s_memtime();
+#endif
 
     // undo the row scales: accumulator element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, wn0 + 32 j + 8 (e / 4) + 4 lh + e % 4)
     {
@@ -133,6 +158,9 @@ static __device__ __forceinline__ void run(const GemmParams& p, int nwg, int wgi
             }
     }
     __syncthreads();                                         // the ring is dead: reuse as epilogue staging
+#if GQ_STAMP
+    q_t[4] = __builtin_amdgcn_s_memtime();
+#endif
     if (GQ_KNOCK == 3) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -167,10 +195,23 @@ static __device__ __forceinline__ void run(const GemmParams& p, int nwg, int wgi
             default: GQ_FAST(4, grappa_bf16_t);
         }
 #undef GQ_FAST
-        return;
-    }
+    } else {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) epilogue_band<QBMt, QBN, QTN>(p, acc[i], wave_buf, m0, n0, mb + 32 * i, n, lane, b4, split, tile_local, p.vec_io != 0);
+        for (int i = 0; i < TM; ++i) epilogue_band<QBMt, QBN, QTN>(p, acc[i], wave_buf, m0, n0, mb + 32 * i, n, lane, b4, split, tile_local, p.vec_io != 0);
+    }
+#if GQ_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores have left
+    q_t[5] = __builtin_amdgcn_s_memtime();
+    q_t[6] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && wgid < QSTAMP_WGS) {
+        unsigned long long* o = g_q_stamps + (size_t)wgid * QSTAMP_WORDS;
+        unsigned hw = 0, xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = q_t[0]; o[1] = q_t[1]; o[2] = q_t[2]; o[3] = q_t[3]; o[4] = q_t[4]; o[5] = q_t[5]; o[6] = q_t[6]; o[7] = q_wait;
+        o[8] = hw; o[9] = xcc; o[10] = (unsigned)tc.tile_m; o[11] = (unsigned)tc.tile_n; o[12] = (unsigned)nslab;
+    }
+#endif
 }
 };
 
@@ -192,75 +233,12 @@ __global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_group4_kernel(G
 // fragment is read, scaled and split into its (hi, lo) by exactly ONE wavefront, in registers: 64 vector instructions per slab beside
 // 24 MFMAs (the fp32-operand kernel: ~200 per 24 across its two wavefronts of a SIMD, plus the LDS stores of the split tile), nothing
 // staged in registers, and the producer side of the model untouched.
-constexpr int WTM = 2, WTN = 4;                 // 32 x 32 accumulators per wavefront (64 x 128)
-struct WRaw { float4 a[WTM][2]; };              // raw fp32 of a lane's 8 k per 32-row block
-struct WBFrags { f16x8 b[WTN][2]; };            // [column block][hi / lo]
-
-__device__ inline void wread_a(const char* __restrict__ stage, const unsigned (&aoff)[2], int wm0, WRaw& f) {
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) f.a[i][e] = *reinterpret_cast<const float4*>(stage + (wm0 + i * 32) * QROWB + aoff[e]);
-}
-__device__ inline void wread_b(const char* __restrict__ stage, const unsigned (&boff)[2], WBFrags& f) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) f.b[j][p] = *reinterpret_cast<const f16x8*>(stage + QA_BYTES + j * 32 * QROWB + boff[p]);
-}
-
-// 8 consecutive-k fp32 values of one row -> its hi / lo fp16 fragments, scaled by the row's power of two (exact) first
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ inline void wsplit(const float4 (&raw)[2], int shift, f16x8& hi, f16x8& lo) {
-    const float r[8] = {__builtin_ldexpf(raw[0].x, shift), __builtin_ldexpf(raw[0].y, shift), __builtin_ldexpf(raw[0].z, shift), __builtin_ldexpf(raw[0].w, shift),
-                        __builtin_ldexpf(raw[1].x, shift), __builtin_ldexpf(raw[1].y, shift), __builtin_ldexpf(raw[1].z, shift), __builtin_ldexpf(raw[1].w, shift)};
-    unsigned uh[4], ul[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        f16x2 h, l;
-        h[0] = (_Float16)r[2 * e];                                // round to nearest even; |r| < 2^15 never overflows
-        h[1] = (_Float16)r[2 * e + 1];
-        l[0] = (_Float16)(r[2 * e] - (float)h[0]);
-        l[1] = (_Float16)(r[2 * e + 1] - (float)h[1]);
-        uh[e] = __builtin_bit_cast(unsigned, h);
-        ul[e] = __builtin_bit_cast(unsigned, l);
-    }
-    hi = __builtin_bit_cast(f16x8, make_uint4(uh[0], uh[1], uh[2], uh[3]));
-    lo = __builtin_bit_cast(f16x8, make_uint4(ul[0], ul[1], ul[2], ul[3]));
-}
-
 struct WLaneSrc { unsigned a[4], b[2]; };
 __device__ inline void wissue(const char* __restrict__ A, const char* __restrict__ B, size_t kb, const WLaneSrc& s, char* __restrict__ stage, int wave) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) glds16(A + kb + s.a[q], stage + (wave + 4 * q) * 1024);
 #pragma unroll
     for (int q = 0; q < 2; ++q) glds16(B + kb + s.b[q], stage + QA_BYTES + (wave + 4 * q) * 1024);
-}
-
-// CLS 1 .. 4: the straight-line fp32 classes of gemm_common.h; 0: the general walk (and split-K slabs).  Every loop has constant
-// bounds and no branch on the class inside: the accumulators stay in registers (a runtime-indexed array would go to scratch)
-template <int CLS>
-__device__ __forceinline__ void wpairs_epilogue(const GemmParams& p, const f32x16 (&acc)[WTM][WTN], float* __restrict__ wave_buf, int m0, int n0, int wm0,
-                                                int lane, int split, int tile_local) {
-    const grappa_gemm_desc& d = p.d;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int n = n0 + 64 * h + ((lane & 15) << 2);
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.bias && p.nsplit == 1) {
-            b4.x = n < d.N ? d.bias[n] : 0.f;
-            b4.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
-            b4.z = n + 2 < d.N ? d.bias[n + 2] : 0.f;
-            b4.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < WTM; ++i) {
-            const f32x16 band[2] = {acc[i][2 * h], acc[i][2 * h + 1]};
-            const int mb = m0 + wm0 + 32 * i;
-            if (CLS != 0) epilogue_band_fast<2, CLS == 0 ? 1 : CLS, float, 4>(p, band, wave_buf, mb, n, lane, b4);
-            else epilogue_band<QBM, 128, 2>(p, band, wave_buf, m0, n0, mb, n, lane, b4, split, tile_local, p.vec_io != 0);
-        }
-    }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_wpairs_kernel(GemmParams p) {
@@ -351,46 +329,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wpairs_kernel(GemmParams p) {
 #undef GW_STEP
     }
 
-    // undo the row scales: element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, 32 j + 8 (e / 4) + 4 lh + e % 4)
-    {
-        const bool b_vec = (reinterpret_cast<uintptr_t>(d.b_amax) & 15) == 0;
-#pragma unroll
-        for (int j = 0; j < WTN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + j * 32 + g * 8 + lh * 4;
-                int eb[4];
-                if (b_vec && n + 3 < d.N) {
-                    const uint4 u = *reinterpret_cast<const uint4*>(d.b_amax + n);
-                    eb[0] = amax_shift(u.x); eb[1] = amax_shift(u.y); eb[2] = amax_shift(u.z); eb[3] = amax_shift(u.w);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) eb[q] = amax_shift(d.b_amax[min(n + q, d.N - 1)]);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int i = 0; i < WTM; ++i) acc[i][j][4 * g + q] = __builtin_ldexpf(acc[i][j][4 * g + q], -(sh[i] + eb[q]));
-            }
-    }
-    __syncthreads();                                         // the ring is dead: reuse as epilogue staging
-    if (GQ_KNOCK == 3) {
-#pragma unroll
-        for (int i = 0; i < WTM; ++i)
-#pragma unroll
-            for (int j = 0; j < WTN; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-    // the wavefront's 64 x 128 block as 2 x 2 bands of 32 rows x 64 columns of the shared row epilogue
-    float* wave_buf = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
-    const int cls = p.nsplit == 1 ? p.epi_class : 0;
-    switch (cls) {
-        case 1: wpairs_epilogue<1>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
-        case 2: wpairs_epilogue<2>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
-        case 3: wpairs_epilogue<3>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
-        case 4: wpairs_epilogue<4>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
-        default: wpairs_epilogue<0>(p, acc, wave_buf, m0, n0, wm0, lane, split, tile_local); break;
-    }
+    wpairs_finish(p, acc, sh, smem, m0, n0, wm0, wave, lane, split, tile_local);
 }
 
 int launch_wpairs(hipStream_t st, GemmParams& p) {
@@ -545,6 +484,13 @@ extern "C" int grappa_split_pairs_f32(void* stream, int R, int C, const float* x
     return grappa_launch_status();
 }
 
+#if GQ_STAMP
+extern "C" int grappa_debug_pairs_stamps(unsigned long long* host, int nwgs) {
+    if (nwgs > QSTAMP_WGS) nwgs = QSTAMP_WGS;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_q_stamps), (size_t)nwgs * QSTAMP_WORDS * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // called by grappa_gemm_f32_group: pair-format products, tile 256 x 128, two workgroups per CU
 int grappa_launch_gemm_pairs_group4(hipStream_t st, const GemmGroup4& g) {
     using S = QShape<128>;
@@ -563,10 +509,17 @@ int grappa_launch_gemm_pairs_group4(hipStream_t st, const GemmGroup4& g) {
 
 // called by grappa_gemm_f32 (gemm_f32.hip) when both operands are in the pair format (precision F32_F16X3); tile 256 x 128
 int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p) {
-    if (!p.d.a_planes) return launch_wpairs(st, p);          // fp32 A, weight pairs
-    if (p.bm == 128) return launch_pairs_small(st, p);
-    static const bool persist = !(getenv("GRAPPA_PAIRS_PERSIST") && atoi(getenv("GRAPPA_PAIRS_PERSIST")) == 0);
+    if (!p.d.a_planes) {                                     // fp32 A, weight pairs
+        static const bool wil = !(getenv("GRAPPA_WPAIRS_IL") && atoi(getenv("GRAPPA_WPAIRS_IL")) == 0);      // the pinned pipeline of gemm_wpairs_il.hip (0: the round-3 loop)
+        const int kw = p.d.K < p.k_per_split ? p.d.K : p.k_per_split;
+        if (wil && (p.d.K & 31) == 0 && (p.k_per_split & 31) == 0 && kw >= 4 * QSLAB) return grappa_launch_gemm_wpairs_il(st, p);
+        return launch_wpairs(st, p);
+    }
     const int kk = p.d.K < p.k_per_split ? p.d.K : p.k_per_split;
+    static const bool il = !(getenv("GRAPPA_PAIRS_IL") && atoi(getenv("GRAPPA_PAIRS_IL")) == 0);      // the pinned pipeline of gemm_pairs_il.hip (0: the round-3 loop)
+    if (il && kk >= 4 * QSLAB) return grappa_launch_gemm_pairs_il(st, p);
+    if (p.bm == 128) return launch_pairs_small(st, p);
+    static const bool persist = getenv("GRAPPA_PAIRS_PERSIST") && atoi(getenv("GRAPPA_PAIRS_PERSIST")) != 0;      // opt-in experiment (profiles/r5_pairs_persist_lab.txt)
     if (persist && p.nsplit == 1 && kk >= 3 * QSLAB) return grappa_launch_gemm_pairs_persist(st, p);
     return p.bn == 256 ? launch_pairs<256>(st, p) : launch_pairs<128>(st, p);
 }

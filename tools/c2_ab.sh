@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU box: the C2 train step under a list of environments, one process each (switches are read once per process), alternating twice
+cd "$(dirname "$0")/.."
+out=gpurun_out/c2_ab_${1:-run}.txt
+: > $out
+shift
+run() { res=$(env "$@" python bench.py --no-extras --no-cpu-baseline --alt-precision '' --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']; print(round(j['ms_per_step'],2), round(r['frac'],4), round(r['kernel_ms_per_step'],2))"); echo "$* : $res" | tee -a $out; }
+for rep in 1 2; do
+  while read -r line; do [ -n "$line" ] && run $line; done <<< "$CONFIGS"
+done

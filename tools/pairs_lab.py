@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gemm_pairs_check as g  # noqa: E402
 
 dev = "cuda"
+WP = "--wpairs" in sys.argv or os.environ.get("LAB_MODE") == "wpairs"          # A = fp32 rows + weight pairs (gemm_wpairs_il.hip) instead of both operands in pairs
+SPLIT = "--split" in sys.argv or os.environ.get("LAB_MODE") == "split"        # timing only: the fp32-operand fp16-split kernel (gemm_bf16x_impl.h MODE H3) on the same shapes
 
 
 def check(M, N, K, gen, dgrad=False, **epi):
@@ -36,7 +38,7 @@ def check(M, N, K, gen, dgrad=False, **epi):
     if epi.get("amax"):
         am_p = torch.zeros(M, dtype=torch.int32, device=dev)
         am_s = torch.zeros(M, dtype=torch.int32, device=dev)
-    g.gemm(ap, bp, o_pairs, M, N, K, am_a, am_b, True, **kw, **({"out_amax": am_p.data_ptr()} if am_p is not None else {}))
+    g.gemm(A if WP else ap, bp, o_pairs, M, N, K, am_a, am_b, "b" if WP else True, **kw, **({"out_amax": am_p.data_ptr()} if am_p is not None else {}))
     g.gemm(A, W, o_split, M, N, K, am_a, am_b, False, b_kcontig=not dgrad, **kw, **({"out_amax": am_s.data_ptr()} if am_s is not None else {}))
     torch.cuda.synchronize()
     same = torch.equal(o_pairs, o_split) and (am_p is None or torch.equal(am_p, am_s))
@@ -51,7 +53,9 @@ def bench(M, N, K, gen, dgrad=False, **epi):
     W = torch.randn((K, N) if dgrad else (N, K), generator=gen, device=dev) * 0.05
     am_a, am_b = g.amax(A), g.amax(W, rows=not dgrad)
     ap, bp = g.split_pairs(A, am_a), g.split_pairs(W, am_b, transpose=dgrad)
-    del A, W
+    if not (WP or SPLIT):
+        del A
+    del W
     kw = {}
     if "bias" in epi:
         kw["bias"] = torch.randn(N, generator=gen, device=dev)
@@ -65,7 +69,10 @@ def bench(M, N, K, gen, dgrad=False, **epi):
         kw["drop_p"], kw["drop_seed"] = 0.5, 1234
     out = torch.empty((M, N), device=dev)
     ws = g.ws_for(M, N, K)
-    t = g.timeit(lambda: g.gemm(ap, bp, out, M, N, K, am_a, am_b, True, ws=ws, **kw), n=30)
+    if SPLIT:
+        Wf = torch.randn((N, K), generator=gen, device=dev) * 0.05
+        return g.timeit(lambda: g.gemm(A, Wf, out, M, N, K, am_a, am_b, False, ws=ws, **kw), n=30)
+    t = g.timeit(lambda: g.gemm(A if WP else ap, bp, out, M, N, K, am_a, am_b, "b" if WP else True, ws=ws, **kw), n=30)
     return t
 
 
@@ -96,6 +103,8 @@ def main():
                                    (45003, 512, 1536, True, dict(res=1)), (40000, 512, 512, False, dict(bias=1, act=1, amax=1)),
                                    (40000, 512, 512, False, dict(aux=1, res=1)), (140000, 512, 64, False, dict(bias=1)), (140000, 640, 512, False, dict(bias=1, res=1)),
                                    (300, 200, 64, False, dict()), (1000, 512, 512, False, dict(bias=1))]:
+            if WP and K % 16:                 # (fp32 rows carry no padding: the weight-pairs kernels take whole slabs only)
+                continue
             ok &= check(M, N, K, gen, dgrad=dg, **epi)
         print(f"== {tag} all bit-identical: {ok}", flush=True)
     if "--no-timing" in sys.argv:
