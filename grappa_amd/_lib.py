@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hip.so")   # override: kernel A/B builds (tools/)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
 GEMM_GROUP4_MAX = 4          # grappa_gemm_f32_group (forward / input-gradient products of the writer heads)
 GEMM_GROUP_MAX = 16
@@ -37,7 +37,9 @@ class GemmDesc(C.Structure):
                 ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p),
                 # ABI 8: pair-format operands of the weight-gradient products (token maxima of the operand)
                 ("a_rowmax", C.c_void_p), ("b_rowmax", C.c_void_p),
-                ("out_amax_parts", C.c_void_p), ("a_amax_nseg", C.c_int)]
+                ("out_amax_parts", C.c_void_p), ("a_amax_nseg", C.c_int),
+                # ABI 10: what used to be process-wide setters, per call
+                ("plan_cfg", C.c_int), ("plan_nsplit", C.c_int), ("plan_tail", C.c_int), ("splitk_reduce", C.c_int), ("drop_salt", C.c_void_p)]
 
 
 class LnFwdItem(C.Structure):
@@ -52,7 +54,7 @@ class LnBwdItem(C.Structure):
 
 class ActDropoutItem(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("dy", C.c_void_p), ("lddy", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("drop_p", C.c_float),
-                ("drop_seed", C.c_uint64), ("dz", C.c_void_p), ("lddz", C.c_int), ("dz_amax", C.c_void_p)]
+                ("drop_seed", C.c_uint64), ("dz", C.c_void_p), ("lddz", C.c_int), ("dz_amax", C.c_void_p), ("drop_salt", C.c_void_p)]
 
 
 class SeqAttnItem(C.Structure):
@@ -97,7 +99,6 @@ SIGNATURES = {
     "grappa_abi_version": (_i, []),
     "grappa_build_arch": (C.c_char_p, []),
     "grappa_launch_count": (C.c_longlong, [_i]),
-    "grappa_set_dropout_salt": (None, [_vp]),
     "grappa_adam_step_dyn_f32": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _f, _vp, _f]),
     "grappa_split_planes_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _sz, _i]),
     "grappa_split_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i]),
@@ -109,9 +110,8 @@ SIGNATURES = {
     "grappa_amax_combine": (_i, [_vp, _i, _i, _vp, _vp]),
     "grappa_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
     "grappa_gemm_f32_plan": (_i, [_i, _i, _i, _i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
-    "grappa_gemm_f32_set_plan_override": (None, [_i, _i, _i]),
-    "grappa_gemm_f32_set_tail_launches": (None, [_i]),
-    "grappa_gemm_f32_set_splitk_reduce_launch": (None, [_i]),
+    "grappa_gemm_f32_plan_desc": (_i, [C.POINTER(GemmDesc), c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "grappa_gemm_f32_workspace_bytes_desc": (_sz, [C.POINTER(GemmDesc)]),
     "grappa_gemm_f32": (_i, [_vp, C.POINTER(GemmDesc), _vp, _sz]),
     "grappa_gemm_f32_grouped_workspace_bytes": (_sz, [C.POINTER(GemmDesc), _i]),
     "grappa_gemm_f32_grouped": (_i, [_vp, C.POINTER(GemmDesc), _i, _vp, _sz]),
@@ -119,14 +119,14 @@ SIGNATURES = {
     "grappa_gemm_f32_group": (_i, [_vp, C.POINTER(GemmDesc), _i, _vp, _sz]),
     "grappa_colsum_workspace_bytes": (_sz, [_i, _i]),
     "grappa_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz]),
-    "grappa_act_dropout_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i]),
-    "grappa_act_dropout_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp]),
+    "grappa_act_dropout_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp]),
+    "grappa_act_dropout_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp, _vp]),
     "grappa_layernorm_fwd_batched_f32": (_i, [_vp, C.POINTER(LnFwdItem), _i]),
     "grappa_layernorm_bwd_batched_f32": (_i, [_vp, C.POINTER(LnBwdItem), _i]),
     "grappa_act_dropout_bwd_batched_f32": (_i, [_vp, C.POINTER(ActDropoutItem), _i]),
     "grappa_seqattn_fwd_batched_f32": (_i, [_vp, C.POINTER(SeqAttnItem), _i]),
     "grappa_seqattn_bwd_batched_f32": (_i, [_vp, C.POINTER(SeqAttnItem), _i]),
-    "grappa_act_dropout_bwd_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp, _vp, _i]),
+    "grappa_act_dropout_bwd_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp, _vp, _i, _vp]),
     "grappa_add_f32": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "grappa_layernorm_fwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "grappa_layernorm_fwd_pairs_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
@@ -136,7 +136,7 @@ SIGNATURES = {
     "grappa_colsum_partials_batched": (_i, [_vp, C.POINTER(ColsumItem), _i]),
     "grappa_layernorm_bwd_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
     "grappa_layernorm_bwd_amax_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
-    "grappa_layernorm_bwd_drop_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _f, _u64, _vp, _i, _vp]),
+    "grappa_layernorm_bwd_drop_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _f, _u64, _vp, _i, _vp, _vp]),
     "grappa_gat_fwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "grappa_gat_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "grappa_neighbor_mean_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i]),
@@ -169,7 +169,7 @@ SIGNATURES = {
     # bf16 storage configuration: same argument lists as the *_f32 entry points
     "grappa_layernorm_fwd_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "grappa_layernorm_bwd_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
-    "grappa_act_dropout_bwd_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i]),
+    "grappa_act_dropout_bwd_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _u64, _vp, _i, _vp]),
     "grappa_gat_fwd_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "grappa_gat_bwd_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "grappa_tuple_gather_fwd_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i]),

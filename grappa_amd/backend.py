@@ -127,7 +127,7 @@ class HipBackend:
             raise RuntimeError("grappa_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self._ws = {}
-        self._ws_need = {}             # (M, N, K, tail-launch setting) -> workspace bytes of a product of that shape
+        self._ws_need = {}             # (M, N, K) -> workspace bytes of a product of that shape (any tail / reduction setting)
         # arithmetic of the dense products (include/grappa_hip.h GRAPPA_GEMM_*): "f32_f16x3" = fp32 operands, every row scaled by a
         # power of two, split into two fp16 pieces (3 partial products on the fp16 matrix cores, fp32 accumulation); "f32_bf16x6" =
         # three bf16 pieces, 6 products (the default until round 2).  Both are at least as close to the exact product as the native
@@ -177,7 +177,11 @@ class HipBackend:
         # pipeline, two workgroups per CU) where that beats the fp32-operand kernel: tables of at least `wpairs_min_rows` rows (on the C2 shapes
         # 1.08 - 1.12 x at >= 28 k rows, slower than the 512-thread kernel on one round of tiles: profiles/r5_pairs_lab_v4.txt)
         self.weight_pairs_min_rows = int(os.environ.get("GRAPPA_WPAIRS_MIN_ROWS", "24000"))
-        self._tails = None             # what set_tail_launches last told the library (None: the library's default)
+        self._tails = None             # tail launches of the products: True / False, None = the library's default (grappa_gemm_desc.plan_tail)
+        self._salt = None
+        self._salt_ptr = None          # address of the dropout salt word while enabled (enable_dropout_salt)
+        self.plan_override = None      # tuning / tests: (cfg or -1, nsplit or 0, tail: -1 model, 0 never, 1 forced) applied to every product
+        self.splitk_reduce = 0         # tests: 0 library default, 1 a reduction launch, 2 inside the product's launch
         self._tails_pinned = False
         if os.environ.get("GRAPPA_PLAN_TAILS", "") != "":
             self.pin_tail_launches(os.environ["GRAPPA_PLAN_TAILS"] != "0")
@@ -603,7 +607,8 @@ class HipBackend:
         w_only = (a_pairs is None and planes_a is None and planes_b is None and a_kcontig and big and M >= self.weight_pairs_min_rows
                   and d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] and precision is None and self.gemm_precision_bwd is None and K % 32 == 0
                   and a.dtype == torch.float32 and b.dtype == torch.float32 and b.requires_grad and a_colsum is None
-                  and a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and a.stride(1) == 1 and getattr(a_scales, "parts", None) is None)
+                  and a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and a.stride(1) == 1 and getattr(a_scales, "parts", None) is None
+                  and M * a.stride(0) * 4 < 2 ** 32)      # (the LDS-DMA kernels address an operand through 32-bit offsets)
         if a_pairs is not None:
             # forward: B = the pairs of W (rows = out features); input gradient (b_kcontig False): B = the pairs of W^T (rows = in features)
             w_pairs = self._pairs_of_weight(b, transposed=not b_kcontig)
@@ -713,6 +718,7 @@ class HipBackend:
                 raise ValueError("gemm: a_colsum needs the row-contiguous A layout and length M")
             d.a_colsum = a_colsum.data_ptr()
         d.act, d.drop_p, d.drop_seed, d.accumulate = int(act), float(drop_p), int(drop_seed) & (2 ** 64 - 1), int(accumulate)
+        self._call_options(d)
         sa = so = None
         if a_pairs is not None:
             sa = a_scales
@@ -750,9 +756,7 @@ class HipBackend:
             else:
                 so = Amax(row=torch.empty(M, dtype=torch.int32, device=dev))
                 d.out_amax = so.row.data_ptr()
-        need = self._ws_need.get((M, N, K, self._tails))
-        if need is None:                         # (the query plans the product for every kernel family: 5 - 10 us, the same answer per shape)
-            need = self._ws_need[(M, N, K, self._tails)] = self.lib.grappa_gemm_f32_workspace_bytes(M, N, K)
+        need = self._ws_bytes(d, (M, N, K))
         ws = self._workspace(need, dev) if need else None
         el = lambda t: 0 if t is None else t.element_size()      # noqa: E731
         # algorithmic bytes of the fused call: both operands once, the result, and what the epilogue has to read / write beside it
@@ -767,6 +771,28 @@ class HipBackend:
                                 and not native and final.dtype == torch.float32)
         self._timed("gemm_f32", 2.0 * M * N * K, nbytes, lambda: self._launch_gemm(d, ws, dev, (M, N, K)), lambda: [self._gemm_detail(d)])
         return ret
+
+    def _call_options(self, d) -> None:
+        """the per-call options of a product (C ABI 10: they used to be process-wide setters of the library)"""
+        d.drop_salt = self._salt_ptr
+        d.plan_tail = 0 if self._tails is None else (1 if self._tails else 2)
+        d.splitk_reduce = self.splitk_reduce
+        if self.plan_override is not None:
+            cfg, ns, tail = self.plan_override
+            d.plan_cfg, d.plan_nsplit = (cfg + 1 if cfg >= 0 else 0), max(int(ns), 0)
+            if tail == 0:
+                d.plan_tail = 2
+            elif tail == 1:
+                d.plan_tail = 3
+
+    def _ws_bytes(self, d, shape) -> int:
+        """workspace of a product: per shape (enough for every tail / reduction setting), or asked per descriptor under a plan override"""
+        if self.plan_override is not None:
+            return self.lib.grappa_gemm_f32_workspace_bytes_desc(C.byref(d))
+        need = self._ws_need.get(shape)
+        if need is None:                         # (the query plans the product for every kernel family: 5 - 10 us, the same answer per shape)
+            need = self._ws_need[shape] = self.lib.grappa_gemm_f32_workspace_bytes(*shape)
+        return need
 
     def gemm_group(self, calls):
         """calls: [(args, kwargs)] of `gemm` -- independent products, e.g. the same product of the four writer heads -- launched as ONE grid
@@ -788,9 +814,7 @@ class HipBackend:
             if len(grp) >= 2 and self._launch_gemm_group(grp):
                 continue
             for q in grp:
-                need = self._ws_need.get(q.shape + (self._tails,))
-                if need is None:
-                    need = self._ws_need[q.shape + (self._tails,)] = self.lib.grappa_gemm_f32_workspace_bytes(*q.shape)
+                need = self._ws_bytes(q.d, q.shape)
                 ws = self._workspace(need, q.dev) if need else None
                 self._timed("gemm_f32", q.flops, q.nbytes, lambda q=q, ws=ws: self._launch_gemm(q.d, ws, q.dev, q.shape), lambda q=q: [self._gemm_detail(q.d)])
         return out
@@ -817,7 +841,7 @@ class HipBackend:
     def _launch_gemm(self, d, ws, dev, shape) -> None:
         rc = self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0)
         if rc == -3:                             # GRAPPA_ERR_WORKSPACE: the cached size predates a plan setting (override, environment): ask again
-            need = self._ws_need[shape + (self._tails,)] = self.lib.grappa_gemm_f32_workspace_bytes(*shape)
+            need = self.lib.grappa_gemm_f32_workspace_bytes_desc(C.byref(d))
             ws = self._workspace(need, dev) if need else None
             rc = self.lib.grappa_gemm_f32(self._stream(), C.byref(d), _ptr(ws), ws.numel() if ws is not None else 0)
         _chk(rc, "grappa_gemm_f32")
@@ -922,16 +946,14 @@ class HipBackend:
     # what is queued and launches it AT ONCE as grouped grids on a side stream, ordered behind the streams that produced the operands; the
     # operands stay referenced until flush_wgrads() has put the caller's stream behind the side stream again.
     def set_tail_launches(self, on: bool) -> None:
-        """split-K tail launches of the products that follow (include/grappa_hip.h grappa_gemm_f32_set_tail_launches).  The model turns
+        """split-K tail launches of the products that follow (include/grappa_hip.h grappa_gemm_desc.plan_tail: sent with every product, C ABI 10).  The model turns
         them off while the writer heads keep several streams busy (a partial last round then runs beside another head's kernels: C2 step
         36.4 -> 36.0 ms) and on again on one stream (37.5 -> 37.4).  Ignored while pinned (pin_tail_launches; GRAPPA_PLAN_TAILS in the
         environment pins at start-up)."""
         if self._tails_pinned:
             return
         on = bool(on)
-        if on != self._tails:
-            self.lib.grappa_gemm_f32_set_tail_launches(int(on))
-            self._tails = on
+        self._tails = on
 
     def pin_tail_launches(self, on: Optional[bool]) -> None:
         """True / False: tail launches on / off whatever the model asks for (comparisons that need the same K cuts on one stream and on
@@ -1042,6 +1064,7 @@ class HipBackend:
             d.C, d.ldc = dw.data_ptr(), dw.stride(0)
             d.a_colsum = None if db is None else db.data_ptr()
             d.accumulate, d.precision = 1, prec
+            d.drop_salt, d.splitk_reduce = self._salt_ptr, self.splitk_reduce
             if am is not None:
                 if self.wgrad_column_maxima:
                     d.a_amax, d.b_amax = am[0].col.data_ptr(), am[1].col.data_ptr()
@@ -1082,7 +1105,7 @@ class HipBackend:
                 _chk(self.lib.grappa_act_dropout_bwd_pairs_f32(self._stream(), M, N, dy.data_ptr(), _f32_2d(dy, "dy", dev), _ptr(y),
                                                                _f32_2d(y, "y", dev) if y is not None else 0, float(drop_p), int(drop_seed) & (2 ** 64 - 1),
                                                                _ptr(dz), _f32_2d(dz, "dz", dev) if dz is not None else 0, row.data_ptr(), pr.data_ptr(),
-                                                               pr.stride(0)), "grappa_act_dropout_bwd_pairs_f32")
+                                                               pr.stride(0), self._salt_ptr), "grappa_act_dropout_bwd_pairs_f32")
             return Amax(row=row, pairs=pr)
         if tuple(dz.shape) != (M, N) or (y is not None and tuple(y.shape) != (M, N)):
             raise ValueError("act_dropout_bwd: shapes")
@@ -1091,9 +1114,9 @@ class HipBackend:
         args = (self._stream(), M, N, dy.data_ptr(), _f32_2d(dy, "dy", dev, dt), _ptr(y), _f32_2d(y, "y", dev, dt) if y is not None else 0,
                 float(drop_p), int(drop_seed) & (2 ** 64 - 1), dz.data_ptr(), _f32_2d(dz, "dz", dev, dt))
         if row is not None:
-            _chk(self.lib.grappa_act_dropout_bwd_amax_f32(*args, row.data_ptr()), "grappa_act_dropout_bwd_amax_f32")
+            _chk(self.lib.grappa_act_dropout_bwd_amax_f32(*args, row.data_ptr(), self._salt_ptr), "grappa_act_dropout_bwd_amax_f32")
             return Amax(row=row)
-        _chk(getattr(self.lib, f"grappa_act_dropout_bwd_{_sfx(dz)}")(*args), "grappa_act_dropout_bwd")
+        _chk(getattr(self.lib, f"grappa_act_dropout_bwd_{_sfx(dz)}")(*args, self._salt_ptr), "grappa_act_dropout_bwd")
         return None
 
     def add(self, x, z, y) -> None:
@@ -1169,8 +1192,8 @@ class HipBackend:
                 raise ValueError("layernorm_bwd: drop needs fp32 rows and the fp16-split arithmetic (drop_fusable)")
             dz = torch.empty_like(dx)
             zrow = torch.empty(M, dtype=torch.int32, device=dev)
-            _chk(self.lib.grappa_layernorm_bwd_drop_f32(*args, _ptr(row), float(p), int(seed) & (2 ** 64 - 1), dz.data_ptr(), dz.stride(0), zrow.data_ptr()),
-                 "grappa_layernorm_bwd_drop_f32")
+            _chk(self.lib.grappa_layernorm_bwd_drop_f32(*args, _ptr(row), float(p), int(seed) & (2 ** 64 - 1), dz.data_ptr(), dz.stride(0), zrow.data_ptr(),
+                                                        self._salt_ptr), "grappa_layernorm_bwd_drop_f32")
             return (Amax(row=row) if row is not None else None), dz, Amax(row=zrow)
         if row is not None:
             _chk(self.lib.grappa_layernorm_bwd_amax_f32(*args, row.data_ptr()), "grappa_layernorm_bwd_amax_f32")
@@ -1266,6 +1289,7 @@ class HipBackend:
             row = torch.empty(M, dtype=torch.int32, device=dy.device)
             a.M, a.N, a.dy, a.lddy, a.y, a.ldy = M, N, dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0
             a.drop_p, a.drop_seed, a.dz, a.lddz, a.dz_amax = float(p), int(seed) & (2 ** 64 - 1), dz.data_ptr(), dz.stride(0), row.data_ptr()
+            a.drop_salt = self._salt_ptr
             out.append((dz, Amax(row=row)))
         _chk(self.lib.grappa_act_dropout_bwd_batched_f32(self._stream(), arr, n), "grappa_act_dropout_bwd_batched_f32")
         return out
@@ -1646,19 +1670,17 @@ class HipBackend:
                                                float(beta1), float(beta2), float(eps), float(weight_decay), step_t.data_ptr(), float(grad_scale),
                                                _ptr(sumsq), float(max_norm)), "grappa_adam_step_dyn_f32")
 
-    # ---- dropout salt (include/grappa_hip.h grappa_set_dropout_salt): one 64-bit word of device memory mixed into every dropout seed
-    def enable_dropout_salt(self) -> None:
-        if getattr(self, "_salt", None) is None:
-            self._salt = torch.zeros(1, dtype=torch.int64, device="cuda")
-            self._salt_off = True
-        if self._salt_off:
-            self.lib.grappa_set_dropout_salt(self._salt.data_ptr())
-            self._salt_off = False
+    # ---- dropout salt (include/grappa_hip.h grappa_gemm_desc.drop_salt, C ABI 10): one 64-bit word of device memory mixed into every dropout
+    # seed.  Nothing process-wide in the library: while enabled, this backend passes the word's address with every call that draws a mask;
+    # a recorded graph keeps the address it was recorded with.
+    def enable_dropout_salt(self, device=None) -> None:
+        if getattr(self, "_salt", None) is None or (device is not None and self._salt.device != torch.device(device)):
+            self._salt = torch.zeros(1, dtype=torch.int64, device=device if device is not None else "cuda")
+        self._salt_ptr = self._salt.data_ptr()
 
     def disable_dropout_salt(self) -> None:
-        """back to the seeds as given (kernels launched afterwards; recorded graphs keep reading the word they were recorded with)"""
-        self.lib.grappa_set_dropout_salt(None)
-        self._salt_off = True
+        """back to the seeds as given (calls made afterwards; recorded graphs keep reading the word they were recorded with)"""
+        self._salt_ptr = None
 
     def bump_dropout_salt(self) -> None:
         """+1 on the device word (a kernel on the current stream: inside a capture it becomes a node of the graph)"""

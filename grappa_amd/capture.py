@@ -8,7 +8,7 @@ launched on torch's capturing stream through the C ABI as always) and replayed.
 
 What makes a TRAIN step replayable although every kernel argument is frozen at capture:
   * dropout: every seed is a constant of the graph; the library mixes a 64-bit word of DEVICE memory into them
-    (`grappa_set_dropout_salt`), and the graph's first node increments that word -- fresh masks per replay, forward and backward of one
+    (`grappa_gemm_desc.drop_salt` and the row-wise kernels' `drop_salt`, C ABI 10: passed per call), and the graph's first node increments that word -- fresh masks per replay, forward and backward of one
     replay agreeing;
   * Adam: learning rate and step count are read from device memory (`grappa_adam_step_dyn_f32`); the graph increments the step count,
     the host writes the learning rate between replays (`FusedAdam.lr = ...`);
@@ -61,7 +61,9 @@ class CapturedTrainStep:
             raise RuntimeError("CapturedTrainStep needs a GPU")
         self.model, self.energy, self.loss_fn, self.opt, self.g = model, energy, loss_fn, opt, g
         self.be = get_backend()
-        self.be.enable_dropout_salt()
+        # the salt word lives on the graph's device and is passed with every call made while this object records; afterwards eager calls go
+        # back to their plain seeds (the recorded kernels keep the address they were recorded with: ADVICE r4)
+        self.be.enable_dropout_salt(g.device)
         opt.enable_dynamic()
         # a recorded step has no host cost per launch, and on the GPU four heads on four streams run their short dependent chains side by
         # side: measured 9.0 ms (head by head, four streams) against 9.5 (layer-locked, one stream) on the batch-32 step -- "auto" means
@@ -70,22 +72,25 @@ class CapturedTrainStep:
         self._merged_was = getattr(pw, "merged_heads", None)
         if self._merged_was == "auto":
             pw.merged_heads = "0"
-        self.stream = torch.cuda.Stream(device=g.device)
-        self.stream.wait_stream(torch.cuda.current_stream(g.device))
-        with torch.cuda.stream(self.stream):
-            for _ in range(max(int(warmup), 1)):           # on the capturing stream: workspaces and side streams are keyed by it
+        try:
+            self.stream = torch.cuda.Stream(device=g.device)
+            self.stream.wait_stream(torch.cuda.current_stream(g.device))
+            with torch.cuda.stream(self.stream):
+                for _ in range(max(int(warmup), 1)):           # on the capturing stream: workspaces and side streams are keyed by it
+                    self.be.bump_dropout_salt()
+                    self._eager()
+            self.stream.synchronize()
+            # (the last warm-up step's optimiser left every per-weight cache stale: the recorded step starts by refreshing them, in the graph)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
                 self.be.bump_dropout_salt()
-                self._eager()
-        self.stream.synchronize()
-        # (the last warm-up step's optimiser left every per-weight cache stale: the recorded step starts by refreshing them, in the graph)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.be.bump_dropout_salt()
-            self.loss = self._eager()
-        self.opt.step_count -= 1                            # (recorded, not executed: the device-side count did not move)
-        self._pinned = _pinned_by_graph(self.be)
-        if self._merged_was == "auto":
-            pw.merged_heads = "auto"
+                self.loss = self._eager()
+            self.opt.step_count -= 1                            # (recorded, not executed: the device-side count did not move)
+            self._pinned = _pinned_by_graph(self.be)
+        finally:
+            if self._merged_was == "auto":
+                pw.merged_heads = "auto"
+            self.be.disable_dropout_salt()
         torch.cuda.current_stream(g.device).wait_stream(self.stream)
         self.replays = 0
 

@@ -39,9 +39,8 @@ __host__ __device__ inline bool grappa_keep(uint64_t seed, uint64_t idx, float p
     return (float)grappa_hash32(seed, idx) * (1.0f / 16777216.0f) >= p;
 }
 
-// dropout salt: a 64-bit word in device memory mixed into the seeds (grappa_set_dropout_salt): the masks of a captured step then change
-// from replay to replay although every seed is a constant of the graph.  nullptr (the default): the seed as given.
-extern const uint64_t* g_grappa_drop_salt;
+// dropout salt: a 64-bit word in device memory mixed into the seeds (the drop_salt argument of every entry point that draws a mask, C ABI
+// 10): the masks of a captured step then change from replay to replay although every seed is a constant of the graph.  nullptr: the seed as given.
 __device__ inline uint64_t grappa_salted(uint64_t seed, const uint64_t* __restrict__ salt) {
     return salt ? seed + salt[0] * 0x9E3779B97F4A7C15ull : seed;
 }

@@ -298,20 +298,36 @@ constexpr int CFG_BM[NCFG] = {128, 64, 128, 32, 128, 128, 256, 256, 128};
 constexpr int CFG_BN[NCFG] = {128, 64, 32, 128, 64, 128, 128, 256, 128};
 constexpr int CFG_CONC[NCFG] = {2, 4, 4, 4, 3, 1, 1, 1, 2};   // co-resident workgroups per CU (LDS 67.6 / 33.8 / 42 / 42 / 50.7 / 72 / 108 KB, VGPR budget)
 
+// Per-call plan options (grappa_gemm_desc, ABI 10; nothing here is process-wide state: the environment only provides the defaults, read once).
+//   cfg / nsplit: force the tile configuration / split-K factor (tuning, tests); tail: -1 the model's choice, 0 never, 1 forced where possible;
+//   tails_on: tail launches allowed at all.  A caller that keeps several streams busy turns them off: a product's partial last round then
+//   overlaps with another stream's kernels, and the tail's two extra launches and slab round trip cost more than they return (C2 step, writer
+//   heads on four streams: 36.4 -> 36.0 ms; on one stream 37.4 -> 37.5; profiles/r3_plan_tails_ab.txt)
+struct PlanOpts {
+    int cfg = -1, nsplit = 0, tail = -1;
+    bool tails_on = true;
+};
+bool env_tails_default() {
+    static const bool env_on = !(getenv("GRAPPA_PLAN_TAILS") && atoi(getenv("GRAPPA_PLAN_TAILS")) == 0);
+    return env_on;
+}
+PlanOpts plan_opts_of(const grappa_gemm_desc& d) {
+    PlanOpts o;
+    o.cfg = d.plan_cfg > 0 ? d.plan_cfg - 1 : -1;
+    o.nsplit = d.plan_nsplit > 0 ? d.plan_nsplit : 0;
+    o.tails_on = d.plan_tail == 0 ? env_tails_default() : d.plan_tail != 2;
+    o.tail = d.plan_tail == 3 ? 1 : -1;
+    return o;
+}
 // split-K summed by a launch of gemm_splitk_reduce_kernel behind the product (default) or inside the product's own launch by the last
-// workgroup of each tile (GRAPPA_SPLITK_IN_KERNEL=1 / grappa_gemm_f32_set_splitk_reduce_launch(0)).  Same bits; the second is the
-// slower one on this chip (profiles/r2_splitk_in_kernel_rejected.txt): one workgroup sums nsplit x 128 KB behind an L2-invalidating
-// acquire while the rest of the chip idles at the end of the launch, the reduction kernel spreads the same reads over 256 CUs
-int g_splitk_launch = -1;
-bool splitk_in_kernel() {
+// workgroup of each tile (grappa_gemm_desc.splitk_reduce = 2 / GRAPPA_SPLITK_IN_KERNEL=1).  Same bits; the second is the slower one on this
+// chip (profiles/r2_splitk_in_kernel_rejected.txt): one workgroup sums nsplit x 128 KB behind an L2-invalidating acquire while the rest of
+// the chip idles at the end of the launch, the reduction kernel spreads the same reads over 256 CUs
+bool splitk_in_kernel(const grappa_gemm_desc& d) {
     static const bool env_in_kernel = getenv("GRAPPA_SPLITK_IN_KERNEL") && atoi(getenv("GRAPPA_SPLITK_IN_KERNEL")) != 0;
-    return g_splitk_launch < 0 ? env_in_kernel : g_splitk_launch == 0;
+    return d.splitk_reduce == 0 ? env_in_kernel : d.splitk_reduce == 2;
 }
 bool use_bf16x(int M, int N, int precision) { return precision != GRAPPA_GEMM_F32_MFMA && M > 32 && N > 32; }
-
-// tuning / tests only (grappa_gemm_f32_set_plan_override): force the tile configuration, split-K factor and tail use
-struct PlanOverride { int cfg = -1, nsplit = 0, tail = -1; };
-PlanOverride g_override;
 
 // Tile choice by a small cost model in CU-cycles.  A workgroup of tile c over k_per_split columns of K costs
 // BM*BN*(k + K0_c) / RATE_c; a CU runs CONC_c of them at once (each then CONC_c times slower), the chip drains the grid in
@@ -324,16 +340,6 @@ PlanOverride g_override;
 long plan_cus() {
     static const int env = getenv("GRAPPA_PLAN_CUS") ? atoi(getenv("GRAPPA_PLAN_CUS")) : 0;
     return env >= 32 && env <= 256 ? env : 256;
-}
-
-// Tail launches on / off (grappa_gemm_f32_set_tail_launches; environment GRAPPA_PLAN_TAILS as the default).  A caller that keeps several
-// streams busy turns them off: a product's partial last round then overlaps with another stream's kernels, and the tail's two extra
-// launches and slab round trip cost more than they return (C2 step, writer heads on four streams: 36.4 -> 36.0 ms; on one stream
-// 37.4 -> 37.5; profiles/r3_plan_tails_ab.txt)
-int g_tails = -1;
-bool plan_tails() {
-    static const bool env_on = !(getenv("GRAPPA_PLAN_TAILS") && atoi(getenv("GRAPPA_PLAN_TAILS")) == 0);
-    return g_tails < 0 ? env_on : g_tails != 0;
 }
 
 struct CostModel {
@@ -369,7 +375,7 @@ int pairs_cfg() {
     return t == 256 ? 7 : 6;
 }
 
-Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false, bool pairs_small = false) {
+Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false, bool pairs_small = false) {
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
@@ -389,7 +395,7 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
     int max_tail_split = K >= 8 * BK ? K / (4 * BK) : 1;      // the tail may be cut finer than a full split-K GEMM
     if (max_tail_split > 64) max_tail_split = 64;
     for (int c = 0; c < NCFG; ++c) {
-        if (g_override.cfg >= 0 && c != g_override.cfg && !planes) continue;
+        if (opt.cfg >= 0 && c != opt.cfg && !planes) continue;
         if (bf16x != (c >= 5)) continue;
         // the plane-format kernels have one tile shape each; the pair kernel (both operands pairs) also a 128 x 128 one
         if (planes && c != (pairs ? pairs_cfg() : 6) && !(pairs_small && c == 8)) continue;
@@ -401,7 +407,7 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
         const long tiles = (long)((M + CFG_BM[c] - 1) / CFG_BM[c]) * ((N + CFG_BN[c] - 1) / CFG_BN[c]);
         const double te = (double)CFG_BM[c] * CFG_BN[c];
         for (int ns = 1; ns <= max_split; ns = ns < 4 ? ns + 1 : ns + (ns + 3) / 4) {
-            if (g_override.nsplit > 0 && ns != g_override.nsplit) continue;
+            if (opt.nsplit > 0 && ns != opt.nsplit) continue;
             int kps = (K + ns - 1) / ns;
             kps = (kps + BK - 1) / BK * BK;
             const int nsplit = (K + kps - 1) / kps;
@@ -416,7 +422,7 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
             cand.tail_k_per_split = 0;
             const long ncu = plan_cus();
             const long rem = tiles % ncu;
-            if (nsplit == 1 && tiles > ncu && rem > 0 && rem <= ncu * 5 / 8 && g_override.tail != 0 && plan_tails()) {
+            if (nsplit == 1 && tiles > ncu && rem > 0 && rem <= ncu * 5 / 8 && opt.tail != 0 && opt.tails_on) {
                 int ts = (int)(ncu / rem);
                 if (ts > max_tail_split) ts = max_tail_split;
                 int tkps = (K + ts - 1) / ts;
@@ -424,7 +430,7 @@ Plan make_plan(int M, int N, int K, bool vec = true, bool bf16x = false, bool pl
                 const int tns = (K + tkps - 1) / tkps;
                 if (tns >= 2) {
                     const double with_tail = cm.grid(c, tiles - rem, kps) + cm.grid(c, rem * tns, tkps) + CostModel::splitk(tns, rem * te);
-                    if (with_tail < cost || g_override.tail == 1) {
+                    if (with_tail < cost || opt.tail == 1) {
                         cost = with_tail;
                         cand.main_tiles = (int)(tiles - rem);
                         cand.tail_nsplit = tns;
@@ -495,28 +501,44 @@ int choose_epi_class(const grappa_gemm_desc& d, bool vec_io, bool bf16x) {
 // placed behind the split-K slabs
 static size_t amax_part_bytes(int M, int N) { return (size_t)M * ((N + 31) / 32) * sizeof(unsigned); }
 
-extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    size_t a = plan_workspace_floats(make_plan(M, N, K, true), M, N);
-    const size_t b = plan_workspace_floats(make_plan(M, N, K, false), M, N);
+static size_t workspace_floats_all(int M, int N, int K, const PlanOpts& o) {
+    size_t a = plan_workspace_floats(make_plan(M, N, K, o, true), M, N);
+    const size_t b = plan_workspace_floats(make_plan(M, N, K, o, false), M, N);
     if (b > a) a = b;
     if (use_bf16x(M, N, GRAPPA_GEMM_F32_BF16X9)) {
-        const size_t c = plan_workspace_floats(make_plan(M, N, K, true, true), M, N);
+        const size_t c = plan_workspace_floats(make_plan(M, N, K, o, true, true), M, N);
         if (c > a) a = c;
-        const size_t e = plan_workspace_floats(make_plan(M, N, K, true, true, true), M, N);
+        const size_t e = plan_workspace_floats(make_plan(M, N, K, o, true, true, true), M, N);
         if (e > a) a = e;
-        const size_t f = plan_workspace_floats(make_plan(M, N, K, true, true, true, true), M, N);
+        const size_t f = plan_workspace_floats(make_plan(M, N, K, o, true, true, true, true), M, N);
         if (f > a) a = f;
-        const size_t g = plan_workspace_floats(make_plan(M, N, K, true, true, true, true, true), M, N);
+        const size_t g = plan_workspace_floats(make_plan(M, N, K, o, true, true, true, true, true), M, N);
         if (g > a) a = g;
     }
-    return a * sizeof(float) + amax_part_bytes(M, N);
+    return a;
 }
 
-extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
+// one ticket (int) per tile beside the slabs when the reduction runs inside the product's launch: plan_workspace_floats counts them
+extern "C" size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    PlanOpts on, off;
+    on.tails_on = true;
+    off.tails_on = false;
+    const size_t a = workspace_floats_all(M, N, K, on), b = workspace_floats_all(M, N, K, off);
+    return (a > b ? a : b) * sizeof(float) + amax_part_bytes(M, N);
+}
+
+extern "C" size_t grappa_gemm_f32_workspace_bytes_desc(const grappa_gemm_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    const size_t a = workspace_floats_all(d->M, d->N, d->K, plan_opts_of(*d)) * sizeof(float) + amax_part_bytes(d->M, d->N);
+    const size_t b = grappa_gemm_f32_workspace_bytes(d->M, d->N, d->K);
+    return a > b ? a : b;
+}
+
+static int plan_report(int M, int N, int K, int precision, const PlanOpts& o, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
     if (M <= 0 || N <= 0 || K <= 0 || !tile_m || !tile_n || !nsplit || !tail_tiles || !tail_nsplit) return GRAPPA_ERR_ARG;
     if (precision < GRAPPA_GEMM_F32_MFMA || precision > GRAPPA_GEMM_F32_F16X3) return GRAPPA_ERR_ARG;
-    Plan pl = make_plan(M, N, K, true, use_bf16x(M, N, precision));
+    Plan pl = make_plan(M, N, K, o, true, use_bf16x(M, N, precision));
     *tile_m = CFG_BM[pl.cfg];
     *tile_n = CFG_BN[pl.cfg];
     *nsplit = pl.nsplit;
@@ -526,14 +548,16 @@ extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* til
     return GRAPPA_OK;
 }
 
-extern "C" void grappa_gemm_f32_set_splitk_reduce_launch(int on) { g_splitk_launch = on < 0 ? -1 : (on != 0); }
+extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
+    PlanOpts o;
+    o.tails_on = env_tails_default();
+    return plan_report(M, N, K, precision, o, tile_m, tile_n, nsplit, tail_tiles, tail_nsplit);
+}
 
-extern "C" void grappa_gemm_f32_set_tail_launches(int on) { g_tails = on < 0 ? -1 : (on != 0); }
-
-extern "C" void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail) {
-    g_override.cfg = cfg;
-    g_override.nsplit = nsplit;
-    g_override.tail = tail;
+// the same for a descriptor's shape, precision and plan options (fp32 operands)
+extern "C" int grappa_gemm_f32_plan_desc(const grappa_gemm_desc* d, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
+    if (!d) return GRAPPA_ERR_ARG;
+    return plan_report(d->M, d->N, d->K, d->precision, plan_opts_of(*d), tile_m, tile_n, nsplit, tail_tiles, tail_nsplit);
 }
 
 // ------------------------------------------------------------------------------------------------ grouped weight gradients
@@ -662,7 +686,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
     GroupIndex ix;
     GroupUpload up;
     ix.wg_begin[0] = ix.blk_begin[0] = 0;
-    const bool in_kernel = splitk_in_kernel();
+    const bool in_kernel = splitk_in_kernel(descs[0]);        // (one launch: the group follows its first product's option)
     int* tickets = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + g.ticket_offset);
     int* next_ticket = tickets;
     auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
@@ -693,7 +717,7 @@ extern "C" int grappa_gemm_f32_grouped(void* stream, const grappa_gemm_desc* des
                 next_ticket += g.tiles[i];
             }
             p.drop_scale = d.drop_p > 0.0f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
-            p.drop_salt = g_grappa_drop_salt;
+            p.drop_salt = d.drop_salt;
             p.bm = 256;
             p.bn = 128;
             p.tiles_m = (d.M + 255) / 256;
@@ -776,7 +800,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool padB = d->b_kcontig || ((d->N + 3) & ~3) <= d->ldb;
     const bool vec = vecA && vecB && padA && padB;
     p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
-    p.drop_salt = g_grappa_drop_salt;
+    p.drop_salt = d->drop_salt;
     auto al16 = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
     p.vec_io = al16(d->C, d->ldc) && al16(d->C2, d->ldc2) && al16(d->pre, d->ldpre) && al16(d->res, d->ldres) && al16(d->aux, d->ldaux);
     if (d->precision < GRAPPA_GEMM_F32_MFMA || d->precision > GRAPPA_GEMM_F32_F16X3) return GRAPPA_ERR_ARG;
@@ -793,8 +817,10 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             return GRAPPA_ERR_ARG;
     }
     static const bool small_tile = !(getenv("GRAPPA_PAIRS_SMALL_TILE") && atoi(getenv("GRAPPA_PAIRS_SMALL_TILE")) == 0);
-    Plan pl = make_plan(d->M, d->N, d->K, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && g_override.cfg < 0);
+    const PlanOpts popt = plan_opts_of(*d);
+    Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
+    if (d->plan_cfg < 0 || d->plan_cfg > NCFG || d->plan_nsplit < 0 || d->plan_tail < 0 || d->plan_tail > 3 || d->splitk_reduce < 0 || d->splitk_reduce > 2) return GRAPPA_ERR_ARG;
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
     if (need > 0 && (!ws || ws_bytes < need)) return GRAPPA_ERR_WORKSPACE;
     p.bm = CFG_BM[pl.cfg];
@@ -815,7 +841,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
         if (nsplit > 1) {
             p.slab = reinterpret_cast<float*>(ws);
             p.cs_slab = p.slab + (size_t)nsplit * ntiles * te;
-            if (bf16x && !planes && splitk_in_kernel()) {                // the last workgroup of a tile reduces it (gemm_common.h splitk_finish_tile)
+            if (bf16x && !planes && splitk_in_kernel(*d)) {                // the last workgroup of a tile reduces it (gemm_common.h splitk_finish_tile)
                 p.tickets = reinterpret_cast<int*>(p.cs_slab + (size_t)nsplit * d->M);
                 if (hipMemsetAsync(p.tickets, 0, (size_t)ntiles * sizeof(int), st) != hipSuccess) return GRAPPA_ERR_LAUNCH;
             }
@@ -929,7 +955,7 @@ extern "C" int grappa_gemm_f32_group(void* stream, const grappa_gemm_desc* descs
         p.cs_slab = nullptr;
         p.tickets = nullptr;
         p.drop_scale = d.drop_p > 0.0f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
-        p.drop_salt = g_grappa_drop_salt;
+        p.drop_salt = d.drop_salt;
         p.vec_io = al16(d.C, d.ldc) && al16(d.C2, d.ldc2) && al16(d.pre, d.ldpre) && al16(d.res, d.ldres) && al16(d.aux, d.ldaux);
         p.epi_class = choose_epi_class(d, p.vec_io != 0, true);
         p.amax_seg = 32;

@@ -496,11 +496,11 @@ struct ActDropBatch {
     int count;
 };
 template <int NCH>
-__global__ __launch_bounds__(256) void act_dropout_bwd_batched_kernel(ActDropBatch b, const uint64_t* __restrict__ salt) {
+__global__ __launch_bounds__(256) void act_dropout_bwd_batched_kernel(ActDropBatch b) {
     int i = 0;
     while (i + 1 < b.count && (int)blockIdx.x >= b.blk_begin[i + 1]) ++i;
     const grappa_act_dropout_item& t = b.it[i];
-    act_dropout_bwd_rows_body<NCH>(t.M, t.N, t.dy, t.lddy, t.y, t.ldy, t.drop_p, t.drop_p > 0.f ? 1.0f / (1.0f - t.drop_p) : 1.0f, t.drop_seed, salt, t.dz, t.lddz,
+    act_dropout_bwd_rows_body<NCH>(t.M, t.N, t.dy, t.lddy, t.y, t.ldy, t.drop_p, t.drop_p > 0.f ? 1.0f / (1.0f - t.drop_p) : 1.0f, t.drop_seed, t.drop_salt, t.dz, t.lddz,
                                    t.dz_amax, (int)blockIdx.x - b.blk_begin[i], b.blk_begin[i + 1] - b.blk_begin[i]);
 }
 
@@ -736,7 +736,7 @@ int layernorm_bwd_impl(void* stream, int M, int W, const T* dy, int lddy, const 
 }
 
 template <typename T>
-int act_dropout_bwd_impl(void* stream, int M, int N, const T* dy, int lddy, const T* y, int ldy, float drop_p, uint64_t drop_seed, T* dz, int lddz) {
+int act_dropout_bwd_impl(void* stream, int M, int N, const T* dy, int lddy, const T* y, int ldy, float drop_p, uint64_t drop_seed, T* dz, int lddz, const uint64_t* drop_salt) {
     if (M < 0 || N < 0 || drop_p < 0.f || drop_p >= 1.f) return GRAPPA_ERR_ARG;
     if (M == 0 || N == 0) return GRAPPA_OK;
     if (!dy || !dz) return GRAPPA_ERR_ARG;
@@ -746,10 +746,10 @@ int act_dropout_bwd_impl(void* stream, int M, int N, const T* dy, int lddy, cons
                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & amask) == 0;
     if (vec)
         GRAPPA_LAUNCH(act_dropout_bwd_vec_kernel<T>, dim3(grid_for((size_t)M * (N >> 2))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, g_grappa_drop_salt, dz, lddz);
+                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, drop_salt, dz, lddz);
     else
         GRAPPA_LAUNCH(act_dropout_bwd_kernel<T>, dim3(grid_for((size_t)M * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, g_grappa_drop_salt, dz, lddz);
+                           M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, drop_salt, dz, lddz);
     return grappa_launch_status();
 }
 
@@ -848,8 +848,8 @@ extern "C" int grappa_layernorm_bwd_amax_f32(void* stream, int M, int W, const f
 extern "C" int grappa_layernorm_bwd_drop_f32(void* stream, int M, int W, const float* dy, int lddy, const float* x, int ldx,
                                              const float* mean, const float* rstd, const float* gamma, float* dx, int lddx,
                                              float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, uint32_t* dx_amax,
-                                             float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax) {
-    const LnBwdDrop dr{drop_p, drop_p > 0.f && drop_p < 1.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_seed, g_grappa_drop_salt, dz, lddz, dz_amax};
+                                             float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, const uint64_t* drop_salt) {
+    const LnBwdDrop dr{drop_p, drop_p > 0.f && drop_p < 1.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_seed, drop_salt, dz, lddz, dz_amax};
     return layernorm_bwd_impl<float>(stream, M, W, dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, accumulate, ws, ws_bytes, dx_amax, &dr);
 }
 extern "C" int grappa_layernorm_bwd_bf16(void* stream, int M, int W, const uint16_t* dy, int lddy, const uint16_t* x, int ldx,
@@ -881,25 +881,25 @@ extern "C" int grappa_colsum_f32(void* stream, int M, int N, const float* x, int
 }
 
 extern "C" int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
-                                          float drop_p, uint64_t drop_seed, float* dz, int lddz) {
-    return act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
+                                          float drop_p, uint64_t drop_seed, float* dz, int lddz, const uint64_t* drop_salt) {
+    return act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz, drop_salt);
 }
 extern "C" int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
-                                               float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax) {
-    if (!dz_amax) return act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
+                                               float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, const uint64_t* drop_salt) {
+    if (!dz_amax) return act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz, drop_salt);
     if (M < 0 || N < 0 || drop_p < 0.f || drop_p >= 1.f) return GRAPPA_ERR_ARG;
     if (M == 0 || N == 0) return GRAPPA_OK;
     if (!dy || !dz) return GRAPPA_ERR_ARG;
     const bool rows = (N & 3) == 0 && N <= 2048 && (lddy & 3) == 0 && (lddz & 3) == 0 && (!y || (ldy & 3) == 0) &&
                       ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     if (!rows) {                                         // odd shapes: the plain kernel, then one pass over dz
-        const int rc = act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
+        const int rc = act_dropout_bwd_impl<float>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz, drop_salt);
         return rc != GRAPPA_OK ? rc : grappa_amax_f32(stream, M, N, dz, lddz, dz_amax, nullptr, nullptr, 0);
     }
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int blocks = (M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4;
-#define GRAPPA_ADB(NCH) GRAPPA_LAUNCH((act_dropout_bwd_rows_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, g_grappa_drop_salt, dz, lddz, dz_amax)
+#define GRAPPA_ADB(NCH) GRAPPA_LAUNCH((act_dropout_bwd_rows_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, drop_salt, dz, lddz, dz_amax)
     if (N <= 256) GRAPPA_ADB(1);
     else if (N <= 512) GRAPPA_ADB(2);
     else if (N <= 1024) GRAPPA_ADB(4);
@@ -986,7 +986,7 @@ extern "C" int grappa_act_dropout_bwd_batched_f32(void* stream, const grappa_act
     for (int i = count; i < GRAPPA_ROW_BATCH_MAX; ++i) b.blk_begin[i + 1] = b.blk_begin[count];
     if (b.blk_begin[count] == 0) return GRAPPA_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define GRAPPA_ADBB(NCH) GRAPPA_LAUNCH((act_dropout_bwd_batched_kernel<NCH>), dim3(b.blk_begin[count]), dim3(256), 0, st, b, g_grappa_drop_salt)
+#define GRAPPA_ADBB(NCH) GRAPPA_LAUNCH((act_dropout_bwd_batched_kernel<NCH>), dim3(b.blk_begin[count]), dim3(256), 0, st, b)
     if (nmax <= 256) GRAPPA_ADBB(1);
     else if (nmax <= 512) GRAPPA_ADBB(2);
     else if (nmax <= 1024) GRAPPA_ADBB(4);
@@ -996,7 +996,7 @@ extern "C" int grappa_act_dropout_bwd_batched_f32(void* stream, const grappa_act
 }
 
 extern "C" int grappa_act_dropout_bwd_pairs_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy, float drop_p,
-                                                uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, uint16_t* pairs, int ldp) {
+                                                uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, uint16_t* pairs, int ldp, const uint64_t* drop_salt) {
     if (M < 0 || N <= 0 || (N & 31) || N > 2048 || drop_p < 0.f || drop_p >= 1.f || (lddy & 3) || (dz && (lddz & 3)) || (y && (ldy & 3)) || ldp < 2 * N || (ldp & 7))
         return GRAPPA_ERR_ARG;
     if (M == 0) return GRAPPA_OK;
@@ -1006,7 +1006,7 @@ extern "C" int grappa_act_dropout_bwd_pairs_f32(void* stream, int M, int N, cons
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int blocks = (M + 3) / 4 > 2048 ? 2048 : (M + 3) / 4;
-#define GRAPPA_ADBP(NCH) GRAPPA_LAUNCH((act_dropout_bwd_pairs_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, g_grappa_drop_salt, dz, lddz, dz_amax, pairs, ldp)
+#define GRAPPA_ADBP(NCH) GRAPPA_LAUNCH((act_dropout_bwd_pairs_kernel<NCH>), dim3(blocks), dim3(256), 0, st, M, N, dy, lddy, y, ldy, drop_p, scale, drop_seed, drop_salt, dz, lddz, dz_amax, pairs, ldp)
     if (N <= 256) GRAPPA_ADBP(1);
     else if (N <= 512) GRAPPA_ADBP(2);
     else if (N <= 1024) GRAPPA_ADBP(4);
@@ -1015,8 +1015,8 @@ extern "C" int grappa_act_dropout_bwd_pairs_f32(void* stream, int M, int N, cons
     return grappa_launch_status();
 }
 extern "C" int grappa_act_dropout_bwd_bf16(void* stream, int M, int N, const uint16_t* dy, int lddy, const uint16_t* y, int ldy,
-                                           float drop_p, uint64_t drop_seed, uint16_t* dz, int lddz) {
-    return act_dropout_bwd_impl<grappa_bf16_t>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz);
+                                           float drop_p, uint64_t drop_seed, uint16_t* dz, int lddz, const uint64_t* drop_salt) {
+    return act_dropout_bwd_impl<grappa_bf16_t>(stream, M, N, dy, lddy, y, ldy, drop_p, drop_seed, dz, lddz, drop_salt);
 }
 
 extern "C" int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float* y) {
@@ -1061,8 +1061,6 @@ extern "C" int grappa_adam_step_dyn_f32(void* stream, size_t n, float* p, const 
 }
 
 // dropout salt (include/grappa_hip.h): one 64-bit word in device memory mixed into every dropout seed of the kernels launched afterwards
-const uint64_t* g_grappa_drop_salt = nullptr;
-extern "C" void grappa_set_dropout_salt(const uint64_t* device_word) { g_grappa_drop_salt = device_word; }
 
 extern "C" int grappa_charge_encoding_f32(void* stream, int N, const float* q, int dim, float lo, float hi, float* out, int ldo, int col0) {
     if (N < 0 || dim <= 0 || (dim & 1) || hi <= lo) return GRAPPA_ERR_ARG;

@@ -7,8 +7,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer (hipMalloc'ed / torch.cuda tensor storage) unless named h_*;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
- *   - no allocation, no global state, re-entrant per stream; scratch comes from the caller
- *     (`ws`, `ws_bytes`; sizes from the *_workspace_bytes() queries);
+ *   - no allocation, no mutable global state, re-entrant per stream and per host thread: every option of a call travels in its arguments
+ *     (ABI 10 removed the four process-wide setters: plan override, tail launches, split-K reduction, dropout salt); scratch comes from the
+ *     caller (`ws`, `ws_bytes`; sizes from the *_workspace_bytes() queries).  Environment variables read once at first use (GRAPPA_PLAN_TAILS,
+ *     GRAPPA_PAIRS_TILE ...) only choose DEFAULTS and never change afterwards;
  *   - return 0 on success, a negative GRAPPA_ERR_* otherwise (never throws / aborts);
  *   - fp32 activations, int32 indices, row-major, leading dimensions in ELEMENTS.
  */
@@ -27,7 +29,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 9
+#define GRAPPA_ABI_VERSION 10
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -160,6 +162,20 @@ typedef struct grappa_gemm_desc {
      * layout, fp32 operands) passes a_amax = parts and a_amax_nseg = nseg and takes the maximum over the segments itself;
      * grappa_amax_reduce over all nseg * M values gives the whole-tensor maximum of a weight-gradient product. */
     uint32_t* out_amax_parts; int a_amax_nseg;
+    /* ---- ABI 10: the options that used to be process-wide setters, per call (all 0 / NULL = the library's defaults).
+     * plan_cfg: tuning and tests -- force the tile configuration index plan_cfg - 1 (0: the plan's own choice); plan_nsplit: force the split-K
+     * factor (0: own choice).  plan_tail: the "tail launch" (when the tile grid is 256 q + rem workgroups, the rem tiles run as a second launch
+     * with their K range cut): 0 = allowed unless the environment says GRAPPA_PLAN_TAILS=0, 1 = allowed, 2 = never (a caller that keeps several
+     * streams busy: the partial last round then runs beside another stream's kernels), 3 = forced where possible (tests).  Results differ only
+     * in the summation order of the tail tiles' K slices.
+     * splitk_reduce: where a split-K product of the fp32-operand split kernels sums its K slices -- 0 = default (a launch of the reduction kernel
+     * behind the product, unless the environment says GRAPPA_SPLITK_IN_KERNEL=1), 1 = the reduction launch, 2 = inside the product's own launch
+     * (the last workgroup of a tile to arrive adds the slabs in the fixed order 0, 1, ...).  Same bits either way.
+     * drop_salt: one uint64 in DEVICE memory (or NULL: none) mixed into drop_seed when the kernel runs: seed + word * 0x9E3779B97F4A7C15.  A
+     * train step captured in a hipGraph increments the word inside the graph: every replay draws fresh masks while forward and backward of
+     * one replay agree.  (The row-wise kernels that draw the same masks take the same pointer as their last argument.) */
+    int plan_cfg, plan_nsplit, plan_tail, splitk_reduce;
+    const uint64_t* drop_salt;
 } grappa_gemm_desc;
 
 /* Largest magnitudes of an fp32 matrix x[R][C] (leading dimension ldx), as fp32 bit patterns: row_amax[r] = max_c |x[r][c]|,
@@ -206,24 +222,15 @@ typedef struct grappa_split_pairs_item {
 } grappa_split_pairs_item;
 int grappa_split_pairs_f32_batched(void* stream, int count, int total_tiles, const grappa_split_pairs_item* items);
 
+/* workspace of a product: enough for every plan the library may choose for this shape whatever plan_tail / splitk_reduce say (plan_cfg and
+ * plan_nsplit = 0); a descriptor that forces a configuration or a split asks grappa_gemm_f32_workspace_bytes_desc */
 size_t grappa_gemm_f32_workspace_bytes(int M, int N, int K);
-/* host-only: the tile (tile_m x tile_n x 32) and split-K factor the launcher will use for this shape, and the "tail": when the
- * tile grid is 256*q + rem workgroups, the rem tiles run as a second launch with their K range split tail_nsplit ways */
+size_t grappa_gemm_f32_workspace_bytes_desc(const grappa_gemm_desc* d);
+/* host-only: the tile (tile_m x tile_n x 32) and split-K factor the launcher will use for this shape (default options), and the "tail": when
+ * the tile grid is 256*q + rem workgroups, the rem tiles run as a second launch with their K range split tail_nsplit ways */
 int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit);
-/* tuning and tests only, not thread safe: force the tile configuration index (0..6, -1 = model's choice), the split-K factor
- * (0 = model's choice) and the tail launch (1 on, 0 off, -1 = model's choice) of every following plan */
-void grappa_gemm_f32_set_plan_override(int cfg, int nsplit, int tail);
-/* not thread safe: tail launches of the following plans on (1), off (0) or back to the default (-1: on, unless the environment has
- * GRAPPA_PLAN_TAILS=0).  A caller that keeps several streams busy turns them off: the partial last round of a product then runs beside
- * another stream's kernels and the tail's extra launches and slab round trip are a loss (HipBackend does, for the writer heads on
- * four streams).  Results differ only in the summation order of the tail tiles' K slices */
-void grappa_gemm_f32_set_tail_launches(int on);
-/* tuning and tests only, not thread safe: where a split-K product of the fp32-operand split kernels sums its K slices.  1 (default):
- * a launch of the reduction kernel behind the product; 0: inside the product's own launch -- the last workgroup of a tile to
- * arrive (a ticket per tile in the workspace) adds the slabs in the fixed order 0, 1, ... and runs the epilogue.  Same bits either
- * way; 0 measured 25 % slower per C2 step on MI355X.  -1 = back to the default (environment
- * GRAPPA_SPLITK_IN_KERNEL=1 selects 0) */
-void grappa_gemm_f32_set_splitk_reduce_launch(int on);
+/* ABI 10: the same for a descriptor's M, N, K, precision and plan options (operands taken as fp32) */
+int grappa_gemm_f32_plan_desc(const grappa_gemm_desc* d, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit);
 int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws, size_t ws_bytes);
 
 /* Grouped weight gradients: n <= GRAPPA_GEMM_GROUP_MAX independent products in the wgrad layout (a_kcontig = b_kcontig = 0, fp32
@@ -251,13 +258,14 @@ int grappa_colsum_f32(void* stream, int M, int N, const float* x, int ldx, float
 /* dz = dy * keep(seed,idx)/(1-p) * (y ? elu'(y) : 1)   elementwise over an [M,N] view (backward of the
  * act+dropout epilogue).  y == NULL: no activation.  dz may alias dy. */
 int grappa_act_dropout_bwd_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
-                               float drop_p, uint64_t drop_seed, float* dz, int lddz);
+                               float drop_p, uint64_t drop_seed, float* dz, int lddz, const uint64_t* drop_salt);
 /* ABI 4, *_amax_f32 variants of the producers of dense-product operands: the same kernel also writes the largest magnitude of every
  * row of its output (M fp32 bit patterns, as grappa_amax_f32's row_amax) -- the scales of a following F32_F16X3 product, without a
  * pass of their own.  A NULL array gives the plain kernel. */
 int grappa_act_dropout_bwd_amax_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy,
-                                    float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax);
-/* ---- ABI 8: batched row-wise kernels.  The writer heads run layer-locked (one autograd node per transformer layer over all heads): their
+                                    float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, const uint64_t* drop_salt);
+/* (drop_salt, ABI 10: see grappa_gemm_desc.drop_salt; NULL = none)
+ * ---- ABI 8: batched row-wise kernels.  The writer heads run layer-locked (one autograd node per transformer layer over all heads): their
  * products go out as one grouped launch (grappa_gemm_f32_group) and their row-wise kernels as ONE launch over up to
  * GRAPPA_ROW_BATCH_MAX independent tensors.  Same arithmetic per tensor as the single-tensor entry points (fp32, row maxima written). */
 #define GRAPPA_ROW_BATCH_MAX 4
@@ -273,6 +281,7 @@ typedef struct grappa_ln_bwd_item {          /* grappa_layernorm_bwd_amax_f32 wi
 int grappa_layernorm_bwd_batched_f32(void* stream, const grappa_ln_bwd_item* items, int count);
 typedef struct grappa_act_dropout_item {     /* = grappa_act_dropout_bwd_amax_f32's arguments (N % 4 == 0, N <= 2048, 16-byte aligned rows); y may be NULL */
     int M, N; const float* dy; int lddy; const float* y; int ldy; float drop_p; uint64_t drop_seed; float* dz; int lddz; uint32_t* dz_amax;
+    const uint64_t* drop_salt;               /* ABI 10 */
 } grappa_act_dropout_item;
 int grappa_act_dropout_bwd_batched_f32(void* stream, const grappa_act_dropout_item* items, int count);
 typedef struct grappa_seqattn_item {         /* = grappa_seqattn_fwd_amax_f32 / grappa_seqattn_bwd_amax_f32's arguments; amax may be NULL */
@@ -284,7 +293,7 @@ int grappa_seqattn_bwd_batched_f32(void* stream, const grappa_seqattn_item* item
  * rows' scales, required); dz (fp32) may be NULL: the products behind -- the input gradient through grappa_gemm_f32's pair operands, the
  * weight gradient through ABI 8's -- read the pairs. */
 int grappa_act_dropout_bwd_pairs_f32(void* stream, int M, int N, const float* dy, int lddy, const float* y, int ldy, float drop_p,
-                                     uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, uint16_t* pairs, int ldp);
+                                     uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, uint16_t* pairs, int ldp, const uint64_t* drop_salt);
 
 /* y = x + z elementwise (used to merge gradient branches); y may alias x */
 int grappa_add_f32(void* stream, size_t n, const float* x, const float* z, float* y);
@@ -337,7 +346,7 @@ int grappa_layernorm_bwd_drop_f32(void* stream, int M, int W, const float* dy, i
                                   const float* mean, const float* rstd, const float* gamma,
                                   float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
                                   void* ws, size_t ws_bytes, uint32_t* dx_amax,
-                                  float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax);
+                                  float drop_p, uint64_t drop_seed, float* dz, int lddz, uint32_t* dz_amax, const uint64_t* drop_salt);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph attention message passing (DGL DotGatConv, graph_attention.py:249/:283 -> DGL u_dot_v +
@@ -532,11 +541,6 @@ int grappa_adam_step_f32(void* stream, size_t n, float* p, const float* g, float
  * for the bias corrections) read from DEVICE memory at execution time. */
 int grappa_adam_step_dyn_f32(void* stream, size_t n, float* p, const float* g, float* m, float* v, const float* lr_dev, float beta1, float beta2,
                              float eps, float weight_decay, const int* step_dev, float grad_scale, const float* sumsq, float max_norm);
-/* ABI 8: dropout salt.  device_word (one uint64 in device memory, or NULL = none: the default) is read by every kernel launched AFTERWARDS
- * that draws a dropout mask (product epilogues, grappa_act_dropout_bwd_*) and mixed into its seed: seed + word * 0x9E3779B97F4A7C15.  A
- * captured step increments the word inside the graph, so every replay draws fresh masks while forward and backward of one replay agree. */
-void grappa_set_dropout_salt(const uint64_t* device_word);
-
 /* ------------------------------------------------------------------------------------------------
  * bf16 storage configuration (BASELINE configs[2]: "bf16, MFMA dense heads"; the reference's Lightning `precision` / its
  * torch.set_float32_matmul_precision('medium'), training/trainrun.py:3): activations and activation gradients are kept as bf16
@@ -550,7 +554,7 @@ int grappa_layernorm_bwd_bf16(void* stream, int M, int W, const uint16_t* dy, in
                               const float* mean, const float* rstd, const float* gamma, uint16_t* dx, int lddx,
                               float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes);
 int grappa_act_dropout_bwd_bf16(void* stream, int M, int N, const uint16_t* dy, int lddy, const uint16_t* y, int ldy,
-                                float drop_p, uint64_t drop_seed, uint16_t* dz, int lddz);
+                                float drop_p, uint64_t drop_seed, uint16_t* dz, int lddz, const uint64_t* drop_salt);
 int grappa_gat_fwd_bf16(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices,
                         const uint16_t* ft, uint16_t* out, float* alpha);
 int grappa_gat_bwd_bf16(void* stream, int N, int E, int H, int D, const int* indptr, const int* indices, const int* rev,

@@ -42,8 +42,9 @@ def _library_defaults(request):
         be = backend._BACKEND
         if be is not None and hasattr(be, "pin_tail_launches"):
             be.pin_tail_launches(None)
-            be.lib.grappa_gemm_f32_set_tail_launches(-1)
             be._tails = None
+            be.plan_override = None
+            be.splitk_reduce = 0
             # ... and from the default arithmetic and storage (a test that switches them and fails before restoring must not move the rest)
             from grappa_amd import ops
             default = os.environ.get("GRAPPA_GEMM_PRECISION", backend.DEFAULT_GEMM_PRECISION)

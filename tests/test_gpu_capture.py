@@ -13,7 +13,7 @@ LK = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0)
 
 @pytest.fixture(autouse=True)
 def _no_salt_left_behind():
-    """the dropout salt is process-wide state of the library: tests that compare masks with the host-side hash expect none"""
+    """the dropout salt is state of the backend object (sent per call, C ABI 10): tests that compare masks with the host-side hash expect none"""
     yield
     from grappa_amd.backend import get_backend
     be = get_backend()

@@ -169,12 +169,12 @@ def test_gemm_bf16x_tile_configurations(hip, ref, M, N, K, ak, bk, cfg):
     cs_r, cs_h = (torch.ones(M), torch.ones(M, device="cuda")) if wgrad else (None, None)
     ref.gemm(A, B, o_r, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), a_colsum=cs_r, **kw)
     kw_h = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
-    hip.lib.grappa_gemm_f32_set_plan_override(cfg, 0, -1)
+    hip.plan_override = (cfg, 0, -1)
     try:
         hip.gemm(A.cuda(), B.cuda(), o_h, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), a_colsum=cs_h, precision="f32_bf16x6", **kw_h)
         torch.cuda.synchronize()
     finally:
-        hip.lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+        hip.plan_override = None
     _cmp(o_h, o_r, 2e-5, f"gemm[f32_bf16x6, cfg {cfg}] {M}x{N}x{K} ak={ak} bk={bk}")
     if wgrad:
         _cmp(cs_h, cs_r, 2e-5, f"fused bias gradient[cfg {cfg}] {M}x{N}x{K}")

@@ -25,12 +25,12 @@ def test_pair_format_product_equals_the_fp32_operand_product_bit_for_bit(M, N, K
     gp.check(M, N, K, gen, dgrad=dgrad, scale_rows=scaled, **epi)                 # the shipped plans: asserts the float64 error inside
     # the two kernels plan their tiles and K cuts independently (the pair kernel: 256 x 128 or, since round 4, 128 x 128): with K in one
     # piece for both, the bits agree
-    gp.lib.grappa_gemm_f32_set_plan_override(-1, 1, -1)
+    gp.EXTRA = {"plan_nsplit": 1}                                                    # (a per-call option of the descriptor since C ABI 10)
     try:
         gen.manual_seed(M * 7 + N)
         same = gp.check(M, N, K, gen, dgrad=dgrad, scale_rows=scaled, **epi)      # (returns bit equality)
     finally:
-        gp.lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+        gp.EXTRA = {}
     assert same
 
 
@@ -166,12 +166,12 @@ def test_product_recomputes_a_layernorm_residual_in_its_epilogue(M, N, K, drop):
     be.gemm(a, w, got, M=M, N=N, K=K, bias=bias, drop_p=drop, drop_seed=7, res=x, res_ln=(mean, rstd, g, b))
     assert torch.equal(want, got)
     if M > 64:                       # forced split-K: the reduction kernel applies the epilogue
-        be.lib.grappa_gemm_f32_set_plan_override(-1, 2, -1)
+        be.plan_override = (-1, 2, -1)
         try:
             be.gemm(a, w, got, M=M, N=N, K=K, bias=bias, drop_p=drop, drop_seed=7, res=x, res_ln=(mean, rstd, g, b))
             be.gemm(a, w, want, M=M, N=N, K=K, bias=bias, drop_p=drop, drop_seed=7, res=y)
         finally:
-            be.lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+            be.plan_override = None
         assert torch.equal(want, got)
     if M > 64:                       # the generic row walk: activation + second output (the GNN's feed-forward form)
         pre_w, pre_g = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")

@@ -159,19 +159,19 @@ def test_split_k_finished_inside_the_launch_equals_the_reduction_launch_bit_for_
         return outs
 
     try:
-        be.lib.grappa_gemm_f32_set_splitk_reduce_launch(1)
+        be.splitk_reduce = 1                       # a reduction launch behind the product
         want = run()
-        be.lib.grappa_gemm_f32_set_splitk_reduce_launch(0)
+        be.splitk_reduce = 2                       # inside the product's own launch
         got = [run() for _ in range(3)]
     finally:
-        be.lib.grappa_gemm_f32_set_splitk_reduce_launch(-1)
+        be.splitk_reduce = 0
     for r in got:
         for a, b in zip(want, r):
             assert torch.equal(a, b)
 
 
 def test_tail_launches_can_be_switched_off_and_the_model_does_so_on_four_streams():
-    """grappa_gemm_f32_set_tail_launches: the planner stops cutting the K of the last partial round; the product is the same to fp32
+    """grappa_gemm_desc.plan_tail (C ABI 10; a process-wide setter before): the planner stops cutting the K of the last partial round; the product is the same to fp32
     summation order; `WriteParameters` turns the tails off while its heads keep four streams busy and on again on one stream, unless pinned"""
     from grappa_amd import GrappaModel
     from grappa_amd.backend import get_backend
@@ -180,8 +180,12 @@ def test_tail_launches_can_be_switched_off_and_the_model_does_so_on_four_streams
     be = get_backend()
 
     def plan(M, N, K):
+        from grappa_amd import _lib
+        d = _lib.GemmDesc()
+        d.M, d.N, d.K, d.precision = M, N, K, 5
+        be._call_options(d)                      # the options this backend would send with the product
         v = [ctypes.c_int() for _ in range(5)]
-        be.lib.grappa_gemm_f32_plan(M, N, K, 5, *[ctypes.byref(x) for x in v])
+        be.lib.grappa_gemm_f32_plan_desc(ctypes.byref(d), *[ctypes.byref(x) for x in v])
         return [x.value for x in v]
 
     try:

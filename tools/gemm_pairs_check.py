@@ -46,8 +46,12 @@ def ws_for(M, N, K):
     return torch.empty(max(lib.grappa_gemm_f32_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=dev)
 
 
+EXTRA = {}          # descriptor fields added to every product (plan_cfg, plan_nsplit, plan_tail ...: C ABI 10's per-call options)
+
+
 def gemm(a, b, out, M, N, K, a_amax, b_amax, pairs, b_kcontig=True, ws=None, **kw):
     d = _lib.GemmDesc()
+    kw = {**EXTRA, **kw}
     d.M, d.N, d.K, d.a_kcontig, d.b_kcontig = M, N, K, 1, int(b_kcontig)
     if pairs == "b":                        # "weight pairs": fp32 A, the weight in pairs
         d.A, d.lda = a.data_ptr(), a.stride(0)
@@ -70,7 +74,8 @@ def gemm(a, b, out, M, N, K, a_amax, b_amax, pairs, b_kcontig=True, ws=None, **k
         else:
             setattr(d, k, v)
     d.precision = F16X3
-    ws = ws if ws is not None else ws_for(M, N, K)
+    if ws is None:
+        ws = torch.empty(max(lib.grappa_gemm_f32_workspace_bytes_desc(C.byref(d)), 16), dtype=torch.uint8, device=dev)
     rc = lib.grappa_gemm_f32(stream(), C.byref(d), ws.data_ptr(), ws.numel())
     assert rc == 0, rc
     return ws

@@ -79,7 +79,7 @@ def main():
         ms = []
         for mode_cfg in modes:
             mode, _, cfg = mode_cfg.partition("@")       # "f32_bf16x6@7": force tile configuration 7 (plan override)
-            be.lib.grappa_gemm_f32_set_plan_override(int(cfg) if cfg else -1, 0, -1)
+            be.plan_override = (int(cfg), 0, -1) if cfg else None
             for _ in range(2):
                 be.gemm(A, B, C, M=M, N=N, K=K, a_kcontig=bool(ak), b_kcontig=bool(bk), precision=mode)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -89,7 +89,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms.append(e0.elapsed_time(e1) / 10)
-            be.lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+            be.plan_override = None
         rows.append((M, N, K, ak, bk, cnt, ms, 2.0 * M * N * K))
     print(f"{'M':>7} {'N':>5} {'K':>7} ak bk  cnt " + " ".join(f"{m + ' ms':>14} {'TF':>6}" for m in modes))
     for M, N, K, ak, bk, cnt, ms, fl in sorted(rows, key=lambda r: -r[5] * r[6][0]):

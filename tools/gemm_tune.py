@@ -1,6 +1,6 @@
 """Compare the GEMM launcher's cost-model plan with an exhaustive search over (tile config, split-K, tail) per workload shape:
    python tools/gemm_tune.py [precision]     (default f32_bf16x6)
-Uses grappa_gemm_f32_set_plan_override (tuning hook of the C ABI).  Prints, per shape, the model's plan and time, the best
+Uses grappa_gemm_desc.plan_cfg / plan_nsplit / plan_tail (the tuning fields of the C ABI, per call since ABI 10).  Prints, per shape, the model's plan and time, the best
 forced plan and time, and the step-weighted total of both."""
 import ctypes as C
 import os
@@ -11,6 +11,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _plan(lib, M, N, K, prec, v, cfg=-1, ns=0, tail=-1):
+    """the plan the library would choose under a forced configuration (C ABI 10: the force is a field of the product's descriptor)"""
+    from grappa_amd import _lib as _L
+    d = _L.GemmDesc()
+    d.M, d.N, d.K, d.precision = M, N, K, prec
+    d.plan_cfg, d.plan_nsplit, d.plan_tail = (cfg + 1 if cfg >= 0 else 0), max(ns, 0), (2 if tail == 0 else 3 if tail == 1 else 0)
+    return lib.grappa_gemm_f32_plan_desc(C.byref(d), *[C.byref(x) for x in v])
 
 
 def timeit(be, A, B, Cm, M, N, K, ak, bk, mode, reps=8):
@@ -43,7 +52,7 @@ def main():
         A = torch.randn((M, K) if ak else (K, M), device="cuda")
         B = torch.randn((N, K) if bk else (K, N), device="cuda")
         Cm = torch.empty((M, N), device="cuda")
-        lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+        be.plan_override = None
         v = [C.c_int() for _ in range(5)]
         lib.grappa_gemm_f32_plan(M, N, K, prec, *[C.byref(x) for x in v])
         model_plan = tuple(x.value for x in v)
@@ -54,8 +63,8 @@ def main():
         for cfg in cfgs:
             for ns in splits:
                 for tail in ((0, 1) if ns == 1 else (0,)):
-                    lib.grappa_gemm_f32_set_plan_override(cfg, ns, tail)
-                    lib.grappa_gemm_f32_plan(M, N, K, prec, *[C.byref(x) for x in v])
+                    be.plan_override = (cfg, ns, tail)
+                    _plan(lib, M, N, K, prec, v, cfg, ns, tail)
                     if v[2].value != ns or (v[0].value, v[1].value) != {5: (128, 128), 6: (256, 128), 0: (128, 128), 1: (64, 64), 4: (128, 64)}[cfg]:
                         continue            # the launcher cannot realise this forced plan (split too fine for K, ...)
                     if tail == 1 and v[4].value == 0:
@@ -66,7 +75,7 @@ def main():
                         continue
                     if t < best[0]:
                         best = (t, f"cfg{cfg} ns{ns} tail{tail}")
-        lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+        be.plan_override = None
         tot_model += cnt * t_model
         tot_best += cnt * best[0]
         rows.append((cnt * (t_model - best[0]), M, N, K, ak, bk, cnt, model_plan, t_model, best))

@@ -31,13 +31,13 @@ def main():
                 for ns in (1, 2, 4):
                     if K // ns < 128:
                         continue
-                    lib.grappa_gemm_f32_set_plan_override(cfg, ns, 0)
+                    g.EXTRA = {"plan_cfg": cfg + 1, "plan_nsplit": ns, "plan_tail": 2}
                     try:
                         t = g.timeit(lambda: g.gemm(ap if pairs else A, bp if pairs else W, out, M, N, K, am_a, am_b, pairs, ws=ws, bias=bias), n=20)
                     except AssertionError as e:
                         continue
                     res.append((t, "pairs" if pairs else "f32  ", cfg, ns))
-            lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+            g.EXTRA = {}
             t = g.timeit(lambda: g.gemm(ap if pairs else A, bp if pairs else W, out, M, N, K, am_a, am_b, pairs, ws=ws, bias=bias), n=20)
             res.append((t, "pairs" if pairs else "f32  ", -1, 0))
         print(f"M={M} N={N} K={K}:")

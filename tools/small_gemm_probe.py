@@ -11,6 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _plan(lib, M, N, K, prec, v, cfg=-1, ns=0, tail=-1):
+    """the plan the library would choose under a forced configuration (C ABI 10: the force is a field of the product's descriptor)"""
+    from grappa_amd import _lib as _L
+    d = _L.GemmDesc()
+    d.M, d.N, d.K, d.precision = M, N, K, prec
+    d.plan_cfg, d.plan_nsplit, d.plan_tail = (cfg + 1 if cfg >= 0 else 0), max(ns, 0), (2 if tail == 0 else 3 if tail == 1 else 0)
+    return lib.grappa_gemm_f32_plan_desc(C.byref(d), *[C.byref(x) for x in v])
+
+
 def main():
     from grappa_amd.backend import get_backend
     be = get_backend()
@@ -49,8 +58,8 @@ def main():
                 sa = be.amax(A, rows=True)
             row = []
             for ns in (0, 1, 2, 4, 7, 15):
-                lib.grappa_gemm_f32_set_plan_override(-1, ns, -1)
-                lib.grappa_gemm_f32_plan(M, N, K, 5, *[C.byref(x) for x in v])
+                be.plan_override = (-1, ns, -1)
+                _plan(lib, M, N, K, 5, v, ns=ns)
                 if ns and v[2].value != ns:
                     continue
                 try:
@@ -59,7 +68,7 @@ def main():
                     row.append(f"ns{ns}: {type(e).__name__}")
                     continue
                 row.append(f"{'model' if ns == 0 else 'ns' + str(ns)} ({v[0].value}x{v[1].value} ns{v[2].value}): {us:5.1f}")
-            lib.grappa_gemm_f32_set_plan_override(-1, 0, -1)
+            be.plan_override = None
             print(f"M={M:5d} N={N:4d} K={K:4d}  " + " | ".join(row))
     x = torch.randn(1024, device="cuda")
     y = torch.empty_like(x)
