@@ -143,7 +143,7 @@ def run_reference(cfg, mols, n_confs, state_dict=None, loss_kwargs=None, with_pa
     for k, p in model.named_parameters():          # named_parameters de-duplicates the gnn.blocks alias
         if p.grad is None:
             continue
-        if grads == "all":
+        if grads == "all" or (callable(grads) and grads(k)):
             out["grad::" + k] = to_np(p.grad)
         gn[k] = float(p.grad.norm())
     out["grad_norm_keys"] = np.array(list(gn.keys()))
@@ -497,6 +497,20 @@ def make_variants_golden(only=None):
         save(name, cfg, mols, out, None, extra)         # weights: golden_utils.keyed_state_dict on both sides (derived from the state-dict keys)
 
 
+def make_prod_nper3_golden():
+    """production widths in the SHIPPED experiment's setting (reference experiments/train-grappa-1.2.1/grappa_config.yaml:98-99:
+    n_periodicity_proper = 3, n_periodicity_improper = 3): outputs, every gradient norm, and the FULL gradients of the last symmetriser
+    layer of the four writer heads (`symmetriser.mlp.2.*`: the layers whose width follows n_periodicity) -- VERDICT r4 item 6c"""
+    loss_kwargs = dict(gradient_weight=0.8, energy_weight=1.0, param_weight=1e-3, proper_regularisation=1e-3, improper_regularisation=1e-3)
+    mols = build_inputs(pick_small(3, 12, 26, start=140), n_confs=4, seed=9)
+    cfg = get_default_model_config()
+    cfg["n_periodicity_proper"], cfg["n_periodicity_improper"] = 3, 3
+    out, sd, _ = run_reference(cfg, mols, 4, loss_kwargs=loss_kwargs, grads=lambda k: "symmetriser.mlp.2." in k)
+    assert sum(k.startswith("grad::") for k in out) >= 16, [k for k in out if k.startswith("grad::")]
+    extra = {"loss_kwargs_keys": np.array(list(loss_kwargs.keys())), "loss_kwargs_vals": np.array(list(loss_kwargs.values()))}
+    save("ref_prod_nper3.npz", cfg, mols, out, None, extra)
+
+
 def make_dataset_golden():
     """the reference's dataset-level logic (data/Dataset.py:80-112 `split`, :236-258 k-fold / partition splits through
     utils/torch_utils.py:11-135, :141-345, :259-294 `where` / `shuffle` / `subsampled`) on synthetic (mol_id, subdataset) lists with
@@ -550,6 +564,8 @@ if __name__ == "__main__":
         make_options_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "variants":
         make_variants_golden(sys.argv[2] if len(sys.argv) > 2 else None)
+    elif len(sys.argv) > 1 and sys.argv[1] == "prod_nper3":
+        make_prod_nper3_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "eval":
         make_eval_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "tuples":

@@ -86,6 +86,39 @@ def test_production_config_against_reference_golden():
     assert checked > 150
 
 
+def test_production_widths_in_the_shipped_experiment_setting_against_reference_golden():
+    """ref_prod_nper3.npz (oracle/make_goldens.py prod_nper3: the imported reference at production widths with n_periodicity_proper =
+    n_periodicity_improper = 3, experiments/train-grappa-1.2.1/grappa_config.yaml:98-99): outputs, every gradient norm, and the full gradients of
+    the four heads' last symmetriser layer (`symmetriser.mlp.2.*`, the layers whose width follows n_periodicity) on the HIP path"""
+    from grappa_amd import Energy, MolwiseLoss, model_from_config
+    fx = gu.load("ref_prod_nper3.npz")
+    cfg = gu.config_of(fx)
+    assert cfg["n_periodicity_proper"] == 3 and cfg["n_periodicity_improper"] == 3
+    model = model_from_config(cfg)
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model = model.to("cuda").eval()
+    g = gu.build_batch(gu.molecules_of(fx), 4, True).to("cuda")
+    g = Energy()(model(g))
+    loss = MolwiseLoss(**gu.loss_kwargs_of(fx))(g)
+    loss.backward()
+    out = gu.outputs_of(fx)
+    assert tuple(g.nodes["n4"].data["k"].shape[1:]) == (3,) and tuple(g.nodes["n4_improper"].data["k"].shape[1:]) == (3,)
+    _check_graph(g, out, loss)
+    full = {k[6:]: v for k, v in out.items() if k.startswith("grad::")}
+    assert len(full) >= 16
+    named = dict(model.named_parameters())
+    for k, ref in full.items():
+        scale = max(float(np.abs(ref).max()), 1e-8)
+        assert float(np.abs(named[k].grad.cpu().numpy() - ref).max()) / scale < TOL, k      # SURVEY 8(d): 1e-4 of the tensor's scale
+    norms = dict(zip(out["grad_norm_keys"].tolist(), out["grad_norm_vals"].tolist()))
+    checked = 0
+    for k, p in model.named_parameters():
+        if k in norms and norms[k] > 1e-6:
+            assert abs(float(p.grad.norm()) - norms[k]) / norms[k] < TOL, k
+            checked += 1
+    assert checked > 150
+
+
 def _oracle_step(cfg, sd, g_cpu, loss_kwargs, double=False):
     """double: the oracle in float64 -- ground truth instead of a second fp32 evaluation (whose own rounding, which moves with the
     host's thread count, is of the size of the tolerance for the torsion energies: sums of ~100 signed terms of small k)"""
@@ -165,7 +198,7 @@ def test_production_config_against_oracle_on_a_larger_batch():
     # The same quantities at SURVEY 8(d)'s own floors (k 1e-3 incl. the torsion constants, eq 1e-4, E 1e-3 kcal/mol, G 1e-2 kcal/mol/A --
     # absolute, not scaled with the tensor): three distances each -- GPU to float64, the fp32 ORACLE to float64 (what the reference's own
     # arithmetic can hold at these floors), GPU to the fp32 oracle.  Where the fp32 oracle itself is beyond 1e-4 of float64 the floors of
-    # this file are fp32's, not this engine's: gate = the GPU's distance from float64 is of the order of the fp32 oracle's own (within 3x -- measured <= 1.8x over the boxes and split-K plans of rounds 3 and 4; at these floors the measure sits on
+    # this file are fp32's, not this engine's: gate = the GPU's distance from float64 is of the order of the fp32 oracle's own (within 2x since round 5 -- measured <= 1.8x over the boxes and split-K plans of rounds 3 and 4; at these floors the measure sits on
     # a few elements that cancel to ~0, and moves by 2x with the summation order of a product -- split-K plan, thread count of the oracle)
     # (or inside the contract).
     def contract(got_g, ref_g):
@@ -184,8 +217,19 @@ def test_production_config_against_oracle_on_a_larger_batch():
     print("at SURVEY 8(d)'s floors --", "; ".join(lines))
     with open("gpurun_out/parity_distance_fp32_vs_fp64_oracle.txt", "a") as fh:
         fh.write("# at SURVEY 8(d)'s floors (k 1e-3, eq 1e-4, E 1e-3, G 1e-2, absolute)\n" + "\n".join(lines) + "\n")
+    ratios = {k: (gpu64[k] / ora64[k] if ora64[k] > 0 else float("inf")) for k in gpu64}
+    with open("gpurun_out/parity_distance_fp32_vs_fp64_oracle.txt", "a") as fh:
+        fh.write("# GPU's distance from float64 over the fp32 oracle's own, per quantity (gate: < 2, or the GPU inside 1e-4)\n" +
+                 "\n".join(f"{k}: {ratios[k]:.2f}" for k in sorted(ratios)) + "\n")
+    # gate 1 (was 3 x): the GPU is no further from float64 than twice what the reference's own fp32 arithmetic is, or inside the contract
     for k in gpu64:
-        assert gpu64[k] < max(TOL, 3.0 * ora64[k]), (k, gpu64[k], ora64[k])
+        assert gpu64[k] < max(TOL, 2.0 * ora64[k]), (k, gpu64[k], ora64[k])
+    # gate 2: the LITERAL north-star contract -- GPU against the fp32 CPU path within 1e-4 at SURVEY 8(d)'s absolute floors -- for
+    # the quantities fp32 itself holds there (bond / angle parameters, their energies, the total energy); the torsion constants and the forces
+    # are where the fp32 oracle is itself 2e-4 .. 2.5e-3 from float64 at these floors and stay under gate 1
+    for k in ("n2_k", "n2_eq", "n3_k", "n3_eq", "energy", "energy_n2", "energy_n3"):
+        assert ora64[k] < TOL, (k, "the fp32 oracle itself leaves the contract here", ora64[k])
+        assert gpu32[k] < TOL, (k, gpu32[k])
 
 
 def test_train_step_decreases_loss_and_matches_oracle_adam():
