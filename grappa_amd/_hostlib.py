@@ -32,11 +32,19 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C grappa_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = C.CDLL(LIB_PATH)
+    # the version first: a stale library lacks the newer symbols, and its callers expect RuntimeError (they fall back to numpy), not AttributeError
+    try:
+        lib.grappa_host_abi_version.restype = C.c_int
+        version = lib.grappa_host_abi_version()
+    except AttributeError:
+        version = None
+    if version != ABI_VERSION:
+        raise RuntimeError(f"libgrappa_host.so: ABI version {version}, this package needs {ABI_VERSION}: rebuild it (`make -C grappa_amd/csrc`)")
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError(f"libgrappa_host.so does not export {name}: rebuild it (`make -C grappa_amd/csrc`)")
         fn.restype, fn.argtypes = res, args
-    if lib.grappa_host_abi_version() != ABI_VERSION:
-        raise RuntimeError("libgrappa_host.so: ABI version mismatch")
     _lib = lib
     return lib
 

@@ -141,6 +141,7 @@ class CapturedForward:
         if self.refresh_weights:
             self.be.invalidate_weights()                     # every per-weight cache is stale now: the recorded forward starts by refreshing them
         self.weights_stamp = self._stamp()
+        self.config_stamp = self._config_stamp()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream), torch.no_grad():
             _drop_outputs(g)
@@ -159,9 +160,22 @@ class CapturedForward:
             ps = self._params = list(self.model.parameters())
         return (self.be._wepoch, sum(p._version for p in ps))
 
+    def _config_stamp(self):
+        """what is baked into the recorded launches besides the weights' values: the backend settings a product's plan and arithmetic
+        depend on, and WHICH tensors the parameters are (model.to(), load_state_dict(assign=True), p.data = ... replace them: the graph
+        would go on reading the old storage, which its pinned caches keep alive)"""
+        be = self.be
+        ps = self.__dict__.get("_params")
+        if ps is None:
+            ps = self._params = list(self.model.parameters())
+        return (be.gemm_precision_name, getattr(be, "gemm_precision_bwd", None), be.inference_pairs, be.training_pairs, be._tails, be.plan_override,
+                be.splitk_reduce, be.weight_pairs_min_rows, be.pairs_min_rows, tuple(p.data_ptr() for p in ps))
+
     def valid(self) -> bool:
         """the per-weight caches (maxima, pair splits) were filled OUTSIDE the graph: a graph captured before the weights changed must not be
-        replayed -- unless it refreshes them itself (refresh_weights)"""
+        replayed -- unless it refreshes them itself (refresh_weights).  Settings and parameter storage are checked in either mode."""
+        if self._config_stamp() != self.config_stamp:
+            return False
         return self.refresh_weights or self._stamp() == self.weights_stamp
 
     def replay(self):
@@ -266,8 +280,8 @@ class ForwardCache:
     """captured forwards by shape signature (`Grappa.predict`): a signature is captured the SECOND time it is seen (a one-off molecule
     never pays for a capture), at most `max_entries` graphs are kept (least recently used out)."""
 
-    def __init__(self, model, device, max_entries: int = 16):
-        self.model, self.device, self.max_entries = model, torch.device(device), int(max_entries)
+    def __init__(self, model, device, max_entries: int = 16, max_seen: int = 512):
+        self.model, self.device, self.max_entries, self.max_seen = model, torch.device(device), int(max_entries), int(max_seen)
         self.seen: Dict[tuple, int] = {}
         self.entries: "Dict[tuple, CapturedForward]" = {}
         self.refresh_weights = False                         # set once the weights were seen to change between two calls
@@ -277,13 +291,20 @@ class ForwardCache:
         sig = CapturedForward.signature(g_host)
         ent = self.entries.get(sig)
         if ent is not None and not ent.valid():
-            # the weights changed: every graph recorded so far reads stale per-weight caches.  From now on the graphs refresh them themselves
-            self.entries.clear()
-            self.refresh_weights = True
+            if ent._config_stamp() != ent.config_stamp:
+                # a backend setting or the parameters' storage changed: what the graphs recorded is no longer what an eager call would launch.
+                # Drop them; the signatures are recorded again (in the current mode) when they come back
+                self.entries.clear()
+            else:
+                # the weights' VALUES changed: every graph recorded so far reads stale per-weight caches.  From now on the graphs refresh them themselves
+                self.entries.clear()
+                self.refresh_weights = True
             ent = None
         if ent is None:
-            n = self.seen.get(sig, 0) + 1
-            self.seen[sig] = n
+            n = self.seen.pop(sig, 0) + 1
+            self.seen[sig] = n                               # (most recently seen last)
+            if len(self.seen) > self.max_seen:               # a long-running service sees arbitrarily many signatures: forget the oldest
+                self.seen.pop(next(iter(self.seen)))
             if n < 2:
                 return None
             if len(self.entries) >= self.max_entries:

@@ -30,10 +30,11 @@ class Grappa:
         return cls(model_from_tag(tag, models_dir), max_element, device)
 
     @classmethod
-    def from_file(cls, path, max_element=constants.MAX_ELEMENT, device: str = "cuda", config=None) -> "Grappa":
-        """an exported `.pth` container or a training checkpoint (`best-model.ckpt`) of the reference or of `grappa_amd.trainer`"""
+    def from_file(cls, path, max_element=constants.MAX_ELEMENT, device: str = "cuda", config=None, trusted=None) -> "Grappa":
+        """an exported `.pth` container or a training checkpoint (`best-model.ckpt`) of the reference or of `grappa_amd.trainer`.  trusted=True:
+        the caller vouches for a file that holds pickled objects beyond tensors (loading._torch_load; default: tensors only)"""
         from .loading import model_from_path
-        return cls(model_from_path(path, config), max_element, device)
+        return cls(model_from_path(path, config, trusted), max_element, device)
 
     def predict(self, molecule: Molecule) -> Parameters:
         if self.model.training:                  # (eval() walks every sub-module: 1 ms of a 7 ms call when there is nothing to switch)

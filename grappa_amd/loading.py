@@ -70,7 +70,6 @@ def model_dict_from_tag(tag: str, directory: Union[str, Path, None] = None) -> D
         path.parent.mkdir(parents=True, exist_ok=True)
         try:
             torch.hub.download_url_to_file(url, str(path))          # fetched, then loaded like any other file: tensors only
-            return _torch_load(path)
         except Exception as e:  # noqa: BLE001
             raise FileNotFoundError(f"{path} does not exist and {url} could not be fetched ({type(e).__name__}: {e}); "
                                     f"put the release file into {path.parent} or point GRAPPA_MODELS_DIR at its directory") from e
@@ -107,11 +106,11 @@ def _run_config_of(checkpoint: Path) -> Optional[Dict]:
     return None
 
 
-def model_dict_from_path(path: Union[str, Path], config: Optional[Dict] = None) -> Dict:
+def model_dict_from_path(path: Union[str, Path], config: Optional[Dict] = None, trusted: Optional[bool] = None) -> Dict:
     """an exported container as it is; a training checkpoint turned into one (prefixes stripped, `config` given or found in the run
     directory; a bare model config is accepted for `config`)"""
     path = Path(path)
-    d = _torch_load(path)
+    d = _torch_load(path, trusted)
     if not isinstance(d, dict) or "state_dict" not in d:
         raise ValueError(f"{path} holds neither an exported model nor a training checkpoint (no 'state_dict')")
     sd = d["state_dict"]
@@ -126,5 +125,6 @@ def model_dict_from_path(path: Union[str, Path], config: Optional[Dict] = None) 
     return {"state_dict": strip_training_prefixes(sd) if trained else sd, "config": cfg, "split_names": d.get("split_names")}
 
 
-def model_from_path(path: Union[str, Path], config: Optional[Dict] = None):
-    return model_from_dict(model_dict_from_path(path, config)).eval()
+def model_from_path(path: Union[str, Path], config: Optional[Dict] = None, trusted: Optional[bool] = None):
+    """trusted=True: the caller vouches for a file that holds pickled objects beyond tensors (see _torch_load)"""
+    return model_from_dict(model_dict_from_path(path, config, trusted)).eval()

@@ -204,7 +204,7 @@ def _ln_bwd(be, dy, x, mean, rstd, w, b, drop=None):
     db = _pgrad(b) if b.requires_grad else torch.zeros_like(b)
     if drop is not None and drop[0] > 0 and getattr(be, "drop_fusable", None) is not None and be.drop_fusable(x):
         sdx, dz, sz = be.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, db, accumulate=True, drop=drop)
-        dx._grappa_masked = (dz, sz, float(drop[0]), int(drop[1]))
+        dx._grappa_masked = (dz, sz, float(drop[0]), int(drop[1]), dx._version, dx.data_ptr())
         return dx, sdx
     sdx = be.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, db, accumulate=True)
     return dx, sdx
@@ -214,6 +214,10 @@ def _masked_grad(dy, drop_p, seed):
     """the dropout backward of dy if the kernel that produced dy wrote it already (see _ln_bwd) -> (dz, record) or None"""
     m = getattr(dy, "_grappa_masked", None)
     if m is None or m[2] != float(drop_p) or m[3] != int(seed) or m[0].shape != dy.shape:
+        return None
+    # the tensor must still hold what the kernel wrote: autograd accumulates a second consumer's gradient IN PLACE into the same object (its
+    # version counter moves) -- the precomputed dz would then be the backward of a part of the gradient only (ADVICE r4)
+    if m[4] != dy._version or m[5] != dy.data_ptr():
         return None
     return m[0], m[1]
 

@@ -210,11 +210,11 @@ class Trainer:
             torch.save(self._plain(self.checkpoint_dict()), tmp)
             os.replace(tmp, path)              # a run killed while writing leaves the previous checkpoint intact
 
-    def load_checkpoint(self, path: str) -> int:
+    def load_checkpoint(self, path: str, trusted=None) -> int:
         """-> the epoch the run continues with (`fit(max_epochs)` picks it up).  Every rank loads the same file."""
         from . import ops
         from .loading import _torch_load
-        ck = _torch_load(path)                   # tensors and plain containers only (a tampered file cannot run code)
+        ck = _torch_load(path, trusted)          # tensors and plain containers only (a tampered file cannot run code) unless the caller vouches
         if ck.get("format") != "grappa_amd.trainer/1":
             raise ValueError(f"{path} is not a trainer checkpoint of this engine (format {ck.get('format')!r})")
         self.model.load_state_dict(ck["model"]["state_dict"])

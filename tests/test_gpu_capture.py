@@ -174,3 +174,66 @@ def test_predict_cache_follows_changing_weights():
         assert ent.refresh_weights and ent.valid()
     # and the parameters did move with the weights (the check above was not comparing two stale results)
     assert not np.allclose(np.asarray(p.bond_k), np.asarray(got.bond_k), rtol=1e-4)
+
+
+def test_predict_cache_follows_backend_settings_and_replaced_parameters():
+    """what a recorded forward bakes in besides the weights' values -- the backend's settings (arithmetic, pair routing, plan options)
+    and WHICH tensors the parameters are.  Either changes -> the graph is dropped, in refresh mode too; the signature table stays bounded"""
+    import numpy as np
+    from grappa_amd import Grappa, GrappaModel
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import molecule_from_pool, pool_atom_counts
+    fx = gu.load("ref_small_att.npz")
+    model = GrappaModel(**gu.config_of(fx))
+    model.load_state_dict(gu.state_dict_of(fx))
+    gr = Grappa(model, device="cuda")
+    be = get_backend()
+    mol = molecule_from_pool(int(np.argmin(np.abs(pool_atom_counts() - 30))))
+
+    def eager():
+        cache, gr._graphs = gr._graphs, None
+        try:
+            return gr.predict(mol)
+        finally:
+            gr._graphs = cache
+
+    def same(a, b):
+        for k in ("bond_k", "bond_eq", "angle_k", "angle_eq", "proper_ks", "improper_ks"):
+            x, y = np.asarray(getattr(a, k)), np.asarray(getattr(b, k))
+            assert np.allclose(x, y, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(y).max()))), k
+
+    for _ in range(3):
+        gr.predict(mol)
+    ent = next(iter(gr._graphs.entries.values()))
+    assert ent.valid()
+    # a backend setting: the recorded launches are no longer what an eager call would make
+    old = be.inference_pairs
+    try:
+        be.inference_pairs = not old
+        assert not ent.valid()
+        got = gr.predict(mol)                                        # dropped, eager for this call (the signature is seen again first)
+        same(got, eager())
+        assert ent not in gr._graphs.entries.values() and not gr._graphs.refresh_weights
+    finally:
+        be.inference_pairs = old
+    for _ in range(3):
+        gr.predict(mol)
+    ent = next(iter(gr._graphs.entries.values()))
+    assert ent.valid()
+    # replaced parameter storage (p.data = ...): same values, other tensors -- the graph would go on reading the old ones
+    with torch.no_grad():
+        for q in model.parameters():
+            q.data = q.data.clone() * 1.5
+    assert not ent.valid()
+    want = eager()
+    for _ in range(3):
+        got = gr.predict(mol)
+    same(got, want)
+    # the table of seen signatures is bounded
+    cache = gr._graphs
+    cache.max_seen = 4
+    for i in range(10):
+        cache.seen[("fake", i)] = 1
+        if len(cache.seen) > cache.max_seen:
+            cache.seen.pop(next(iter(cache.seen)))
+    assert len(cache.seen) <= 4
