@@ -375,7 +375,8 @@ int pairs_cfg() {
     return t == 256 ? 7 : 6;
 }
 
-Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false, bool pairs_small = false) {
+Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false, bool pairs_small = false,
+               bool planes_tile256 = false) {
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
@@ -398,7 +399,7 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
         if (opt.cfg >= 0 && c != opt.cfg && !planes) continue;
         if (bf16x != (c >= 5)) continue;
         // the plane-format kernels have one tile shape each; the pair kernel (both operands pairs) also a 128 x 128 one
-        if (planes && c != (pairs ? pairs_cfg() : 6) && !(pairs_small && c == 8)) continue;
+        if (planes && c != (pairs ? pairs_cfg() : (planes_tile256 ? 7 : 6)) && !(pairs_small && c == 8)) continue;
         if (!planes && (c == 7 || c == 8)) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
@@ -409,7 +410,9 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
         for (int ns = 1; ns <= max_split; ns = ns < 4 ? ns + 1 : ns + (ns + 3) / 4) {
             if (opt.nsplit > 0 && ns != opt.nsplit) continue;
             int kps = (K + ns - 1) / ns;
-            kps = (kps + BK - 1) / BK * BK;
+            const int kround = (planes_tile256 && c == 7) ? 64 : BK;      // (the bf16 pinned-pipeline kernel walks pairs of 32-deep slabs)
+            kps = (kps + kround - 1) / kround * kround;
+            if (planes_tile256 && c == 7 && kps < 128) continue;
             const int nsplit = (K + kps - 1) / kps;
             double cost = cm.grid(c, tiles * nsplit, kps);
             if (nsplit > 1) cost += CostModel::splitk(nsplit, (double)M * N);
@@ -514,6 +517,8 @@ static size_t workspace_floats_all(int M, int N, int K, const PlanOpts& o) {
         if (f > a) a = f;
         const size_t g = plan_workspace_floats(make_plan(M, N, K, o, true, true, true, true, true), M, N);
         if (g > a) a = g;
+        const size_t h = plan_workspace_floats(make_plan(M, N, K, o, true, true, true, false, false, true), M, N);
+        if (h > a) a = h;
     }
     return a;
 }
@@ -818,7 +823,13 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     }
     static const bool small_tile = !(getenv("GRAPPA_PAIRS_SMALL_TILE") && atoi(getenv("GRAPPA_PAIRS_SMALL_TILE")) == 0);
     const PlanOpts popt = plan_opts_of(*d);
-    Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0);
+    // experiment (GRAPPA_BF16_TILE=256): the bf16 storage configuration's K-contiguous one-plane products on the 256 x 256 tile of the pinned-pipeline
+    // kernel (gemm_pairs_il.hip ARITH 1) -- 31 instead of 47 operand bytes per CU-cycle, and no faster: at K = N = 512 these products are bound by
+    // their HBM bytes (1.2 GB per 400 k-row product: 250 us at 5 TB/s against 84 us of MFMAs), not by the intake (C3 bf16 step 75.7 ms either way)
+    static const bool bf16_tile256 = getenv("GRAPPA_BF16_TILE") && atoi(getenv("GRAPPA_BF16_TILE")) == 256;
+    const bool bf16_il256 = bf16_tile256 && planes && !pairs && d->precision == GRAPPA_GEMM_BF16 && d->a_planes && d->a_kcontig && d->b_kcontig && (d->K & 63) == 0 && d->K >= 128 &&
+                            (size_t)d->M * d->lda * 2 < (1ull << 32) && (size_t)d->N * d->ldb * 2 < (1ull << 32);
+    Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0, bf16_il256);
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     if (d->plan_cfg < 0 || d->plan_cfg > NCFG || d->plan_nsplit < 0 || d->plan_tail < 0 || d->plan_tail > 3 || d->splitk_reduce < 0 || d->splitk_reduce > 2) return GRAPPA_ERR_ARG;
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);

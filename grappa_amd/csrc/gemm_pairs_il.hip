@@ -33,11 +33,19 @@ struct SgRep<0, NM, MASK> {
     static __device__ __forceinline__ void emit() {}
 };
 
-template <int QBN, int QBMt>
+// ARITH 0: the pair format (fp16 hi / lo, three products per slab of 16 k).  ARITH 1 (round 5, the bf16 STORAGE configuration, BASELINE
+// configs[2]): both operands plain bf16 rows (one plane), a 64-byte granule = 32 k, two v_mfma_f32_32x32x16_bf16 per accumulator and slab.
+// Same tile, ring, LDS image and fragment addresses (the "hi" chunks are k 0 .. 15 of the granule, the "lo" chunks k 16 .. 31); no row scales.
+// The plane kernel this replaces for forward / input-gradient products (gemm_planes.hip, 8 wavefronts of 64 x 64, two barriers per slab of
+// 8 MFMAs) ran at 0.2 of the bf16 peak.
+typedef __bf16 bf16x8_il __attribute__((ext_vector_type(8)));
+
+template <int QBN, int QBMt, int ARITH = 0>
 struct PairsIL {
     using S = QShape<QBN, QBMt>;
     static constexpr int TM = S::TM;
-    static constexpr int NMFMA = 3 * TM * QTN, NREAD = 2 * (TM + QTN), NDMA = S::PIECES;
+    static constexpr int KSLAB = ARITH == 1 ? 32 : QSLAB;          // k per 64-byte granule
+    static constexpr int NMFMA = (ARITH == 1 ? 2 : 3) * TM * QTN, NREAD = 2 * (TM + QTN), NDMA = S::PIECES;
     // reads ride on the first MFMAs (one or two per MFMA), copies on the following ones
     static constexpr int READS_PER_MFMA = NREAD <= NMFMA / 2 ? 1 : 2;
     static constexpr int MFMA_WITH_READS = NREAD / READS_PER_MFMA;
@@ -61,6 +69,20 @@ struct PairsIL {
         __builtin_amdgcn_sched_group_barrier(SG_MFMA, NMFMA, 0);      // whatever MFMAs are left
     }
 
+    static __device__ __forceinline__ void mfma_slab(const QFrags<TM>& f, f32x16 (&acc)[TM][QTN]) {
+        if (ARITH == 0) {
+            qmfma<TM>(f, acc);
+        } else {
+#pragma unroll
+            for (int pk = 0; pk < 2; ++pk)                         // k 0 .. 15, then 16 .. 31 of the granule
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < QTN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_il, f.b[j][pk]), __builtin_bit_cast(bf16x8_il, f.a[i][pk]), acc[i][j], 0, 0, 0);
+        }
+    }
+
     static __device__ __forceinline__ void run(const GemmParams& p, int nwg, int wgid) {
         constexpr int QSTAGE = S::STAGE, QPIECES = S::PIECES;
         extern __shared__ char smem[];
@@ -75,7 +97,7 @@ struct PairsIL {
         const int kend = min(d.K, kbeg + p.k_per_split);
         // an EVEN number of slabs >= 4 (host): the rows are zero beyond K up to the next multiple of 32 -- the step pair of the unrolled loop
         // then always leaves exactly four steps behind it, ONE tail path
-        const int nslab = (kend - kbeg + 2 * QSLAB - 1) / (2 * QSLAB) * 2;
+        const int nslab = (kend - kbeg + 2 * KSLAB - 1) / (2 * KSLAB) * 2;
 
 #if GQ_STAMP
         unsigned long long q_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q_wait = 0, q_ta = 0, q_tb = 0;
@@ -101,7 +123,8 @@ struct PairsIL {
         const int rin = lane >> 2, ch = (lane & 3) ^ ((lane >> 4) & 3);
         const int voffA = ((wave * 16 + rin) * d.lda + 8 * ch) * 2, voffB = ((wave * 16 + rin) * d.ldb + 8 * ch) * 2;
         const int strideA = S::NW * 16 * d.lda * 2, strideB = S::NW * 16 * d.ldb * 2;      // bytes between a wavefront's pieces
-        const int sA0 = m0 * d.lda * 2 + kbeg * 4, sB0 = n0 * d.ldb * 2 + kbeg * 4;        // 16 k = 64 bytes of a row
+        const int kb0 = kbeg * (64 / KSLAB);                                              // 16 k (pairs) or 32 k (bf16) = 64 bytes of a row
+        const int sA0 = m0 * d.lda * 2 + kb0, sB0 = n0 * d.ldb * 2 + kb0;
         auto issue = [&](int slab, char* stage) {
 #pragma unroll
             for (int q = 0; q < S::A_PIECES; ++q)
@@ -142,7 +165,7 @@ struct PairsIL {
         }                                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                                             \
         GI_STAMP_B                                                                                                                     \
-        qmfma<TM>(FC, acc);                                                                                                            \
+        mfma_slab(FC, acc);                                                                                                            \
         if (READ) qread_frags<TM>(smem + st * QSTAGE, S::A_BYTES, off, wm0, wn0, FN);                                                  \
         if (ISSUE) issue((T) + QNSTAGE, cur_);                                                                                         \
         pattern<ISSUE, READ>();                                                                                                        \
@@ -162,7 +185,7 @@ struct PairsIL {
         q_wait += q_tb - q_ta;
         q_t[3] = __builtin_amdgcn_s_memtime();
 #endif
-        pairs_finish<QBN, QBMt>(p, acc, smem, m0, n0, wm0, wn0, wave, lane, split, tile_local);
+        pairs_finish<QBN, QBMt, ARITH == 0>(p, acc, smem, m0, n0, wm0, wn0, wave, lane, split, tile_local);
 #if GQ_STAMP
         q_t[4] = __builtin_amdgcn_s_memtime();                    // (issue of the last store; scale-back and epilogue are one phase here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,6 +206,9 @@ struct PairsIL {
 template <int QBN>
 __global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_pairs_il_kernel(GemmParams p) { PairsIL<QBN, QBM>::run(p, gridDim.x, blockIdx.x); }
 __global__ __launch_bounds__(256, 2) void gemm_pairs_il_small_kernel(GemmParams p) { PairsIL<128, 128>::run(p, gridDim.x, blockIdx.x); }
+
+template <int QBN>
+__global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_bf16_il_kernel(GemmParams p) { PairsIL<QBN, QBM, 1>::run(p, gridDim.x, blockIdx.x); }
 
 template <int BN, int BM, typename K>
 int launch_il(hipStream_t st, GemmParams& p, K kern, bool& attr_set) {
@@ -212,4 +238,12 @@ int grappa_launch_gemm_pairs_il(hipStream_t st, GemmParams& p) {
     if (p.bm == 128) return launch_il<128, 128>(st, p, gemm_pairs_il_small_kernel, a0);
     if (p.bn == 256) return launch_il<256, QBM>(st, p, gemm_pairs_il_kernel<256>, a1);
     return launch_il<128, QBM>(st, p, gemm_pairs_il_kernel<128>, a2);
+}
+
+// both operands ONE bf16 plane, K-contiguous, K (and every K cut) a multiple of 64, at least four slabs of 32 per workgroup, tile 256 x 128
+// (the caller checks): the bf16 storage configuration's forward / input-gradient products
+int grappa_launch_gemm_bf16_il(hipStream_t st, GemmParams& p) {
+    static bool a0 = false, a1 = false;
+    if (p.bn == 256) return launch_il<256, QBM>(st, p, gemm_bf16_il_kernel<256>, a1);
+    return launch_il<128, QBM>(st, p, gemm_bf16_il_kernel<128>, a0);
 }

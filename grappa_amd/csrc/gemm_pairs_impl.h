@@ -107,7 +107,8 @@ __device__ inline void qmfma(const QFrags<TM>& f, f32x16 (&acc)[TM][QTN]) {
 
 // the tail of a tile, shared by the kernels that end with the ring dead: undo the row scales, then the row epilogue through the (reused)
 // LDS.  acc element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, wn0 + 32 j + 8 (e / 4) + 4 lh + e % 4)
-template <int QBN, int QBMt>
+// SCALED = false: the accumulators are final as they stand (plain bf16 operands: no row scales to undo)
+template <int QBN, int QBMt, bool SCALED = true>
 __device__ __forceinline__ void pairs_finish(const GemmParams& p, f32x16 (&acc)[QShape<QBN, QBMt>::TM][QTN], char* smem, int m0, int n0, int wm0, int wn0, int wave,
                                              int lane, int split, int tile_local) {
     using S = QShape<QBN, QBMt>;
@@ -115,7 +116,7 @@ __device__ __forceinline__ void pairs_finish(const GemmParams& p, f32x16 (&acc)[
     const grappa_gemm_desc& d = p.d;
     const int lr = lane & 31, lh = lane >> 5;
     // undo the row scales: accumulator element e of block (i, j) is (m, n) = (wm0 + 32 i + lr, wn0 + 32 j + 8 (e / 4) + 4 lh + e % 4)
-    {
+    if (SCALED) {
         int ea[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) ea[i] = amax_shift(d.a_amax[min(m0 + wm0 + i * 32 + lr, d.M - 1)]);

@@ -28,9 +28,12 @@
 // (115 -> 145 VGPRs: the bf16 storage configuration's step went 86 -> 91 ms with them, 99 ms with the registers but without the classes)
 #define GRAPPA_NO_FAST_EPI
 #define GRAPPA_EPI_RES_LN 0          // (the host refuses res_ln for the plane kernels)
+#include <cstdlib>
 #include "gemm_common.h"
 
 using namespace grappa_gemm;
+
+int grappa_launch_gemm_bf16_il(hipStream_t st, GemmParams& p);      // gemm_pairs_il.hip
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -676,7 +679,16 @@ int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision) {
         case GRAPPA_GEMM_F32_MFMA:                      // plane operands carry no fp32 copy: the fp32-grade product is the x6 one
         case GRAPPA_GEMM_F32_BF16X6: return launch_planes_layout<PX6>(st, p);
         case GRAPPA_GEMM_BF16X3: return launch_planes_layout<PX3>(st, p);
-        case GRAPPA_GEMM_BF16: return launch_planes_layout<PX1>(st, p);
+        case GRAPPA_GEMM_BF16: {
+            // round 5: K-contiguous one-plane products take the pinned pipeline of gemm_pairs_il.hip (GRAPPA_BF16_IL=0: the plane kernel)
+            static const bool il = !(getenv("GRAPPA_BF16_IL") && atoi(getenv("GRAPPA_BF16_IL")) == 0);
+            const int kk = p.d.K < p.k_per_split ? p.d.K : p.k_per_split;
+            if (il && p.d.a_kcontig && p.d.b_kcontig && p.bm == 256 && (p.bn == 128 || p.bn == 256) && (p.d.K & 63) == 0 && (p.k_per_split & 63) == 0 && kk >= 128 &&
+                (size_t)p.d.M * p.d.lda * 2 < (1ull << 32) && (size_t)p.d.N * p.d.ldb * 2 < (1ull << 32))
+                return grappa_launch_gemm_bf16_il(st, p);
+            if (p.bn != 128) return GRAPPA_ERR_ARG;              // (the plane kernel has the 256 x 128 tile only: the plan and this check agree by construction)
+            return launch_planes_layout<PX1>(st, p);
+        }
         default: return GRAPPA_ERR_ARG;
     }
 }
