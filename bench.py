@@ -536,7 +536,18 @@ def main():
                                "scaling": None, "n_gpus": 1, "gemm_precision": be.gemm_precision_name,
                                "activation_storage": "bf16" if bf16 else "f32", "final_loss": l2, "config": j2.describe()}
                 r2, g2, _, _ = instrument(j2, 2 if key != "scale_n1" else 1)
-                for k_ in ("traffic", "traffic_source"):        # PMC counters cannot be read in-process: only the headline carries a committed summary
+                # PMC counters cannot be read in-process: a committed rocprofv3 --pmc summary of the same workload and storage is reported while the
+                # kernel sources it was measured on are the ones running (profiles/pmc_traffic_c3.json, pmc_traffic_c3_bf16.json: tools/pmc_only.sh)
+                tp2 = os.path.join(ROOT, "profiles", {"c3": "pmc_traffic_c3.json", "c3_bf16": "pmc_traffic_c3_bf16.json"}.get(key, "-"))
+                if os.path.exists(tp2):
+                    try:
+                        tj2 = json.load(open(tp2))
+                        if tj2.get("kernel_source_hash") == kernel_source_hash():
+                            r2["traffic"] = tj2["families"]["dense_products"]["hbm_bytes_per_step"] / max(r2["launches_per_step"], 1.0)
+                            r2["traffic_source"] = f"profiles/{os.path.basename(tp2)} (as the headline's)"
+                    except Exception:
+                        pass
+                for k_ in ("traffic", "traffic_source"):
                     if r2.get(k_) is None:
                         r2.pop(k_, None)
                 extras[key]["roofline"], extras[key]["roofline_gat"] = r2, g2

@@ -607,7 +607,7 @@ class HipBackend:
         w_only = (a_pairs is None and planes_a is None and planes_b is None and a_kcontig and big and M >= self.weight_pairs_min_rows
                   and d.precision == _lib.GEMM_PRECISIONS["f32_f16x3"] and precision is None and self.gemm_precision_bwd is None and K % 32 == 0
                   and a.dtype == torch.float32 and b.dtype == torch.float32 and b.requires_grad and a_colsum is None
-                  and a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and a.stride(1) == 1 and getattr(a_scales, "parts", None) is None
+                  and a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and a.stride(1) == 1
                   and M * a.stride(0) * 4 < 2 ** 32)      # (the LDS-DMA kernels address an operand through 32-bit offsets)
         if a_pairs is not None:
             # forward: B = the pairs of W (rows = out features); input gradient (b_kcontig False): B = the pairs of W^T (rows = in features)
@@ -620,13 +620,18 @@ class HipBackend:
         elif w_only:
             w_pairs = self._pairs_of_weight(b, transposed=not b_kcontig)
             wm = self._amax_of_weight(b)
-            sa_w = self.amax(a, a_scales, rows=True)
-            if sa_w.row.numel() != M:
-                raise ValueError("gemm: operand maxima do not match the operands")
+            if a_scales is not None and a_scales.row is None and a_scales.parts is not None and a_scales.parts.numel() == a_scales.nseg * M:
+                sa_w, am_w = a_scales, a_scales.parts          # the producer's per-segment partials: the kernel combines them (a_amax_nseg)
+                d.a_amax_nseg = a_scales.nseg
+            else:
+                sa_w = self.amax(a, a_scales, rows=True)
+                am_w = sa_w.row
+                if am_w.numel() != M:
+                    raise ValueError("gemm: operand maxima do not match the operands")
             d.A, d.lda = a.data_ptr(), _f32_2d(a, "A", dev)
             d.B, d.ldb, d.b_planes = w_pairs.data_ptr(), w_pairs.stride(0), 1
             d.a_kcontig, d.b_kcontig = 1, 1
-            d.a_amax, d.b_amax = sa_w.row.data_ptr(), (wm.row if b_kcontig else wm.col).data_ptr()
+            d.a_amax, d.b_amax = am_w.data_ptr(), (wm.row if b_kcontig else wm.col).data_ptr()
         elif planes_a is not None:
             d.A, d.lda, d.a_planes, d.a_plane_stride = planes_a.data_ptr(), planes_a.stride(0), 1, 0
             _f32_2d(planes_a, "A", dev, bf16)

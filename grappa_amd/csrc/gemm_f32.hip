@@ -396,10 +396,11 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
     int max_tail_split = K >= 8 * BK ? K / (4 * BK) : 1;      // the tail may be cut finer than a full split-K GEMM
     if (max_tail_split > 64) max_tail_split = 64;
     for (int c = 0; c < NCFG; ++c) {
-        if (opt.cfg >= 0 && c != opt.cfg && !planes) continue;
+        const bool forced_pairs = pairs && opt.cfg >= 6 && opt.cfg <= 8;       // tuning: the pair kernels' tile (6: 256 x 128, 7: 256 x 256, 8: 128 x 128) can be forced too
+        if (opt.cfg >= 0 && c != opt.cfg && (!planes || forced_pairs)) continue;
         if (bf16x != (c >= 5)) continue;
         // the plane-format kernels have one tile shape each; the pair kernel (both operands pairs) also a 128 x 128 one
-        if (planes && c != (pairs ? pairs_cfg() : (planes_tile256 ? 7 : 6)) && !(pairs_small && c == 8)) continue;
+        if (planes && !forced_pairs && c != (pairs ? pairs_cfg() : (planes_tile256 ? 7 : 6)) && !(pairs_small && c == 8)) continue;
         if (!planes && (c == 7 || c == 8)) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
@@ -830,6 +831,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool bf16_il256 = bf16_tile256 && planes && !pairs && d->precision == GRAPPA_GEMM_BF16 && d->a_planes && d->a_kcontig && d->b_kcontig && (d->K & 63) == 0 && d->K >= 128 &&
                             (size_t)d->M * d->lda * 2 < (1ull << 32) && (size_t)d->N * d->ldb * 2 < (1ull << 32);
     Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0, bf16_il256);
+    if (pairs && !d->a_planes && pl.cfg != 6) return GRAPPA_ERR_ARG;      // (fp32 A + weight pairs: the 256 x 128 tile only)
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     if (d->plan_cfg < 0 || d->plan_cfg > NCFG || d->plan_nsplit < 0 || d->plan_tail < 0 || d->plan_tail > 3 || d->splitk_reduce < 0 || d->splitk_reduce > 2) return GRAPPA_ERR_ARG;
     const size_t need = plan_workspace_floats(pl, d->M, d->N) * sizeof(float);
@@ -873,7 +875,9 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     // one small launch combines them; the native fp32 kernel (tiny or non-default products) leaves them to one pass over its output
     const bool amax_fused = (d->out_amax || d->out_amax_parts) && bf16x;
     if (d->out_amax_parts && (!bf16x || d->out_amax)) return GRAPPA_ERR_ARG;          // partials: the split kernels' epilogue only, instead of out_amax
-    if (d->a_amax_nseg > 1 && (!d->a_kcontig || planes || !bf16x || (d->amax_bcast & 1))) return GRAPPA_ERR_ARG;   // a consumer of partials: fp32 A of the split kernels
+    // a consumer of partials: fp32 A of the split kernels, or (round 5) of the pinned-pipeline weight-pairs kernel (the round-3 weight-pairs loop has no combine)
+    const bool wpairs_il_ok = pairs && !d->a_planes && (d->K & 31) == 0 && d->K >= 64;
+    if (d->a_amax_nseg > 1 && (!d->a_kcontig || (planes && !wpairs_il_ok) || !bf16x || (d->amax_bcast & 1))) return GRAPPA_ERR_ARG;
     if (d->out_amax && !amax_fused && !d->C) return GRAPPA_ERR_ARG;
     p.amax_part = nullptr;
     p.amax_seg = 32;                                        // segments of 32 columns whatever the tile (ABI 8: the consumer may combine them)

@@ -74,7 +74,14 @@ __global__ __launch_bounds__(256, 2) void gemm_wpairs_il_kernel(GemmParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     int sh[WTM];
 #pragma unroll
-    for (int i = 0; i < WTM; ++i) sh[i] = amax_shift(d.a_amax[min(m0 + wm0 + i * 32 + lr, d.M - 1)]);
+    for (int i = 0; i < WTM; ++i) {
+        // the row's largest magnitude: one array, or the maximum over the per-segment partials its producer's epilogue left (a_amax_nseg, C ABI 8):
+        // the combine launch between two products goes away
+        const int row = min(m0 + wm0 + i * 32 + lr, d.M - 1);
+        unsigned v = d.a_amax[row];
+        for (int sg = 1; sg < d.a_amax_nseg; ++sg) v = max(v, d.a_amax[(size_t)sg * d.M + row]);
+        sh[i] = amax_shift(v);
+    }
 
     // buffer resources: A rows are fp32 (lda floats apart), B rows pairs (ldb fp16 apart); rows beyond M / N read as zeros
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, (int)((unsigned)d.M * (unsigned)d.lda * 4u), 0x00020000);
