@@ -63,7 +63,15 @@ __device__ inline int amax_shift(unsigned bits) { return 141 - (int)((bits >> 23
 // largest magnitude of row m of A: one array, or the maximum over the per-segment partials its producer left (grappa_gemm_desc.a_amax_nseg)
 __device__ inline unsigned a_row_amax(const grappa_gemm_desc& d, int m) {
     unsigned v = d.a_amax[m];
-    for (int s = 1; s < d.a_amax_nseg; ++s) v = max(v, d.a_amax[(size_t)s * d.M + m]);
+    // (eight independent loads in flight per trip: one load per trip is one L2 round trip per segment, 16 in a row for a 512-wide producer,
+    //  in the prologue of a kernel that has nothing else to do yet -- measured +1.1 ms per C2 step)
+    for (int s0 = 1; s0 < d.a_amax_nseg; s0 += 8) {
+        unsigned t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = d.a_amax[(size_t)min(s0 + u, d.a_amax_nseg - 1) * d.M + m];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = max(v, t[u]);
+    }
     return v;
 }
 

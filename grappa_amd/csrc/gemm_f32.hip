@@ -368,7 +368,33 @@ struct CostModel {
         return (double)((wgs + ncu * conc - 1) / (ncu * conc)) * conc * t;
     }
     static double splitk(int nsplit, double elems) { return 14000.0 + nsplit * elems / 200.0; }   // two launches + slab write / reduce (the reduction launch alone: 5.4 us)
+
+    // The pinned-pipeline pair kernels (gemm_pairs_il.hip), round 5: a launch is a staircase of rounds of one workgroup per CU (the 128 x 128 tile's two
+    // co-resident workgroups share the CU's MFMA time: rounds of half the length), fitted to profiles/r5_pairs_tile_sweep.txt (15 row counts x 6 layer
+    // shapes x 3 tiles; us at the chip's ~2.1 GHz -> the model's cycles).  256 x 256: a round that fills the chip runs 2x longer than a lone workgroup
+    // (the operand intake is shared), so its last, partly filled round is priced by its fill.
+    double pairs_grid(int c, long wgs, int kps) const {
+        const double ncu = (double)plan_cus();
+        const long rounds = (long)((wgs + ncu - 1) / ncu);
+        double us;
+        if (c == 6) {
+            us = rounds * 0.034 * (kps + 132.0) * ((rounds >= 3 && kps > 1024) ? 1.17 : 1.0);
+        } else if (c == 8) {
+            us = rounds * 0.019 * (kps + 150.0) * ((rounds >= 5 && kps > 1024) ? 1.2 : 1.0);
+        } else {
+            const double lone = 14.0 + 0.019 * kps, full = 16.0 + 0.069 * kps;
+            const double fill = (double)(wgs - (rounds - 1) * (long)ncu) / ncu;
+            us = (rounds - 1) * full + lone + fill * (full - lone);
+        }
+        return us * 2100.0;
+    }
 };
+
+// GRAPPA_PAIRS_TILE_CHOICE=0: the round-4 planner (one tile for the pair kernels, the generic cost model)
+bool pairs_tile_choice() {
+    static const bool on = !(getenv("GRAPPA_PAIRS_TILE_CHOICE") && atoi(getenv("GRAPPA_PAIRS_TILE_CHOICE")) == 0);
+    return on;
+}
 
 int pairs_cfg() {
     static const int t = getenv("GRAPPA_PAIRS_TILE") ? atoi(getenv("GRAPPA_PAIRS_TILE")) : 128;
@@ -400,7 +426,8 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
         if (opt.cfg >= 0 && c != opt.cfg && (!planes || forced_pairs)) continue;
         if (bf16x != (c >= 5)) continue;
         // the plane-format kernels have one tile shape each; the pair kernel (both operands pairs) also a 128 x 128 one
-        if (planes && !forced_pairs && c != (pairs ? pairs_cfg() : (planes_tile256 ? 7 : 6)) && !(pairs_small && c == 8)) continue;
+        // (pairs_small: both operands pairs and no forced tile -- round 5: all three tiles compete under the fitted staircase model)
+        if (planes && !forced_pairs && c != (pairs ? pairs_cfg() : (planes_tile256 ? 7 : 6)) && !(pairs_small && (c == 8 || (c == 7 && pairs_tile_choice())))) continue;
         if (!planes && (c == 7 || c == 8)) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
@@ -415,7 +442,8 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
             kps = (kps + kround - 1) / kround * kround;
             if (planes_tile256 && c == 7 && kps < 128) continue;
             const int nsplit = (K + kps - 1) / kps;
-            double cost = cm.grid(c, tiles * nsplit, kps);
+            const bool il_model = pairs && pairs_tile_choice() && c >= 6;
+            double cost = il_model ? cm.pairs_grid(c, tiles * nsplit, kps) : cm.grid(c, tiles * nsplit, kps);
             if (nsplit > 1) cost += CostModel::splitk(nsplit, (double)M * N);
             Plan cand = best;
             cand.cfg = c;
@@ -426,14 +454,17 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
             cand.tail_k_per_split = 0;
             const long ncu = plan_cus();
             const long rem = tiles % ncu;
-            if (nsplit == 1 && tiles > ncu && rem > 0 && rem <= ncu * 5 / 8 && opt.tail != 0 && opt.tails_on) {
+            // (pair kernels, measured: a tail launch pays only for a deep K and a handful of leftover tiles -- at K = 512 it lost 4-15% on every row count)
+            const bool tail_ok = !il_model || opt.tail == 1 || (K >= 1024 && rem <= ncu / 8);
+            if (nsplit == 1 && tiles > ncu && rem > 0 && rem <= ncu * 5 / 8 && opt.tail != 0 && opt.tails_on && tail_ok) {
                 int ts = (int)(ncu / rem);
                 if (ts > max_tail_split) ts = max_tail_split;
                 int tkps = (K + ts - 1) / ts;
                 tkps = (tkps + BK - 1) / BK * BK;
                 const int tns = (K + tkps - 1) / tkps;
                 if (tns >= 2) {
-                    const double with_tail = cm.grid(c, tiles - rem, kps) + cm.grid(c, rem * tns, tkps) + CostModel::splitk(tns, rem * te);
+                    const double with_tail = il_model ? cm.pairs_grid(c, tiles - rem, kps) + cm.pairs_grid(c, rem * tns, tkps) + CostModel::splitk(tns, rem * te)
+                                                      : cm.grid(c, tiles - rem, kps) + cm.grid(c, rem * tns, tkps) + CostModel::splitk(tns, rem * te);
                     if (with_tail < cost || opt.tail == 1) {
                         cost = with_tail;
                         cand.main_tiles = (int)(tiles - rem);

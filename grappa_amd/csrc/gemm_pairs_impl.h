@@ -44,6 +44,20 @@ template <int BN, int BM = QBM> struct QShape {
 
 __device__ inline int amax_shift(unsigned bits) { return 141 - (int)((bits >> 23) & 0xffu); }
 
+// largest magnitude of row m of A: one array, or the maximum over the per-segment partials its producer left (grappa_gemm_desc.a_amax_nseg);
+// eight independent loads per trip (gemm_bf16x_impl.h a_row_amax)
+__device__ inline unsigned a_row_amax(const grappa_gemm_desc& d, int m) {
+    unsigned v = d.a_amax[m];
+    for (int s0 = 1; s0 < d.a_amax_nseg; s0 += 8) {
+        unsigned t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = d.a_amax[(size_t)min(s0 + u, d.a_amax_nseg - 1) * d.M + m];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = max(v, t[u]);
+    }
+    return v;
+}
+
 __device__ inline void glds16(const char* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }

@@ -77,10 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wpairs_il_kernel(GemmParams p) {
     for (int i = 0; i < WTM; ++i) {
         // the row's largest magnitude: one array, or the maximum over the per-segment partials its producer's epilogue left (a_amax_nseg, C ABI 8):
         // the combine launch between two products goes away
-        const int row = min(m0 + wm0 + i * 32 + lr, d.M - 1);
-        unsigned v = d.a_amax[row];
-        for (int sg = 1; sg < d.a_amax_nseg; ++sg) v = max(v, d.a_amax[(size_t)sg * d.M + row]);
-        sh[i] = amax_shift(v);
+        sh[i] = amax_shift(a_row_amax(d, min(m0 + wm0 + i * 32 + lr, d.M - 1)));
     }
 
     // buffer resources: A rows are fp32 (lda floats apart), B rows pairs (ldb fp16 apart); rows beyond M / N read as zeros
