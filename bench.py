@@ -624,6 +624,58 @@ def main():
             extras["b32_train"] = {"value": None, "error": repr(e)[:400]}
         finally:
             torch.cuda.empty_cache()
+        # ---- recorded training on REAL epochs at batch 32: a resident dataset, shuffled batches padded to a handful of shapes, one hipGraph
+        # per shape (grappa_amd/trainer.py Trainer(recorded=True), device_dataset.ShapeBuckets) -- every batch different
+        try:
+            import copy
+            from grappa_amd.datasets import graph_from_pool
+            from grappa_amd.device_dataset import DeviceDataset
+            from grappa_amd.trainer import Trainer
+            n_mols, n_epochs = 1024, 8
+            pool_ids = select_molecules(n_mols, seed=11, min_atoms=WORKLOADS["C2-pubchem-b256"][1], max_atoms=WORKLOADS["C2-pubchem-b256"][2])
+            t_b = time.perf_counter()
+            items = [(graph_from_pool(int(i), n_confs=32, seed=0), "pool") for i in pool_ids]
+            ds = DeviceDataset(items, device=dev)
+            t_build = time.perf_counter() - t_b
+            res = {}
+            for mode in ("eager", "recorded"):
+                m2 = copy.deepcopy(model)
+                m2.train()
+                tr = Trainer(m2, ds, None, batch_size=32, conf_strategy=32, lr=1e-5, gradient_clip_val=10.0, start_qm_epochs=0, warmup_steps=2,
+                             energy_weight=1.0, gradient_weight=0.8, param_weight=0.0, recorded=(mode == "recorded"), shape_buckets=4, seed=3)
+                ep = []
+                for e in range(n_epochs if mode == "recorded" else 3):
+                    sync()
+                    t_e = time.perf_counter()
+                    loss_e = tr.train_epoch(e)
+                    sync()
+                    ep.append((time.perf_counter() - t_e, loss_e))
+                steady = ep[1:]
+                n_b = (n_mols // 32) * len(steady)
+                res[mode] = {"value": n_mols * len(steady) / sum(t for t, _ in steady), "ms_per_step": 1e3 * sum(t for t, _ in steady) / n_b,
+                             "batches": n_b, "epochs_timed": len(steady), "first_epoch_s": ep[0][0], "last_epoch_loss": ep[-1][1]}
+                if mode == "recorded":
+                    st = tr.recorded_stats
+                    res[mode].update({"graphs_recorded": st["graphs_recorded"], "replayed_steps": st["replayed"], "eager_fallback_steps": st["eager"],
+                                      "padding_rows_over_real_rows": st["padding_rows"] / max(st["real_rows"], 1),
+                                      "bucket_caps": [dict(c) for c in tr._buckets.caps]})
+                del tr, m2
+                torch.cuda.empty_cache()
+            extras["b32_train_epochs"] = dict(res["recorded"], unit="molecules/s", eager=res["eager"], dataset_molecules=n_mols, dataset_build_s=t_build,
+                                              mode="Trainer(recorded=True): shuffled epochs over a resident dataset, every batch padded to one of a handful of "
+                                                   "shapes by a padding molecule the loss skips, one recorded hipGraph per shape, batches copied into its inputs",
+                                              note="the first epoch (bucket calibration + recording the graphs) is reported apart (first_epoch_s); every "
+                                                   "timed step is a DIFFERENT batch of 32 molecules x 32 conformations incl. device collate, padding and the copy-in; "
+                                                   "production model, train mode, Adam + clip 10")
+            log(f"b32_train_epochs: eager {res['eager']['ms_per_step']:.1f} ms/step ({res['eager']['value']:.0f} mol/s), recorded "
+                f"{res['recorded']['ms_per_step']:.1f} ms/step = {res['recorded']['value']:.0f} mol/s over {res['recorded']['batches']} batches, "
+                f"{res['recorded']['graphs_recorded']} graphs, padding {100 * res['recorded']['padding_rows_over_real_rows']:.1f}%")
+            del ds, items
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            extras["b32_train_epochs"] = {"value": None, "error": repr(e)[:400], "trace": traceback.format_exc()[-1200:]}
+        finally:
+            torch.cuda.empty_cache()
         # ---- Grappa.predict on ONE ~40-atom molecule (grappa.py:36-57): eager and through the cache of recorded forwards
         try:
             import numpy as np

@@ -44,6 +44,14 @@ def _chk(rc: int, what: str) -> None:
         raise GrappaHipError(f"{what} failed: {_ERR.get(rc, rc)}")
 
 
+def _loss_mols(plan) -> int:
+    """molecules the loss runs over: all of the batch, or its leading `n_real_mols` when the batch ends in a padding molecule
+    (DeviceDataset.collate(pad_to=...): the kernels are one workgroup per molecule, the gradient arrays are zero-initialised, so rows of the
+    padding molecule get exactly 0 from the loss)"""
+    n = getattr(plan, "n_real_mols", None)
+    return plan.B if n is None else int(n)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -1587,7 +1595,7 @@ class HipBackend:
     # ------------------------------------------------------------------ loss
     def loss_ef(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, wE, wG, inv_B, loss_mol, gE, gG) -> None:
         dev = loss_mol.device
-        B = plan.B
+        B = _loss_mols(plan)
         Cc = energy.shape[1] if energy is not None else grad.shape[1]
         for t, n in ((energy, "energy"), (energy_ref, "energy_ref"), (is_dummy, "is_dummy"), (grad, "grad"), (grad_ref, "grad_ref"),
                      (gE, "gE"), (gG, "gG"), (loss_mol, "loss_mol")):
@@ -1635,7 +1643,7 @@ class HipBackend:
         dev = loss_mol.device
         lv = ["n2", "n2", "n3", "n3", "n4", "n4_improper"]
         d = _lib.PLossDesc()
-        d.B = plan.B
+        d.B = _loss_mols(plan)
         for l in range(6):
             p = params[l]
             d.mol_ptr[l] = plan.mol_ptr[lv[l]].data_ptr()

@@ -56,11 +56,27 @@ class CapturedTrainStep:
 
     `opt` (optim.FusedAdam) is switched to device-side scalars (`opt.enable_dynamic()`); `opt.lr = x` between replays takes effect."""
 
-    def __init__(self, model, energy, loss_fn, opt, g, warmup: int = 3):
+    def __init__(self, model, energy, loss_fn, opt, g, warmup: int = 3, preserve_state: bool = False, static_inputs: bool = False):
+        """preserve_state: parameters, Adam moments and step count are put back after the warm-up steps and the recording, so that making the
+        graph does not train (a trainer that records in the middle of an epoch); the first replay is then that batch's one real step.
+        static_inputs: every input of the step (index plan, position tables, features and references of all levels) is moved into ONE device
+        buffer the recorded kernels read from, and `load(g2)` copies another batch of the same shape signature in (`DeviceDataset.collate(
+        pad_to=...)` makes batches of one signature): the graph then serves every such batch."""
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedTrainStep needs a GPU")
         self.model, self.energy, self.loss_fn, self.opt, self.g = model, energy, loss_fn, opt, g
         self.be = get_backend()
+        self.static_inputs = bool(static_inputs)
+        if self.static_inputs:
+            self.plan = g.plan()
+            for lvl in ("n2", "n3", "n4", "n4_improper"):     # built eagerly: their construction sorts (host-synchronising torch ops)
+                if self.plan.T[lvl]:
+                    self.plan.position_tables(lvl)
+            self.signature = train_signature(g)
+            self._rehome_inputs()
+        saved = None
+        if preserve_state:
+            saved = (opt.flat.data.clone(), opt.m.clone(), opt.v.clone(), opt.step_count)
         # the salt word lives on the graph's device and is passed with every call made while this object records; afterwards eager calls go
         # back to their plain seeds (the recorded kernels keep the address they were recorded with: ADVICE r4)
         self.be.enable_dropout_salt(g.device)
@@ -92,7 +108,78 @@ class CapturedTrainStep:
                 pw.merged_heads = "auto"
             self.be.disable_dropout_salt()
         torch.cuda.current_stream(g.device).wait_stream(self.stream)
+        if saved is not None:
+            opt.flat.data.copy_(saved[0])
+            opt.m.copy_(saved[1])
+            opt.v.copy_(saved[2])
+            opt.step_count = saved[3]
+            opt.sync_dynamic()
+            self.be.invalidate_weights()
         self.replays = 0
+
+    # ---- every input of the recorded step in ONE device buffer (as CapturedForward, plus the features and references of every level)
+    def _input_slots(self, plan, g):
+        slots = dict(CapturedForward._plan_tensors(plan))
+        for nt, d in g._data.items():
+            for k, t in d.items():
+                if torch.is_tensor(t):
+                    slots[f"data.{nt}.{k}"] = t
+        slots["graph.src"], slots["graph.dst"] = g._src, g._dst
+        return slots
+
+    def _rehome_inputs(self) -> None:
+        slots = self._input_slots(self.plan, self.g)
+        self._layout, off = {}, 0
+        for name, t in slots.items():
+            nbytes = t.numel() * t.element_size()
+            self._layout[name] = (off, nbytes, t.dtype, tuple(t.shape))
+            off += (nbytes + 15) // 16 * 16
+        self._in_dev = torch.zeros(max(off, 16), dtype=torch.uint8, device=self.g.device)
+        self._views = {}
+        for name, (o, nbytes, dtype, shape) in self._layout.items():
+            v = self._in_dev[o:o + nbytes].view(dtype).view(shape)
+            v.copy_(slots[name])
+            self._views[name] = v
+        for name, v in self._views.items():
+            parts = name.split(".")
+            if parts[0] == "data":
+                self.g._data[parts[1]][name[len("data.") + len(parts[1]) + 1:]] = v
+            elif parts[0] == "graph":
+                setattr(self.g, "_" + parts[1], v)
+            elif len(parts) == 1:
+                setattr(self.plan, name, v)
+            elif len(parts) == 2:
+                getattr(self.plan, parts[0])[parts[1]] = v
+            else:
+                d = getattr(self.plan, parts[0])
+                tup = list(d[parts[1]])
+                tup[int(parts[2])] = v
+                d[parts[1]] = tuple(tup)
+
+    def load(self, g) -> None:
+        """another batch of this step's signature (on the device) into the recorded step's inputs: one multi-tensor copy, stream-ordered
+        behind the previous replay"""
+        if not self.static_inputs:
+            raise RuntimeError("load: this step was recorded on its batch's own tensors (static_inputs=False)")
+        plan = g.plan()
+        for lvl in self.plan.__dict__.get("_pos_tables", {}):
+            plan.position_tables(lvl)
+        src = self._input_slots(plan, g)
+        if set(src) != set(self._layout):
+            raise ValueError(f"load: the batch has other input tables than the recorded one ({sorted(set(src) ^ set(self._layout))})")
+        dsts, srcs = [], []
+        for name, (o, nbytes, dtype, shape) in self._layout.items():
+            t = src[name]
+            if tuple(t.shape) != shape or t.dtype != dtype:
+                raise ValueError(f"load: {name} is {t.dtype} {tuple(t.shape)}, the recorded step holds {dtype} {shape}")
+            if t.numel():
+                dsts.append(self._views[name])
+                srcs.append(t if t.is_contiguous() else t.contiguous())
+        torch._foreach_copy_(dsts, srcs)
+        # host-side mirrors the eager modules read (molecule counts per level; nothing the recorded kernels depend on)
+        self.g._bnn = {k: v.copy() for k, v in g._bnn.items()}
+        self.plan.n_real_mols = getattr(plan, "n_real_mols", None)
+        self.plan.max_degree = plan.max_degree
 
     def _eager(self):
         self.opt.zero_grad()
@@ -109,6 +196,14 @@ class CapturedTrainStep:
         self.be.invalidate_weights()                        # the weights moved under the host-side caches' feet
         _touch_weight_caches(self.be)
         return self.loss
+
+
+def train_signature(g) -> tuple:
+    """everything the recorded train step's kernel arguments and grids depend on: rows of every level, edges, molecules (incl. a padding
+    molecule), real molecules (the loss's grid and its 1 / B), the shape of every input tensor"""
+    plan = g.plan()
+    return (tuple(int(g.num_nodes(nt)) for nt in ("n1", "n2", "n3", "n4", "n4_improper", "g")), int(g.num_edges()), getattr(plan, "n_real_mols", None),
+            tuple(sorted((nt, k, tuple(v.shape), str(v.dtype)) for nt, d in g._data.items() for k, v in d.items() if torch.is_tensor(v))))
 
 
 class CapturedForward:

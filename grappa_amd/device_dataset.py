@@ -73,6 +73,36 @@ class _Table:
         self.start = np.asarray(starts, dtype=np.int64)       # first row (conf tables: first WORD) of every molecule
         self.rows = np.asarray(rows, dtype=np.int64)
         self.conf = conf
+        self.used = acc                                       # rows (conf tables: words) the molecules occupy
+        self.pad_cap = 0
+
+    def reserve(self, rows_cap: int) -> None:
+        """room for ONE more molecule of up to rows_cap rows behind the packed ones (entry len(start) - 1 afterwards): the padding molecule of
+        `DeviceDataset.collate(pad_to=...)`, rewritten for every batch.  Conformational tables hold it with one conformation."""
+        words_cap = max(int(rows_cap), 1) * self.width
+        base_words = self.used if self.conf else self.used * self.width
+        data = torch.zeros(base_words + words_cap, dtype=torch.int32, device=self.data.device)
+        n = min(base_words, self.data.numel())
+        data[:n] = self.data[:n]
+        self.data = data
+        if self.pad_cap == 0:
+            self.start = np.concatenate([self.start, [self.used]])
+            self.rows = np.concatenate([self.rows, [0]])
+        self.pad_cap = max(int(rows_cap), 1)
+        self.pad_words0 = base_words
+
+    def write_pad(self, part: torch.Tensor) -> None:
+        """the padding molecule's rows of this table (host tensor, conformational tables: (rows, 1, ...)) into the reserved region"""
+        rows = int(part.shape[0])
+        if rows > self.pad_cap:
+            raise ValueError(f"padding molecule: {rows} rows, {self.pad_cap} reserved")
+        self.rows[-1] = rows
+        if rows == 0 or part.numel() == 0:
+            return
+        w = part.contiguous().reshape(-1).view(torch.int32)
+        if w.numel() != rows * self.width:
+            raise ValueError("padding molecule: a table of another width than the dataset's")
+        self.data[self.pad_words0:self.pad_words0 + w.numel()].copy_(w.pin_memory() if self.data.is_cuda else w, non_blocking=True)
 
 
 class DeviceDataset:
@@ -121,6 +151,9 @@ class DeviceDataset:
                     raise NotImplementedError("per-tuple energies are outputs of the model, not dataset features")
                 self.feat[(nt, k)] = _Table(parts, dev, v0, conf=conf)
         self._i64 = self._i32 = None
+        self.pad_caps: Optional[Dict[str, int]] = None        # enable_padding(): the largest padding molecule the tables have room for
+        # every bond is two directed edges and one n2 tuple (Molecule.py:465-472): the padding molecule keeps that, so a padded batch has E = 2 T_n2
+        self.bonds_are_n2 = bool(np.all(self.n_edges == 2 * self.count["n2"]))
 
     def __len__(self) -> int:
         return len(self.names)
@@ -137,10 +170,141 @@ class DeviceDataset:
             return int(np.mean(counts))
         raise ValueError(f"Unknown conf_strategy: {conf_strategy}")
 
-    def collate(self, ids: Sequence[int], conf_strategy: Union[str, int] = "min") -> Tuple[MolBatch, Tuple[str, ...]]:
-        """the batch of molecules `ids` (in that order), assembled on the device; same result as
-        `get_collate_fn(conf_strategy)([dataset[i] for i in ids])` followed by `.to(device)` and `.plan()`"""
+    # ---- batches of a fixed shape: a padding molecule behind the real ones ---------------------------------------------------------
+    PAD_DIMS = ("n1", "n2", "n3", "n4", "n4_improper")
+
+    def totals(self, ids) -> Dict[str, int]:
+        """rows of every level the batch of molecules `ids` has (host arithmetic on the per-molecule counts)"""
         ids = np.asarray(ids, dtype=np.int64)
+        return {nt: int(self.count[nt][ids].sum()) for nt in self.PAD_DIMS}
+
+    @staticmethod
+    def pad_sizes(totals: Dict[str, int], caps: Dict[str, int]) -> Optional[Dict[str, int]]:
+        """rows the padding molecule needs at every level to bring a batch of `totals` to `caps`; None if no valid molecule does: it needs
+        at least four atoms (its tuples are runs of consecutive atoms), every atom in a bond (the index plan refuses unbonded atoms: at least
+        ceil(n / 2) bonds) and not more bonds than atom pairs"""
+        p = {nt: int(caps[nt]) - int(totals[nt]) for nt in DeviceDataset.PAD_DIMS}
+        n, b = p["n1"], p["n2"]
+        if n < 4 or min(p.values()) < 0 or b < (n + 1) // 2 or b > n * (n - 1) // 2:
+            return None
+        return p
+
+    def enable_padding(self, max_pad: Dict[str, int]) -> None:
+        """room for a padding molecule of up to max_pad[level] rows in every packed table (entry len(self) of the tables: not a molecule of the
+        dataset -- `names`, `len()` and the samplers do not see it)"""
+        if not self.bonds_are_n2:
+            raise ValueError("padded batches need a dataset whose bonds are its n2 tuples (two directed edges per n2 row)")
+        caps = {nt: max(int(max_pad.get(nt, 0)), 4 if nt == "n1" else 0) for nt in self.PAD_DIMS}
+        if self.pad_caps is not None and all(caps[k] <= self.pad_caps[k] for k in caps):
+            return
+        if self.pad_caps is not None:
+            caps = {k: max(caps[k], self.pad_caps[k]) for k in caps}
+        first = self.pad_caps is None
+        N, E = caps["n1"], 2 * caps["n2"]
+        P = self.plan_tables
+        for name in ("deg", "inc_cnt"):
+            P[name].reserve(N)
+        P["indices"].reserve(E)
+        P["rev"].reserve(E)
+        inc = 0
+        for lvl in TUPLE_LEVELS:
+            P[f"idx/{lvl}"].reserve(caps[lvl])
+            P[f"inv_cnt/{lvl}"].reserve(N)
+            P[f"inv_rows/{lvl}"].reserve(caps[lvl] * LEVEL_ARITY[lvl])
+            inc += caps[lvl] * LEVEL_ARITY[lvl]
+        P["inc_code"].reserve(inc)
+        for (nt, k), table in self.feat.items():
+            table.reserve(1 if nt == "g" else caps[nt])
+        if first:
+            for nt in NTYPES:
+                self.count[nt] = np.concatenate([self.count[nt], [1 if nt == "g" else 0]])
+            self.n_edges = np.concatenate([self.n_edges, [0]])
+            self.max_degree = np.concatenate([self.max_degree, [0]])
+            self.n_confs = np.concatenate([self.n_confs, [1 if self.has_confs else 0]])
+        self.pad_caps = caps
+
+    @staticmethod
+    def _pad_topology(p: Dict[str, int]):
+        """the padding molecule: n atoms on a zigzag (no two coincide, no three in a line, no four in a plane: every internal coordinate and its
+        derivative is finite), bonds = the first b of [pairs covering every atom, the rest of the chain, chords (i, i + d) of growing span d],
+        tuples = runs of consecutive atoms, repeated cyclically"""
+        n, b = p["n1"], p["n2"]
+        i = np.arange(n - 1, dtype=np.int64)
+        # first the bonds that put every atom into one -- (0,1), (2,3), ... and (n-2, n-1) for an odd n --, then the rest of the chain, then chords
+        first = i[::2] if n % 2 == 0 else np.concatenate([i[:-1:2], [n - 2]])
+        rest = np.setdiff1d(i, first)
+        i = np.concatenate([first, rest])
+        bonds = [np.stack([i, i + 1], axis=1)]
+        have, d = n - 1, 2
+        while have < b:
+            j = np.arange(min(n - d, b - have), dtype=np.int64)
+            bonds.append(np.stack([j, j + d], axis=1))
+            have += len(j)
+            d += 1
+        bonds = np.concatenate(bonds)[:b]
+        idxs = {"n2": bonds}
+        for lvl in ("n3", "n4", "n4_improper"):
+            s = LEVEL_ARITY[lvl]
+            first = np.arange(p[lvl], dtype=np.int64) % (n - s + 1)
+            idxs[lvl] = first.reshape(-1, 1) + np.arange(s, dtype=np.int64).reshape(1, s)
+        a = np.arange(n, dtype=np.float64)
+        # (the plain zigzag has every four consecutive atoms in one plane: the two incommensurate wobbles take them out of it)
+        xyz = np.stack([1.3 * a, 0.9 * (np.arange(n) % 2) + 0.23 * np.sin(1.7 * a + 0.3), 0.7 * ((np.arange(n) // 2) % 2) + 0.31 * np.cos(2.9 * a + 0.1)],
+                       axis=1).astype(np.float32)
+        return bonds, idxs, xyz
+
+    def _write_pad(self, p: Dict[str, int]) -> None:
+        """build the padding molecule of p[level] rows on the host (graph, index plan: the same BatchPlan code as for a molecule of the dataset)
+        and write it into the reserved region of every table; features are zeros except the conformation (one, the zigzag)"""
+        if self.pad_caps is None or any(p[k] > self.pad_caps[k] for k in self.PAD_DIMS):
+            raise ValueError(f"padding molecule {p} exceeds the reserved room {self.pad_caps}: call enable_padding with larger sizes")
+        bonds, idxs, xyz = self._pad_topology(p)
+        n = p["n1"]
+        src = torch.from_numpy(np.concatenate([bonds[:, 0], bonds[:, 1]]))
+        dst = torch.from_numpy(np.concatenate([bonds[:, 1], bonds[:, 0]]))
+        data = {nt: {} for nt in NTYPES}
+        for lvl in TUPLE_LEVELS:
+            data[lvl]["idxs"] = torch.from_numpy(idxs[lvl].reshape(-1, LEVEL_ARITY[lvl]))
+        bnn = {nt: np.array([1 if nt == "g" else p[nt]], dtype=np.int64) for nt in NTYPES}
+        plan = BatchPlan(MolBatch(src, dst, data, bnn), "cpu")
+        P = self.plan_tables
+        P["deg"].write_pad(plan.indptr[1:] - plan.indptr[:-1])
+        P["indices"].write_pad(plan.indices)
+        P["rev"].write_pad(plan.rev)
+        for lvl in TUPLE_LEVELS:
+            P[f"idx/{lvl}"].write_pad(plan.idx32[lvl])
+            P[f"inv_cnt/{lvl}"].write_pad(plan.inv_ptr[lvl][1:] - plan.inv_ptr[lvl][:-1])
+            P[f"inv_rows/{lvl}"].write_pad(plan.inv_rows[lvl])
+        P["inc_cnt"].write_pad(plan.inc_ptr[1:] - plan.inc_ptr[:-1])
+        P["inc_code"].write_pad(plan.inc_code)
+        for (nt, k), table in self.feat.items():
+            rows = 1 if nt == "g" else p[nt]
+            if nt == "n1" and k == "xyz" and table.conf:
+                part = torch.from_numpy(xyz).view(n, 1, 3)
+            else:
+                part = torch.zeros((rows,) + ((1,) if table.conf else ()) + table.trailing, dtype=table.dtype)
+            table.write_pad(part)
+        for nt in self.PAD_DIMS:
+            self.count[nt][-1] = p[nt]
+        self.n_edges[-1] = plan.E
+        self.max_degree[-1] = plan.max_degree
+
+    def collate(self, ids: Sequence[int], conf_strategy: Union[str, int] = "min", pad_to: Optional[Dict[str, int]] = None) -> Tuple[MolBatch, Tuple[str, ...]]:
+        """the batch of molecules `ids` (in that order), assembled on the device; same result as
+        `get_collate_fn(conf_strategy)([dataset[i] for i in ids])` followed by `.to(device)` and `.plan()`.
+
+        pad_to = {level: rows} (n1, n2, n3, n4, n4_improper): a batch of EXACTLY these sizes -- the molecules `ids` followed by ONE padding
+        molecule (`_write_pad`) that owns the missing rows of every level; all its conformations are dummies, `plan.n_real_mols = len(ids)` and
+        the loss runs over the real molecules only, so the padding rows get exactly zero gradient.  The conformation selection draws the same
+        random numbers as without padding.  Raises ValueError if no valid padding molecule fills the gap (`pad_sizes`)."""
+        ids = np.asarray(ids, dtype=np.int64)
+        n_real = len(ids)
+        if pad_to is not None:
+            p = self.pad_sizes(self.totals(ids), pad_to)
+            if p is None:
+                raise ValueError(f"collate: the batch ({self.totals(ids)}) cannot be padded to {dict(pad_to)}")
+            self._write_pad(p)
+            ids = np.concatenate([ids, [len(self.names)]])
         B, dev = len(ids), self.device
         cnt = {nt: self.count[nt][ids] for nt in NTYPES}
         off = {nt: np.concatenate([[0], np.cumsum(cnt[nt])]) for nt in NTYPES}
@@ -150,10 +314,11 @@ class DeviceDataset:
         # ---- conformation selection, the same torch calls and order as set_number_confs (utils/dgl_utils.py:132-171)
         n_out, sel, is_dummy = 0, None, None
         if self.has_confs:
-            present = self.n_confs[ids]
+            present = self.n_confs[ids[:n_real]]
             n_out = self._n_confs_of(present, conf_strategy)
-            sel = np.empty((B, n_out), dtype=np.int32)
+            sel = np.zeros((B, n_out), dtype=np.int32)
             is_dummy = np.zeros((B, n_out), dtype=np.float32)
+            is_dummy[n_real:] = 1.0                    # (the padding molecule: its one conformation repeated, all dummies)
             ar = np.arange(n_out, dtype=np.int32)
             for j, c in enumerate(present.tolist()):
                 if c == n_out:
@@ -254,6 +419,7 @@ class DeviceDataset:
             plan.inv_rows[lvl] = out[f"inv_rows/{lvl}"][:Tl * s]
         plan.inc_ptr, plan.inc_code = ptr_of("inc_cnt"), out["inc_code"][:int(inc_rows.sum())]
         plan.device = plan.indptr.device
+        plan.n_real_mols = n_real if pad_to is not None else None
         # ---- the graph object
         data: Dict[str, Dict[str, torch.Tensor]] = {nt: {} for nt in NTYPES}
         for (nt, k), table in self.feat.items():
@@ -273,4 +439,39 @@ class DeviceDataset:
                if N else torch.zeros(0, dtype=torch.long, device=dev))
         g = MolBatch(plan.indices.long(), dst, data, {nt: cnt[nt] for nt in NTYPES})
         g._plan = plan
-        return g, tuple(self.names[i] for i in ids.tolist())
+        return g, tuple(self.names[i] for i in ids[:n_real].tolist())
+
+
+class ShapeBuckets:
+    """A handful of batch shapes (rows per level) that every batch of an epoch is padded to, so that a recorded train step (capture.
+    CapturedTrainStep: shapes are part of a hipGraph) serves real epochs: the batches of one epoch are sorted by their atom count and cut into
+    `n_buckets` groups; a bucket's caps are its group's largest rows per level plus room for the padding molecule (`min_pad` atoms at least),
+    rounded up, the last bucket with `margin` on top for the batches of later epochs.  `choose` returns the smallest bucket a batch fits."""
+
+    def __init__(self, dataset: DeviceDataset, batches: Sequence[np.ndarray], n_buckets: int = 4, min_pad: int = 16, round_to: int = 32, margin: float = 0.06):
+        tot = [dataset.totals(b) for b in batches]
+        if not tot:
+            raise ValueError("ShapeBuckets: no batches to calibrate on")
+        order = np.argsort([t["n1"] for t in tot], kind="stable")
+        groups = [g for g in np.array_split(order, max(1, min(int(n_buckets), len(tot)))) if len(g)]
+        up = lambda v, r: int((int(v) + r - 1) // r * r)      # noqa: E731
+        self.caps: List[Dict[str, int]] = []
+        for gi, grp in enumerate(groups):
+            m = 1.0 + (margin if gi == len(groups) - 1 else 0.0)
+            c = {nt: max(tot[i][nt] for i in grp) for nt in DeviceDataset.PAD_DIMS}
+            c = {nt: up(c[nt] * m + (min_pad if nt in ("n1", "n2") else 0), round_to) for nt in c}
+            while any(DeviceDataset.pad_sizes(tot[i], c) is None for i in grp):      # (a batch with few atoms and many bonds: more padding atoms hold more bonds)
+                c["n1"] += round_to
+                c["n2"] += round_to
+                if c["n1"] > 4 * max(tot[i]["n1"] for i in grp) + 1024:
+                    raise ValueError("ShapeBuckets: no caps found that every batch of the group can be padded to")
+            if not self.caps or any(c[k] > self.caps[-1][k] for k in c):
+                self.caps.append(c)
+        self.max_pad = {nt: max(c[nt] for c in self.caps) - min(t[nt] for t in tot) for nt in DeviceDataset.PAD_DIMS}
+        self.max_pad = {nt: int(v * 1.25) + 64 for nt, v in self.max_pad.items()}
+
+    def choose(self, totals: Dict[str, int]) -> Optional[Dict[str, int]]:
+        for c in self.caps:
+            if DeviceDataset.pad_sizes(totals, c) is not None:
+                return c
+        return None

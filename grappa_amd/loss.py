@@ -34,15 +34,25 @@ class MolwiseLoss(torch.nn.Module):
         self.global_batch_size = None      # data-parallel runs set this to the number of molecules over all ranks
         self.last_per_molecule = None
 
+    def param_weights_of(self, dsnames: List[str], B: int) -> torch.Tensor:
+        """(B,) host tensor: the parameter-loss weight of every molecule (param_weight, or its dataset's entry of param_weights_by_dataset)"""
+        pw = torch.full((B,), float(self.param_weight), dtype=torch.float32)
+        for i, n in enumerate(dsnames or []):
+            if i < B and n in self.param_weights_by_dataset:
+                pw[i] = float(self.param_weights_by_dataset[n])
+        return pw
+
     def forward(self, g, dsnames: List[str] = None):
         assert not (self.gradient_weight == 0 and self.energy_weight == 0 and self.param_weight == 0), \
             "At least one of the weights must be non-zero."
         assert self.tuplewise_weight == 0., f"Tuplewise loss not implemented yet., but weight is {self.tuplewise_weight}."
         plan = g.plan()
         B = plan.B
+        # a batch that ends in a padding molecule (DeviceDataset.collate(pad_to=...)): the loss is over its real molecules only
+        B_real = B if getattr(plan, "n_real_mols", None) is None else int(plan.n_real_mols)
         dev = plan.device
         gd, n1 = g.nodes["g"].data, g.nodes["n1"].data
-        cfg = {"inv_B": 1.0 / float(self.global_batch_size or B), "energy_weight": float(self.energy_weight),
+        cfg = {"inv_B": 1.0 / float(self.global_batch_size or B_real), "energy_weight": float(self.energy_weight),
                "gradient_weight": float(self.gradient_weight), "energy_ref": None, "gradient_ref": None, "is_dummy": None}
         energy = gradient = None
         if "is_dummy" in gd:
@@ -65,6 +75,11 @@ class MolwiseLoss(torch.nn.Module):
         if bool((pw != 0).any()) and not have_refs and not self.skip_params_if_not_present:
             raise KeyError("reference parameters (k_ref / eq_ref) are missing in the graph")
         use_mse = bool((pw != 0).any()) and have_refs
+        # recorded steps (capture.CapturedTrainStep): the per-molecule weights are an INPUT of the graph -- a device tensor on the plan that the
+        # trainer fills per batch (`param_weights_of`), not a host tensor uploaded inside the step
+        pw_rows = getattr(plan, "param_weight_rows", None)
+        if pw_rows is not None:
+            use_mse = have_refs and (float(self.param_weight) != 0. or any(float(v) != 0. for v in self.param_weights_by_dataset.values()))
         params = [g.nodes[lvl].data.get(name) for lvl, name in _LEVELS]
         refs, fac, reg, used = [None] * 6, [1.0] * 6, [0.0] * 6, [False] * 6
         for i, (lvl, name) in enumerate(_LEVELS):
@@ -77,7 +92,7 @@ class MolwiseLoss(torch.nn.Module):
         if self.improper_regularisation > 0.:
             reg[5], used[5] = 2.0 * float(self.improper_regularisation), True      # added twice in the reference (loss.py:128-132)
         cfg.update({"param_active": any(used), "param_used": used, "refs": refs, "fac": fac, "reg": reg,
-                    "pw": pw.to(dev) if use_mse else None})
+                    "pw": (pw_rows if pw_rows is not None else pw.to(dev)) if use_mse else None})
         if any(used):
             for i, u in enumerate(used):
                 if u and params[i] is None:

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.distributed as tdist
 
-from .device_dataset import DeviceDataset
+from .device_dataset import DeviceDataset, ShapeBuckets
 from .dist import BucketedGradReducer, shard_indices
 from .energy import Energy
 from .evaluation import FastEvaluator
@@ -85,8 +85,18 @@ class Trainer:
                  conf_strategy: Union[str, int] = 32, val_batch_size: int = 32, val_conf_strategy: Union[str, int] = "max",
                  lr: float = 1.5e-5, weight_decay: float = 0., gradient_clip_val: Optional[float] = 10.0,
                  proper_regularisation: float = 1e-3, improper_regularisation: float = 0., param_weights_by_dataset: Dict[str, float] = {},
-                 weights: Dict[str, float] = {}, balance_factor: float = 0., seed: int = 0, size_window: int = 0, **schedule_kwargs):
+                 weights: Dict[str, float] = {}, balance_factor: float = 0., seed: int = 0, size_window: int = 0, recorded: bool = False,
+                 shape_buckets: int = 4, max_recorded_steps: int = 16, **schedule_kwargs):
+        """recorded: every train step is the replay of a hipGraph (capture.CapturedTrainStep) -- the batches of an epoch are padded to a handful
+        of shapes (`shape_buckets`, device_dataset.ShapeBuckets: a padding molecule with all-dummy conformations behind the real ones, which the
+        loss skips), one graph is recorded per shape the first time it occurs and every later batch of that shape is copied into the graph's
+        inputs.  The step is then bound by the GPU instead of the host's ~640 launches (batch 32: 2x).  One GPU only; a batch that fits no
+        bucket runs eagerly (counted in `recorded_stats`)."""
         self.model, self.train_set, self.val_set = model, train_set, val_set
+        self.recorded, self.shape_buckets, self.max_recorded_steps = bool(recorded), int(shape_buckets), int(max_recorded_steps)
+        self._buckets: Optional[ShapeBuckets] = None
+        self._steps: Dict[tuple, object] = {}
+        self.recorded_stats = {"replayed": 0, "eager": 0, "graphs_recorded": 0, "padding_rows": 0, "real_rows": 0}
         self.batch_size, self.conf_strategy = batch_size, conf_strategy
         self.val_batch_size, self.val_conf_strategy = val_batch_size, val_conf_strategy
         self.weights, self.balance_factor = dict(weights), balance_factor
@@ -124,13 +134,62 @@ class Trainer:
         self.opt.step()
         return loss.detach()
 
+    # ---- recorded steps -------------------------------------------------------------------------------------------------------------
+    def _step_stamp(self) -> tuple:
+        """what a recorded step has baked in besides the batch's shape: the loss weights the schedule moves, the optimiser's constants"""
+        lf, o = self.loss_fn, self.opt
+        return (float(lf.gradient_weight), float(lf.energy_weight), float(lf.param_weight), float(lf.tuplewise_weight), float(lf.proper_regularisation),
+                float(lf.improper_regularisation), tuple(sorted(lf.weights.items())), tuple(sorted(lf.param_weights_by_dataset.items())),
+                tuple(o.betas), float(o.eps), float(o.weight_decay), o.max_grad_norm, bool(self.model.training))
+
+    def calibrate_buckets(self, batches: Sequence[np.ndarray]) -> ShapeBuckets:
+        self._buckets = ShapeBuckets(self.train_set, batches, n_buckets=self.shape_buckets)
+        self.train_set.enable_padding(self._buckets.max_pad)
+        return self._buckets
+
+    def train_step_recorded(self, ids: np.ndarray) -> torch.Tensor:
+        from .capture import CapturedTrainStep, train_signature
+        ids = np.asarray(ids)
+        tot = self.train_set.totals(ids)
+        caps = self._buckets.choose(tot) if self._buckets is not None else None
+        if caps is None or self.world > 1 or any(caps[k] - tot[k] > self.train_set.pad_caps[k] for k in tot):
+            self.recorded_stats["eager"] += 1
+            return self.train_step(ids)
+        lr = self.schedule.next_lr()
+        g, names = self.train_set.collate(ids, self.conf_strategy, pad_to=caps)
+        plan = g.plan()
+        # the per-molecule weights of the parameter loss are an input of the graph (MolwiseLoss reads plan.param_weight_rows)
+        plan.param_weight_rows = self.loss_fn.param_weights_of(list(names), plan.B).to(plan.device, non_blocking=True)
+        self.loss_fn.global_batch_size = None
+        key = (train_signature(g), self._step_stamp())
+        step = self._steps.pop(key, None)
+        if step is None:
+            if len(self._steps) >= self.max_recorded_steps:
+                self._steps.pop(next(iter(self._steps)))                 # least recently used out
+            step = CapturedTrainStep(self.model, self.energy, self.loss_fn, self.opt, g, preserve_state=True, static_inputs=True)
+            self.recorded_stats["graphs_recorded"] += 1
+        else:
+            step.load(g)
+        self._steps[key] = step                                          # most recently used last
+        self.opt.lr = lr
+        self.recorded_stats["replayed"] += 1
+        self.recorded_stats["real_rows"] += sum(tot.values())
+        self.recorded_stats["padding_rows"] += sum(caps[k] - tot[k] for k in tot)
+        return step()
+
     def train_epoch(self, epoch: int) -> float:
         self.model.train()
         self.schedule.on_train_epoch_start(epoch, self.loss_fn, self.opt)
         total, count = None, 0
-        for ids in epoch_batches(self.train_set.names, self.batch_size, True, self.weights, self.balance_factor, self.gen, min_last=self.world,
-                                 sizes=self.train_set.count["n1"] if self.size_window >= 2 else None, size_window=self.size_window):
-            loss = self.train_step(ids)
+        batches = epoch_batches(self.train_set.names, self.batch_size, True, self.weights, self.balance_factor, self.gen, min_last=self.world,
+                                sizes=self.train_set.count["n1"] if self.size_window >= 2 else None, size_window=self.size_window)
+        use_graphs = self.recorded and self.world == 1 and torch.cuda.is_available()
+        if use_graphs and self._buckets is None:
+            self.calibrate_buckets(batches)
+        for ids in batches:
+            loss = self.train_step_recorded(ids) if use_graphs else self.train_step(ids)
+            if use_graphs:
+                loss = loss.clone()                    # (a recorded step returns the graph's own loss tensor: the next replay overwrites it)
             total = loss * len(ids) if total is None else total + loss * len(ids)      # stays on the device
             count += len(ids)
         if self.world > 1:                 # a rank's loss is its share of sum_m l_m / B_global: the batch loss is the sum over ranks

@@ -486,7 +486,12 @@ class RefBackend:
         dev = loss_mol.device
         Cc = energy.shape[1] if energy is not None else grad.shape[1]
         m = torch.ones((B, Cc), device=dev) if is_dummy is None else (is_dummy == 0).float()
-        nreal = m.sum(1, keepdim=True)
+        # a batch that ends in a padding molecule (plan.n_real_mols): the product's kernels run over the real molecules only; here the
+        # padding molecule is masked out (its conformations are all dummies: no real-conformation count to divide by)
+        n_real = getattr(plan, "n_real_mols", None)
+        real = torch.arange(B, device=dev) < (B if n_real is None else int(n_real))
+        m = m * real[:, None].float()
+        nreal = torch.where(real[:, None], m.sum(1, keepdim=True), torch.ones((B, 1), device=dev))
         loss = torch.zeros(B, device=dev)
         if wE != 0:
             me = (m * energy).sum(1, keepdim=True) / nreal
@@ -524,6 +529,9 @@ class RefBackend:
                 w = params[l].numel() // T if T else 1
                 den = den + (ptr[1:] - ptr[:-1]).float() * w
         pwv = pw if pw is not None else torch.zeros(B, device=dev)
+        n_real = getattr(plan, "n_real_mols", None)
+        real = (torch.arange(B, device=dev) < (B if n_real is None else int(n_real))).float()      # (see loss_ef)
+        pwv = pwv * real
         num = torch.zeros(B, device=dev)
         regsum = torch.zeros(B, device=dev)
         for l in range(6):
@@ -550,7 +558,7 @@ class RefBackend:
                 g = g + torch.where(active, pwv[seg][:, None] * fac[l] ** 2 * 2.0 * diff / den[seg][:, None], torch.zeros_like(g))
             if reg[l] > 0 and T:
                 c = (cnt.float() * w)
-                regc = torch.where(cnt > 0, reg[l] / c.clamp(min=1), torch.zeros_like(c))
+                regc = torch.where(cnt > 0, reg[l] / c.clamp(min=1), torch.zeros_like(c)) * real
                 regsum = regsum + regc * torch.zeros(B, device=dev).index_add(0, seg, (pv * pv).sum(1))
                 g = g + regc[seg][:, None] * 2.0 * pv
             if gps[l] is not None:
