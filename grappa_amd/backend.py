@@ -1625,9 +1625,11 @@ class HipBackend:
             d.p0, d.p1 = _ptr(t.get("p0")), _ptr(t.get("p1"))
             d.c0, d.width, d.mode = int(t.get("c0", 0)), int(t["width"]), _lib.COLLATE_MODES[t["mode"]]
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        descs = host.to(dev)
+        if dev.type == "cuda":
+            host = host.pin_memory()       # (a pageable upload waits for everything queued on the stream before the host may go on)
+        descs = host.to(dev, non_blocking=True)
         _chk(self.lib.grappa_collate_batch(self._stream(), descs.data_ptr(), arr, len(tables), int(B)), "grappa_collate_batch")
-        self._keep = descs                 # the kernel reads the descriptors asynchronously: keep them alive until the next call
+        self._keep = (descs, host)         # the copy and the kernel read them asynchronously: keep them alive until the next call
 
     def eval_se(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, out) -> None:
         """out (B,4) = per molecule {se_E, n_E, se_G, n_G} (include/grappa_hip.h grappa_eval_se_f32)"""

@@ -178,6 +178,9 @@ def _plan_position_tables(self, lvl: str):
 BatchPlan.position_tables = _plan_position_tables
 
 
+_POS_CONST: Dict[tuple, tuple] = {}
+
+
 def _position_tables(plan: "BatchPlan", lvl: str):
     """index tables of the (atom, position) formulation of a writer's first layer (ops.ProjFirstLayerFn), built on the plan's device
     from idx32 and cached: table row pos*N + n holds atom n at position pos.
@@ -221,15 +224,23 @@ def _position_tables(plan: "BatchPlan", lvl: str):
         return v[0].view(N, s), v[1], v[2], v[3].view(T, s), v[4], v[5]
     i32 = dict(dtype=torch.int32, device=dev)
     pos = torch.arange(s, **i32)
-    idx_id = torch.arange(N, **i32).view(N, 1).expand(N, s).contiguous()
-    invid_ptr = (torch.arange(N + 1, **i32) * s).contiguous()
-    invid_rows = (pos.view(1, s) * N + torch.arange(N, **i32).view(N, 1)).reshape(-1).contiguous()
+    # the three tables that depend on (N, s) alone: built once per atom count and device (batches padded to a few shapes ask for the same ones
+    # every step: a dozen launches per level saved); read-only everywhere
+    ck = (N, s, str(dev))
+    const = _POS_CONST.get(ck)
+    if const is None:
+        if len(_POS_CONST) >= 64:
+            _POS_CONST.pop(next(iter(_POS_CONST)))
+        const = _POS_CONST[ck] = (torch.arange(N, **i32).view(N, 1).expand(N, s).contiguous(), (torch.arange(N + 1, **i32) * s).contiguous(),
+                                  (pos.view(1, s) * N + torch.arange(N, **i32).view(N, 1)).reshape(-1).contiguous())
+    idx_id, invid_ptr, invid_rows = const
     idx_tab = (plan.idx32[lvl] + pos.view(1, s) * N).contiguous()
     key = idx_tab.t().reshape(-1).long()                           # token row r = pos*T + t -> its table row
     invtab_rows = torch.argsort(key, stable=True).to(torch.int32).contiguous()
-    counts = torch.bincount(key, minlength=s * N)
+    # (index_add_, not bincount: bincount reads the largest key back to the host -- a synchronisation per level and batch)
+    counts = torch.zeros(s * N, dtype=torch.int32, device=dev).index_add_(0, key, torch.ones(key.shape[0], dtype=torch.int32, device=dev))
     invtab_ptr = torch.zeros(s * N + 1, **i32)
-    invtab_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    invtab_ptr[1:] = torch.cumsum(counts, 0, dtype=torch.int32)
     return idx_id, invid_ptr, invid_rows, idx_tab, invtab_ptr, invtab_rows
 
 

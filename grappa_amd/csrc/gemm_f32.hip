@@ -438,7 +438,8 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
         for (int ns = 1; ns <= max_split; ns = ns < 4 ? ns + 1 : ns + (ns + 3) / 4) {
             if (opt.nsplit > 0 && ns != opt.nsplit) continue;
             int kps = (K + ns - 1) / ns;
-            const int kround = (planes_tile256 && c == 7) ? 64 : BK;      // (the bf16 pinned-pipeline kernel walks pairs of 32-deep slabs)
+            // (the pinned-pipeline kernels walk pairs of slabs -- 2 x 16 columns in the pair format, 2 x 32 in the bf16 one: split ranges in whole pairs)
+            const int kround = (planes_tile256 && c == 7) ? 64 : (pairs ? 32 : BK);
             kps = (kps + kround - 1) / kround * kround;
             if (planes_tile256 && c == 7 && kps < 128) continue;
             const int nsplit = (K + kps - 1) / kps;
@@ -460,7 +461,7 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
                 int ts = (int)(ncu / rem);
                 if (ts > max_tail_split) ts = max_tail_split;
                 int tkps = (K + ts - 1) / ts;
-                tkps = (tkps + BK - 1) / BK * BK;
+                tkps = (tkps + kround - 1) / kround * kround;
                 const int tns = (K + tkps - 1) / tkps;
                 if (tns >= 2) {
                     const double with_tail = il_model ? cm.pairs_grid(c, tiles - rem, kps) + cm.pairs_grid(c, rem * tns, tkps) + CostModel::splitk(tns, rem * te)

@@ -91,8 +91,9 @@ class _Table:
         self.pad_cap = max(int(rows_cap), 1)
         self.pad_words0 = base_words
 
-    def write_pad(self, part: torch.Tensor) -> None:
-        """the padding molecule's rows of this table (host tensor, conformational tables: (rows, 1, ...)) into the reserved region"""
+    def write_pad(self, part: torch.Tensor, todo: list) -> None:
+        """the padding molecule's rows of this table (host tensor, conformational tables: (rows, 1, ...)) for the reserved region: appended to
+        `todo` as (destination view, host words) -- DeviceDataset._write_pad sends all tables in ONE transfer"""
         rows = int(part.shape[0])
         if rows > self.pad_cap:
             raise ValueError(f"padding molecule: {rows} rows, {self.pad_cap} reserved")
@@ -102,7 +103,7 @@ class _Table:
         w = part.contiguous().reshape(-1).view(torch.int32)
         if w.numel() != rows * self.width:
             raise ValueError("padding molecule: a table of another width than the dataset's")
-        self.data[self.pad_words0:self.pad_words0 + w.numel()].copy_(w.pin_memory() if self.data.is_cuda else w, non_blocking=True)
+        todo.append((self.data[self.pad_words0:self.pad_words0 + w.numel()], w))
 
 
 class DeviceDataset:
@@ -268,22 +269,35 @@ class DeviceDataset:
         bnn = {nt: np.array([1 if nt == "g" else p[nt]], dtype=np.int64) for nt in NTYPES}
         plan = BatchPlan(MolBatch(src, dst, data, bnn), "cpu")
         P = self.plan_tables
-        P["deg"].write_pad(plan.indptr[1:] - plan.indptr[:-1])
-        P["indices"].write_pad(plan.indices)
-        P["rev"].write_pad(plan.rev)
+        todo: list = []
+        P["deg"].write_pad(plan.indptr[1:] - plan.indptr[:-1], todo)
+        P["indices"].write_pad(plan.indices, todo)
+        P["rev"].write_pad(plan.rev, todo)
         for lvl in TUPLE_LEVELS:
-            P[f"idx/{lvl}"].write_pad(plan.idx32[lvl])
-            P[f"inv_cnt/{lvl}"].write_pad(plan.inv_ptr[lvl][1:] - plan.inv_ptr[lvl][:-1])
-            P[f"inv_rows/{lvl}"].write_pad(plan.inv_rows[lvl])
-        P["inc_cnt"].write_pad(plan.inc_ptr[1:] - plan.inc_ptr[:-1])
-        P["inc_code"].write_pad(plan.inc_code)
+            P[f"idx/{lvl}"].write_pad(plan.idx32[lvl], todo)
+            P[f"inv_cnt/{lvl}"].write_pad(plan.inv_ptr[lvl][1:] - plan.inv_ptr[lvl][:-1], todo)
+            P[f"inv_rows/{lvl}"].write_pad(plan.inv_rows[lvl], todo)
+        P["inc_cnt"].write_pad(plan.inc_ptr[1:] - plan.inc_ptr[:-1], todo)
+        P["inc_code"].write_pad(plan.inc_code, todo)
         for (nt, k), table in self.feat.items():
             rows = 1 if nt == "g" else p[nt]
             if nt == "n1" and k == "xyz" and table.conf:
                 part = torch.from_numpy(xyz).view(n, 1, 3)
             else:
                 part = torch.zeros((rows,) + ((1,) if table.conf else ()) + table.trailing, dtype=table.dtype)
-            table.write_pad(part)
+            table.write_pad(part, todo)
+        if todo:
+            # ONE pinned buffer, ONE transfer, one multi-tensor copy into the tables' reserved regions (was: ~40 small transfers per batch)
+            flat = torch.cat([w for _, w in todo])
+            if self.device.type == "cuda":
+                flat = flat.pin_memory()
+            stage = flat.to(self.device, non_blocking=True)
+            srcs, o = [], 0
+            for _, w in todo:
+                srcs.append(stage[o:o + w.numel()])
+                o += w.numel()
+            torch._foreach_copy_([d for d, _ in todo], srcs)
+            self._pad_stage = (flat, stage)
         for nt in self.PAD_DIMS:
             self.count[nt][-1] = p[nt]
         self.n_edges[-1] = plan.E
@@ -355,6 +369,12 @@ class DeviceDataset:
         inc_rows = sum(cnt[lvl] * LEVEL_ARITY[lvl] for lvl in TUPLE_LEVELS)
         row_ptr["inc"] = put64(np.concatenate([[0], np.cumsum(inc_rows)]))
         t_off4 = put32(np.stack([off[lvl][:-1] for lvl in TUPLE_LEVELS], axis=1))
+        # (the plan's molecule pointers and the dummy mask ride in the same pinned upload: a pageable host-to-device copy of their own would
+        #  wait for everything queued on the stream -- the previous train step -- before the host may go on)
+        molptr32 = {"n1": put32(off["n1"])}
+        for lvl in TUPLE_LEVELS:
+            molptr32[lvl] = put32(off[lvl])
+        dummy32 = put32(is_dummy.view(np.int32)) if self.has_confs else None
         out: Dict[str, torch.Tensor] = {}
 
         def add(name, table: _Table, rows_total, dst_key, mode, p0=None, p1=None, c0=0, words_per_row=None):
@@ -408,13 +428,14 @@ class DeviceDataset:
         plan.N, plan.E, plan.B = N, E, B
         plan.indptr, plan.indices, plan.rev = ptr_of("deg"), out["indices"][:E], out["rev"][:E]
         plan.max_degree = int(self.max_degree[ids].max()) if B else 0
-        plan.atom_molptr = torch.from_numpy(off["n1"].astype(np.int32)).to(dev)
+        take32 = lambda slot: d32[slot[0]:slot[0] + slot[1]]      # noqa: E731
+        plan.atom_molptr = take32(molptr32["n1"])
         plan.idx32, plan.mol_ptr, plan.T, plan.inv_ptr, plan.inv_rows = {}, {}, {}, {}, {}
         for lvl in TUPLE_LEVELS:
             Tl, s = int(off[lvl][-1]), LEVEL_ARITY[lvl]
             plan.T[lvl] = Tl
             plan.idx32[lvl] = out[f"idx/{lvl}"][:Tl * s].view(Tl, s)
-            plan.mol_ptr[lvl] = torch.from_numpy(off[lvl].astype(np.int32)).to(dev)
+            plan.mol_ptr[lvl] = take32(molptr32[lvl])
             plan.inv_ptr[lvl] = ptr_of(f"inv_cnt/{lvl}")
             plan.inv_rows[lvl] = out[f"inv_rows/{lvl}"][:Tl * s]
         plan.inc_ptr, plan.inc_code = ptr_of("inc_cnt"), out["inc_code"][:int(inc_rows.sum())]
@@ -433,7 +454,7 @@ class DeviceDataset:
         for lvl in TUPLE_LEVELS:
             data[lvl]["idxs"] = plan.idx32[lvl].long()
         if self.has_confs:
-            data["g"]["is_dummy"] = torch.from_numpy(is_dummy).to(dev)
+            data["g"]["is_dummy"] = take32(dummy32).view(torch.float32).view(B, n_out)
         # (output_size: without it repeat_interleave reads the total back from the device -- the one host sync of a collate)
         dst = (torch.repeat_interleave(torch.arange(N, device=dev), (plan.indptr[1:] - plan.indptr[:-1]).long(), output_size=int(plan.E))
                if N else torch.zeros(0, dtype=torch.long, device=dev))
