@@ -86,17 +86,19 @@ class Trainer:
                  lr: float = 1.5e-5, weight_decay: float = 0., gradient_clip_val: Optional[float] = 10.0,
                  proper_regularisation: float = 1e-3, improper_regularisation: float = 0., param_weights_by_dataset: Dict[str, float] = {},
                  weights: Dict[str, float] = {}, balance_factor: float = 0., seed: int = 0, size_window: int = 0, recorded: bool = False,
-                 shape_buckets: int = 4, max_recorded_steps: int = 16, **schedule_kwargs):
+                 shape_buckets: int = 4, max_recorded_steps: int = 16, pipelined: bool = True, **schedule_kwargs):
         """recorded: every train step is the replay of a hipGraph (capture.CapturedTrainStep) -- the batches of an epoch are padded to a handful
         of shapes (`shape_buckets`, device_dataset.ShapeBuckets: a padding molecule with all-dummy conformations behind the real ones, which the
         loss skips), one graph is recorded per shape the first time it occurs and every later batch of that shape is copied into the graph's
         inputs.  The step is then bound by the GPU instead of the host's ~640 launches (batch 32: 2x).  One GPU only; a batch that fits no
-        bucket runs eagerly (counted in `recorded_stats`)."""
+        bucket runs eagerly (counted in `recorded_stats`).  pipelined: the next batch is prepared (padding molecule, device collate, position tables:
+        ~3 ms of host work, on a side stream) by a worker thread while this thread launches the current batch's graph."""
         self.model, self.train_set, self.val_set = model, train_set, val_set
         self.recorded, self.shape_buckets, self.max_recorded_steps = bool(recorded), int(shape_buckets), int(max_recorded_steps)
         self._buckets: Optional[ShapeBuckets] = None
         self._steps: Dict[tuple, object] = {}
         self._prep_stream, self._load_done = None, None
+        self.pipelined, self._prep_pool = bool(pipelined), None
         self.recorded_stats = {"replayed": 0, "eager": 0, "graphs_recorded": 0, "padding_rows": 0, "real_rows": 0}
         self.batch_size, self.conf_strategy = batch_size, conf_strategy
         self.val_batch_size, self.val_conf_strategy = val_batch_size, val_conf_strategy
@@ -171,19 +173,36 @@ class Trainer:
             ready.record(side)
         return g, names, ready
 
-    def train_step_recorded(self, ids: np.ndarray) -> torch.Tensor:
-        from .capture import CapturedTrainStep, train_signature
-        ids = np.asarray(ids)
+    def _prepare(self, ids: np.ndarray):
+        """what a recorded step needs of the batch `ids`: None if no bucket takes it (it runs eagerly), else (graph, names, event, totals, caps).
+        Called on the trainer's thread, or -- pipelined epochs -- on its worker thread while the trainer's thread launches the previous graph"""
         tot = self.train_set.totals(ids)
         caps = self._buckets.choose(tot) if self._buckets is not None else None
         if caps is None or self.world > 1 or any(caps[k] - tot[k] > self.train_set.pad_caps[k] for k in tot):
+            return None
+        if self.train_set.device.type == "cuda" and self.train_set.device.index is not None:
+            torch.cuda.set_device(self.train_set.device)       # (a worker thread starts on device 0)
+        return self._prepare_padded(ids, caps, tot) + (tot, caps)
+
+    def train_step_recorded(self, ids: np.ndarray, prepared="unset", after_load=None) -> torch.Tensor:
+        """prepared: the result of `_prepare(ids)` if the caller made it ahead; after_load: called once this batch is in the graph's inputs and before
+        the graph is launched (pipelined epochs start the next batch's preparation there: launching a hipGraph of ~650 kernel nodes keeps the
+        launching thread in the runtime for ~5 ms -- with the interpreter lock released)"""
+        from .capture import CapturedTrainStep, train_signature
+        ids = np.asarray(ids)
+        if isinstance(prepared, str):
+            prepared = self._prepare(ids)
+        if prepared is None:
             self.recorded_stats["eager"] += 1
             if self._prep_stream is not None:
                 torch.cuda.current_stream(self.train_set.device).wait_stream(self._prep_stream)
                 self._prep_stream.wait_stream(torch.cuda.current_stream(self.train_set.device))     # (the eager collate rewrites nothing of the side stream's, but keep the order plain)
-            return self.train_step(ids)
+            loss = self.train_step(ids)
+            if after_load is not None:
+                after_load()                    # (after the eager collate: the conformation selection draws from the same host generator, batch by batch)
+            return loss
         lr = self.schedule.next_lr()
-        g, names, ready = self._prepare_padded(ids, caps, tot)
+        g, names, ready, tot, caps = prepared
         main = torch.cuda.current_stream(self.train_set.device)
         main.wait_event(ready)
         self.loss_fn.global_batch_size = None
@@ -198,6 +217,8 @@ class Trainer:
             step.load(g)
         self._load_done = torch.cuda.Event()
         self._load_done.record(main)
+        if after_load is not None:
+            after_load()
         self._steps[key] = step                                          # most recently used last
         self.opt.lr = lr
         self.recorded_stats["replayed"] += 1
@@ -214,8 +235,22 @@ class Trainer:
         use_graphs = self.recorded and self.world == 1 and torch.cuda.is_available()
         if use_graphs and self._buckets is None:
             self.calibrate_buckets(batches)
-        for ids in batches:
-            loss = self.train_step_recorded(ids) if use_graphs else self.train_step(ids)
+        nxt = None
+        if use_graphs and self.pipelined and len(batches) > 1:
+            if self._prep_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._prep_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="grappa-prep")
+            nxt = self._prep_pool.submit(self._prepare, np.asarray(batches[0]))
+        for bi, ids in enumerate(batches):
+            if nxt is not None:
+                # the batch was prepared while the previous graph was being launched; the next one is handed to the worker as soon as this one
+                # sits in its graph's inputs
+                prepared, box = nxt.result(), []
+                follow = (lambda j=bi + 1: box.append(self._prep_pool.submit(self._prepare, np.asarray(batches[j])))) if bi + 1 < len(batches) else None
+                loss = self.train_step_recorded(ids, prepared, follow)
+                nxt = box[0] if box else None
+            else:
+                loss = self.train_step_recorded(ids) if use_graphs else self.train_step(ids)
             if use_graphs:
                 loss = loss.clone()                    # (a recorded step returns the graph's own loss tensor: the next replay overwrites it)
             total = loss * len(ids) if total is None else total + loss * len(ids)      # stays on the device
