@@ -627,7 +627,6 @@ def main():
         # ---- recorded training on REAL epochs at batch 32: a resident dataset, shuffled batches padded to a handful of shapes, one hipGraph
         # per shape (grappa_amd/trainer.py Trainer(recorded=True), device_dataset.ShapeBuckets) -- every batch different
         try:
-            import copy
             from grappa_amd.datasets import graph_from_pool
             from grappa_amd.device_dataset import DeviceDataset
             from grappa_amd.trainer import Trainer
@@ -639,7 +638,8 @@ def main():
             t_build = time.perf_counter() - t_b
             res = {}
             for mode in ("eager", "recorded"):
-                m2 = copy.deepcopy(model)
+                m2 = model_from_config(model_cfg).to(dev)          # (a model object holds its head streams: not copyable; same weights through the state dict)
+                m2.load_state_dict(model.state_dict())
                 m2.train()
                 tr = Trainer(m2, ds, None, batch_size=32, conf_strategy=32, lr=1e-5, gradient_clip_val=10.0, start_qm_epochs=0, warmup_steps=2,
                              energy_weight=1.0, gradient_weight=0.8, param_weight=0.0, recorded=(mode == "recorded"), shape_buckets=4, seed=3)
