@@ -421,6 +421,11 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
     if (max_split > 64) max_split = 64;
     int max_tail_split = K >= 8 * BK ? K / (4 * BK) : 1;      // the tail may be cut finer than a full split-K GEMM
     if (max_tail_split > 64) max_tail_split = 64;
+    // a forced number of K ranges (plan_nsplit, tuning) that this K cannot be cut into means the finest cut that exists, not "no plan"
+    int want_split = 0;
+    if (opt.nsplit > 0)
+        for (int ns = 1; ns <= max_split; ns = ns < 4 ? ns + 1 : ns + (ns + 3) / 4)
+            if (ns <= opt.nsplit) want_split = ns;
     for (int c = 0; c < NCFG; ++c) {
         const bool forced_pairs = pairs && opt.cfg >= 6 && opt.cfg <= 8;       // tuning: the pair kernels' tile (6: 256 x 128, 7: 256 x 256, 8: 128 x 128) can be forced too
         if (opt.cfg >= 0 && c != opt.cfg && (!planes || forced_pairs)) continue;
@@ -436,7 +441,7 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
         const long tiles = (long)((M + CFG_BM[c] - 1) / CFG_BM[c]) * ((N + CFG_BN[c] - 1) / CFG_BN[c]);
         const double te = (double)CFG_BM[c] * CFG_BN[c];
         for (int ns = 1; ns <= max_split; ns = ns < 4 ? ns + 1 : ns + (ns + 3) / 4) {
-            if (opt.nsplit > 0 && ns != opt.nsplit) continue;
+            if (want_split > 0 && ns != want_split) continue;
             int kps = (K + ns - 1) / ns;
             // (the pinned-pipeline kernels walk pairs of slabs -- 2 x 16 columns in the pair format, 2 x 32 in the bf16 one: split ranges in whole pairs)
             const int kround = (planes_tile256 && c == 7) ? 64 : (pairs ? 32 : BK);
@@ -577,6 +582,7 @@ static int plan_report(int M, int N, int K, int precision, const PlanOpts& o, in
     if (M <= 0 || N <= 0 || K <= 0 || !tile_m || !tile_n || !nsplit || !tail_tiles || !tail_nsplit) return GRAPPA_ERR_ARG;
     if (precision < GRAPPA_GEMM_F32_MFMA || precision > GRAPPA_GEMM_F32_F16X3) return GRAPPA_ERR_ARG;
     Plan pl = make_plan(M, N, K, o, true, use_bf16x(M, N, precision));
+    if (pl.main_tiles <= 0) return GRAPPA_ERR_ARG;          // a forced tile this product has no kernel for
     *tile_m = CFG_BM[pl.cfg];
     *tile_n = CFG_BN[pl.cfg];
     *nsplit = pl.nsplit;
@@ -863,6 +869,7 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool bf16_il256 = bf16_tile256 && planes && !pairs && d->precision == GRAPPA_GEMM_BF16 && d->a_planes && d->a_kcontig && d->b_kcontig && (d->K & 63) == 0 && d->K >= 128 &&
                             (size_t)d->M * d->lda * 2 < (1ull << 32) && (size_t)d->N * d->ldb * 2 < (1ull << 32);
     Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0, bf16_il256);
+    if (pl.main_tiles <= 0) return GRAPPA_ERR_ARG;                       // a forced tile (plan_cfg) that no kernel of this product's operand formats has: refused, not skipped
     if (pairs && !d->a_planes && pl.cfg != 6) return GRAPPA_ERR_ARG;      // (fp32 A + weight pairs: the 256 x 128 tile only)
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
     if (d->plan_cfg < 0 || d->plan_cfg > NCFG || d->plan_nsplit < 0 || d->plan_tail < 0 || d->plan_tail > 3 || d->splitk_reduce < 0 || d->splitk_reduce > 2) return GRAPPA_ERR_ARG;

@@ -60,6 +60,14 @@ def test_split_k_ranges_of_the_pair_kernels_do_not_overlap(cfg, M, N, K, nsplit)
     assert err < 3e-6, err
 
 
+def test_randomised_shapes_formats_plans_and_epilogues_stay_inside_the_arithmetic_error():
+    """48 seeded random cases (tools/gemm_fuzz.py: shape, operand format, forced tile / split-K / tail launch, epilogue) against float64"""
+    import gemm_fuzz
+    worst, refused, bad = gemm_fuzz.run(48, 0, verbose=False)
+    assert not bad, bad
+    assert refused < 24, refused
+
+
 def test_pair_layout_and_rejections():
     """element (r, k): HI at r * ld + 32 * (k // 16) + k % 16, LO 16 further; (HI + LO) * 2^-s reproduces the value to 2^-22 of the row maximum"""
     import ctypes as C
