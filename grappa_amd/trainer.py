@@ -92,7 +92,10 @@ class Trainer:
         loss skips), one graph is recorded per shape the first time it occurs and every later batch of that shape is copied into the graph's
         inputs.  The step is then bound by the GPU instead of the host's ~640 launches (batch 32: 2x).  One GPU only; a batch that fits no
         bucket runs eagerly (counted in `recorded_stats`).  pipelined: the next batch is prepared (padding molecule, device collate, position tables:
-        ~3 ms of host work, on a side stream) by a worker thread while this thread launches the current batch's graph."""
+        ~3 ms of host work, on a side stream) by a worker thread while this thread launches the current batch's graph.
+        Without a GPU the same epochs run eagerly.  A run resumed from a checkpoint records its graphs anew: with dropout on it continues with
+        other masks than the uninterrupted run (a recorded step's dropout seeds are constants of its graph, salted by a device word), i.e. it
+        is equivalent but not bit-identical; the eager trainer's resume is bit for bit."""
         self.model, self.train_set, self.val_set = model, train_set, val_set
         self.recorded, self.shape_buckets, self.max_recorded_steps = bool(recorded), int(shape_buckets), int(max_recorded_steps)
         self._buckets: Optional[ShapeBuckets] = None

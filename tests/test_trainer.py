@@ -69,6 +69,25 @@ def test_trainer_cpu(ref_backend):
     _run("cpu")
 
 
+def test_recorded_trainer_without_a_gpu_is_the_eager_trainer(ref_backend):
+    """`recorded=True` asks for hipGraph replays; on a machine without a GPU (this suite's test-only backend) the trainer runs the same
+    epochs eagerly -- same batches, same losses -- instead of failing"""
+    from grappa_amd import GrappaModel, ops
+    from grappa_amd.device_dataset import DeviceDataset
+    from grappa_amd.trainer import Trainer
+    losses = []
+    for recorded in (False, True):
+        torch.manual_seed(0)
+        ops.manual_seed(5)
+        model = GrappaModel(**TINY)
+        train = DeviceDataset(_items(list(range(300, 312))), device="cpu")
+        tr = Trainer(model, train, None, batch_size=4, conf_strategy=4, lr=2e-3, start_qm_epochs=0, warmup_steps=2, energy_weight=1.0,
+                     gradient_weight=0.8, param_weight=0.0, recorded=recorded)
+        losses.append([h["train_loss"] for h in tr.fit(2)])
+        assert tr.recorded_stats["replayed"] == 0
+    assert losses[0] == losses[1]
+
+
 @pytest.mark.gpu
 def test_trainer_gpu():
     _run("cuda")
