@@ -107,14 +107,18 @@ class CapturedTrainStep:
             if self._merged_was == "auto":
                 pw.merged_heads = "auto"
             self.be.disable_dropout_salt()
+            if saved is not None:
+                # also when the warm-up or the recording failed: the caller gets its training state back as it was and may go on eagerly
+                stream = getattr(self, "stream", None)
+                if stream is not None:
+                    stream.synchronize()
+                opt.flat.data.copy_(saved[0])
+                opt.m.copy_(saved[1])
+                opt.v.copy_(saved[2])
+                opt.step_count = saved[3]
+                opt.sync_dynamic()
+                self.be.invalidate_weights()
         torch.cuda.current_stream(g.device).wait_stream(self.stream)
-        if saved is not None:
-            opt.flat.data.copy_(saved[0])
-            opt.m.copy_(saved[1])
-            opt.v.copy_(saved[2])
-            opt.step_count = saved[3]
-            opt.sync_dynamic()
-            self.be.invalidate_weights()
         self.replays = 0
 
     # ---- every input of the recorded step in ONE device buffer (as CapturedForward, plus the features and references of every level)

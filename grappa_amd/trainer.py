@@ -101,6 +101,7 @@ class Trainer:
         self._buckets: Optional[ShapeBuckets] = None
         self._steps: Dict[tuple, object] = {}
         self._prep_stream, self._load_done = None, None
+        self._unrecordable: Dict[tuple, str] = {}          # shape signatures whose recording failed (reason): served eagerly
         self.pipelined, self._prep_pool = bool(pipelined), None
         self.recorded_stats = {"replayed": 0, "eager": 0, "graphs_recorded": 0, "padding_rows": 0, "real_rows": 0}
         self.batch_size, self.conf_strategy = batch_size, conf_strategy
@@ -210,14 +211,33 @@ class Trainer:
         main.wait_event(ready)
         self.loss_fn.global_batch_size = None
         key = (train_signature(g), self._step_stamp())
-        step = self._steps.pop(key, None)
-        if step is None:
+        step = self._steps.pop(key, None) if key not in self._unrecordable else None
+        if step is None and key not in self._unrecordable:
             if len(self._steps) >= self.max_recorded_steps:
                 self._steps.pop(next(iter(self._steps)))                 # least recently used out
-            step = CapturedTrainStep(self.model, self.energy, self.loss_fn, self.opt, g, preserve_state=True, static_inputs=True)
-            self.recorded_stats["graphs_recorded"] += 1
-        else:
+            try:
+                step = CapturedTrainStep(self.model, self.energy, self.loss_fn, self.opt, g, preserve_state=True, static_inputs=True)
+                self.recorded_stats["graphs_recorded"] += 1
+            except Exception as e:  # noqa: BLE001  (a recording that fails -- memory, a call a capture cannot hold -- must not end the run)
+                import warnings
+                self._unrecordable[key] = repr(e)
+                warnings.warn(f"Trainer(recorded=True): recording a train step failed ({e!r}); batches of this shape run eagerly")
+                step = None
+        elif step is not None:
             step.load(g)
+        if step is None:
+            # the padded batch itself, eagerly: the loss skips its padding molecule (parameters and optimiser state are as before the attempt)
+            self.recorded_stats["eager"] += 1
+            self.opt.lr = lr
+            self.opt.zero_grad()
+            loss = self.loss_fn(self.energy(self.model(g)), list(names))
+            loss.backward()
+            self.opt.step()
+            self._load_done = torch.cuda.Event()
+            self._load_done.record(main)
+            if after_load is not None:
+                after_load()
+            return loss.detach()
         self._load_done = torch.cuda.Event()
         self._load_done.record(main)
         if after_load is not None:

@@ -200,3 +200,40 @@ def test_recorded_epochs_match_the_eager_trainer():
     assert 0 < stats["padding_rows"] < 0.6 * stats["real_rows"], stats
     for a, b in zip(eager, rec):
         assert abs(a - b) <= 2e-5 * abs(a), (eager, rec)
+
+
+@pytest.mark.gpu
+def test_recorded_trainer_survives_a_failed_recording(monkeypatch):
+    """a recording that fails (memory, a call a capture cannot hold) must not end the run: batches of that shape run eagerly -- the padded
+    batch itself, whose padding molecule the loss skips -- and the epochs' losses are the eager trainer's"""
+    import warnings
+
+    import grappa_amd.capture as capture
+    from grappa_amd import GrappaModel, ops
+    from grappa_amd.trainer import Trainer
+
+    class Failing:
+        def __init__(self, *a, **k):
+            raise RuntimeError("capture refused (test)")
+
+    cfg = dict(TINY, gnn_dropout_attention=0.0, gnn_dropout_initial=0.0, gnn_dropout_conv=0.0, gnn_dropout_final=0.0, parameter_dropout=0.0)
+    items = [(graph_from_pool(300 + i, n_confs=4, seed=2), f"ds{i % 2}") for i in range(24)]
+    hist = []
+    for recorded in (False, True):
+        torch.manual_seed(0)
+        ops.manual_seed(5)
+        model = GrappaModel(**cfg).to("cuda")
+        train = DeviceDataset(items, device="cuda")
+        tr = Trainer(model, train, None, batch_size=8, conf_strategy=4, lr=2e-3, proper_regularisation=1e-3, start_qm_epochs=0, warmup_steps=2,
+                     energy_weight=1.0, gradient_weight=0.8, param_weight=0.0, recorded=recorded, shape_buckets=2)
+        if recorded:
+            monkeypatch.setattr(capture, "CapturedTrainStep", Failing)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            hist.append([h["train_loss"] for h in tr.fit(2)])
+        if recorded:
+            assert tr.recorded_stats["replayed"] == 0 and tr.recorded_stats["eager"] == 6 and tr.recorded_stats["graphs_recorded"] == 0
+            assert any("recording a train step failed" in str(x.message) for x in w)
+            assert 1 <= len(tr._unrecordable) <= 4
+    for a, b in zip(*hist):
+        assert abs(a - b) <= 2e-5 * abs(a), hist
