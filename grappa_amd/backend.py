@@ -1637,7 +1637,8 @@ class HipBackend:
         for t, n in ((energy, "energy"), (energy_ref, "energy_ref"), (is_dummy, "is_dummy"), (grad, "grad"), (grad_ref, "grad_ref"), (out, "out")):
             if t is not None:
                 _flat(t, n, dev)
-        _chk(self.lib.grappa_eval_se_f32(self._stream(), plan.B, energy.shape[1], plan.N, plan.atom_molptr.data_ptr(), energy.data_ptr(),
+        # (a batch that ends in a padding molecule: the kernel is one workgroup per molecule -- run over the real ones, the caller zeroes `out`)
+        _chk(self.lib.grappa_eval_se_f32(self._stream(), _loss_mols(plan), energy.shape[1], plan.N, plan.atom_molptr.data_ptr(), energy.data_ptr(),
                                          energy_ref.data_ptr(), _ptr(is_dummy), _ptr(grad), _ptr(grad_ref), out.data_ptr()), "grappa_eval_se_f32")
 
     def loss_param(self, plan, params, refs, fac, reg, pw, inv_B, loss_mol, gps) -> None:

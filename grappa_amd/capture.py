@@ -48,7 +48,75 @@ def _drop_outputs(g) -> None:
             g.nodes[lvl].data.pop(k, None)
 
 
-class CapturedTrainStep:
+class _StaticInputs:
+    """every input of a recorded step (index plan, position tables, features and references of every level) in ONE device buffer the recorded
+    kernels read from; `load(g2)` copies another batch of the same shape signature in.  Users set self.g, self.plan, self.static_inputs."""
+
+    def _input_slots(self, plan, g):
+        slots = dict(CapturedForward._plan_tensors(plan))
+        for nt, d in g._data.items():
+            for k, t in d.items():
+                if torch.is_tensor(t):
+                    slots[f"data.{nt}.{k}"] = t
+        slots["graph.src"], slots["graph.dst"] = g._src, g._dst
+        return slots
+
+    def _rehome_inputs(self) -> None:
+        slots = self._input_slots(self.plan, self.g)
+        self._layout, off = {}, 0
+        for name, t in slots.items():
+            nbytes = t.numel() * t.element_size()
+            self._layout[name] = (off, nbytes, t.dtype, tuple(t.shape))
+            off += (nbytes + 15) // 16 * 16
+        self._in_dev = torch.zeros(max(off, 16), dtype=torch.uint8, device=self.g.device)
+        self._views = {}
+        for name, (o, nbytes, dtype, shape) in self._layout.items():
+            v = self._in_dev[o:o + nbytes].view(dtype).view(shape)
+            v.copy_(slots[name])
+            self._views[name] = v
+        for name, v in self._views.items():
+            parts = name.split(".")
+            if parts[0] == "data":
+                self.g._data[parts[1]][name[len("data.") + len(parts[1]) + 1:]] = v
+            elif parts[0] == "graph":
+                setattr(self.g, "_" + parts[1], v)
+            elif len(parts) == 1:
+                setattr(self.plan, name, v)
+            elif len(parts) == 2:
+                getattr(self.plan, parts[0])[parts[1]] = v
+            else:
+                d = getattr(self.plan, parts[0])
+                tup = list(d[parts[1]])
+                tup[int(parts[2])] = v
+                d[parts[1]] = tuple(tup)
+
+    def load(self, g) -> None:
+        """another batch of this step's signature (on the device) into the recorded step's inputs: one multi-tensor copy, stream-ordered
+        behind the previous replay"""
+        if not self.static_inputs:
+            raise RuntimeError("load: this step was recorded on its batch's own tensors (static_inputs=False)")
+        plan = g.plan()
+        for lvl in self.plan.__dict__.get("_pos_tables", {}):
+            plan.position_tables(lvl)
+        src = self._input_slots(plan, g)
+        if set(src) != set(self._layout):
+            raise ValueError(f"load: the batch has other input tables than the recorded one ({sorted(set(src) ^ set(self._layout))})")
+        dsts, srcs = [], []
+        for name, (o, nbytes, dtype, shape) in self._layout.items():
+            t = src[name]
+            if tuple(t.shape) != shape or t.dtype != dtype:
+                raise ValueError(f"load: {name} is {t.dtype} {tuple(t.shape)}, the recorded step holds {dtype} {shape}")
+            if t.numel():
+                dsts.append(self._views[name])
+                srcs.append(t if t.is_contiguous() else t.contiguous())
+        torch._foreach_copy_(dsts, srcs)
+        # host-side mirrors the eager modules read (molecule counts per level; nothing the recorded kernels depend on)
+        self.g._bnn = {k: v.copy() for k, v in g._bnn.items()}
+        self.plan.n_real_mols = getattr(plan, "n_real_mols", None)
+        self.plan.max_degree = plan.max_degree
+
+
+class CapturedTrainStep(_StaticInputs):
     """zero_grad -> GrappaModel -> Energy -> MolwiseLoss -> backward -> clip + Adam on ONE resident batch, as a hipGraph.
 
         step = CapturedTrainStep(model, energy, loss_fn, opt, g)     # warms up (3 eager steps: these DO train) and captures
@@ -121,70 +189,6 @@ class CapturedTrainStep:
         torch.cuda.current_stream(g.device).wait_stream(self.stream)
         self.replays = 0
 
-    # ---- every input of the recorded step in ONE device buffer (as CapturedForward, plus the features and references of every level)
-    def _input_slots(self, plan, g):
-        slots = dict(CapturedForward._plan_tensors(plan))
-        for nt, d in g._data.items():
-            for k, t in d.items():
-                if torch.is_tensor(t):
-                    slots[f"data.{nt}.{k}"] = t
-        slots["graph.src"], slots["graph.dst"] = g._src, g._dst
-        return slots
-
-    def _rehome_inputs(self) -> None:
-        slots = self._input_slots(self.plan, self.g)
-        self._layout, off = {}, 0
-        for name, t in slots.items():
-            nbytes = t.numel() * t.element_size()
-            self._layout[name] = (off, nbytes, t.dtype, tuple(t.shape))
-            off += (nbytes + 15) // 16 * 16
-        self._in_dev = torch.zeros(max(off, 16), dtype=torch.uint8, device=self.g.device)
-        self._views = {}
-        for name, (o, nbytes, dtype, shape) in self._layout.items():
-            v = self._in_dev[o:o + nbytes].view(dtype).view(shape)
-            v.copy_(slots[name])
-            self._views[name] = v
-        for name, v in self._views.items():
-            parts = name.split(".")
-            if parts[0] == "data":
-                self.g._data[parts[1]][name[len("data.") + len(parts[1]) + 1:]] = v
-            elif parts[0] == "graph":
-                setattr(self.g, "_" + parts[1], v)
-            elif len(parts) == 1:
-                setattr(self.plan, name, v)
-            elif len(parts) == 2:
-                getattr(self.plan, parts[0])[parts[1]] = v
-            else:
-                d = getattr(self.plan, parts[0])
-                tup = list(d[parts[1]])
-                tup[int(parts[2])] = v
-                d[parts[1]] = tuple(tup)
-
-    def load(self, g) -> None:
-        """another batch of this step's signature (on the device) into the recorded step's inputs: one multi-tensor copy, stream-ordered
-        behind the previous replay"""
-        if not self.static_inputs:
-            raise RuntimeError("load: this step was recorded on its batch's own tensors (static_inputs=False)")
-        plan = g.plan()
-        for lvl in self.plan.__dict__.get("_pos_tables", {}):
-            plan.position_tables(lvl)
-        src = self._input_slots(plan, g)
-        if set(src) != set(self._layout):
-            raise ValueError(f"load: the batch has other input tables than the recorded one ({sorted(set(src) ^ set(self._layout))})")
-        dsts, srcs = [], []
-        for name, (o, nbytes, dtype, shape) in self._layout.items():
-            t = src[name]
-            if tuple(t.shape) != shape or t.dtype != dtype:
-                raise ValueError(f"load: {name} is {t.dtype} {tuple(t.shape)}, the recorded step holds {dtype} {shape}")
-            if t.numel():
-                dsts.append(self._views[name])
-                srcs.append(t if t.is_contiguous() else t.contiguous())
-        torch._foreach_copy_(dsts, srcs)
-        # host-side mirrors the eager modules read (molecule counts per level; nothing the recorded kernels depend on)
-        self.g._bnn = {k: v.copy() for k, v in g._bnn.items()}
-        self.plan.n_real_mols = getattr(plan, "n_real_mols", None)
-        self.plan.max_degree = plan.max_degree
-
     def _eager(self):
         self.opt.zero_grad()
         _drop_outputs(self.g)
@@ -200,6 +204,49 @@ class CapturedTrainStep:
         self.be.invalidate_weights()                        # the weights moved under the host-side caches' feet
         _touch_weight_caches(self.be)
         return self.loss
+
+
+class CapturedEvalStep(_StaticInputs):
+    """GrappaModel -> Energy in eval mode under no_grad on batches of ONE shape signature, as a hipGraph (the validation pass of
+    `Trainer(recorded=True)`): `load(g)` copies a batch in, `()` replays and returns the resident graph whose `energy` / `gradient` the evaluator
+    reads.  The per-weight caches are refreshed INSIDE the graph (the weights change between two validation passes)."""
+
+    def __init__(self, model, energy, g, warmup: int = 2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("CapturedEvalStep needs a GPU")
+        self.model, self.energy, self.g = model, energy, g
+        self.be = get_backend()
+        self.static_inputs = True
+        self.plan = g.plan()
+        for lvl in ("n2", "n3", "n4", "n4_improper"):
+            if self.plan.T[lvl]:
+                self.plan.position_tables(lvl)
+        self.signature = train_signature(g)
+        self._rehome_inputs()
+        self.stream = torch.cuda.Stream(device=g.device)
+        self.stream.wait_stream(torch.cuda.current_stream(g.device))
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for _ in range(max(int(warmup), 3)):
+                # (three epochs of eager refreshes: weights of other models age out of the backend's tables and the tables are rebuilt NOW -- a
+                # rebuild is a host-to-device copy, which a capture cannot hold; as CapturedForward(refresh_weights=True))
+                self.be.invalidate_weights()
+                self._eager()
+        self.stream.synchronize()
+        self.be.invalidate_weights()                         # every per-weight cache is stale: the recorded pass starts by refreshing them
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream), torch.no_grad():
+            self._eager()
+        self._pinned = _pinned_by_graph(self.be)
+        torch.cuda.current_stream(g.device).wait_stream(self.stream)
+
+    def _eager(self):
+        _drop_outputs(self.g)
+        return self.energy(self.model(self.g))
+
+    def __call__(self):
+        self.graph.replay()
+        _touch_weight_caches(self.be)
+        return self.g
 
 
 def train_signature(g) -> tuple:

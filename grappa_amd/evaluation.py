@@ -56,7 +56,9 @@ class FastEvaluator:
     @torch.no_grad()
     def step(self, g, dsnames: List[str]):
         plan = g.plan()
-        assert len(dsnames) == plan.B, f"one dataset name per molecule: {len(dsnames)} names for {plan.B} molecules"
+        # a batch padded to a fixed shape (DeviceDataset.collate(pad_to=...)) ends in a padding molecule that is no molecule of any dataset
+        nB = plan.B if getattr(plan, "n_real_mols", None) is None else int(plan.n_real_mols)
+        assert len(dsnames) == nB, f"one dataset name per molecule: {len(dsnames)} names for {nB} molecules"
         gd, n1 = g.nodes["g"].data, g.nodes["n1"].data
         energy, energy_ref = gd["energy"].detach().float().contiguous(), gd["energy_ref"].detach().float().contiguous()
         assert energy.dim() == 2 and energy.shape[1] > 0, f"energies must be a tensor of shape (n_mols, n_confs) but is {tuple(energy.shape)}"
@@ -69,7 +71,7 @@ class FastEvaluator:
         is_dummy = gd["is_dummy"].float().contiguous() if "is_dummy" in gd else None
         out = torch.zeros((plan.B, 8), dtype=torch.float32, device=energy.device)
         be = get_backend()
-        first = torch.empty((plan.B, 4), dtype=torch.float32, device=energy.device)
+        first = torch.zeros((plan.B, 4), dtype=torch.float32, device=energy.device)
         be.eval_se(plan, energy, energy_ref, is_dummy, grad, grad_ref, first)
         out[:, :4] = first
         if self.log_classical_values:
@@ -78,7 +80,7 @@ class FastEvaluator:
             be.eval_se(plan, e_cl, energy, is_dummy, g_cl, grad, first)
             out[:, 4:] = first
         idx = self._index_of(list(dsnames), energy.device)
-        self._acc.index_add_(0, idx, out.double())
+        self._acc.index_add_(0, idx, out[:nB].double())
 
     def pool(self):
         """per-dataset metrics (energies: per conformation; gradients: per 3-vector; crmse: per component) and their unweighted

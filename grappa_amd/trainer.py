@@ -102,6 +102,8 @@ class Trainer:
         self._steps: Dict[tuple, object] = {}
         self._prep_stream, self._load_done = None, None
         self._unrecordable: Dict[tuple, str] = {}          # shape signatures whose recording failed (reason): served eagerly
+        self._val_buckets: Optional[ShapeBuckets] = None
+        self._eval_steps: Dict[tuple, object] = {}
         self.pipelined, self._prep_pool = bool(pipelined), None
         self.recorded_stats = {"replayed": 0, "eager": 0, "graphs_recorded": 0, "padding_rows": 0, "real_rows": 0}
         self.batch_size, self.conf_strategy = batch_size, conf_strategy
@@ -291,8 +293,16 @@ class Trainer:
         # ranks before they are pooled (every rank ends with the same metrics, hence the same schedule decisions)
         if self.world > 1:
             self.evaluator.register(sorted(set(self.val_set.names)), self.flat.data.device)
-        for b, ids in enumerate(epoch_batches(self.val_set.names, self.val_batch_size, shuffle=False)):
+        batches = epoch_batches(self.val_set.names, self.val_batch_size, shuffle=False)
+        use_graphs = self.recorded and self.world == 1 and torch.cuda.is_available() and self.val_set.bonds_are_n2
+        if use_graphs and self._val_buckets is None:
+            # the validation batches are the same every epoch: their shapes (bucket x conformations) are recorded once and replayed from then on
+            self._val_buckets = ShapeBuckets(self.val_set, batches, n_buckets=self.shape_buckets)
+            self.val_set.enable_padding(self._val_buckets.max_pad)
+        for b, ids in enumerate(batches):
             if b % self.world != self.rank:
+                continue
+            if use_graphs and self._validate_recorded(np.asarray(ids)):
                 continue
             g, names = self.val_set.collate(ids, self.val_conf_strategy)
             self.evaluator.step(self.energy(self.model(g)), list(names))
@@ -301,6 +311,37 @@ class Trainer:
         metrics = self.evaluator.pool()
         es = self.schedule.on_validation_epoch_end(epoch, metrics)
         return metrics, es
+
+    def _validate_recorded(self, ids: np.ndarray) -> bool:
+        """one validation batch through a recorded forward + energy pass (capture.CapturedEvalStep); False: no bucket takes it or its recording
+        failed -- the caller runs it eagerly"""
+        from .capture import CapturedEvalStep, train_signature
+        tot = self.val_set.totals(ids)
+        caps = self._val_buckets.choose(tot)
+        if caps is None or any(caps[k] - tot[k] > self.val_set.pad_caps[k] for k in tot):
+            return False
+        g, names = self.val_set.collate(ids, self.val_conf_strategy, pad_to=caps)
+        key = (train_signature(g), "eval")
+        if key in self._unrecordable:
+            return False
+        step = self._eval_steps.pop(key, None)
+        if step is None:
+            if len(self._eval_steps) >= 2 * self.max_recorded_steps:
+                self._eval_steps.pop(next(iter(self._eval_steps)))
+            try:
+                step = CapturedEvalStep(self.model, self.energy, g)
+                self.recorded_stats["eval_graphs_recorded"] = self.recorded_stats.get("eval_graphs_recorded", 0) + 1
+            except Exception as e:  # noqa: BLE001
+                import warnings
+                self._unrecordable[key] = repr(e)
+                warnings.warn(f"Trainer(recorded=True): recording a validation pass failed ({e!r}); batches of this shape run eagerly")
+                return False
+        else:
+            step.load(g)
+        self._eval_steps[key] = step
+        self.evaluator.step(step(), list(names))
+        self.recorded_stats["eval_replayed"] = self.recorded_stats.get("eval_replayed", 0) + 1
+        return True
 
     def fit(self, max_epochs: int, log=None, checkpoint: Optional[str] = None, checkpoint_every: int = 1) -> List[Dict]:
         """epochs [next_epoch, max_epochs): a fresh trainer starts at 0, one that has loaded a checkpoint where that run stopped.

@@ -465,12 +465,16 @@ class RefBackend:
         """training/evaluation.py:53-113 per molecule (after unbatch: dummy conformations deleted, energies centred)"""
         B, dev = plan.B, out.device
         m = torch.ones_like(energy) if is_dummy is None else (is_dummy == 0).float()
+        n_real = getattr(plan, "n_real_mols", None)              # a batch that ends in a padding molecule: its rows of `out` stay zero (see loss_ef)
+        real = torch.arange(B, device=dev) < (B if n_real is None else int(n_real))
+        m = m * real[:, None].float()
         nreal = m.sum(1)
+        nreal = torch.where(real, nreal, torch.ones_like(nreal))
         me = (m * energy).sum(1, keepdim=True) / nreal[:, None]
         mr = (m * energy_ref).sum(1, keepdim=True) / nreal[:, None]
         diff = (energy - me) - (energy_ref - mr)
         out[:, 0] = (m * diff * diff).sum(1)
-        out[:, 1] = nreal
+        out[:, 1] = nreal * real.float()
         out[:, 2:] = 0
         if grad is not None:
             ptr = plan.atom_molptr.long()
@@ -479,7 +483,7 @@ class RefBackend:
             d = grad - grad_ref
             sq = (m[seg][..., None] * d * d).sum((1, 2))
             out[:, 2] = torch.zeros(B, device=dev).index_add(0, seg, sq)
-            out[:, 3] = cnt.float() * nreal
+            out[:, 3] = cnt.float() * nreal * real.float()
 
     def loss_ef(self, plan, energy, energy_ref, is_dummy, grad, grad_ref, wE, wG, inv_B, loss_mol, gE, gG):
         B = plan.B

@@ -184,15 +184,18 @@ def test_recorded_epochs_match_the_eager_trainer():
     from grappa_amd.trainer import Trainer
     cfg = dict(TINY, gnn_dropout_attention=0.0, gnn_dropout_initial=0.0, gnn_dropout_conv=0.0, gnn_dropout_final=0.0, parameter_dropout=0.0)
     items = [(graph_from_pool(300 + i, n_confs=4, seed=2), f"ds{i % 2}") for i in range(44)]
-    hist, stats = [], None
+    val_items = [(graph_from_pool(360 + i, n_confs=4 + (i % 3), seed=2), f"ds{i % 2}") for i in range(14)]
+    hist, vals, stats = [], [], None
     for recorded in (False, True):
         torch.manual_seed(0)
         ops.manual_seed(5)
         model = GrappaModel(**cfg).to("cuda")
-        train = DeviceDataset(items, device="cuda")
-        tr = Trainer(model, train, None, batch_size=8, conf_strategy=4, lr=2e-3, proper_regularisation=1e-3, start_qm_epochs=0, warmup_steps=2,
-                     energy_weight=1.0, gradient_weight=0.8, param_weight=0.0, recorded=recorded, shape_buckets=2)
-        hist.append([h["train_loss"] for h in tr.fit(2)])
+        train, val = DeviceDataset(items, device="cuda"), DeviceDataset(val_items, device="cuda")
+        tr = Trainer(model, train, val, batch_size=8, conf_strategy=4, val_batch_size=4, val_conf_strategy="max", lr=2e-3, proper_regularisation=1e-3,
+                     start_qm_epochs=0, warmup_steps=2, energy_weight=1.0, gradient_weight=0.8, param_weight=0.0, recorded=recorded, shape_buckets=2)
+        h = tr.fit(2)
+        hist.append([e["train_loss"] for e in h])
+        vals.append([e["val_metrics"] for e in h])
         if recorded:
             stats = dict(tr.recorded_stats)
     eager, rec = hist
@@ -200,6 +203,13 @@ def test_recorded_epochs_match_the_eager_trainer():
     assert 0 < stats["padding_rows"] < 0.6 * stats["real_rows"], stats
     for a, b in zip(eager, rec):
         assert abs(a - b) <= 2e-5 * abs(a), (eager, rec)
+    # the validation passes too: every batch of the second epoch is a replay (the validation batches are the same every epoch), same metrics
+    assert stats["eval_replayed"] == 8 and 1 <= stats["eval_graphs_recorded"] <= 4, stats
+    for ve, vr in zip(*vals):
+        for ds in ve:
+            for k, v in ve[ds].items():
+                if v is not None:
+                    assert abs(vr[ds][k] - v) <= 2e-5 * abs(v), (ds, k, v, vr[ds][k])
 
 
 @pytest.mark.gpu
