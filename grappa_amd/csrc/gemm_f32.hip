@@ -402,7 +402,7 @@ int pairs_cfg() {
 }
 
 Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false, bool pairs_small = false,
-               bool planes_tile256 = false) {
+               int planes_tile = 0) {      // 256 / 128: the bf16 pinned-pipeline kernel's other tiles (GRAPPA_BF16_TILE)
     Plan best;
     best.cfg = 1;
     best.nsplit = 1;
@@ -432,7 +432,7 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
         if (bf16x != (c >= 5)) continue;
         // the plane-format kernels have one tile shape each; the pair kernel (both operands pairs) also a 128 x 128 one
         // (pairs_small: both operands pairs and no forced tile -- round 5: all three tiles compete under the fitted staircase model)
-        if (planes && !forced_pairs && c != (pairs ? pairs_cfg() : (planes_tile256 ? 7 : 6)) && !(pairs_small && (c == 8 || (c == 7 && pairs_tile_choice())))) continue;
+        if (planes && !forced_pairs && c != (pairs ? pairs_cfg() : (planes_tile == 256 ? 7 : (planes_tile == 128 ? 8 : 6))) && !(pairs_small && (c == 8 || (c == 7 && pairs_tile_choice())))) continue;
         if (!planes && (c == 7 || c == 8)) continue;
         if (!vec && (c == 0 || c == 4)) continue;        // the scalar-load kernel is only built for the small tiles
         if (c == 2 && N > 32) continue;
@@ -444,9 +444,10 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
             if (want_split > 0 && ns != want_split) continue;
             int kps = (K + ns - 1) / ns;
             // (the pinned-pipeline kernels walk pairs of slabs -- 2 x 16 columns in the pair format, 2 x 32 in the bf16 one: split ranges in whole pairs)
-            const int kround = (planes_tile256 && c == 7) ? 64 : (pairs ? 32 : BK);
+            const bool bf16_il_tile = (planes_tile == 256 && c == 7) || (planes_tile == 128 && c == 8);      // no plane-kernel fallback for these tiles: plan what the pipeline takes
+            const int kround = bf16_il_tile ? 64 : (pairs ? 32 : BK);
             kps = (kps + kround - 1) / kround * kround;
-            if (planes_tile256 && c == 7 && kps < 128) continue;
+            if (bf16_il_tile && (kps < 128 || K - ((K + kps - 1) / kps - 1) * kps < 128)) continue;      // every K range holds the pipeline's four slabs of 32
             const int nsplit = (K + kps - 1) / kps;
             const bool il_model = pairs && pairs_tile_choice() && c >= 6;
             double cost = il_model ? cm.pairs_grid(c, tiles * nsplit, kps) : cm.grid(c, tiles * nsplit, kps);
@@ -555,8 +556,10 @@ static size_t workspace_floats_all(int M, int N, int K, const PlanOpts& o) {
         if (f > a) a = f;
         const size_t g = plan_workspace_floats(make_plan(M, N, K, o, true, true, true, true, true), M, N);
         if (g > a) a = g;
-        const size_t h = plan_workspace_floats(make_plan(M, N, K, o, true, true, true, false, false, true), M, N);
+        const size_t h = plan_workspace_floats(make_plan(M, N, K, o, true, true, true, false, false, 256), M, N);
         if (h > a) a = h;
+        const size_t h2 = plan_workspace_floats(make_plan(M, N, K, o, true, true, true, false, false, 128), M, N);
+        if (h2 > a) a = h2;
     }
     return a;
 }
@@ -865,10 +868,10 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     // experiment (GRAPPA_BF16_TILE=256): the bf16 storage configuration's K-contiguous one-plane products on the 256 x 256 tile of the pinned-pipeline
     // kernel (gemm_pairs_il.hip ARITH 1) -- 31 instead of 47 operand bytes per CU-cycle, and no faster: at K = N = 512 these products are bound by
     // their HBM bytes (1.2 GB per 400 k-row product: 250 us at 5 TB/s against 84 us of MFMAs), not by the intake (C3 bf16 step 75.7 ms either way)
-    static const bool bf16_tile256 = getenv("GRAPPA_BF16_TILE") && atoi(getenv("GRAPPA_BF16_TILE")) == 256;
-    const bool bf16_il256 = bf16_tile256 && planes && !pairs && d->precision == GRAPPA_GEMM_BF16 && d->a_planes && d->a_kcontig && d->b_kcontig && (d->K & 63) == 0 && d->K >= 128 &&
+    static const int bf16_tile = getenv("GRAPPA_BF16_TILE") ? atoi(getenv("GRAPPA_BF16_TILE")) : 0;
+    const bool bf16_il256 = (bf16_tile == 256 || bf16_tile == 128) && planes && !pairs && d->precision == GRAPPA_GEMM_BF16 && d->a_planes && d->a_kcontig && d->b_kcontig && (d->K & 63) == 0 && d->K >= 128 &&
                             (size_t)d->M * d->lda * 2 < (1ull << 32) && (size_t)d->N * d->ldb * 2 < (1ull << 32);
-    Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0, bf16_il256);
+    Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0, bf16_il256 ? bf16_tile : 0);
     if (pl.main_tiles <= 0) return GRAPPA_ERR_ARG;                       // a forced tile (plan_cfg) that no kernel of this product's operand formats has: refused, not skipped
     if (pairs && !d->a_planes && pl.cfg != 6) return GRAPPA_ERR_ARG;      // (fp32 A + weight pairs: the 256 x 128 tile only)
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only

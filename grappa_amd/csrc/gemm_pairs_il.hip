@@ -210,6 +210,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs_il_small_kernel(GemmParams 
 template <int QBN>
 __global__ __launch_bounds__(QShape<QBN>::NT, 2) void gemm_bf16_il_kernel(GemmParams p) { PairsIL<QBN, QBM, 1>::run(p, gridDim.x, blockIdx.x); }
 
+__global__ __launch_bounds__(256, 2) void gemm_bf16_il_small_kernel(GemmParams p) { PairsIL<128, 128, 1>::run(p, gridDim.x, blockIdx.x); }
+
 template <int BN, int BM, typename K>
 int launch_il(hipStream_t st, GemmParams& p, K kern, bool& attr_set) {
     using S = QShape<BN, BM>;
@@ -243,7 +245,8 @@ int grappa_launch_gemm_pairs_il(hipStream_t st, GemmParams& p) {
 // both operands ONE bf16 plane, K-contiguous, K (and every K cut) a multiple of 64, at least four slabs of 32 per workgroup, tile 256 x 128
 // (the caller checks): the bf16 storage configuration's forward / input-gradient products
 int grappa_launch_gemm_bf16_il(hipStream_t st, GemmParams& p) {
-    static bool a0 = false, a1 = false;
+    static bool a0 = false, a1 = false, a2 = false;
+    if (p.bm == 128) return launch_il<128, 128>(st, p, gemm_bf16_il_small_kernel, a2);      // experiment (GRAPPA_BF16_TILE=128)
     if (p.bn == 256) return launch_il<256, QBM>(st, p, gemm_bf16_il_kernel<256>, a1);
     return launch_il<128, QBM>(st, p, gemm_bf16_il_kernel<128>, a0);
 }
