@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPPA_HIP_LIB") or os.path.join(_HERE, "libgrappa_hip.so")   # override: kernel A/B builds (tools/)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 # grappa_gemm_desc.precision (include/grappa_hip.h GRAPPA_GEMM_*)
 GEMM_GROUP4_MAX = 4          # grappa_gemm_f32_group (forward / input-gradient products of the writer heads)
 GEMM_GROUP_MAX = 16
@@ -87,6 +87,20 @@ class CollateDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_row", C.c_void_p), ("dst_row", C.c_void_p), ("p0", C.c_void_p),
                 ("p1", C.c_void_p), ("c0", C.c_int64), ("width", C.c_int32), ("mode", C.c_int32)]
 
+
+class WriterLayerDesc(C.Structure):
+    """grappa_writer_layer_desc (ABI 11): one fused transformer layer of a writer head"""
+    _fields_ = [("s", C.c_int), ("T", C.c_int), ("F", C.c_int), ("nheads", C.c_int), ("dtype", C.c_int), ("x", C.c_void_p), ("out", C.c_void_p),
+                ("w_in_pk", C.c_void_p), ("w_o_pk", C.c_void_p), ("w1_pk", C.c_void_p), ("w2_pk", C.c_void_p),
+                ("b_in", C.c_void_p), ("b_o", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p),
+                ("n1_gamma", C.c_void_p), ("n1_beta", C.c_void_p), ("nf_gamma", C.c_void_p), ("nf_beta", C.c_void_p),
+                ("drop_p", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64), ("drop_salt", C.c_void_p),
+                ("save_mean1", C.c_void_p), ("save_rstd1", C.c_void_p), ("save_meanf", C.c_void_p), ("save_rstdf", C.c_void_p),
+                ("save_x1", C.c_void_p), ("save_qkv", C.c_void_p), ("save_att", C.c_void_p), ("save_x2", C.c_void_p), ("save_x3", C.c_void_p),
+                ("save_u", C.c_void_p)]
+
+
+WRITER_BF16 = 1
 
 COLLATE_MODES = {"copy": 0, "add": 1, "inv_rows": 2, "inc_code": 3, "conf": 4}
 
@@ -180,6 +194,10 @@ SIGNATURES = {
     "grappa_perm_concat_bwd_bf16": (_i, [_vp, _i, _i, _i, _i, c_int_p, _vp, _vp]),
     "grappa_convert_f32_to_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _i]),
     "grappa_convert_bf16_to_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i]),
+    # ABI 11: the fused writer-head layer
+    "grappa_writer_head_fwd": (_i, [_vp, C.POINTER(WriterLayerDesc)]),
+    "grappa_writer_pack_bytes": (_sz, [_i, _i, _i]),
+    "grappa_writer_pack_weight": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -198,6 +198,9 @@ class HipBackend:
         self._side_streams = {}        # (device, caller's stream handle) -> the side stream of launch_wgrads_aside
         self._aside = []               # (side stream, items kept alive) since the last flush
         self.weight_planes = os.environ.get("GRAPPA_WEIGHT_PLANES", "0") not in ("0", "")
+        # round 6: a transformer layer of a writer head as ONE kernel (csrc/writer_layer.hip, grappa_writer_head_fwd) where its shape allows:
+        # bf16 storage configuration, 512 features, 8 heads.  GRAPPA_FUSED_WRITER_LAYER=0: the unfused sequence (A/B, tests)
+        self.fused_writer_layer = os.environ.get("GRAPPA_FUSED_WRITER_LAYER", "1") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
         self._wpairs = {}      # (data_ptr, rows, cols, "pairs" | "pairsT") -> [version key, pairs, weakref of the weight, epoch of last use, transposed, maxima record]
         self._wptable = None   # (device table of grappa_split_pairs_item, count, tiles, records kept alive)
@@ -1464,6 +1467,83 @@ class HipBackend:
             return Amax(row=row)
         _chk(getattr(self.lib, f"grappa_seqattn_fwd_{_sfx(out)}")(*args), "grappa_seqattn_fwd")
         return None
+
+    # ------------------------------------------------------------------ the fused writer-head layer (C ABI 11)
+    def _packed_weight(self, w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+        """W (out x in features) -- or W^T -- as bf16 in the MFMA fragment order of the fused writer layer (grappa_writer_pack_weight);
+        cached per weight and refreshed when the weight changed, like _planes_of_weight"""
+        R, Cc = w.shape
+        key = (w.data_ptr(), R, Cc, "packT" if transposed else "pack")
+        ver = (w._version, self._wepoch)
+        hit = self._wplanes.get(key)
+        if hit is not None and hit[2]() is not w:
+            hit = None
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        N, K = (Cc, R) if transposed else (R, Cc)
+        if hit is not None:
+            pk = hit[1]
+        else:
+            pk = torch.empty(N * K, dtype=torch.bfloat16, device=w.device)
+            for k in [k for k, e in self._wplanes.items() if e[2]() is None]:
+                del self._wplanes[k]
+        _chk(self.lib.grappa_writer_pack_weight(self._stream(), N, K, w.data_ptr(), _f32_2d(w, "W", w.device), int(transposed), _lib.WRITER_BF16,
+                                                pk.data_ptr()), "grappa_writer_pack_weight")
+        self._wplanes[key] = (ver, pk, weakref.ref(w))
+        return pk
+
+    def writer_layer_ok(self, x: torch.Tensor, s: int, nheads: int, *params) -> bool:
+        """can grappa_writer_head_fwd run this transformer layer?  (bf16 storage configuration, 512 features, 8 heads, tuples of 2 - 4 tokens,
+        both LayerNorms present)"""
+        if not self.fused_writer_layer or x.dtype != torch.bfloat16 or x.dim() != 2 or x.shape[1] != 512 or nheads != 8 or s not in (2, 3, 4):
+            return False
+        if x.shape[0] == 0:
+            return False
+        return all(p is not None and p.dtype == torch.float32 and p.is_contiguous() for p in params)
+
+    def writer_layer_fwd(self, x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, out, save=None):
+        """out = the transformer layer of a writer head applied to the token table x (s*T, 512) in ONE launch (include/grappa_hip.h
+        grappa_writer_head_fwd; reference models/network_utils.py:112-133, :44-54).  save: None (inference) or the tensors the unfused
+        backward reads, written as by-products: dict(mean1, rstd1, x1, qkv, att, x2, meanf, rstdf, x3, u)."""
+        dev = x.device
+        M, Fd = x.shape
+        if M != s * T or tuple(out.shape) != (M, Fd) or out.dtype != x.dtype:
+            raise ValueError("writer_layer_fwd: shapes")
+        d = _lib.WriterLayerDesc()
+        d.s, d.T, d.F, d.nheads, d.dtype = s, T, Fd, nheads, _lib.WRITER_BF16
+        _flat(x, "x", dev, torch.bfloat16), _flat(out, "out", dev, torch.bfloat16)
+        d.x, d.out = x.data_ptr(), out.data_ptr()
+        for name, wt, shape in (("w_in_pk", w_in, (3 * Fd, Fd)), ("w_o_pk", w_o, (Fd, Fd)), ("w1_pk", w1, (Fd, Fd)), ("w2_pk", w2, (Fd, Fd))):
+            if tuple(wt.shape) != shape:
+                raise ValueError(f"writer_layer_fwd: {name[:-3]} has shape {tuple(wt.shape)}, expected {shape}")
+            setattr(d, name, self._packed_weight(wt).data_ptr())
+        for name, v, n in (("b_in", b_in, 3 * Fd), ("b_o", b_o, Fd), ("b1", b1, Fd), ("b2", b2, Fd), ("n1_gamma", n1_w, Fd), ("n1_beta", n1_b, Fd),
+                           ("nf_gamma", nf_w, Fd), ("nf_beta", nf_b, Fd)):
+            _flat(v, name, dev)
+            if v.numel() != n:
+                raise ValueError(f"writer_layer_fwd: {name} length")
+            setattr(d, name, v.data_ptr())
+        d.drop_p, d.seed1, d.seed2 = float(drop_p), int(seed1) & (2 ** 64 - 1), int(seed2) & (2 ** 64 - 1)
+        d.drop_salt = self._salt_ptr
+        keep = None
+        if save is not None:
+            for name in ("mean1", "rstd1", "meanf", "rstdf"):
+                t = save[name]
+                _flat(t, name, dev)
+                if t.numel() != M:
+                    raise ValueError(f"writer_layer_fwd: save[{name!r}] length")
+                setattr(d, "save_" + name, t.data_ptr())
+            for name in ("x1", "qkv", "att", "x2", "x3", "u"):
+                t = save[name]
+                _flat(t, name, dev, torch.bfloat16)
+                if tuple(t.shape) != (M, 3 * Fd if name == "qkv" else Fd):
+                    raise ValueError(f"writer_layer_fwd: save[{name!r}] shape")
+                setattr(d, "save_" + name, t.data_ptr())
+            keep = save
+        flops = 2.0 * M * Fd * (6 * Fd) + 4.0 * M * s * Fd
+        nbytes = 2.0 * M * Fd * (2 + (9 if save is not None else 0)) + 2.0 * 6 * Fd * Fd
+        self._timed("writer_layer", flops, nbytes, lambda: _chk(self.lib.grappa_writer_head_fwd(self._stream(), C.byref(d)), "grappa_writer_head_fwd"),
+                    lambda: [{"M": M, "s": s, "save": keep is not None}])
 
     def seqattn_bwd(self, qkv, dout, s, T, nheads, dqkv, amax=None):
         dev = dqkv.device

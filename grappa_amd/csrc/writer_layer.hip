@@ -1,0 +1,480 @@
+// The fused writer-head layer (C ABI 11: grappa_writer_head_fwd, include/grappa_hip.h): ONE kernel per transformer layer of a writer head
+//
+//     x1 = LN(x); qkv = x1 W_in^T + b_in; a = MHA(q, k, v) over the s tokens of a tuple; x2 = drop(a W_o^T + b_o) + x1;
+//     x3 = LN(x2); u = ELU(x3 W_1^T + b_1); out = drop(u W_2^T + b_2) + x3
+//
+// (reference models/network_utils.py:112-133 DottedAttWithMLP with :44-54 FeedForwardLayer; the stack is models/perm_equiv_transformer.py:121-151).
+// A workgroup owns a tile of 64 token rows = all s tokens of 32 / 21 / 16 tuples and walks the whole layer on it: the 512-wide
+// activations never leave the CU.  bf16 storage configuration (BASELINE configs[2]).
+//
+//  * LDS (135 KB): image A [64][512] bf16 (x1, later x3), a staging area for the q, k, v of TWO heads [64][384] and their attention
+//    output [64][128]; the ELU output u [64][512] overlays the staging area once the attention is done.  Rows are 16 bytes longer than
+//    their data so that the 16 token rows of a fragment read start 4 banks apart (conflict-free ds_read_b128).
+//  * every product is computed TRANSPOSED, out^T = W act^T, on v_mfma_f32_16x16x32_bf16: the weight is the A operand, read straight from
+//    HBM / L2 into registers from a copy packed in fragment order (grappa_writer_pack_weight: one contiguous KB per wave-instruction, every
+//    weight byte is loaded once per workgroup -- the eight wavefronts own disjoint 64-feature slices); the activation is the B operand,
+//    read from the LDS image.  An accumulator then holds 4 CONSECUTIVE features of one token per lane: results go back into the next
+//    image with one 8-byte ds_write per fragment, row statistics are sums over registers and 2 lane exchanges.
+//  * the out-projection is accumulated head pair by head pair (K = 128 at a time) in registers while the q, k, v of the next pair are
+//    being produced, so the full attention output never exists.
+//  * training (save pointers non-NULL): every tensor the unfused backward pass reads is written as a by-product, never re-read.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 wl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wl_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float wl_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WL_F = 512, WL_ROWS = 64, WL_THREADS = 512;
+constexpr int WL_LDA = 520;      // elements per row of a full-width image (1,040 bytes)
+constexpr int WL_LDQ = 392;      // q | k | v of two heads: 384 + 8
+constexpr int WL_LDT = 136;      // attention output of two heads: 128 + 8
+constexpr int WL_OFF_A = 0;
+constexpr int WL_OFF_Q = WL_ROWS * WL_LDA * 2;
+constexpr int WL_OFF_T = WL_OFF_Q + WL_ROWS * WL_LDQ * 2;
+constexpr int WL_OFF_B = WL_OFF_Q;
+constexpr int WL_OFF_RED = WL_OFF_T + WL_ROWS * WL_LDT * 2;
+constexpr int WL_SMEM = WL_OFF_RED + 2 * 8 * WL_ROWS * 4;
+static_assert(WL_OFF_B + WL_ROWS * WL_LDA * 2 <= WL_OFF_RED, "the u image must fit into the staging area");
+static_assert(WL_SMEM <= 160 * 1024, "LDS of one CU");
+
+__device__ __forceinline__ void wl_unpack8(const uint4& u, float (&v)[8]) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 wl_pack8(const float (&v)[8]) {
+    wl_bf16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
+    return __builtin_bit_cast(uint4, h);
+}
+__device__ __forceinline__ uint2 wl_pack4(const float (&v)[4]) {
+    wl_bf16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+    return __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ void wl_unpack4(const uint2& u, float (&v)[4]) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ __forceinline__ float wl_round_bf16(float v) {
+    const __bf16 h = (__bf16)v;
+    return (float)h;
+}
+
+// acc[i][mb] += W[n-block i](:, ks0 ... ks0 + KSN) act^T: pa[i] = the lane's first fragment of n-block i (consecutive k-steps are 64 uint4
+// apart), bimg = the lane's first fragment in the LDS image (row lr, k = 8 lq), rows `ldb` bytes apart.  PD k-steps of weights in flight.
+template <int NB, int KSN, int PD>
+__device__ __forceinline__ void wl_product(const uint4* const (&pa)[NB], const char* bimg, const int ldb, wl_f32x4 (&acc)[NB][4]) {
+    static_assert(KSN % PD == 0, "whole rings");
+    uint4 ring[PD][NB];
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) ring[d][i] = pa[i][d * 64];
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KSN; ks0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int ks = ks0 + d;
+            wl_bf16x8 b[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) b[mb] = __builtin_bit_cast(wl_bf16x8, *reinterpret_cast<const uint4*>(bimg + mb * 16 * ldb + ks * 64));
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const wl_bf16x8 a = __builtin_bit_cast(wl_bf16x8, ring[d][i]);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[i][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[mb], acc[i][mb], 0, 0, 0);
+            }
+            if (ks + PD < KSN) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) ring[d][i] = pa[i][(ks + PD) * 64];
+            }
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void wl_zero(wl_f32x4 (&acc)[NB][4]) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[i][mb] = wl_f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// sum over the four lanes that hold the same token (l, l ^ 16, l ^ 32, l ^ 48)
+__device__ __forceinline__ float wl_quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int S>
+__global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const grappa_writer_layer_desc d) {
+    constexpr int TT = WL_ROWS / S;                 // tuples per tile: 32, 21, 16
+    extern __shared__ char smem[];
+    uint16_t* imgA = reinterpret_cast<uint16_t*>(smem + WL_OFF_A);
+    uint16_t* imgQ = reinterpret_cast<uint16_t*>(smem + WL_OFF_Q);
+    uint16_t* imgT = reinterpret_cast<uint16_t*>(smem + WL_OFF_T);
+    uint16_t* imgB = reinterpret_cast<uint16_t*>(smem + WL_OFF_B);
+    float* red = reinterpret_cast<float*>(smem + WL_OFF_RED);          // [2][8 wavefronts][64 rows]
+
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
+    const int T = d.T;
+    const int t0 = blockIdx.x * TT;
+    const int ntup = min(TT, T - t0);
+    const uint16_t* __restrict__ x = reinterpret_cast<const uint16_t*>(d.x);
+    uint16_t* __restrict__ out = reinterpret_cast<uint16_t*>(d.out);
+    uint16_t* __restrict__ sv_x1 = reinterpret_cast<uint16_t*>(d.save_x1);
+    uint16_t* __restrict__ sv_qkv = reinterpret_cast<uint16_t*>(d.save_qkv);
+    uint16_t* __restrict__ sv_att = reinterpret_cast<uint16_t*>(d.save_att);
+    uint16_t* __restrict__ sv_x2 = reinterpret_cast<uint16_t*>(d.save_x2);
+    uint16_t* __restrict__ sv_x3 = reinterpret_cast<uint16_t*>(d.save_x3);
+    uint16_t* __restrict__ sv_u = reinterpret_cast<uint16_t*>(d.save_u);
+    const float drop_p = d.drop_p;
+    const float drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+
+    // ---- phase 0: x1 = LN(x) -> image A; wavefront w owns tile rows 8 w ... 8 w + 7, a lane 8 consecutive columns
+    {
+        uint4 raw[8];
+        long grow8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = w * 8 + i, p = r / TT, j = r - p * TT;
+            const bool ok = p < S && j < ntup;
+            grow8[i] = ok ? (long)p * T + t0 + j : -1;
+            raw[i] = ok ? *reinterpret_cast<const uint4*>(x + (size_t)grow8[i] * WL_F + 8 * l) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        float g[8], b[8];
+        {
+            const float4 g0 = reinterpret_cast<const float4*>(d.n1_gamma)[2 * l], g1 = reinterpret_cast<const float4*>(d.n1_gamma)[2 * l + 1];
+            const float4 b0 = reinterpret_cast<const float4*>(d.n1_beta)[2 * l], b1 = reinterpret_cast<const float4*>(d.n1_beta)[2 * l + 1];
+            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = w * 8 + i;
+            float v[8];
+            wl_unpack8(raw[i], v);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) s += v[e] + v[e + 1];
+            const float mean = wave_sum(s) / (float)WL_F;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float a0 = v[e] - mean, a1 = v[e + 1] - mean;
+                q += a0 * a0 + a1 * a1;
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)WL_F + 1e-5f);
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = grappa_ln_apply(v[e], mean, rstd, g[e], b[e]);
+            const uint4 pk = wl_pack8(y);
+            *reinterpret_cast<uint4*>(imgA + r * WL_LDA + 8 * l) = pk;
+            if (grow8[i] >= 0) {
+                if (sv_x1) *reinterpret_cast<uint4*>(sv_x1 + (size_t)grow8[i] * WL_F + 8 * l) = pk;
+                if (d.save_mean1 && l == 0) {
+                    d.save_mean1[grow8[i]] = mean;
+                    d.save_rstd1[grow8[i]] = rstd;
+                }
+            }
+        }
+    }
+    // the four tokens (one per 16-row block) this lane holds in every accumulator: global row or -1
+    long grow[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int r = mb * 16 + lr, p = r / TT, j = r - p * TT;
+        grow[mb] = (p < S && j < ntup) ? (long)p * T + t0 + j : -1;
+    }
+    const uint64_t seed1 = grappa_salted(d.seed1, d.drop_salt), seed2 = grappa_salted(d.seed2, d.drop_salt);
+    const uint4* __restrict__ wq_in = reinterpret_cast<const uint4*>(d.w_in_pk);
+    const uint4* __restrict__ wq_o = reinterpret_cast<const uint4*>(d.w_o_pk);
+    const uint4* __restrict__ wq_1 = reinterpret_cast<const uint4*>(d.w1_pk);
+    const uint4* __restrict__ wq_2 = reinterpret_cast<const uint4*>(d.w2_pk);
+    const char* fragA = smem + WL_OFF_A + (lr * WL_LDA + 8 * lq) * 2;
+    const char* fragT = smem + WL_OFF_T + (lr * WL_LDT + 8 * lq) * 2;
+    const char* fragB = smem + WL_OFF_B + (lr * WL_LDA + 8 * lq) * 2;
+    __syncthreads();
+
+    // ---- phase 1: head pair by head pair: q, k, v of two heads -> staging; attention -> staging; x2 accumulator += a W_o^T (K = 128)
+    wl_f32x4 oacc[4][4];
+    wl_zero<4>(oacc);
+#pragma unroll 1
+    for (int hp = 0; hp < 4; ++hp) {
+        {
+            wl_f32x4 acc[3][4];
+            wl_zero<3>(acc);
+            const uint4* pa[3];
+            int nbw[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int cb = 3 * w + i;                        // 16-feature block of the chunk [q(128) | k(128) | v(128)]
+                nbw[i] = (cb >> 3) * 32 + hp * 8 + (cb & 7);     // its block of W_in's 1536 rows
+                pa[i] = wq_in + ((size_t)nbw[i] * 16) * 64 + l;
+            }
+            wl_product<3, 16, 4>(pa, fragA, WL_LDA * 2, acc);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int n = nbw[i] * 16 + 4 * lq;
+                const float4 bi = *reinterpret_cast<const float4*>(d.b_in + n);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const float v[4] = {acc[i][mb][0] + bi.x, acc[i][mb][1] + bi.y, acc[i][mb][2] + bi.z, acc[i][mb][3] + bi.w};
+                    const uint2 pk = wl_pack4(v);
+                    *reinterpret_cast<uint2*>(imgQ + (mb * 16 + lr) * WL_LDQ + (3 * w + i) * 16 + 4 * lq) = pk;
+                    if (sv_qkv && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_qkv + (size_t)grow[mb] * (3 * WL_F) + n) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // attention of (tuple j, head 2 hp + hh): 8 lanes, 8 features each (the arithmetic of csrc/tuples.hip seqattn_fwd_kernel_e)
+            const int sub = tid & 7, pair = tid >> 3, hh = pair & 1, j = pair >> 1;
+            if (j < ntup) {
+                float q[S][8], k[S][8], v[S][8];
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const uint16_t* row = imgQ + (i * TT + j) * WL_LDQ + hh * 64 + sub * 8;
+                    wl_unpack8(*reinterpret_cast<const uint4*>(row), q[i]);
+                    wl_unpack8(*reinterpret_cast<const uint4*>(row + 128), k[i]);
+                    wl_unpack8(*reinterpret_cast<const uint4*>(row + 256), v[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    float sc[S], mx = -INFINITY;
+#pragma unroll
+                    for (int jj = 0; jj < S; ++jj) {
+                        float dt = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) dt += q[i][e] * k[jj][e] + q[i][e + 1] * k[jj][e + 1];
+                        sc[jj] = group_sum(dt, 8) * 0.125f;
+                        mx = fmaxf(mx, sc[jj]);
+                    }
+                    float den = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < S; ++jj) {
+                        sc[jj] = expf(sc[jj] - mx);
+                        den += sc[jj];
+                    }
+                    const float inv = 1.0f / den;
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < S; ++jj) {
+                        const float pw = sc[jj] * inv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += pw * v[jj][e];
+                    }
+                    const uint4 pk = wl_pack8(o);
+                    *reinterpret_cast<uint4*>(imgT + (i * TT + j) * WL_LDT + hh * 64 + sub * 8) = pk;
+                    if (sv_att) *reinterpret_cast<uint4*>(sv_att + ((size_t)i * T + t0 + j) * WL_F + (2 * hp + hh) * 64 + sub * 8) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const uint4* pa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pa[i] = wq_o + ((size_t)(4 * w + i) * 16 + hp * 4) * 64 + l;
+            wl_product<4, 4, 4>(pa, fragT, WL_LDT * 2, oacc);
+        }
+    }
+
+    // ---- phase 2: x2 = drop(acc + b_o) + x1 (rounded to bf16 like the stored tensor); x3 = LN(x2) -> image A
+    {
+        float x2v[4][4][4];
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+            const float4 bo = *reinterpret_cast<const float4*>(d.b_o + n);
+            const float bb[4] = {bo.x, bo.y, bo.z, bo.w};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float x1v[4];
+                wl_unpack4(*reinterpret_cast<const uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n), x1v);
+                const uint64_t idx = (uint64_t)(grow[mb] >= 0 ? grow[mb] : 0) * WL_F + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = oacc[i][mb][e] + bb[e];
+                    if (drop_p > 0.f) v = grappa_keep(seed1, idx + e, drop_p) ? v * drop_scale : 0.f;
+                    v = wl_round_bf16(v + x1v[e]);
+                    x2v[i][mb][e] = v;
+                    part[mb] += v;
+                }
+                if (sv_x2 && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_x2 + (size_t)grow[mb] * WL_F + n) = wl_pack4(x2v[i][mb]);
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            part[mb] = wl_quad_sum(part[mb]);
+            if (lq == 0) red[w * WL_ROWS + mb * 16 + lr] = part[mb];
+        }
+        __syncthreads();
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) s += red[ww * WL_ROWS + mb * 16 + lr];
+            mean[mb] = s / (float)WL_F;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = x2v[i][mb][e] - mean[mb];
+                    q += a * a;
+                }
+            q = wl_quad_sum(q);
+            if (lq == 0) red[(8 + w) * WL_ROWS + mb * 16 + lr] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            float q = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) q += red[(8 + ww) * WL_ROWS + mb * 16 + lr];
+            rstd[mb] = 1.0f / sqrtf(q / (float)WL_F + 1e-5f);
+            if (d.save_meanf && w == 0 && lq == 0 && grow[mb] >= 0) {
+                d.save_meanf[grow[mb]] = mean[mb];
+                d.save_rstdf[grow[mb]] = rstd[mb];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+            const float4 g4 = *reinterpret_cast<const float4*>(d.nf_gamma + n), b4 = *reinterpret_cast<const float4*>(d.nf_beta + n);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = grappa_ln_apply(x2v[i][mb][e], mean[mb], rstd[mb], gg[e], bb[e]);
+                const uint2 pk = wl_pack4(y);
+                *reinterpret_cast<uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n) = pk;
+                if (sv_x3 && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_x3 + (size_t)grow[mb] * WL_F + n) = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: u = ELU(x3 W_1^T + b_1) -> image B
+    {
+        wl_f32x4 acc[4][4];
+        wl_zero<4>(acc);
+        const uint4* pa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[i] = wq_1 + ((size_t)(4 * w + i) * 16) * 64 + l;
+        wl_product<4, 16, 4>(pa, fragA, WL_LDA * 2, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+            const float4 b4 = *reinterpret_cast<const float4*>(d.b1 + n);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = grappa_elu(acc[i][mb][e] + bb[e]);
+                const uint2 pk = wl_pack4(y);
+                *reinterpret_cast<uint2*>(imgB + (mb * 16 + lr) * WL_LDA + n) = pk;
+                if (sv_u && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_u + (size_t)grow[mb] * WL_F + n) = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: out = drop(u W_2^T + b_2) + x3
+    {
+        wl_f32x4 acc[4][4];
+        wl_zero<4>(acc);
+        const uint4* pa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[i] = wq_2 + ((size_t)(4 * w + i) * 16) * 64 + l;
+        wl_product<4, 16, 4>(pa, fragB, WL_LDA * 2, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+            const float4 b4 = *reinterpret_cast<const float4*>(d.b2 + n);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                if (grow[mb] < 0) continue;
+                float x3v[4], y[4];
+                wl_unpack4(*reinterpret_cast<const uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n), x3v);
+                const uint64_t idx = (uint64_t)grow[mb] * WL_F + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][mb][e] + bb[e];
+                    if (drop_p > 0.f) v = grappa_keep(seed2, idx + e, drop_p) ? v * drop_scale : 0.f;
+                    y[e] = v + x3v[e];
+                }
+                *reinterpret_cast<uint2*>(out + (size_t)grow[mb] * WL_F + n) = wl_pack4(y);
+            }
+        }
+    }
+}
+
+// W (N x K fp32, rows ldw apart; transpose: the operand is W^T, K x N) -> bf16 in fragment order: block (nb, ks) = 16 rows x 32 k is one
+// contiguous KB, lane l of a wavefront holds rows nb 16 + (l & 15), k = ks 32 + 8 (l >> 4) ... + 7 as its 16 bytes
+__global__ __launch_bounds__(256) void writer_pack_bf16_kernel(int N, int K, const float* __restrict__ W, int ldw, int transpose, uint16_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one lane fragment (8 elements) per thread
+    const int KS = K >> 5;
+    if (i >= (size_t)(N >> 4) * KS * 64) return;
+    const int l = (int)(i & 63);
+    const size_t blk = i >> 6;
+    const int ks = (int)(blk % KS), nb = (int)(blk / KS);
+    const int n = nb * 16 + (l & 15), k0 = ks * 32 + 8 * (l >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = transpose ? W[(size_t)(k0 + e) * ldw + n] : W[(size_t)n * ldw + k0 + e];
+    reinterpret_cast<uint4*>(out)[i] = wl_pack8(v);
+}
+
+}  // namespace
+
+extern "C" size_t grappa_writer_pack_bytes(int N, int K, int dtype) {
+    if (N <= 0 || K <= 0 || N % 16 || K % 32 || dtype != GRAPPA_WRITER_BF16) return 0;
+    return (size_t)N * K * 2;
+}
+
+extern "C" int grappa_writer_pack_weight(void* stream, int N, int K, const float* W, int ldw, int transpose, int dtype, void* out) {
+    if (N <= 0 || K <= 0 || N % 16 || K % 32 || !W || !out || dtype != GRAPPA_WRITER_BF16) return GRAPPA_ERR_ARG;
+    if (ldw < (transpose ? N : K)) return GRAPPA_ERR_ARG;
+    const size_t frags = (size_t)(N / 16) * (K / 32) * 64;
+    GRAPPA_LAUNCH(writer_pack_bf16_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), N, K, W, ldw,
+                  transpose, reinterpret_cast<uint16_t*>(out));
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_writer_head_fwd(void* stream, const grappa_writer_layer_desc* d) {
+    if (!d || d->dtype != GRAPPA_WRITER_BF16 || d->F != WL_F || d->nheads != 8 || d->s < 2 || d->s > 4 || d->T < 0) return GRAPPA_ERR_ARG;
+    if (d->T == 0) return GRAPPA_OK;
+    if (!d->x || !d->out || !d->w_in_pk || !d->w_o_pk || !d->w1_pk || !d->w2_pk || !d->b_in || !d->b_o || !d->b1 || !d->b2 || !d->n1_gamma ||
+        !d->n1_beta || !d->nf_gamma || !d->nf_beta)
+        return GRAPPA_ERR_ARG;
+    if (!(d->drop_p >= 0.f && d->drop_p < 1.f)) return GRAPPA_ERR_ARG;
+    if ((d->save_mean1 == nullptr) != (d->save_rstd1 == nullptr) || (d->save_meanf == nullptr) != (d->save_rstdf == nullptr)) return GRAPPA_ERR_ARG;
+    const uintptr_t al = (uintptr_t)d->x | (uintptr_t)d->out | (uintptr_t)d->w_in_pk | (uintptr_t)d->w_o_pk | (uintptr_t)d->w1_pk | (uintptr_t)d->w2_pk |
+                         (uintptr_t)d->b_in | (uintptr_t)d->b_o | (uintptr_t)d->b1 | (uintptr_t)d->b2 | (uintptr_t)d->n1_gamma | (uintptr_t)d->n1_beta |
+                         (uintptr_t)d->nf_gamma | (uintptr_t)d->nf_beta | (uintptr_t)d->save_x1 | (uintptr_t)d->save_qkv | (uintptr_t)d->save_att |
+                         (uintptr_t)d->save_x2 | (uintptr_t)d->save_x3 | (uintptr_t)d->save_u;
+    if (al & 15) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int tt = WL_ROWS / d->s;
+    const dim3 grid((unsigned)((d->T + tt - 1) / tt));
+    void (*kern)(const grappa_writer_layer_desc) =
+        d->s == 2 ? writer_layer_fwd_bf16_kernel<2> : (d->s == 3 ? writer_layer_fwd_bf16_kernel<3> : writer_layer_fwd_bf16_kernel<4>);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WL_SMEM) != hipSuccess) return GRAPPA_ERR_LAUNCH;
+    GRAPPA_LAUNCH(kern, grid, dim3(WL_THREADS), WL_SMEM, st, *d);
+    return grappa_launch_status();
+}

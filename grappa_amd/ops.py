@@ -547,6 +547,26 @@ class TransformerLayerFn(Function):
         x = _c(x)
         M, Fd = x.shape
         infer = _infer(ctx)
+        fused = getattr(be, "writer_layer_ok", None)
+        if fused is not None and T and fused(x, s, nheads, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2):
+            # the whole layer as ONE launch (C ABI 11 grappa_writer_head_fwd, csrc/writer_layer.hip); training: the tensors the backward pass
+            # below reads are by-products of that launch
+            out = _new((M, Fd), x)
+            sv = None
+            if infer != 1:
+                sv = dict(mean1=_new((M,), x, F32), rstd1=_new((M,), x, F32), meanf=_new((M,), x, F32), rstdf=_new((M,), x, F32),
+                          x1=_new((M, Fd), x), qkv=_new((M, 3 * Fd), x), att=_new((M, Fd), x), x2=_new((M, Fd), x), x3=_new((M, Fd), x),
+                          u=_new((M, Fd), x))
+            be.writer_layer_fwd(x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, out, save=sv)
+            ctx.cfg, ctx.scales = (s, T, nheads, drop_p, seed1, seed2), (None, None)
+            if sv is not None:
+                ctx.ff_saved = (sv["x2"], sv["meanf"], sv["rstdf"], sv["x3"], sv["u"], None, None, None)
+                ctx.save_for_backward(x, sv["mean1"], sv["rstd1"], sv["x1"], sv["qkv"], sv["att"], n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)
+            else:
+                ctx.ff_saved = None
+            if drop_p > 0:
+                out._grappa_drop = (drop_p, seed2)
+            return out
         lean = _pairs(be, x, infer) and n1_w is not None and M > 32 and Fd > 32      # x1 as pairs only; the out-projection recomputes it as its residual
         x1, mean1, rstd1, sx1 = _ln_fwd(be, x, n1_w, n1_b, infer, need_y=not lean)
         qkv = _new((M, 3 * Fd), x)

@@ -29,7 +29,7 @@ extern "C" {
 #define GRAPPA_ERR_LAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch */
 #define GRAPPA_ERR_WORKSPACE (-3)  /* ws_bytes too small */
 
-#define GRAPPA_ABI_VERSION 10
+#define GRAPPA_ABI_VERSION 11
 int grappa_abi_version(void);
 /* name of the offload arch the library was compiled for ("gfx950") */
 const char* grappa_build_arch(void);
@@ -571,6 +571,39 @@ int grappa_perm_concat_bwd_bf16(void* stream, int s, int T, int F, int P, const 
 /* element-type conversion of a [M,N] view (round to nearest even), for the few places where the two configurations meet */
 int grappa_convert_f32_to_bf16(void* stream, int M, int N, const float* x, int ldx, uint16_t* y, int ldy);
 int grappa_convert_bf16_to_f32(void* stream, int M, int N, const uint16_t* x, int ldx, float* y, int ldy);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI 11: the FUSED writer-head layer (SURVEY section 8(b) "grappa_writer_head_fwd/bwd"): one kernel per transformer layer of a writer head,
+ * one workgroup per tile of 64 token rows (= every token of 32 / 21 / 16 tuples), the 512-wide activations resident in LDS:
+ *     x1 = LN(x; n1);  qkv = x1 W_in^T + b_in;  a = multi-head attention over the s tokens of each tuple (nheads x 64, softmax over the s keys);
+ *     x2 = drop(a W_o^T + b_o; seed1) + x1;  x3 = LN(x2; nf);  u = ELU(x3 W_1^T + b_1);  out = drop(u W_2^T + b_2; seed2) + x3
+ * Replaces: models/network_utils.py:112-133 (DottedAttWithMLP.forward) with :44-54 (FeedForwardLayer.forward), one layer of the stack of
+ * models/perm_equiv_transformer.py:121-151; nn.MultiheadAttention's in_proj / out_proj as in grappa_gemm_f32 above.
+ * Token rows as everywhere: row = pos * T + t, tensors contiguous with F = 512 columns (qkv: 1536).  Dropout as grappa_gemm_f32 (element index
+ * row * 512 + column).  dtype GRAPPA_WRITER_BF16: x, out and the saved activations are bf16 (the bf16 storage configuration), products on
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation, LayerNorm / softmax / ELU in fp32; every stored tensor is rounded exactly where the
+ * unfused kernels round it.  Weights travel PACKED in MFMA fragment order (grappa_writer_pack_weight, once per optimiser step).
+ * save_* (all or none; training): the tensors the backward pass reads -- x1, qkv, att, x2, x3, u and the statistics of both LayerNorms -- are
+ * written as by-products.  Supported: F = 512, nheads = 8, s = 2, 3, 4; anything else GRAPPA_ERR_ARG (the caller runs the unfused sequence). */
+#define GRAPPA_WRITER_BF16 1
+typedef struct grappa_writer_layer_desc {
+    int s, T, F, nheads, dtype;
+    const void* x;                                        /* (s*T, F) */
+    void* out;                                            /* (s*T, F) */
+    const void *w_in_pk, *w_o_pk, *w1_pk, *w2_pk;         /* packed (3F x F), (F x F), (F x F), (F x F) */
+    const float *b_in, *b_o, *b1, *b2;                    /* 3F, F, F, F */
+    const float *n1_gamma, *n1_beta, *nf_gamma, *nf_beta; /* F each */
+    float drop_p;
+    uint64_t seed1, seed2;
+    const uint64_t* drop_salt;                            /* device word mixed into both seeds, or NULL (grappa_gemm_desc.drop_salt) */
+    float *save_mean1, *save_rstd1, *save_meanf, *save_rstdf;      /* (s*T) each, or NULL */
+    void *save_x1, *save_qkv, *save_att, *save_x2, *save_x3, *save_u;      /* (s*T, F), qkv (s*T, 3F), or NULL */
+} grappa_writer_layer_desc;
+int grappa_writer_head_fwd(void* stream, const grappa_writer_layer_desc* d);
+/* W (N x K fp32, rows ldw elements apart; transpose != 0: the operand is W^T, i.e. W is K x N) in the fragment order of the fused layer: block
+ * (n / 16, k / 32) is one contiguous KB, 16 bytes per lane.  N % 16 == 0, K % 32 == 0; `out` holds grappa_writer_pack_bytes(N, K, dtype) bytes. */
+size_t grappa_writer_pack_bytes(int N, int K, int dtype);
+int grappa_writer_pack_weight(void* stream, int N, int K, const float* W, int ldw, int transpose, int dtype, void* out);
 
 /* the dropout decision used by every kernel above, exposed for tests: 1 = keep */
 int grappa_dropout_keep(uint64_t seed, uint64_t index, float p);

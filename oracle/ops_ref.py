@@ -211,6 +211,40 @@ class RefBackend:
         dv = torch.einsum("thij,ithd->jthd", p, go)
         dqkv.copy_(torch.cat([t.reshape(s * T, -1) for t in (dq, dk, dv)], dim=1))
 
+    def writer_layer(self, x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, rnd=None):
+        """one transformer layer of a writer head, restated from /root/reference/src/grappa/models/network_utils.py:112-133
+        (DottedAttWithMLP.forward: norm1 -> nn.MultiheadAttention -> dropout -> + normed input -> ff) and :44-54 (FeedForwardLayer.forward:
+        norm1 -> linear1 -> ELU -> linear2 -> dropout -> + normed input), on a token table x (s*T, F), row = pos*T + t.  The checker of the
+        fused kernel grappa_writer_head_fwd (include/grappa_hip.h).  rnd: the rounding a storage configuration applies to every tensor the
+        unfused kernels store (identity for fp32; `lambda t: t.bfloat16().float()` for the bf16 storage configuration).
+        -> dict(x1, mean1, rstd1, qkv, att, x2, meanf, rstdf, x3, u, out)"""
+        rnd = rnd or (lambda t: t)
+        M, Fd = x.shape
+        new = lambda *sh: torch.empty(sh, dtype=x.dtype, device=x.device)      # noqa: E731
+        r = {}
+        x1, mean1, rstd1 = new(M, Fd), new(M), new(M)
+        self.layernorm_fwd(x, n1_w, n1_b, x1, mean1, rstd1)
+        x1 = rnd(x1)
+        qkv = new(M, 3 * Fd)
+        self.gemm(x1, w_in, qkv, M=M, N=3 * Fd, K=Fd, bias=b_in)
+        qkv = rnd(qkv)
+        att = new(M, Fd)
+        self.seqattn_fwd(qkv, s, T, nheads, att)
+        att = rnd(att)
+        x2 = new(M, Fd)
+        self.gemm(att, w_o, x2, M=M, N=Fd, K=Fd, bias=b_o, drop_p=drop_p, drop_seed=seed1, res=x1)
+        x2 = rnd(x2)
+        x3, meanf, rstdf = new(M, Fd), new(M), new(M)
+        self.layernorm_fwd(x2, nf_w, nf_b, x3, meanf, rstdf)
+        x3 = rnd(x3)
+        u = new(M, Fd)
+        self.gemm(x3, w1, u, M=M, N=Fd, K=Fd, bias=b1, act=1)
+        u = rnd(u)
+        out = new(M, Fd)
+        self.gemm(u, w2, out, M=M, N=Fd, K=Fd, bias=b2, drop_p=drop_p, drop_seed=seed2, res=x3)
+        out = rnd(out)
+        return dict(x1=x1, mean1=mean1, rstd1=rstd1, qkv=qkv, att=att, x2=x2, meanf=meanf, rstdf=rstdf, x3=x3, u=u, out=out)
+
     def perm_concat_fwd(self, x, s, T, perms, z):
         Fd = x.shape[1]
         xv = x.view(s, T, Fd)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_only_entry_points():
     lib = _lib.load()
-    assert lib.grappa_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.grappa_abi_version() == _lib.ABI_VERSION == 11
     assert lib.grappa_build_arch() == b"gfx950"
     # pure host helpers: workspace queries and the dropout hash
     assert lib.grappa_gemm_f32_workspace_bytes(512, 512, 100000) > 0

@@ -1,0 +1,159 @@
+"""GPU (-m gpu): the fused writer-head layer (C ABI 11 grappa_writer_head_fwd, csrc/writer_layer.hip) against the oracle's restatement of the
+reference layer (oracle/ops_ref.py RefBackend.writer_layer: models/network_utils.py:112-133, :44-54) and against the unfused kernel sequence.
+
+bf16 storage configuration: every tensor the unfused kernels store is rounded to bf16 at the same place by the fused kernel, so the two agree
+up to the roundings that a different summation order of the fp32 accumulators flips (one bf16 step on a few elements); against the fp32 oracle
+run with the same roundings (`rnd`) the same holds.  The tolerance is written with each assert.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+F = 512
+
+
+def _params(gen, scale=1.0):
+    rn = lambda *s: torch.randn(s, generator=gen, device="cuda")      # noqa: E731
+    k = scale / F ** 0.5
+    return dict(n1_w=1 + 0.1 * rn(F), n1_b=0.1 * rn(F), w_in=rn(3 * F, F) * k, b_in=0.1 * rn(3 * F), w_o=rn(F, F) * k, b_o=0.1 * rn(F),
+                nf_w=1 + 0.1 * rn(F), nf_b=0.1 * rn(F), w1=rn(F, F) * k, b1=0.1 * rn(F), w2=rn(F, F) * k, b2=0.1 * rn(F))
+
+
+ORDER = ("n1_w", "n1_b", "w_in", "b_in", "w_o", "b_o", "nf_w", "nf_b", "w1", "b1", "w2", "b2")
+
+
+def _close_bf16(got16, want32, what, frac=0.97, steps=2.0):
+    """bf16 tensors of one arithmetic, two summation orders: most elements equal, the rest within `steps` bf16 steps (2^-7 relative) of the
+    value -- or of the tensor's typical magnitude where a sum cancels"""
+    got = got16.float()
+    want16 = want32.to(BF).float()
+    same = float((got == want16).float().mean())
+    d = (got - want32).abs()
+    bound = steps * 2.0 ** -7 * (want32.abs() + want32.pow(2).mean().sqrt())
+    bad = int((d > bound).sum())
+    assert same >= frac and bad == 0, f"{what}: equal {same:.4f}, outside {steps} steps: {bad}, worst {float((d / bound.clamp_min(1e-30)).max()):.2f}"
+
+
+def test_pack_weight_layout_is_the_mfma_fragment_order():
+    from grappa_amd import _lib
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    N, K = 48, 96
+    w = torch.arange(N * K, device="cuda", dtype=torch.float32).reshape(N, K) % 251      # exact in bf16
+    for transposed in (False, True):
+        src = w.t().contiguous() if transposed else w
+        pk = torch.empty(N * K, dtype=BF, device="cuda")
+        assert be.lib.grappa_writer_pack_bytes(N, K, _lib.WRITER_BF16) == N * K * 2
+        rc = be.lib.grappa_writer_pack_weight(be._stream(), N, K, src.data_ptr(), src.stride(0), int(transposed), _lib.WRITER_BF16, pk.data_ptr())
+        assert rc == 0
+        got = pk.float().cpu().numpy().reshape(N // 16, K // 32, 64, 8)
+        wn = w.cpu().numpy()
+        for nb in range(N // 16):
+            for ks in range(K // 32):
+                for l in (0, 5, 16, 37, 63):
+                    n, k0 = nb * 16 + (l & 15), ks * 32 + 8 * (l >> 4)
+                    assert np.array_equal(got[nb, ks, l], wn[n, k0:k0 + 8]), (transposed, nb, ks, l)
+    assert be.lib.grappa_writer_pack_weight(be._stream(), 40, 96, w.data_ptr(), K, 0, _lib.WRITER_BF16, pk.data_ptr()) != 0      # N % 16
+    assert be.lib.grappa_writer_pack_bytes(48, 100, _lib.WRITER_BF16) == 0
+
+
+@pytest.mark.parametrize("s,T", [(2, 1), (2, 32), (2, 33), (2, 1000), (3, 1), (3, 21), (3, 22), (3, 707), (4, 1), (4, 16), (4, 17), (4, 1501)])
+@pytest.mark.parametrize("drop_p", [0.0, 0.3])
+def test_fused_layer_matches_the_oracle_and_the_unfused_kernels(s, T, drop_p):
+    if drop_p > 0 and T not in (33, 707, 1501):
+        pytest.skip("dropout on the ragged big cases only")
+    from oracle.ops_ref import RefBackend
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(100 * s + T)
+    P = _params(gen)
+    M = s * T
+    x16 = (torch.randn(M, F, generator=gen, device="cuda") * 1.5 + 0.2).to(BF)
+    seed1, seed2 = 1234567 + T, 7654321 + s
+    names = ("mean1", "rstd1", "meanf", "rstdf", "x1", "qkv", "att", "x2", "x3", "u")
+    sv = {n: torch.full((M,) if n in names[:4] else (M, 3 * F if n == "qkv" else F), float("nan"), device="cuda", dtype=torch.float32 if n in names[:4] else BF)
+          for n in names}
+    out = torch.full((M, F), float("nan"), device="cuda", dtype=BF)
+    args = [P[k] for k in ORDER]
+    assert be.writer_layer_ok(x16, s, 8, *args)
+    be.writer_layer_fwd(x16, s, T, 8, drop_p, seed1, seed2, *args, out, save=sv)
+    torch.cuda.synchronize()
+    # inference: the same result without the by-products
+    out_i = torch.empty_like(out)
+    be.writer_layer_fwd(x16, s, T, 8, drop_p, seed1, seed2, *args, out_i, save=None)
+    assert torch.equal(out_i, out)
+    # the oracle on the CPU in fp32, rounding where the storage configuration rounds; weights as the kernel sees them (bf16)
+    ref = RefBackend()
+    Pc = {k: (v.to(BF).float() if k.startswith("w") else v).cpu() for k, v in P.items()}
+    want = ref.writer_layer(x16.float().cpu(), s, T, 8, drop_p, seed1, seed2, *[Pc[k] for k in ORDER], rnd=lambda t: t.to(BF).float())
+    for n in ("mean1", "rstd1", "meanf", "rstdf"):
+        a, b = sv[n].cpu(), want[n]
+        tol = 2e-5 if n.endswith("1") else 2e-2      # the second LayerNorm's input carries flipped bf16 roundings
+        assert torch.allclose(a, b, rtol=tol, atol=tol * float(b.abs().max())), (n, float((a - b).abs().max()))
+    for n in ("x1", "qkv", "att", "x2", "x3", "u"):
+        _close_bf16(sv[n].cpu(), want[n], n, frac=0.93 if n in ("x3", "u") else 0.97)
+    _close_bf16(out.cpu(), want["out"], "out", frac=0.90, steps=3.0)
+    # the unfused kernel sequence of the product on the same inputs (ops.TransformerLayerFn with the fused layer switched off); tables of at
+    # most 32 rows take the native fp32 product there (fp32 copies of the operands: other roundings), so they are compared with the oracle only
+    if M <= 32:
+        return
+    from grappa_amd import ops
+    be.fused_writer_layer = False
+    try:
+        ops._INFERENCE["on"] = True
+        with torch.no_grad():
+            o2 = ops.TransformerLayerFn.apply(x16, s, T, 8, drop_p, seed1, seed2, *args)
+    finally:
+        be.fused_writer_layer = True
+        ops._INFERENCE["on"] = False
+    _close_bf16(out.cpu(), o2.float().cpu(), "out vs unfused", frac=0.90, steps=3.0)
+
+
+def test_training_through_the_fused_forward_equals_the_unfused_layer():
+    """forward fused (by-products saved), backward = the unfused kernels: loss and every gradient against the all-unfused layer"""
+    from grappa_amd import ops
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    s, T = 3, 500
+    res = {}
+    for fused in (True, False):
+        g2 = torch.Generator(device="cuda").manual_seed(11)
+        P = {k: v.clone().requires_grad_(True) for k, v in _params(g2).items()}
+        x = (torch.randn(s * T, F, generator=torch.Generator(device="cuda").manual_seed(12), device="cuda")).to(BF).requires_grad_(True)
+        be.fused_writer_layer = fused
+        try:
+            ops._INFERENCE["on"] = False
+            y = ops.TransformerLayerFn.apply(x, s, T, 8, 0.1, 77, 88, *[P[k] for k in ORDER])
+            wgt = torch.randn(y.shape, generator=torch.Generator(device="cuda").manual_seed(13), device="cuda").to(BF)
+            (y.float() * wgt.float()).sum().backward()
+        finally:
+            be.fused_writer_layer = True
+        torch.cuda.synchronize()
+        res[fused] = (y.detach().float(), x.grad.float(), {k: v.grad.clone() for k, v in P.items()})
+    ya, xa, ga = res[True]
+    yb, xb, gb = res[False]
+    _close_bf16(ya.to(BF), yb, "out", frac=0.90, steps=3.0)
+    assert float((xa - xb).abs().max()) <= 3e-2 * float(xb.abs().max())
+    for k in ORDER:
+        d = float((ga[k] - gb[k]).abs().max())
+        assert d <= 2e-2 * float(gb[k].abs().max()), (k, d, float(gb[k].abs().max()))
+
+
+def test_fused_layer_refuses_what_it_cannot_run():
+    from grappa_amd import _lib
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    d = _lib.WriterLayerDesc()
+    d.s, d.T, d.F, d.nheads, d.dtype = 2, 4, 256, 8, _lib.WRITER_BF16
+    assert be.lib.grappa_writer_head_fwd(be._stream(), C.byref(d)) == -1      # F != 512
+    d.F, d.s = 512, 5
+    assert be.lib.grappa_writer_head_fwd(be._stream(), C.byref(d)) == -1      # s > 4
+    d.s = 2
+    assert be.lib.grappa_writer_head_fwd(be._stream(), C.byref(d)) == -1      # null pointers
+    x32 = torch.zeros(8, 512, device="cuda")
+    assert not be.writer_layer_ok(x32, 2, 8)                                  # fp32 storage: the unfused sequence
