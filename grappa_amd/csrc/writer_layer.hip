@@ -7,9 +7,9 @@
 // A workgroup owns a tile of 64 token rows = all s tokens of 32 / 21 / 16 tuples and walks the whole layer on it: the 512-wide
 // activations never leave the CU.  bf16 storage configuration (BASELINE configs[2]).
 //
-//  * LDS (135 KB): image A [64][512] bf16 (x1, later x3), a staging area for the q, k, v of TWO heads [64][384] and their attention
-//    output [64][128]; the ELU output u [64][512] overlays the staging area once the attention is done.  Rows are 16 bytes longer than
-//    their data so that the 16 token rows of a fragment read start 4 banks apart (conflict-free ds_read_b128).
+//  * LDS (138 KB): image A [64][512] bf16 (x1, later x3), a staging area for the q, k, v of TWO heads [64][384] and their attention
+//    output [64][128]; the ELU output u [64][512] overlays the staging area once the attention is done.  Rows are 32 bytes longer than
+//    their data (conflict-free ds_read_b128 of the fragments, see WL_LDA).
 //  * every product is computed TRANSPOSED, out^T = W act^T, on v_mfma_f32_16x16x32_bf16: the weight is the A operand, read straight from
 //    HBM / L2 into registers from a copy packed in fragment order (grappa_writer_pack_weight: one contiguous KB per wave-instruction, every
 //    weight byte is loaded once per workgroup -- the eight wavefronts own disjoint 64-feature slices); the activation is the B operand,
@@ -27,9 +27,11 @@ typedef __bf16 wl_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float wl_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WL_F = 512, WL_ROWS = 64, WL_THREADS = 512;
-constexpr int WL_LDA = 520;      // elements per row of a full-width image (1,040 bytes)
-constexpr int WL_LDQ = 392;      // q | k | v of two heads: 384 + 8
-constexpr int WL_LDT = 136;      // attention output of two heads: 128 + 8
+// row strides = 32 bytes more than the data, i.e. 32 (mod 256): the 16 token rows x 4 k-chunks of a ds_read_b128 fragment read then touch
+// every bank once per lane group (MI355X LDS: groups {0-3, 12-15, 20-27}, ... : 8 rows on the even 16-byte slots, the other 8 on the odd ones)
+constexpr int WL_LDA = 528;      // elements per row of a full-width image (1,056 bytes)
+constexpr int WL_LDQ = 400;      // q | k | v of two heads: 384 + 16
+constexpr int WL_LDT = 144;      // attention output of two heads: 128 + 16
 constexpr int WL_OFF_A = 0;
 constexpr int WL_OFF_Q = WL_ROWS * WL_LDA * 2;
 constexpr int WL_OFF_T = WL_OFF_Q + WL_ROWS * WL_LDQ * 2;
@@ -87,12 +89,25 @@ __device__ __forceinline__ void wl_product(const uint4* const (&pa)[NB], const c
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const wl_bf16x8 a = __builtin_bit_cast(wl_bf16x8, ring[d][i]);
+#ifdef WL_LAB_NO_MFMA      // tools/writer_layer_lab.sh: a build without the matrix instructions (what the rest of the kernel costs)
+                {
+                    const uint4 b0 = __builtin_bit_cast(uint4, b[0]), b1 = __builtin_bit_cast(uint4, b[1]), b2 = __builtin_bit_cast(uint4, b[2]), b3 = __builtin_bit_cast(uint4, b[3]);
+                    asm volatile("" ::"v"(ring[d][i].x ^ ring[d][i].y ^ ring[d][i].z ^ ring[d][i].w), "v"(b0.x ^ b0.y ^ b0.z ^ b0.w), "v"(b1.x ^ b1.y ^ b1.z ^ b1.w),
+                                 "v"(b2.x ^ b2.y ^ b2.z ^ b2.w), "v"(b3.x ^ b3.y ^ b3.z ^ b3.w));
+                }
+                (void)a;
+#else
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[i][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[mb], acc[i][mb], 0, 0, 0);
+#endif
             }
             if (ks + PD < KSN) {
 #pragma unroll
+#ifdef WL_LAB_NO_WLOAD     // lab: every weight fragment from the same KB (served by the CU's L1): what streaming the weights from L2 costs
+                for (int i = 0; i < NB; ++i) ring[d][i] = pa[i][0];
+#else
                 for (int i = 0; i < NB; ++i) ring[d][i] = pa[i][(ks + PD) * 64];
+#endif
             }
         }
     }
@@ -106,6 +121,22 @@ __device__ __forceinline__ void wl_zero(wl_f32x4 (&acc)[NB][4]) {
         for (int mb = 0; mb < 4; ++mb) acc[i][mb] = wl_f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// sums over aligned groups of 8 / 16 lanes on the DPP data path (no LDS crossbar round trips); every lane gets the sum
+template <int CTRL>
+__device__ __forceinline__ float wl_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wl_sum8(float v) {
+    v = wl_dpp_add<0xB1>(v);        // quad_perm [1, 0, 3, 2]
+    v = wl_dpp_add<0x4E>(v);        // quad_perm [2, 3, 0, 1]
+    return wl_dpp_add<0x141>(v);    // row_half_mirror
+}
+__device__ __forceinline__ float wl_sum64(float v) {
+    v = wl_dpp_add<0x140>(wl_sum8(v));      // row_mirror: the 16 lanes of a row
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 // sum over the four lanes that hold the same token (l, l ^ 16, l ^ 32, l ^ 48)
 __device__ __forceinline__ float wl_quad_sum(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -164,14 +195,14 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e += 2) s += v[e] + v[e + 1];
-            const float mean = wave_sum(s) / (float)WL_F;
+            const float mean = wl_sum64(s) / (float)WL_F;
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 const float a0 = v[e] - mean, a1 = v[e + 1] - mean;
                 q += a0 * a0 + a1 * a1;
             }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)WL_F + 1e-5f);
+            const float rstd = 1.0f / sqrtf(wl_sum64(q) / (float)WL_F + 1e-5f);
             float y[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = grappa_ln_apply(v[e], mean, rstd, g[e], b[e]);
@@ -237,7 +268,11 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
         {
             // attention of (tuple j, head 2 hp + hh): 8 lanes, 8 features each (the arithmetic of csrc/tuples.hip seqattn_fwd_kernel_e)
             const int sub = tid & 7, pair = tid >> 3, hh = pair & 1, j = pair >> 1;
+#ifdef WL_LAB_NO_ATT       // lab: without the attention arithmetic
+            if (false) {
+#else
             if (j < ntup) {
+#endif
                 float q[S][8], k[S][8], v[S][8];
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
@@ -254,7 +289,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
                         float dt = 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; e += 2) dt += q[i][e] * k[jj][e] + q[i][e + 1] * k[jj][e + 1];
-                        sc[jj] = group_sum(dt, 8) * 0.125f;
+                        sc[jj] = wl_sum8(dt) * 0.125f;
                         mx = fmaxf(mx, sc[jj]);
                     }
                     float den = 0.f;
