@@ -57,6 +57,13 @@ __device__ inline int group4_find(const GemmGroup4& g, int wg) {
     while (i + 1 < g.count && wg >= g.wg_begin[i + 1]) ++i;
     return i;
 }
+// fp32 A + weight pairs: does EVERY K range of a launch (nsplit ranges of k_per_split columns, the last one shorter) hold the four 16-column slabs
+// of the pinned pipeline (gemm_wpairs_il.hip)?  One predicate for the dispatch (gemm_pairs.hip) and for the host's check of per-segment operand
+// maxima (gemm_f32.hip, a_amax_nseg): only that kernel combines them
+inline bool grappa_wpairs_il_takes(int K, int nsplit, int k_per_split) {
+    const int last = K - (nsplit - 1) * k_per_split;
+    return (K & 31) == 0 && (k_per_split & 31) == 0 && last >= 64;
+}
 __device__ inline uint64_t drop_seed_of(const GemmParams& p) { return grappa_salted(p.d.drop_seed, p.drop_salt); }
 
 // ---- plane format (include/grappa_hip.h): X = P0 + P1 + P2, three bf16 planes

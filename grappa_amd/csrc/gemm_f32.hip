@@ -307,25 +307,21 @@ struct PlanOpts {
     int cfg = -1, nsplit = 0, tail = -1;
     bool tails_on = true;
 };
-bool env_tails_default() {
-    static const bool env_on = !(getenv("GRAPPA_PLAN_TAILS") && atoi(getenv("GRAPPA_PLAN_TAILS")) == 0);
-    return env_on;
-}
+constexpr bool TAILS_DEFAULT = true;      // grappa_gemm_desc.plan_tail == 0 (callers that care say 1 or 2)
 PlanOpts plan_opts_of(const grappa_gemm_desc& d) {
     PlanOpts o;
     o.cfg = d.plan_cfg > 0 ? d.plan_cfg - 1 : -1;
     o.nsplit = d.plan_nsplit > 0 ? d.plan_nsplit : 0;
-    o.tails_on = d.plan_tail == 0 ? env_tails_default() : d.plan_tail != 2;
+    o.tails_on = d.plan_tail == 0 ? TAILS_DEFAULT : d.plan_tail != 2;
     o.tail = d.plan_tail == 3 ? 1 : -1;
     return o;
 }
 // split-K summed by a launch of gemm_splitk_reduce_kernel behind the product (default) or inside the product's own launch by the last
-// workgroup of each tile (grappa_gemm_desc.splitk_reduce = 2 / GRAPPA_SPLITK_IN_KERNEL=1).  Same bits; the second is the slower one on this
+// workgroup of each tile (grappa_gemm_desc.splitk_reduce = 2).  Same bits; the second is the slower one on this
 // chip (profiles/r2_splitk_in_kernel_rejected.txt): one workgroup sums nsplit x 128 KB behind an L2-invalidating acquire while the rest of
 // the chip idles at the end of the launch, the reduction kernel spreads the same reads over 256 CUs
 bool splitk_in_kernel(const grappa_gemm_desc& d) {
-    static const bool env_in_kernel = getenv("GRAPPA_SPLITK_IN_KERNEL") && atoi(getenv("GRAPPA_SPLITK_IN_KERNEL")) != 0;
-    return d.splitk_reduce == 0 ? env_in_kernel : d.splitk_reduce == 2;
+    return d.splitk_reduce == 2;
 }
 bool use_bf16x(int M, int N, int precision) { return precision != GRAPPA_GEMM_F32_MFMA && M > 32 && N > 32; }
 
@@ -334,13 +330,9 @@ bool use_bf16x(int M, int N, int precision) { return precision != GRAPPA_GEMM_F3
 // ceil(workgroups / (256*CONC_c)) such rounds.  Split-K adds the slab round trip and two launches.  With an unsplit K the
 // tiles beyond the last full 256 can run as a second, split-K "tail" launch (rem * ts workgroups, each 1/ts long) instead of
 // costing a whole extra round.  This avoids the "one extra workgroup = one extra round" cliffs of a fixed tile.
-// CUs a product plans for.  Experiment only (GRAPPA_PLAN_CUS, tools/plan_cus_ab.sh): with the writer heads on four streams each product
-// could plan for a share of the chip (fewer K cuts); measured 36.1 -> 37.1 ms per C2 step at 128, 37.2 at 64 -- every product keeps
-// planning for all 256 (profiles/r3_plan_cus_rejected.txt)
-long plan_cus() {
-    static const int env = getenv("GRAPPA_PLAN_CUS") ? atoi(getenv("GRAPPA_PLAN_CUS")) : 0;
-    return env >= 32 && env <= 256 ? env : 256;
-}
+// CUs a product plans for: all 256, also with the writer heads on four streams (planning for a share of the chip measured 36.1 -> 37.1 ms per
+// C2 step at 128, 37.2 at 64: profiles/r3_plan_cus_rejected.txt)
+constexpr long plan_cus() { return 256; }
 
 struct CostModel {
     // MACs per cycle per CU sustained in the main loop, and the per-tile prologue + epilogue expressed in columns of K
@@ -390,16 +382,8 @@ struct CostModel {
     }
 };
 
-// GRAPPA_PAIRS_TILE_CHOICE=0: the round-4 planner (one tile for the pair kernels, the generic cost model)
-bool pairs_tile_choice() {
-    static const bool on = !(getenv("GRAPPA_PAIRS_TILE_CHOICE") && atoi(getenv("GRAPPA_PAIRS_TILE_CHOICE")) == 0);
-    return on;
-}
-
-int pairs_cfg() {
-    static const int t = getenv("GRAPPA_PAIRS_TILE") ? atoi(getenv("GRAPPA_PAIRS_TILE")) : 128;
-    return t == 256 ? 7 : 6;
-}
+constexpr bool pairs_tile_choice() { return true; }      // the round-5 planner: a tile per product from the fitted staircase model
+constexpr int pairs_cfg() { return 6; }                   // the 256 x 128 tile where the model has no say (fp32 A + weight pairs)
 
 Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool bf16x = false, bool planes = false, bool pairs = false, bool pairs_small = false,
                int planes_tile = 0) {      // 256 / 128: the bf16 pinned-pipeline kernel's other tiles (GRAPPA_BF16_TILE)
@@ -412,9 +396,9 @@ Plan make_plan(int M, int N, int K, const PlanOpts& opt, bool vec = true, bool b
     best.tail_k_per_split = 0;
     double best_cost = 1e300;
     const CostModel cm;
-    // the shortest K range of a split: one slab of BK (GRAPPA_PLAN_MIN_KSTEPS=8: rounds 1-3' limit of eight): the model may cut K = 512 sixteen ways instead of
+    // the shortest K range of a split: one slab of BK (rounds 1-3: eight): the model may cut K = 512 sixteen ways instead of
     // two (small products -- one molecule, a batch of 32 -- are a few workgroups that each take in their whole K range at a CU's ~30 GB/s)
-    static const int min_ksteps = [] { const char* e = getenv("GRAPPA_PLAN_MIN_KSTEPS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+    constexpr int min_ksteps = 1;
     // (the bf16 plane kernels keep the limit of eight: their configuration's parity sits at its 2e-2 tolerance and moves with the K cuts)
     const int mk = (planes && !pairs) ? 8 : min_ksteps;
     int max_split = K >= 2 * mk * BK ? K / (mk * BK) : 1;
@@ -527,8 +511,7 @@ int choose_epi_class(const grappa_gemm_desc& d, bool vec_io, bool bf16x) {
     const bool f32_only = vec_io && d.C && !d.Cp && !d.resp && !d.auxp;
     const bool bf16_only = d.Cp && !d.C && !d.res && !d.aux && d.cp_nplanes == 1 && (!d.resp || d.resp_nplanes == 1) &&
                            (!d.auxp || d.auxp_nplanes == 1);
-    static const int fast_mask = getenv("GRAPPA_EPI_FAST") ? atoi(getenv("GRAPPA_EPI_FAST")) : 3;      // tuning only: bit 0 fp32, bit 1 bf16 classes
-    if (!((f32_only && (fast_mask & 1)) || (bf16_only && (fast_mask & 2)))) return 0;
+    if (!(f32_only || bf16_only)) return 0;
     const bool has_aux = d.aux || d.auxp, has_res = d.res || d.resp;
     int cls;
     if (has_aux) cls = (!d.bias && d.act == GRAPPA_ACT_NONE && d.drop_p == 0.0f) ? 4 : 0;
@@ -597,7 +580,7 @@ static int plan_report(int M, int N, int K, int precision, const PlanOpts& o, in
 
 extern "C" int grappa_gemm_f32_plan(int M, int N, int K, int precision, int* tile_m, int* tile_n, int* nsplit, int* tail_tiles, int* tail_nsplit) {
     PlanOpts o;
-    o.tails_on = env_tails_default();
+    o.tails_on = TAILS_DEFAULT;
     return plan_report(M, N, K, precision, o, tile_m, tile_n, nsplit, tail_tiles, tail_nsplit);
 }
 
@@ -670,8 +653,7 @@ GroupPlan plan_group(const grappa_gemm_desc* descs, int n) {
     }
     double best = 1e300;
     g.kps = (kmax + 31) / 32 * 32;
-    static const int forced = getenv("GRAPPA_GROUP_KPS") ? atoi(getenv("GRAPPA_GROUP_KPS")) : 0;      // tuning only (tools/)
-    for (int R = 1; R <= 12 && !forced; ++R) {
+    for (int R = 1; R <= 12; ++R) {
         int kps = (int)(work / (256.0 * R));
         kps = (kps + 31) / 32 * 32;
         if (kps < 1024) kps = 1024;
@@ -689,7 +671,6 @@ GroupPlan plan_group(const grappa_gemm_desc* descs, int n) {
             g.kps = kps;
         }
     }
-    if (forced) g.kps = (forced + 31) / 32 * 32;
     g.total_wgs = 0;
     size_t off = 0;
     for (int i = 0; i < n; ++i) {
@@ -863,15 +844,9 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
             ((reinterpret_cast<uintptr_t>(d->res_ln_gamma) | reinterpret_cast<uintptr_t>(d->res_ln_beta)) & 15) != 0 || (planes && !pairs))
             return GRAPPA_ERR_ARG;
     }
-    static const bool small_tile = !(getenv("GRAPPA_PAIRS_SMALL_TILE") && atoi(getenv("GRAPPA_PAIRS_SMALL_TILE")) == 0);
+    constexpr bool small_tile = true;
     const PlanOpts popt = plan_opts_of(*d);
-    // experiment (GRAPPA_BF16_TILE=256): the bf16 storage configuration's K-contiguous one-plane products on the 256 x 256 tile of the pinned-pipeline
-    // kernel (gemm_pairs_il.hip ARITH 1) -- 31 instead of 47 operand bytes per CU-cycle, and no faster: at K = N = 512 these products are bound by
-    // their HBM bytes (1.2 GB per 400 k-row product: 250 us at 5 TB/s against 84 us of MFMAs), not by the intake (C3 bf16 step 75.7 ms either way)
-    static const int bf16_tile = getenv("GRAPPA_BF16_TILE") ? atoi(getenv("GRAPPA_BF16_TILE")) : 0;
-    const bool bf16_il256 = (bf16_tile == 256 || bf16_tile == 128) && planes && !pairs && d->precision == GRAPPA_GEMM_BF16 && d->a_planes && d->a_kcontig && d->b_kcontig && (d->K & 63) == 0 && d->K >= 128 &&
-                            (size_t)d->M * d->lda * 2 < (1ull << 32) && (size_t)d->N * d->ldb * 2 < (1ull << 32);
-    Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0, bf16_il256 ? bf16_tile : 0);
+    Plan pl = make_plan(d->M, d->N, d->K, popt, vec || planes, bf16x, planes, pairs, pairs && d->a_planes && small_tile && popt.cfg < 0, 0);
     if (pl.main_tiles <= 0) return GRAPPA_ERR_ARG;                       // a forced tile (plan_cfg) that no kernel of this product's operand formats has: refused, not skipped
     if (pairs && !d->a_planes && pl.cfg != 6) return GRAPPA_ERR_ARG;      // (fp32 A + weight pairs: the 256 x 128 tile only)
     if (d->a_colsum && d->a_kcontig) return GRAPPA_ERR_ARG;          // column sums ride on the row-contiguous (wgrad) A operand only
@@ -918,7 +893,10 @@ extern "C" int grappa_gemm_f32(void* stream, const grappa_gemm_desc* d, void* ws
     const bool amax_fused = (d->out_amax || d->out_amax_parts) && bf16x;
     if (d->out_amax_parts && (!bf16x || d->out_amax)) return GRAPPA_ERR_ARG;          // partials: the split kernels' epilogue only, instead of out_amax
     // a consumer of partials: fp32 A of the split kernels, or (round 5) of the pinned-pipeline weight-pairs kernel (the round-3 weight-pairs loop has no combine)
-    const bool wpairs_il_ok = pairs && !d->a_planes && (d->K & 31) == 0 && d->K >= 64;
+    // (the SAME predicate as the dispatch, grappa_wpairs_il_takes in gemm_common.h -- the round-3 fall-back loop reads one maximum per
+    //  row, so partial maxima are refused wherever a launch of this plan would fall back to it, e.g. a short last split-K range)
+    const bool wpairs_il_ok = pairs && !d->a_planes && grappa_wpairs_il_takes(d->K, pl.nsplit, pl.k_per_split) &&
+                              (pl.tail_nsplit <= 1 || pl.main_tiles >= tiles || grappa_wpairs_il_takes(d->K, pl.tail_nsplit, pl.tail_k_per_split));
     if (d->a_amax_nseg > 1 && (!d->a_kcontig || (planes && !wpairs_il_ok) || !bf16x || (d->amax_bcast & 1))) return GRAPPA_ERR_ARG;
     if (d->out_amax && !amax_fused && !d->C) return GRAPPA_ERR_ARG;
     p.amax_part = nullptr;

@@ -29,7 +29,6 @@
 
 using namespace grappa_gemm;
 
-int grappa_launch_gemm_pairs_persist(hipStream_t st, GemmParams& p);      // gemm_pairs_persist.hip
 int grappa_launch_gemm_pairs_il(hipStream_t st, GemmParams& p);           // gemm_pairs_il.hip
 int grappa_launch_gemm_wpairs_il(hipStream_t st, GemmParams& p);          // gemm_wpairs_il.hip
 
@@ -510,19 +509,16 @@ int grappa_launch_gemm_pairs_group4(hipStream_t st, const GemmGroup4& g) {
 // called by grappa_gemm_f32 (gemm_f32.hip) when both operands are in the pair format (precision F32_F16X3); tile 256 x 128
 int grappa_launch_gemm_pairs(hipStream_t st, GemmParams& p) {
     if (!p.d.a_planes) {                                     // fp32 A, weight pairs
-        static const bool wil = !(getenv("GRAPPA_WPAIRS_IL") && atoi(getenv("GRAPPA_WPAIRS_IL")) == 0);      // the pinned pipeline of gemm_wpairs_il.hip (0: the round-3 loop)
-        // (the SHORTEST K range of the launch -- the last one -- has to hold the pipeline's four slabs, not only the first)
-        const int kw = p.d.K - (p.nsplit - 1) * p.k_per_split;
-        if (wil && (p.d.K & 31) == 0 && (p.k_per_split & 31) == 0 && kw >= 4 * QSLAB) return grappa_launch_gemm_wpairs_il(st, p);
+        // the pinned pipeline of gemm_wpairs_il.hip wherever every K range of the launch holds its four slabs (grappa_wpairs_il_takes: the host's
+        // check of a_amax_nseg uses the same predicate); the round-3 loop for the rest
+        if (grappa_wpairs_il_takes(p.d.K, p.nsplit, p.k_per_split)) return grappa_launch_gemm_wpairs_il(st, p);
+        if (p.d.a_amax_nseg > 1) return GRAPPA_ERR_ARG;          // (it reads ONE maximum per row; unreachable through grappa_gemm_f32)
         return launch_wpairs(st, p);
     }
     const int kk = p.d.K - (p.nsplit - 1) * p.k_per_split;       // the shortest K range of the launch (the last)
-    static const bool il = !(getenv("GRAPPA_PAIRS_IL") && atoi(getenv("GRAPPA_PAIRS_IL")) == 0);      // the pinned pipeline of gemm_pairs_il.hip (0: the round-3 loop)
     // (the pinned pipeline walks PAIRS of slabs: a K range that is not a multiple of 32 is rounded up, which is harmless at the end of a row -- the
     //  pair format pads rows with zeros -- and wrong at the boundary between two split-K ranges, where the 16 extra columns belong to the next range)
-    if (il && kk >= 4 * QSLAB && (p.nsplit == 1 || (p.k_per_split & 31) == 0)) return grappa_launch_gemm_pairs_il(st, p);
+    if (kk >= 4 * QSLAB && (p.nsplit == 1 || (p.k_per_split & 31) == 0)) return grappa_launch_gemm_pairs_il(st, p);      // the pinned pipeline (gemm_pairs_il.hip)
     if (p.bm == 128) return launch_pairs_small(st, p);
-    static const bool persist = getenv("GRAPPA_PAIRS_PERSIST") && atoi(getenv("GRAPPA_PAIRS_PERSIST")) != 0;      // opt-in experiment (profiles/r5_pairs_persist_lab.txt)
-    if (persist && p.nsplit == 1 && kk >= 3 * QSLAB) return grappa_launch_gemm_pairs_persist(st, p);
     return p.bn == 256 ? launch_pairs<256>(st, p) : launch_pairs<128>(st, p);
 }

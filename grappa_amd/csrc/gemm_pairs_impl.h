@@ -1,4 +1,4 @@
-// Device pieces shared by the pair-format GEMM kernels (gemm_pairs.hip: one tile per workgroup; gemm_pairs_persist.hip: the persistent walk):
+// Device pieces shared by the pair-format GEMM kernels (gemm_pairs.hip: one tile per workgroup; the pinned-pipeline kernels of gemm_pairs_il.hip / gemm_wpairs_il.hip):
 // tile shapes, LDS-DMA slab issue, fragment reads, the MFMA block.  The pair format itself: gemm_pairs.hip / include/grappa_hip.h.
 #pragma once
 #include "gemm_common.h"

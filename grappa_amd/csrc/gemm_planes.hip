@@ -680,10 +680,9 @@ int grappa_launch_gemm_planes(hipStream_t st, GemmParams& p, int precision) {
         case GRAPPA_GEMM_F32_BF16X6: return launch_planes_layout<PX6>(st, p);
         case GRAPPA_GEMM_BF16X3: return launch_planes_layout<PX3>(st, p);
         case GRAPPA_GEMM_BF16: {
-            // round 5: K-contiguous one-plane products take the pinned pipeline of gemm_pairs_il.hip (GRAPPA_BF16_IL=0: the plane kernel)
-            static const bool il = !(getenv("GRAPPA_BF16_IL") && atoi(getenv("GRAPPA_BF16_IL")) == 0);
+            // round 5: K-contiguous one-plane products take the pinned pipeline of gemm_pairs_il.hip
             const int kk = p.d.K - (p.nsplit - 1) * p.k_per_split;       // the shortest K range of the launch (the last): it has to hold the pipeline's four slabs too
-            if (il && p.d.a_kcontig && p.d.b_kcontig && ((p.bm == 256 && (p.bn == 128 || p.bn == 256)) || (p.bm == 128 && p.bn == 128)) && (p.d.K & 63) == 0 && (p.k_per_split & 63) == 0 && kk >= 128 &&
+            if (p.d.a_kcontig && p.d.b_kcontig && ((p.bm == 256 && (p.bn == 128 || p.bn == 256)) || (p.bm == 128 && p.bn == 128)) && (p.d.K & 63) == 0 && (p.k_per_split & 63) == 0 && kk >= 128 &&
                 (size_t)p.d.M * p.d.lda * 2 < (1ull << 32) && (size_t)p.d.N * p.d.ldb * 2 < (1ull << 32))
                 return grappa_launch_gemm_bf16_il(st, p);
             if (p.bn != 128 || p.bm != 256) return GRAPPA_ERR_ARG;              // (the plane kernel has the 256 x 128 tile only: the plan and this check agree by construction)

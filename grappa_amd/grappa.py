@@ -11,7 +11,10 @@ from .parameters import Parameters
 
 
 class Grappa:
-    def __init__(self, model: GrappaModel, max_element: int = constants.MAX_ELEMENT, device: str = "cuda") -> None:
+    def __init__(self, model: GrappaModel, max_element: int = constants.MAX_ELEMENT, device: str = "cuda", reference_water_guard: bool = False) -> None:
+        # reference_water_guard=True: `predict` behaves exactly like the reference's on a graph that holds water (it parametrises it: the
+        # reference's guard never fires, see batch.check_disconnected_graphs); default: the intended guard, which raises
+        self.reference_water_guard = bool(reference_water_guard)
         self.model = model.to(device)
         self.model.eval()
         self.max_element = max_element
@@ -24,17 +27,17 @@ class Grappa:
             self._graphs = ForwardCache(self.model, device)
 
     @classmethod
-    def from_tag(cls, tag: str = "latest", max_element=constants.MAX_ELEMENT, device: str = "cuda", models_dir=None) -> "Grappa":
+    def from_tag(cls, tag: str = "latest", max_element=constants.MAX_ELEMENT, device: str = "cuda", models_dir=None, reference_water_guard: bool = False) -> "Grappa":
         """a released model ('latest', 'grappa-1.2', 'grappa-1.1', ...) or a `.pth` exported into the models directory (grappa.py:26-35)"""
         from .loading import model_from_tag
-        return cls(model_from_tag(tag, models_dir), max_element, device)
+        return cls(model_from_tag(tag, models_dir), max_element, device, reference_water_guard)
 
     @classmethod
-    def from_file(cls, path, max_element=constants.MAX_ELEMENT, device: str = "cuda", config=None, trusted=None) -> "Grappa":
+    def from_file(cls, path, max_element=constants.MAX_ELEMENT, device: str = "cuda", config=None, trusted=None, reference_water_guard: bool = False) -> "Grappa":
         """an exported `.pth` container or a training checkpoint (`best-model.ckpt`) of the reference or of `grappa_amd.trainer`.  trusted=True:
         the caller vouches for a file that holds pickled objects beyond tensors (loading._torch_load; default: tensors only)"""
         from .loading import model_from_path
-        return cls(model_from_path(path, config, trusted), max_element, device)
+        return cls(model_from_path(path, config, trusted), max_element, device, reference_water_guard)
 
     def predict(self, molecule: Molecule) -> Parameters:
         if self.model.training:                  # (eval() walks every sub-module: 1 ms of a 7 ms call when there is nothing to switch)
@@ -42,7 +45,7 @@ class Grappa:
         g = molecule.to_dgl(max_element=self.max_element, exclude_feats=[])
         # water guard.  NOTE: the reference compares argmax(one-hot) (= Z-1) with {1, 8} and therefore never
         # fires (utils/dgl_utils.py:231-234); the intended check (elements {H, O}) is implemented here.
-        check_disconnected_graphs(g)
+        check_disconnected_graphs(g, reference_water_guard=self.reference_water_guard)
         if self._graphs is not None:
             done = self._graphs(g)
             if done is not None:

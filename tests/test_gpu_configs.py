@@ -198,3 +198,88 @@ def test_c4_shard_of_4096_against_oracle_and_gradient_sum_over_shards():
         s = float(b.abs().max())
         if s > 0:
             assert float((a - b).abs().max()) <= 1e-3 * s
+
+
+def test_c2_full_size_train_step_against_the_oracle_on_the_benchmarked_routing():
+    """the C2 workload (BASELINE configs[1]: 256 molecules x 32 conformations, what bench.py's headline times) as ONE train
+    step with dropout off, every output and EVERY parameter gradient against oracle/cpu_ref.py on the same batch -- at the size where the
+    benchmarked routing engages: the pair kernels (tables >= 12,288 rows) and the weight-pair kernels (>= 24,000 rows) are asserted to have
+    run (the profile's per-launch operand formats).  Distances are reported at SURVEY 8(d)'s own floors (k 1e-3 incl. torsions, eq 1e-4,
+    E 1e-3 kcal/mol, G 1e-2 kcal/mol/A) for GPU vs float64 oracle, fp32 oracle vs float64 oracle and GPU vs fp32 oracle
+    (gpurun_out/parity_c2_full.txt -> profiles/); gate: the GPU is inside the 1e-4 contract or no further from float64 than twice the fp32
+    oracle itself (the rule of tests/test_gpu_e2e.py), parameter gradients within 1e-4 of each tensor's largest magnitude against float64."""
+    import os
+    import time
+    from grappa_amd import Energy, MolwiseLoss
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import WORKLOADS, build_batch_from_pool, workload_molecule_ids
+    from test_gpu_e2e import _oracle_step
+    name = "C2-pubchem-b256"
+    ids = workload_molecule_ids(name, seed=0)
+    C = WORKLOADS[name][3]
+    assert len(ids) == 256 and C == 32
+    model, cfg, sd = _model(train=False)
+    be = get_backend()
+    g = build_batch_from_pool(ids, n_confs=C, seed=0).to("cuda")
+    be.start_profile()
+    g = Energy()(model(g))
+    loss = MolwiseLoss(**LOSS_KW)(g)
+    loss.backward()
+    be.stop_profile()
+    fmts = {}
+    for fam, det, _ms, _fl, _by in be.last_profile_details:
+        if fam == "gemm_f32":
+            for d in det:
+                fmts[d["fmt"]] = fmts.get(d["fmt"], 0) + 1
+    assert fmts.get("pairs", 0) > 0 and fmts.get("wpairs", 0) > 0, f"the benchmarked routing did not engage: {fmts}"
+    t0 = time.time()
+    ref64, rg64, rl64 = _oracle_step(cfg, sd, build_batch_from_pool(ids, n_confs=C, seed=0), LOSS_KW, double=True)
+    t64 = time.time() - t0
+    ref32, rg32, rl32 = _oracle_step(cfg, sd, build_batch_from_pool(ids, n_confs=C, seed=0), LOSS_KW, double=False)
+    t32 = time.time() - t0 - t64
+
+    def contract(got_g, ref_g):
+        gd, rd = got_g.nodes["g"].data, ref_g.nodes["g"].data
+        m = {"h": gu.rel_err(got_g.nodes["n1"].data["h"].detach().cpu().double(), ref_g.nodes["n1"].data["h"].detach().double().numpy(), 1e-2)}
+        for lvl in LEVELS:
+            m[f"{lvl}_k"] = gu.rel_err(got_g.nodes[lvl].data["k"].detach().cpu().double(), ref_g.nodes[lvl].data["k"].detach().double().numpy(), 1e-3)
+            if lvl in ("n2", "n3"):
+                m[f"{lvl}_eq"] = gu.rel_err(got_g.nodes[lvl].data["eq"].detach().cpu().double(), ref_g.nodes[lvl].data["eq"].detach().double().numpy(), 1e-4)
+            m[f"energy_{lvl}"] = gu.rel_err(gd[f"energy_{lvl}"].detach().cpu().double(), rd[f"energy_{lvl}"].detach().double().numpy(), 1e-3)
+        m["energy"] = gu.rel_err(gd["energy"].detach().cpu().double(), rd["energy"].detach().double().numpy(), 1e-3)
+        m["gradient"] = gu.rel_err(got_g.nodes["n1"].data["gradient"].detach().cpu().double(), ref_g.nodes["n1"].data["gradient"].detach().double().numpy(), 1e-2)
+        return m
+
+    gpu64, ora64, gpu32 = contract(g, rg64), contract(rg32, rg64), contract(g, rg32)
+    lines = [f"# C2 full size: {len(ids)} molecules x {C} conformations, N = {g.plan().N} atoms, operand formats of the step's products: {fmts}",
+             f"# oracle step: float64 {t64:.1f} s, fp32 {t32:.1f} s on this box's host",
+             f"loss: GPU {float(loss):.8g} | fp32 oracle {float(rl32):.8g} | float64 oracle {float(rl64):.10g}",
+             "# quantity: GPU vs fp64 | fp32 oracle vs fp64 | GPU vs fp32 oracle   (relative, at SURVEY 8(d)'s absolute floors; h: floor 1e-2)"]
+    lines += [f"{k}: {gpu64[k]:.2e} | {ora64[k]:.2e} | {gpu32[k]:.2e}" for k in sorted(gpu64)]
+    g64 = dict(ref64.named_parameters())
+    g32 = dict(ref32.named_parameters())
+    worst, worst32, worst_name = 0.0, 0.0, ""
+    n_checked = 0
+    for k, p in model.named_parameters():
+        r = g64[k].grad
+        if r is None:
+            continue
+        n_checked += 1
+        scale = max(float(r.abs().max()), 1e-12)
+        e = float((p.grad.cpu().double() - r).abs().max()) / scale
+        e32 = float((g32[k].grad.double() - r).abs().max()) / scale
+        if e > worst:
+            worst, worst_name = e, k
+        worst32 = max(worst32, e32)
+    lines.append(f"parameter gradients ({n_checked} tensors), worst |d| / max|grad| vs float64: GPU {worst:.2e} ({worst_name}) | fp32 oracle {worst32:.2e}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_c2_full.txt", "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    assert abs(float(loss) - float(rl64)) <= 1e-4 * abs(float(rl64))
+    for k in gpu64:
+        assert gpu64[k] < max(TOL, 2.0 * ora64[k]), (k, gpu64[k], ora64[k])
+    for k in ("n2_k", "n2_eq", "n3_k", "n3_eq", "energy", "energy_n2", "energy_n3"):      # the literal contract where fp32 itself holds it
+        if ora64[k] < TOL:
+            assert gpu32[k] < TOL, (k, gpu32[k])
+    assert n_checked > 300 and worst < TOL, (worst_name, worst)

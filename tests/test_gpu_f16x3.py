@@ -365,3 +365,41 @@ def test_train_step_with_outlier_bearing_activations_default_and_column_maxima_a
     finally:
         be.wgrad_column_maxima = old
     print("worst parameter-gradient error vs float64 with outlier-bearing activations: one scale per operand", worst[False], "| per-column scales", worst[True])
+
+
+@pytest.mark.parametrize("nsplit", [0, 3, 5, 6, 7, 11, 13, 16])
+def test_weight_pairs_with_partial_row_maxima_never_reach_the_loop_that_cannot_combine_them(hip, nsplit):
+    """fp32 A + weight pairs (tables of >= weight_pairs_min_rows rows) with A's row maxima given as the producer's per-segment
+    partials (a_amax_nseg > 1).  Only the pinned-pipeline kernel combines them; a plan whose last split-K range is shorter than that
+    kernel's four slabs (K = 512 cut six ways: ranges of 96, last one 32) falls back to the round-3 loop, which reads one maximum per
+    row -- such a call must be REFUSED by the library (host check and dispatch share one predicate), never computed with the first
+    segment's maximum; the backend then hands it the combined array.  Rows whose first segment is tiny make the old failure loud."""
+    g = torch.Generator().manual_seed(5 + nsplit)
+    M, N, K = 24576, 512, 512
+    A = torch.randn(M, K, generator=g)
+    A[:, :32] *= 1e-3                     # the first 32-column segment's maximum is 1000 x below the row's
+    A = A.cuda()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).cuda().requires_grad_(True)
+    exact = A.double().cpu() @ W.detach().double().cpu().t()
+    row = hip.amax(A, None, rows=True).row
+    nseg = K // 32
+    from grappa_amd.backend import Amax
+    parts = torch.stack([hip.amax(A[:, 32 * i:32 * (i + 1)].contiguous(), None, rows=True).row for i in range(nseg)]).contiguous()
+    assert torch.equal(parts.view(nseg, M).amax(0).int(), row)
+    keep = hip.plan_override
+    hip.plan_override = (-1, nsplit, 0) if nsplit else None
+    try:
+        out_p, out_r = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        try:
+            hip.gemm(A, W, out_p, M=M, N=N, K=K, a_scales=Amax(parts=parts.view(-1), nseg=nseg))
+            refused = False
+        except Exception as e:      # the library's GRAPPA_ERR_ARG: the plan has a range the pinned kernel does not take
+            refused = True
+            assert "ARG" in str(e) or "arg" in str(e), e
+        hip.gemm(A, W, out_r, M=M, N=N, K=K, a_scales=Amax(row=row))
+        torch.cuda.synchronize()
+    finally:
+        hip.plan_override = keep
+    assert bool(torch.isfinite(out_r).all()) and _rowrel(out_r, exact) < 3e-6
+    if not refused:                 # (which forced cuts end in a short range is the planner's business: refused or right, never silently wrong)
+        assert bool(torch.isfinite(out_p).all()) and _rowrel(out_p, exact) < 3e-6

@@ -88,6 +88,12 @@ def test_water_guard_still_fires_through_the_native_components():
     g = mol.to_dgl(max_element=53, exclude_feats=[])
     with pytest.raises(Exception):
         B.check_disconnected_graphs(g)
+    # the reference's literal check (Z - 1 compared with {1, 8}, utils/dgl_utils.py:231-234) never fires on water: the switch reproduces that
+    B.check_disconnected_graphs(g, print_information=False, reference_water_guard=True)
+    # ... and fires where the reference's would: a three-atom component of He and F only
+    hef = Molecule(atoms=[1, 2, 3], bonds=[(1, 2), (1, 3)], impropers=[], atomic_numbers=[9, 2, 2], partial_charges=[0., 0., 0.])
+    with pytest.raises(ValueError):
+        B.check_disconnected_graphs(hef.to_dgl(max_element=53, exclude_feats=[]), print_information=False, reference_water_guard=True)
 
 
 @pytest.mark.parametrize("ids", [[0], [17], [3, 50, 900]])
