@@ -128,13 +128,142 @@ def cpu_baseline_child(workload: str, n_mols: int, steps: int, warmup: int, swee
                       "warmup": warmup, "sweep": tried}), flush=True)
 
 
+def cpu_quota_cores():
+    """CPUs this job may use at once: the cgroup's bandwidth limit (cpu.max = quota period) if there is one, else the affinity mask"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def numa_cpulists():
+    out = []
+    base = "/sys/devices/system/node"
+    try:
+        for name in sorted(os.listdir(base)):
+            if name.startswith("node") and name[4:].isdigit():
+                cpus = set()
+                for part in open(os.path.join(base, name, "cpulist")).read().strip().split(","):
+                    lo, _, hi = part.partition("-")
+                    cpus.update(range(int(lo), int(hi or lo) + 1))
+                if cpus:
+                    out.append(sorted(cpus))
+    except OSError:
+        pass
+    return out
+
+
+def cpu_baseline_mp_child(rank: int, world: int, port: int, workload: str, n_mols: int, steps: int, warmup: int, threads: int, limit_s: float):
+    """the same oracle train step with the sample's molecules sharded over `world` processes (one per NUMA domain, `threads`
+    threads each, pinned to the domain's CPUs), gradients summed once per step (gloo all-reduce of every parameter gradient), clip + Adam on
+    every process: molecules are independent, so this is the host-side analogue of the engine's own data parallelism."""
+    import torch.distributed as dist
+    from grappa_amd import get_default_model_config
+    from grappa_amd.datasets import build_batch_from_pool, workload_molecule_ids
+    from oracle import cpu_ref
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_utils as gu
+    nodes = numa_cpulists()
+    if len(nodes) >= 2:
+        try:
+            os.sched_setaffinity(0, nodes[rank % len(nodes)])
+        except OSError:
+            pass
+    torch.set_num_threads(threads)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    t_begin = time.time()
+    ids = workload_molecule_ids(workload, seed=0)[:n_mols]
+    mine = ids[rank::world]
+    model = cpu_ref.RefGrappaModel(**get_default_model_config())
+    model.load_state_dict(gu.keyed_state_dict(model))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1.5e-5)
+    loss_fn, energy = cpu_ref.RefMolwiseLoss(**LOSS_KW), cpu_ref.RefEnergy()
+    params = [p for p in model.parameters()]
+    times = []
+    for it in range(steps + warmup):
+        g = build_batch_from_pool(mine, n_confs=32, seed=0)
+        dist.barrier()
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = loss_fn(energy(model(g))) * (len(mine) / n_mols)          # (the loss is a mean over the batch's molecules)
+        loss.backward()
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+        dist.all_reduce(flat)
+        o = 0
+        for p in params:
+            n = p.numel()
+            p.grad = flat[o:o + n].view_as(p).clone()
+            o += n
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        opt.step()
+        dist.barrier()
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+        stop = torch.tensor([1.0 if (time.time() - t_begin > limit_s and times) else 0.0])
+        dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+        if float(stop) > 0:
+            break
+    if rank == 0:
+        t = sorted(times)[len(times) // 2] if times else None
+        print(json.dumps({"value": n_mols / t if t else None, "processes": world, "threads_per_process": threads, "median_step_s": t,
+                          "steps": len(times), "warmup": warmup, "numa_domains": len(nodes)}), flush=True)
+    dist.destroy_process_group()
+
+
+def cpu_baseline_mp(workload: str, n_mols: int, steps: int, warmup: int, limit_s: float, quota: int):
+    """-> the multi-process record (one process per NUMA domain, the quota's cores split between them) or a note why there is none"""
+    import socket
+    import subprocess
+    nodes = numa_cpulists()
+    world = max(2, min(len(nodes), 8)) if len(nodes) >= 2 else 2
+    threads = max(1, quota // world)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-mp-child", str(r), str(world), str(port), workload, str(n_mols),
+                               str(steps), str(warmup), str(threads), str(limit_s)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(world)]
+    rec = None
+    try:
+        out0, err0 = procs[0].communicate(timeout=limit_s + 120)
+        for line in reversed(out0.splitlines()):
+            if line.startswith("{"):
+                rec = json.loads(line)
+                break
+        if rec is None:
+            rec = {"value": None, "note": f"rank 0 failed: {err0[-300:]}"}
+    except subprocess.TimeoutExpired:
+        rec = {"value": None, "note": "did not finish in time"}
+    finally:
+        for pr in procs:                      # (exact PIDs of the children started here)
+            if pr.poll() is None:
+                try:
+                    pr.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+    rec["layout"] = f"{world} processes x {threads} threads, one per NUMA domain (sched_setaffinity), gloo all-reduce of the gradients once per step"
+    return rec
+
+
 def cpu_baseline(workload: str, n_mols: int, steps: int, warmup: int, limit_s: float):
     """BASELINE.md section 2 on a bounded sample, in ONE child process started before this process touches the GPU: thread sweep over
     {16, 32, 64, 128} (capped by the host), the best setting timed for `steps` steps after `warmup` on `n_mols` molecules of the workload;
     `cores` = the threads the reported figure ran on"""
     import subprocess
     ncpu = os.cpu_count() or 1
-    settings = sorted({min(t, ncpu) for t in (16, 32, 64, 128)})
+    quota = min(cpu_quota_cores(), ncpu)
+    # the threads worth trying are bounded by what the job may use at once: on the driver's GPU box the cgroup grants 16 of the host's 256
+    # logical CPUs (cpu.max = 1600000 100000), which is why 64 and 128 threads measured SLOWER than 16 in round 5
+    settings = sorted({max(1, min(t, ncpu)) for t in (quota // 2, quota, 2 * quota)})
+    limit_total, limit_s = limit_s, 0.6 * limit_s
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", workload, str(n_mols), str(steps), str(warmup),
            ",".join(map(str, settings)), str(limit_s)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(max(settings)))
@@ -154,8 +283,20 @@ def cpu_baseline(workload: str, n_mols: int, steps: int, warmup: int, limit_s: f
               f"loss, backward, clip, Adam), median of {rec.get('steps')} timed steps after {warmup} warm-up on {rec.get('threads')} threads "
               f"(oracle/cpu_ref.py, torch {torch.__version__} CPU); thread sweep on {max(n_mols // 4, 8)} molecules (1 warm-up + 2 steps each): {sweep}"
               + (f"; {rec['note']}" if rec.get("note") else ""))
-    return {"value": rec.get("value"), "unit": "molecules/s", "cores": rec.get("threads"), "host_cores": ncpu, "threads_used": rec.get("threads"),
-            "cpu_model": cpu_model_name(), "kind": "port", "sample": sample, "median_step_s": rec.get("median_step_s")}
+    single = {"value": rec.get("value"), "cores": rec.get("threads"), "median_step_s": rec.get("median_step_s")}
+    # the same sample sharded over one process per NUMA domain (molecules are independent), gradients summed once per step
+    try:
+        mp = cpu_baseline_mp(workload, n_mols, max(2, steps - 2), 1, 0.4 * limit_total, quota)
+    except Exception as e:  # noqa: BLE001
+        mp = {"value": None, "note": repr(e)[:200]}
+    best_is_mp = bool(mp.get("value")) and (not single["value"] or mp["value"] > single["value"])
+    value = mp["value"] if best_is_mp else single["value"]
+    cores = (mp.get("processes", 0) * mp.get("threads_per_process", 0)) if best_is_mp else rec.get("threads")
+    sample += (f"; ALSO sharded over processes: {mp.get('layout')}: " + (f"{mp['value']:.1f} molecules/s (median of {mp.get('steps')} steps)" if mp.get("value") else f"no figure ({mp.get('note')})")
+               + f"; the job may use {quota} of the host's {ncpu} logical CPUs at once (cgroup cpu.max), `value` = the faster of the two layouts")
+    return {"value": value, "unit": "molecules/s", "cores": cores, "host_cores": ncpu, "cpu_quota_cores": quota, "threads_used": rec.get("threads"),
+            "cpu_model": cpu_model_name(), "kind": "port", "sample": sample, "median_step_s": rec.get("median_step_s"),
+            "single_process": single, "multi_process": mp}
 
 
 def log(*a):
@@ -163,6 +304,10 @@ def log(*a):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-mp-child":
+        a = sys.argv[2:]
+        cpu_baseline_mp_child(int(a[0]), int(a[1]), int(a[2]), a[3], int(a[4]), int(a[5]), int(a[6]), int(a[7]), float(a[8]))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
         cpu_baseline_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], float(sys.argv[7]))
         return
@@ -352,6 +497,32 @@ def main():
     else:
         job = Job(workload, WORKLOADS[workload][0] * world, workload_molecule_ids(workload, seed=rank), seed=rank)
     log(f"workload {job.name} ready: molecules {job.n_local} atoms {job.atoms} tuples {job.tuples}; warmup")
+    def recorded_step(j, steps):
+        """the train step of job `j` (one chunk) as ONE hipGraph replay on its resident batch (grappa_amd/capture.py CapturedTrainStep: zero_grad ->
+        forward -> Energy -> loss -> backward -> clip + Adam, the four writer heads as branches of the graph): `steps` replays between two
+        synchronisations.  The recording trains (3 warm-up steps); training state is put back afterwards so that later measurements start
+        from the same weights."""
+        from grappa_amd.capture import CapturedTrainStep
+        if len(j.graphs) != 1:
+            raise RuntimeError("recorded_step: one resident chunk only")
+        cap = CapturedTrainStep(model, energy, j.loss_fn, opt, j.graphs[0], warmup=3, preserve_state=True)
+        try:
+            for _ in range(2):
+                cap()
+            sync()
+            t0_ = time.perf_counter()
+            for _ in range(steps):
+                cap()
+            sync()
+            d_ = time.perf_counter() - t0_
+            return {"value": j.global_batch * steps / d_, "unit": "molecules/s", "ms_per_step": 1e3 * d_ / steps, "steps": steps, "warmup": 2,
+                    "mode": "hipGraph replay of the whole train step on the resident batch (CapturedTrainStep), dropout masks fresh per replay",
+                    "final_loss": float(cap.loss), "gemm_precision": be.gemm_precision_name,
+                    "activation_storage": "bf16" if ops.act_dtype() is not None else "f32"}
+        finally:
+            del cap
+            torch.cuda.empty_cache()
+
     dt, final_loss = job.timed(args.steps, args.warmup)
     log(f"timed region done: {1e3 * dt / args.steps:.1f} ms/step; instrumented pass")
 
@@ -560,6 +731,13 @@ def main():
                                            "weights / weight gradients fp32; parameters within 2e-2 of the oracle (tests/test_gpu_bf16.py); reported "
                                            "beside, never as, the fp32-grade headline")
                 log(f"{key}: {extras[key]['ms_per_step']:.1f} ms/step = {extras[key]['value']:.0f} molecules/s")
+                if key in ("c3", "c3_bf16"):
+                    # the same step as ONE recorded hipGraph on the resident batch: what is left when the host's enqueue is gone
+                    try:
+                        extras[key + "_recorded"] = recorded_step(j2, 5)
+                        log(f"{key}_recorded: {extras[key + '_recorded']['ms_per_step']:.1f} ms/step")
+                    except Exception as e:  # noqa: BLE001
+                        extras[key + "_recorded"] = {"value": None, "error": repr(e)[:300]}
                 del j2
             except Exception as e:  # noqa: BLE001  (an extra must never take the headline line down)
                 extras[key] = {"value": None, "error": repr(e)[:300]}
@@ -568,6 +746,13 @@ def main():
                 be.set_gemm_precision(default_precision)
                 torch.cuda.empty_cache()
         job.graphs = headline_graphs
+        try:
+            extras["c2_recorded"] = recorded_step(job, args.steps)
+            log(f"c2_recorded: {extras['c2_recorded']['ms_per_step']:.2f} ms/step (eager headline {1e3 * dt / args.steps:.2f})")
+        except Exception as e:  # noqa: BLE001
+            extras["c2_recorded"] = {"value": None, "error": repr(e)[:300]}
+        finally:
+            torch.cuda.empty_cache()
         # ---- launch counts and host enqueue time of one headline step: the library counts its own launches; the host time is
         # taken with an empty queue in front of every step, so it is the time Python + the C ABI need to ISSUE the step, not to run it
         try:
@@ -856,6 +1041,16 @@ def main():
             "writer_heads_other_stream_setting": heads_alt,
         }
         out.update(extras)
+        # where ONE recorded hipGraph replay per step (same kernels, same optimiser step, fresh dropout masks per replay;
+        # grappa_amd/capture.py CapturedTrainStep, replay == eager step in tests/test_gpu_capture.py) is at least 3 % faster than the eager
+        # step, IT is the headline's mode -- K replays between two synchronisations after the eager warm-up and timing above -- and the
+        # eager figure stays beside it
+        rec = extras.get("c2_recorded") if (world == 1 and workload == "C2-pubchem-b256" and args.act_dtype == "f32") else None
+        out["step_mode"] = "eager (one Python-issued launch sequence per step)"
+        if isinstance(rec, dict) and rec.get("value") and rec.get("steps") == args.steps and rec["ms_per_step"] <= 0.97 * out["ms_per_step"]:
+            out["eager"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "steps": args.steps, "warmup": args.warmup}
+            out["value"], out["ms_per_step"] = rec["value"], rec["ms_per_step"]
+            out["step_mode"] = rec["mode"]
         # the driver's record keeps `config` verbatim and only the NAMES of other top-level keys: the numbers the extras stand for travel in
         # config.extras too (value, unit, ms per step, the products' roofline fraction) -- VERDICT r4 item 7
         def _brief(e):
