@@ -100,6 +100,18 @@ class WriterLayerDesc(C.Structure):
                 ("save_u", C.c_void_p)]
 
 
+class WriterLayerBwdDesc(C.Structure):
+    """grappa_writer_layer_bwd_desc (ABI 11): the input-gradient chain of one fused transformer layer"""
+    _fields_ = [("s", C.c_int), ("T", C.c_int), ("F", C.c_int), ("nheads", C.c_int), ("dtype", C.c_int), ("dout", C.c_void_p),
+                ("x", C.c_void_p), ("qkv", C.c_void_p), ("x2", C.c_void_p), ("u", C.c_void_p),
+                ("mean1", C.c_void_p), ("rstd1", C.c_void_p), ("meanf", C.c_void_p), ("rstdf", C.c_void_p),
+                ("n1_gamma", C.c_void_p), ("nf_gamma", C.c_void_p),
+                ("w_in_tpk", C.c_void_p), ("w_o_tpk", C.c_void_p), ("w1_tpk", C.c_void_p), ("w2_tpk", C.c_void_p),
+                ("drop_p", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64), ("drop_salt", C.c_void_p),
+                ("dx", C.c_void_p), ("dz2", C.c_void_p), ("dz1", C.c_void_p), ("dzo", C.c_void_p), ("dqkv", C.c_void_p),
+                ("ln1_part", C.c_void_p), ("lnf_part", C.c_void_p)]
+
+
 WRITER_BF16 = 1
 
 COLLATE_MODES = {"copy": 0, "add": 1, "inv_rows": 2, "inc_code": 3, "conf": 4}
@@ -196,6 +208,8 @@ SIGNATURES = {
     "grappa_convert_bf16_to_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i]),
     # ABI 11: the fused writer-head layer
     "grappa_writer_head_fwd": (_i, [_vp, C.POINTER(WriterLayerDesc)]),
+    "grappa_writer_head_bwd": (_i, [_vp, C.POINTER(WriterLayerBwdDesc)]),
+    "grappa_writer_head_tiles": (_i, [_i, _i]),
     "grappa_writer_pack_bytes": (_sz, [_i, _i, _i]),
     "grappa_writer_pack_weight": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
 }

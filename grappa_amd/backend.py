@@ -201,6 +201,9 @@ class HipBackend:
         # round 6: a transformer layer of a writer head as ONE kernel (csrc/writer_layer.hip, grappa_writer_head_fwd) where its shape allows:
         # bf16 storage configuration, 512 features, 8 heads.  GRAPPA_FUSED_WRITER_LAYER=0: the unfused sequence (A/B, tests)
         self.fused_writer_layer = os.environ.get("GRAPPA_FUSED_WRITER_LAYER", "1") not in ("0", "")
+        # ... and its backward pass: the input-gradient chain as one kernel (grappa_writer_head_bwd); 0: the unfused backward over the tensors
+        # the fused forward saved
+        self.fused_writer_layer_bwd = os.environ.get("GRAPPA_FUSED_WRITER_LAYER_BWD", "1") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
         self._wpairs = {}      # (data_ptr, rows, cols, "pairs" | "pairsT") -> [version key, pairs, weakref of the weight, epoch of last use, transposed, maxima record]
         self._wptable = None   # (device table of grappa_split_pairs_item, count, tiles, records kept alive)
@@ -1544,6 +1547,59 @@ class HipBackend:
         nbytes = 2.0 * M * Fd * (2 + (9 if save is not None else 0)) + 2.0 * 6 * Fd * Fd
         self._timed("writer_layer", flops, nbytes, lambda: _chk(self.lib.grappa_writer_head_fwd(self._stream(), C.byref(d)), "grappa_writer_head_fwd"),
                     lambda: [{"M": M, "s": s, "save": keep is not None}])
+
+    def writer_layer_bwd(self, dout, x, s, T, nheads, drop_p, seed1, seed2, saved, n1_w, n1_b, w_in, w_o, nf_w, nf_b, w1, w2):
+        """the input-gradient chain of the fused layer in ONE launch (grappa_writer_head_bwd) -> (dx, dz2, dz1, dzo, dqkv): dx = the gradient of
+        the layer's input, the other four = the operands of the weight-gradient products (against saved u, x3, att, x1).  The LayerNorm
+        parameter gradients (per-tile partials) are queued for the end-of-pass reduction like layernorm_bwd's, or reduced at once.
+        saved: the dict `writer_layer_fwd` filled."""
+        dev = dout.device
+        M, Fd = x.shape
+        bf = torch.bfloat16
+        if M != s * T or tuple(dout.shape) != (M, Fd):
+            raise ValueError("writer_layer_bwd: shapes")
+        d = _lib.WriterLayerBwdDesc()
+        d.s, d.T, d.F, d.nheads, d.dtype = s, T, Fd, nheads, _lib.WRITER_BF16
+        for name, t, shape in (("dout", dout, (M, Fd)), ("x", x, (M, Fd)), ("qkv", saved["qkv"], (M, 3 * Fd)), ("x2", saved["x2"], (M, Fd)), ("u", saved["u"], (M, Fd))):
+            _flat(t, name, dev, bf)
+            if tuple(t.shape) != shape:
+                raise ValueError(f"writer_layer_bwd: {name} shape")
+            setattr(d, name, t.data_ptr())
+        for name in ("mean1", "rstd1", "meanf", "rstdf"):
+            _flat(saved[name], name, dev)
+            setattr(d, name, saved[name].data_ptr())
+        _flat(n1_w, "n1_gamma", dev), _flat(nf_w, "nf_gamma", dev)
+        d.n1_gamma, d.nf_gamma = n1_w.data_ptr(), nf_w.data_ptr()
+        for name, wt in (("w_in_tpk", w_in), ("w_o_tpk", w_o), ("w1_tpk", w1), ("w2_tpk", w2)):
+            setattr(d, name, self._packed_weight(wt, transposed=True).data_ptr())
+        d.drop_p, d.seed1, d.seed2, d.drop_salt = float(drop_p), int(seed1) & (2 ** 64 - 1), int(seed2) & (2 ** 64 - 1), self._salt_ptr
+        new = lambda *sh: torch.empty(sh, dtype=bf, device=dev)      # noqa: E731
+        dx, dz2, dz1, dzo, dqkv = new(M, Fd), new(M, Fd), new(M, Fd), new(M, Fd), new(M, 3 * Fd)
+        ntiles = self.lib.grappa_writer_head_tiles(s, T)
+        parts = torch.empty((2, ntiles, 2, Fd), dtype=torch.float32, device=dev)
+        d.dx, d.dz2, d.dz1, d.dzo, d.dqkv = dx.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), dzo.data_ptr(), dqkv.data_ptr()
+        d.ln1_part, d.lnf_part = parts[0].data_ptr(), parts[1].data_ptr()
+        flops = 2.0 * M * Fd * (6 * Fd) + 8.0 * M * s * Fd
+        self._timed("writer_layer", flops, 2.0 * M * Fd * 15 + 2.0 * 6 * Fd * Fd,
+                    lambda: _chk(self.lib.grappa_writer_head_bwd(self._stream(), C.byref(d)), "grappa_writer_head_bwd"), lambda: [{"M": M, "s": s, "bwd": True}])
+        for part, g, b in ((parts[0], n1_w, n1_b), (parts[1], nf_w, nf_b)):
+            self._reduce_ln_partials(part, ntiles, Fd, g, b)
+        return dx, dz2, dz1, dzo, dqkv
+
+    def _reduce_ln_partials(self, part, nrows, W, gamma, beta) -> None:
+        """per-block partial sums [nrows][dgamma | dbeta][W] of a LayerNorm's parameter gradients -> accumulated into the parameters' gradient
+        buffers: with the other LayerNorms' at the end of the backward pass where that queue is open (layernorm_bwd), else now"""
+        from .ops import _pgrad
+        dg = _pgrad(gamma) if gamma.requires_grad else torch.zeros_like(gamma)
+        db = _pgrad(beta) if beta.requires_grad else torch.zeros_like(beta)
+        task = self._queue_flush() if (self.defer_wgrads and self.defer_ln) else -1
+        if task >= 0 and all(q[3] != dg.data_ptr() for q in self._lnq if q[8] == task):
+            self._lnq.append((part, nrows, W, dg.data_ptr(), db.data_ptr(), dg, db, torch.cuda.current_stream(), task))
+            return
+        arr = (_lib.ColsumItem * 1)()
+        a = arr[0]
+        a.part, a.nrows, a.n, a.out, a.out2, a.n_first, a.accumulate = part.data_ptr(), nrows, 2 * W, dg.data_ptr(), db.data_ptr(), W, 1
+        _chk(self.lib.grappa_colsum_partials_batched(self._stream(), arr, 1), "grappa_colsum_partials_batched")
 
     def seqattn_bwd(self, qkv, dout, s, T, nheads, dqkv, amax=None):
         dev = dqkv.device

@@ -459,6 +459,408 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
     }
 }
 
+// sum over the 16 lanes of a DPP row (the 16 tokens of an accumulator block); every lane gets the sum
+__device__ __forceinline__ float wl_sum16(float v) { return wl_dpp_add<0x140>(wl_sum8(v)); }
+
+// ---- the backward pass of the layer: the input-gradient chain on a tile of 64 token rows; the four weight gradients are ordinary grouped products
+// over the operands this kernel writes as by-products (dz2, dz1, dzo, dqkv) and the activations the forward saved (u, x3, att, x1).
+//   dz2 = dropmask2(dout)                      dz1 = (dz2 W_2) * ELU'(u)                 dx3 = dz1 W_1 + dout
+//   dx2 = LN'(dx3; x2, nf)                     dzo = dropmask1(dx2)                      datt = dzo W_o
+//   dqkv = attention'(qkv, datt)               dx1 = dqkv W_in + dx2                     dx  = LN'(dx1; x, n1)
+// every tensor the unfused kernels store is rounded to bf16 at the same place.  Products as in the forward kernel, with the TRANSPOSED weights
+// packed (grappa_writer_pack_weight transpose = 1): out^T = W^T act^T.  LDS: image A (dz2, then dzo, then the staging of one head pair's dq | dk | dv),
+// image B (dz1, then datt).  LayerNorm parameter gradients: per-tile partial sums [tile][dgamma | dbeta][512], reduced by the caller.
+template <int S>
+__global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const grappa_writer_layer_bwd_desc d) {
+    constexpr int TT = WL_ROWS / S;
+    extern __shared__ char smem[];
+    uint16_t* imgA = reinterpret_cast<uint16_t*>(smem + WL_OFF_A);
+    uint16_t* imgQ = reinterpret_cast<uint16_t*>(smem + WL_OFF_A);          // staging of a head pair's dq | dk | dv: inside image A (dzo is dead by then)
+    uint16_t* imgB = reinterpret_cast<uint16_t*>(smem + WL_OFF_B);
+    float* red = reinterpret_cast<float*>(smem + WL_OFF_RED);              // [2][8 wavefronts][64 rows]
+
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
+    const int T = d.T;
+    const int t0 = blockIdx.x * TT;
+    const int ntup = min(TT, T - t0);
+    const uint16_t* __restrict__ dout = reinterpret_cast<const uint16_t*>(d.dout);
+    const uint16_t* __restrict__ xin = reinterpret_cast<const uint16_t*>(d.x);
+    const uint16_t* __restrict__ qkv = reinterpret_cast<const uint16_t*>(d.qkv);
+    const uint16_t* __restrict__ x2s = reinterpret_cast<const uint16_t*>(d.x2);
+    const uint16_t* __restrict__ us = reinterpret_cast<const uint16_t*>(d.u);
+    uint16_t* __restrict__ dx = reinterpret_cast<uint16_t*>(d.dx);
+    uint16_t* __restrict__ o_dz2 = reinterpret_cast<uint16_t*>(d.dz2);
+    uint16_t* __restrict__ o_dz1 = reinterpret_cast<uint16_t*>(d.dz1);
+    uint16_t* __restrict__ o_dzo = reinterpret_cast<uint16_t*>(d.dzo);
+    uint16_t* __restrict__ o_dqkv = reinterpret_cast<uint16_t*>(d.dqkv);
+    const float drop_p = d.drop_p;
+    const float drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const uint64_t seed1 = grappa_salted(d.seed1, d.drop_salt), seed2 = grappa_salted(d.seed2, d.drop_salt);
+
+    // ---- phase 0: dz2 = dropout mask of the forward's last dropout applied to dout -> image A (+ global: operand of dW_2)
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = w * 8 + i, p = r / TT, j = r - p * TT;
+            const bool ok = p < S && j < ntup;
+            const long gr = ok ? (long)p * T + t0 + j : -1;
+            uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) {
+                float v[8];
+                wl_unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)gr * WL_F + 8 * l), v);
+                if (drop_p > 0.f) {
+                    const uint64_t idx = (uint64_t)gr * WL_F + 8 * l;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = grappa_keep(seed2, idx + e, drop_p) ? v[e] * drop_scale : 0.f;
+                }
+                pk = wl_pack8(v);
+                *reinterpret_cast<uint4*>(o_dz2 + (size_t)gr * WL_F + 8 * l) = pk;
+            }
+            *reinterpret_cast<uint4*>(imgA + r * WL_LDA + 8 * l) = pk;
+        }
+    }
+    long grow[4];
+    float mean_f[4], rstd_f[4], mean_1[4], rstd_1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int r = mb * 16 + lr, p = r / TT, j = r - p * TT;
+        grow[mb] = (p < S && j < ntup) ? (long)p * T + t0 + j : -1;
+        const bool ok = grow[mb] >= 0;
+        mean_f[mb] = ok ? d.meanf[grow[mb]] : 0.f;
+        rstd_f[mb] = ok ? d.rstdf[grow[mb]] : 0.f;
+        mean_1[mb] = ok ? d.mean1[grow[mb]] : 0.f;
+        rstd_1[mb] = ok ? d.rstd1[grow[mb]] : 0.f;
+    }
+    const uint4* __restrict__ wq_in = reinterpret_cast<const uint4*>(d.w_in_tpk);
+    const uint4* __restrict__ wq_o = reinterpret_cast<const uint4*>(d.w_o_tpk);
+    const uint4* __restrict__ wq_1 = reinterpret_cast<const uint4*>(d.w1_tpk);
+    const uint4* __restrict__ wq_2 = reinterpret_cast<const uint4*>(d.w2_tpk);
+    const char* fragA = smem + WL_OFF_A + (lr * WL_LDA + 8 * lq) * 2;
+    const char* fragB = smem + WL_OFF_B + (lr * WL_LDA + 8 * lq) * 2;
+    const char* fragQ = smem + WL_OFF_A + (lr * WL_LDQ + 8 * lq) * 2;
+    float* part_f = d.lnf_part + (size_t)blockIdx.x * 2 * WL_F;
+    float* part_1 = d.ln1_part + (size_t)blockIdx.x * 2 * WL_F;
+    __syncthreads();
+
+    // ---- phase 1: dz1 = (dz2 W_2) * ELU'(u) -> image B (+ global: operand of dW_1)
+    {
+        uint2 upk[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                upk[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(us + (size_t)grow[mb] * WL_F + (4 * w + i) * 16 + 4 * lq) : make_uint2(0u, 0u);
+        wl_f32x4 acc[4][4];
+        wl_zero<4>(acc);
+        const uint4* pa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[i] = wq_2 + ((size_t)(4 * w + i) * 16) * 64 + l;
+        wl_product<4, 16, 4>(pa, fragA, WL_LDA * 2, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float uv[4], y[4];
+                wl_unpack4(upk[i][mb], uv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = acc[i][mb][e] * grappa_elu_grad_from_out(uv[e]);
+                const uint2 pk = wl_pack4(y);
+                *reinterpret_cast<uint2*>(imgB + (mb * 16 + lr) * WL_LDA + n) = pk;
+                if (grow[mb] >= 0) *reinterpret_cast<uint2*>(o_dz1 + (size_t)grow[mb] * WL_F + n) = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: dx3 = dz1 W_1 + dout; dx2 = LN'(dx3; x2); dzo = dropout mask of the forward's first dropout applied to dx2 -> image A
+    uint2 dx2p[4][4];                     // dx2 as stored (bf16): the skip branch into dx1, phase 5
+    {
+        uint2 dop[4][4], x2p[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const size_t o = (size_t)(grow[mb] >= 0 ? grow[mb] : 0) * WL_F + (4 * w + i) * 16 + 4 * lq;
+                dop[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(dout + o) : make_uint2(0u, 0u);
+                x2p[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(x2s + o) : make_uint2(0u, 0u);
+            }
+        wl_f32x4 acc[4][4];
+        wl_zero<4>(acc);
+        const uint4* pa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[i] = wq_1 + ((size_t)(4 * w + i) * 16) * 64 + l;
+        wl_product<4, 16, 4>(pa, fragB, WL_LDA * 2, acc);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+            const float4 g4 = *reinterpret_cast<const float4*>(d.nf_gamma + n);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+            float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float dov[4], xv[4], y[4];
+                wl_unpack4(dop[i][mb], dov);
+                wl_unpack4(x2p[i][mb], xv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = wl_round_bf16(acc[i][mb][e] + dov[e]);                  // dx3 as the unfused product stores it
+                    const float xh = (xv[e] - mean_f[mb]) * rstd_f[mb], g = y[e] * gg[e];
+                    s1[mb] += g;
+                    s2[mb] += g * xh;
+                    dgam[e] += y[e] * xh;
+                    dbet[e] += y[e];
+                }
+                dop[i][mb] = wl_pack4(y);                                          // (dout is done: the registers now hold dx3)
+            }
+            // LayerNorm parameter gradients of this tile: sum over its 64 tokens = the 4 blocks (above) and the 16 lanes of a row
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dgam[e] = wl_sum16(dgam[e]);
+                dbet[e] = wl_sum16(dbet[e]);
+            }
+            if (lr == 0) {
+                *reinterpret_cast<float4*>(part_f + n) = make_float4(dgam[0], dgam[1], dgam[2], dgam[3]);
+                *reinterpret_cast<float4*>(part_f + WL_F + n) = make_float4(dbet[0], dbet[1], dbet[2], dbet[3]);
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            s1[mb] = wl_quad_sum(s1[mb]);
+            s2[mb] = wl_quad_sum(s2[mb]);
+            if (lq == 0) {
+                red[w * WL_ROWS + mb * 16 + lr] = s1[mb];
+                red[(8 + w) * WL_ROWS + mb * 16 + lr] = s2[mb];
+            }
+        }
+        __syncthreads();
+        float m1[4], m2[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                a += red[ww * WL_ROWS + mb * 16 + lr];
+                b += red[(8 + ww) * WL_ROWS + mb * 16 + lr];
+            }
+            m1[mb] = a / (float)WL_F;
+            m2[mb] = b / (float)WL_F;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+            const float4 g4 = *reinterpret_cast<const float4*>(d.nf_gamma + n);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float dyv[4], xv[4], o[4], z[4];
+                wl_unpack4(dop[i][mb], dyv);
+                wl_unpack4(x2p[i][mb], xv);
+                const uint64_t idx = (uint64_t)(grow[mb] >= 0 ? grow[mb] : 0) * WL_F + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xv[e] - mean_f[mb]) * rstd_f[mb];
+                    o[e] = wl_round_bf16(rstd_f[mb] * (dyv[e] * gg[e] - m1[mb] - xh * m2[mb]));      // dx2 as stored
+                    z[e] = (drop_p > 0.f) ? (grappa_keep(seed1, idx + e, drop_p) ? o[e] * drop_scale : 0.f) : o[e];
+                }
+                dx2p[i][mb] = wl_pack4(o);
+                const uint2 pk = wl_pack4(z);
+                *reinterpret_cast<uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n) = pk;
+                if (grow[mb] >= 0) *reinterpret_cast<uint2*>(o_dzo + (size_t)grow[mb] * WL_F + n) = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: datt = dzo W_o -> image B
+    {
+        wl_f32x4 acc[4][4];
+        wl_zero<4>(acc);
+        const uint4* pa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[i] = wq_o + ((size_t)(4 * w + i) * 16) * 64 + l;
+        wl_product<4, 16, 4>(pa, fragA, WL_LDA * 2, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float y[4] = {acc[i][mb][0], acc[i][mb][1], acc[i][mb][2], acc[i][mb][3]};
+                *reinterpret_cast<uint2*>(imgB + (mb * 16 + lr) * WL_LDA + n) = wl_pack4(y);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: head pair by head pair: dq | dk | dv of two heads -> staging (+ global: operand of dW_in); dx1 accumulator += dqkv W_in (K = 384)
+    wl_f32x4 xacc[4][4];
+    wl_zero<4>(xacc);
+#pragma unroll 1
+    for (int hp = 0; hp < 4; ++hp) {
+        // the backward of the attention of (tuple j, head 2 hp + hh): 16 lanes, 4 features each (the arithmetic of csrc/tuples.hip seqattn_bwd_kernel_e)
+#pragma unroll 1
+        for (int pass = 0; pass < (2 * TT + 31) / 32; ++pass) {
+            const int sub = tid & 15, pair = pass * 32 + (tid >> 4), hh = pair & 1, j = pair >> 1;
+            if (j < ntup) {
+                float q[S][4], k[S][4], v[S][4], go[S][4], dq[S][4], dk[S][4], dv[S][4];
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const uint16_t* row = qkv + ((size_t)i * T + t0 + j) * (3 * WL_F) + (2 * hp + hh) * 64 + sub * 4;
+                    wl_unpack4(*reinterpret_cast<const uint2*>(row), q[i]);
+                    wl_unpack4(*reinterpret_cast<const uint2*>(row + WL_F), k[i]);
+                    wl_unpack4(*reinterpret_cast<const uint2*>(row + 2 * WL_F), v[i]);
+                    wl_unpack4(*reinterpret_cast<const uint2*>(imgB + (i * TT + j) * WL_LDA + (2 * hp + hh) * 64 + sub * 4), go[i]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq[i][e] = dk[i][e] = dv[i][e] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    float pr[S], dp[S], mx = -INFINITY;
+#pragma unroll
+                    for (int jj = 0; jj < S; ++jj) {
+                        const float dt = (q[i][0] * k[jj][0] + q[i][1] * k[jj][1]) + (q[i][2] * k[jj][2] + q[i][3] * k[jj][3]);
+                        pr[jj] = wl_sum16(dt) * 0.125f;
+                        mx = fmaxf(mx, pr[jj]);
+                    }
+                    float den = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < S; ++jj) {
+                        pr[jj] = expf(pr[jj] - mx);
+                        den += pr[jj];
+                    }
+                    const float inv = 1.0f / den;
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < S; ++jj) {
+                        pr[jj] *= inv;
+                        const float dt = (go[i][0] * v[jj][0] + go[i][1] * v[jj][1]) + (go[i][2] * v[jj][2] + go[i][3] * v[jj][3]);
+                        dp[jj] = wl_sum16(dt);
+                        dsum += pr[jj] * dp[jj];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < S; ++jj) {
+                        const float ds = pr[jj] * (dp[jj] - dsum) * 0.125f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            dq[i][e] += ds * k[jj][e];
+                            dk[jj][e] += ds * q[i][e];
+                            dv[jj][e] += pr[jj] * go[i][e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const uint2 pq = wl_pack4(dq[i]), pk = wl_pack4(dk[i]), pv = wl_pack4(dv[i]);
+                    uint16_t* st = imgQ + (i * TT + j) * WL_LDQ + hh * 64 + sub * 4;
+                    *reinterpret_cast<uint2*>(st) = pq;
+                    *reinterpret_cast<uint2*>(st + 128) = pk;
+                    *reinterpret_cast<uint2*>(st + 256) = pv;
+                    uint16_t* gp = o_dqkv + ((size_t)i * T + t0 + j) * (3 * WL_F) + (2 * hp + hh) * 64 + sub * 4;
+                    *reinterpret_cast<uint2*>(gp) = pq;
+                    *reinterpret_cast<uint2*>(gp + WL_F) = pk;
+                    *reinterpret_cast<uint2*>(gp + 2 * WL_F) = pv;
+                }
+            }
+        }
+        __syncthreads();
+        // dx1^T += W_in^T (:, the pair's q | k | v rows) dqkv^T: three runs of 4 k-steps (rows hp 128 ... of each of W_in's three blocks of 512)
+#pragma unroll
+        for (int seg = 0; seg < 3; ++seg) {
+            const uint4* pa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pa[i] = wq_in + ((size_t)(4 * w + i) * 48 + seg * 16 + hp * 4) * 64 + l;
+            wl_product<4, 4, 4>(pa, fragQ + seg * 256, WL_LDQ * 2, xacc);
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 5: dx1 = acc + dx2; dx = LN'(dx1; x)
+    {
+        uint2 xp[4][4], d1p[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                xp[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(xin + (size_t)grow[mb] * WL_F + (4 * w + i) * 16 + 4 * lq) : make_uint2(0u, 0u);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+            const float4 g4 = *reinterpret_cast<const float4*>(d.n1_gamma + n);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+            float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float skip[4], xv[4], y[4];
+                wl_unpack4(dx2p[i][mb], skip);
+                wl_unpack4(xp[i][mb], xv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // dx1 as the unfused product stores it; rows beyond the tile's tuples: their staging rows were never written (whatever the
+                    // LDS held went through the product), they must not reach the parameter gradients
+                    y[e] = grow[mb] >= 0 ? wl_round_bf16(xacc[i][mb][e] + skip[e]) : 0.f;
+                    const float xh = (xv[e] - mean_1[mb]) * rstd_1[mb], g = y[e] * gg[e];
+                    s1[mb] += g;
+                    s2[mb] += g * xh;
+                    dgam[e] += y[e] * xh;
+                    dbet[e] += y[e];
+                }
+                d1p[i][mb] = wl_pack4(y);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dgam[e] = wl_sum16(dgam[e]);
+                dbet[e] = wl_sum16(dbet[e]);
+            }
+            if (lr == 0) {
+                *reinterpret_cast<float4*>(part_1 + n) = make_float4(dgam[0], dgam[1], dgam[2], dgam[3]);
+                *reinterpret_cast<float4*>(part_1 + WL_F + n) = make_float4(dbet[0], dbet[1], dbet[2], dbet[3]);
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            s1[mb] = wl_quad_sum(s1[mb]);
+            s2[mb] = wl_quad_sum(s2[mb]);
+            if (lq == 0) {
+                red[w * WL_ROWS + mb * 16 + lr] = s1[mb];
+                red[(8 + w) * WL_ROWS + mb * 16 + lr] = s2[mb];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                a += red[ww * WL_ROWS + mb * 16 + lr];
+                b += red[(8 + ww) * WL_ROWS + mb * 16 + lr];
+            }
+            s1[mb] = a / (float)WL_F;
+            s2[mb] = b / (float)WL_F;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (4 * w + i) * 16 + 4 * lq;
+            const float4 g4 = *reinterpret_cast<const float4*>(d.n1_gamma + n);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                if (grow[mb] < 0) continue;
+                float dyv[4], xv[4], o[4];
+                wl_unpack4(d1p[i][mb], dyv);
+                wl_unpack4(xp[i][mb], xv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xv[e] - mean_1[mb]) * rstd_1[mb];
+                    o[e] = rstd_1[mb] * (dyv[e] * gg[e] - s1[mb] - xh * s2[mb]);
+                }
+                *reinterpret_cast<uint2*>(dx + (size_t)grow[mb] * WL_F + n) = wl_pack4(o);
+            }
+        }
+    }
+}
+
 // W (N x K fp32, rows ldw apart; transpose: the operand is W^T, K x N) -> bf16 in fragment order: block (nb, ks) = 16 rows x 32 k is one
 // contiguous KB, lane l of a wavefront holds rows nb 16 + (l & 15), k = ks 32 + 8 (l >> 4) ... + 7 as its 16 bytes
 __global__ __launch_bounds__(256) void writer_pack_bf16_kernel(int N, int K, const float* __restrict__ W, int ldw, int transpose, uint16_t* __restrict__ out) {
@@ -509,6 +911,34 @@ extern "C" int grappa_writer_head_fwd(void* stream, const grappa_writer_layer_de
     const dim3 grid((unsigned)((d->T + tt - 1) / tt));
     void (*kern)(const grappa_writer_layer_desc) =
         d->s == 2 ? writer_layer_fwd_bf16_kernel<2> : (d->s == 3 ? writer_layer_fwd_bf16_kernel<3> : writer_layer_fwd_bf16_kernel<4>);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WL_SMEM) != hipSuccess) return GRAPPA_ERR_LAUNCH;
+    GRAPPA_LAUNCH(kern, grid, dim3(WL_THREADS), WL_SMEM, st, *d);
+    return grappa_launch_status();
+}
+
+extern "C" int grappa_writer_head_tiles(int s, int T) {
+    if (s < 2 || s > 4 || T < 0) return -1;
+    const int tt = WL_ROWS / s;
+    return (T + tt - 1) / tt;
+}
+
+extern "C" int grappa_writer_head_bwd(void* stream, const grappa_writer_layer_bwd_desc* d) {
+    if (!d || d->dtype != GRAPPA_WRITER_BF16 || d->F != WL_F || d->nheads != 8 || d->s < 2 || d->s > 4 || d->T < 0) return GRAPPA_ERR_ARG;
+    if (d->T == 0) return GRAPPA_OK;
+    const void* ptrs[] = {d->dout, d->x, d->qkv, d->x2, d->u, d->mean1, d->rstd1, d->meanf, d->rstdf, d->n1_gamma, d->nf_gamma, d->w_in_tpk, d->w_o_tpk,
+                          d->w1_tpk, d->w2_tpk, d->dx, d->dz2, d->dz1, d->dzo, d->dqkv, d->ln1_part, d->lnf_part};
+    uintptr_t al = 0;
+    for (const void* q : ptrs) {
+        if (!q) return GRAPPA_ERR_ARG;
+        al |= (uintptr_t)q;
+    }
+    if (al & 15) return GRAPPA_ERR_ARG;
+    if (!(d->drop_p >= 0.f && d->drop_p < 1.f)) return GRAPPA_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int tt = WL_ROWS / d->s;
+    const dim3 grid((unsigned)((d->T + tt - 1) / tt));
+    void (*kern)(const grappa_writer_layer_bwd_desc) =
+        d->s == 2 ? writer_layer_bwd_bf16_kernel<2> : (d->s == 3 ? writer_layer_bwd_bf16_kernel<3> : writer_layer_bwd_bf16_kernel<4>);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WL_SMEM) != hipSuccess) return GRAPPA_ERR_LAUNCH;
     GRAPPA_LAUNCH(kern, grid, dim3(WL_THREADS), WL_SMEM, st, *d);
     return grappa_launch_status();

@@ -559,6 +559,7 @@ class TransformerLayerFn(Function):
                           u=_new((M, Fd), x))
             be.writer_layer_fwd(x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, out, save=sv)
             ctx.cfg, ctx.scales = (s, T, nheads, drop_p, seed1, seed2), (None, None)
+            ctx.fused_saved = sv if (sv is not None and getattr(be, "fused_writer_layer_bwd", False)) else None
             if sv is not None:
                 ctx.ff_saved = (sv["x2"], sv["meanf"], sv["rstdf"], sv["x3"], sv["u"], None, None, None)
                 ctx.save_for_backward(x, sv["mean1"], sv["rstd1"], sv["x1"], sv["qkv"], sv["att"], n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)
@@ -594,6 +595,17 @@ class TransformerLayerFn(Function):
         M, Fd = x.shape
         if M == 0:
             return (torch.zeros_like(x),) + (None,) * 18
+        sv = getattr(ctx, "fused_saved", None)
+        if sv is not None:
+            # the input-gradient chain as ONE launch (grappa_writer_head_bwd); the four weight gradients = the grouped products of the pass over
+            # the operands it leaves behind
+            ctx.fused_saved = ctx.ff_saved = None
+            dx, dz2, dz1, dzo, dqkv = be.writer_layer_bwd(_c(dout), x, s, T, nheads, drop_p, seed1, seed2, sv, n1_w, n1_b, w_in, w_o, nf_w, nf_b, w1, w2)
+            _linear_bwd_params(be, dz2, sv["u"], w2, b2, None, None)
+            _linear_bwd_params(be, dz1, sv["x3"], w1, b1, None, None)
+            _linear_bwd_params(be, dzo, att, w_o, b_o, None, None)
+            _linear_bwd_params(be, dqkv, x1, w_in, b_in, None, None)
+            return (dx,) + (None,) * 18
         dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True, then_drop=(drop_p, seed1))
         ctx.ff_saved = None
         dzo, sz = _drop_bwd(be, dx2, drop_p, seed1, w_o)

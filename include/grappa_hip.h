@@ -600,6 +600,30 @@ typedef struct grappa_writer_layer_desc {
     void *save_x1, *save_qkv, *save_att, *save_x2, *save_x3, *save_u;      /* (s*T, F), qkv (s*T, 3F), or NULL */
 } grappa_writer_layer_desc;
 int grappa_writer_head_fwd(void* stream, const grappa_writer_layer_desc* d);
+/* The backward pass of the same layer: the whole input-gradient chain in one kernel per tile of 64 token rows
+ *     dz2 = mask2(dout);  dz1 = (dz2 W_2) * ELU'(u);  dx3 = dz1 W_1 + dout;  dx2 = LN'(dx3; x2, nf);  dzo = mask1(dx2);  datt = dzo W_o;
+ *     dqkv = attention'(qkv, datt);  dx1 = dqkv W_in + dx2;  dx = LN'(dx1; x, n1)
+ * (the derivative of models/network_utils.py:112-133 with :44-54; mask1 / mask2: the forward's dropout masks, regenerated from seed1 / seed2).
+ * The four weight (and bias) gradients are ordinary grouped weight-gradient products (grappa_gemm_f32_grouped) over the operands this kernel
+ * writes as by-products -- dz2, dz1, dzo (s*T, F), dqkv (s*T, 3F) -- and the activations the forward saved (u, x3, att, x1).  LayerNorm parameter
+ * gradients: per-tile partial sums, ln*_part[tile][0][F] = dgamma, [tile][1][F] = dbeta, grappa_writer_head_tiles(s, T) tiles (the layout
+ * grappa_colsum_partials_batched reduces).  Weights packed TRANSPOSED (grappa_writer_pack_weight(F, 3F or F, W, ld, 1, ...)). */
+typedef struct grappa_writer_layer_bwd_desc {
+    int s, T, F, nheads, dtype;
+    const void* dout;                                     /* (s*T, F): gradient of the layer's output */
+    const void *x, *qkv, *x2, *u;                         /* the layer's input and what grappa_writer_head_fwd saved */
+    const float *mean1, *rstd1, *meanf, *rstdf;
+    const float *n1_gamma, *nf_gamma;
+    const void *w_in_tpk, *w_o_tpk, *w1_tpk, *w2_tpk;     /* packed W_in^T (F x 3F), W_o^T, W_1^T, W_2^T (F x F) */
+    float drop_p;
+    uint64_t seed1, seed2;
+    const uint64_t* drop_salt;
+    void* dx;                                             /* (s*T, F): gradient of the layer's input */
+    void *dz2, *dz1, *dzo, *dqkv;
+    float *ln1_part, *lnf_part;                           /* (tiles, 2, F) each */
+} grappa_writer_layer_bwd_desc;
+int grappa_writer_head_bwd(void* stream, const grappa_writer_layer_bwd_desc* d);
+int grappa_writer_head_tiles(int s, int T);
 /* W (N x K fp32, rows ldw elements apart; transpose != 0: the operand is W^T, i.e. W is K x N) in the fragment order of the fused layer: block
  * (n / 16, k / 32) is one contiguous KB, 16 bytes per lane.  N % 16 == 0, K % 32 == 0; `out` holds grappa_writer_pack_bytes(N, K, dtype) bytes. */
 size_t grappa_writer_pack_bytes(int N, int K, int dtype);

@@ -157,3 +157,69 @@ def test_fused_layer_refuses_what_it_cannot_run():
     assert be.lib.grappa_writer_head_fwd(be._stream(), C.byref(d)) == -1      # null pointers
     x32 = torch.zeros(8, 512, device="cuda")
     assert not be.writer_layer_ok(x32, 2, 8)                                  # fp32 storage: the unfused sequence
+
+
+def _layer_grads(be, ops, s, T, p, fused_fwd, fused_bwd, seed=21):
+    P = {k: v.clone().requires_grad_(True) for k, v in _params(torch.Generator(device="cuda").manual_seed(seed)).items()}
+    x = (torch.randn(s * T, F, generator=torch.Generator(device="cuda").manual_seed(seed + 1), device="cuda") * 1.3).to(BF).requires_grad_(True)
+    keep = (be.fused_writer_layer, be.fused_writer_layer_bwd)
+    be.fused_writer_layer, be.fused_writer_layer_bwd = fused_fwd, fused_bwd
+    try:
+        ops._INFERENCE["on"] = False
+        y = ops.TransformerLayerFn.apply(x, s, T, 8, p, 77, 88, *[P[k] for k in ORDER])
+        wgt = torch.randn(y.shape, generator=torch.Generator(device="cuda").manual_seed(seed + 2), device="cuda").to(BF)
+        (y.float() * wgt.float()).sum().backward()
+        be.flush_wgrads() if hasattr(be, "flush_wgrads") else None
+    finally:
+        be.fused_writer_layer, be.fused_writer_layer_bwd = keep
+    torch.cuda.synchronize()
+    return y.detach().float(), x.grad.float(), {k: v.grad.clone() for k, v in P.items()}, (x.detach(), {k: v.detach() for k, v in P.items()}, wgt)
+
+
+@pytest.mark.parametrize("s,T,p", [(2, 1, 0.0), (2, 33, 0.1), (2, 1000, 0.1), (3, 22, 0.1), (3, 707, 0.0), (4, 17, 0.3), (4, 1501, 0.1)])
+def test_fused_backward_equals_the_unfused_backward(s, T, p):
+    """grappa_writer_head_bwd (one launch: the whole input-gradient chain, operands of the weight gradients as by-products, LayerNorm parameter
+    gradients as per-tile partials) against the unfused kernel sequence run over the SAME saved tensors (both forwards fused): dx within 3 bf16
+    steps, every parameter gradient within 2e-2 of its largest magnitude (bf16 operands of K = s*T-long sums, two summation orders)."""
+    from grappa_amd import ops
+    from grappa_amd.backend import get_backend
+    be = get_backend()
+    ya, xa, ga, _ = _layer_grads(be, ops, s, T, p, True, True)
+    yb, xb, gb, _ = _layer_grads(be, ops, s, T, p, True, False)
+    assert torch.equal(ya, yb)
+    _close_bf16(xa.to(BF), xb, "dx", frac=0.90 if s * T > 32 else 0.0, steps=3.0)      # (<= 32 rows: the unfused products run on fp32 copies)
+    for k in ORDER:
+        d, scale = float((ga[k] - gb[k]).abs().max()), float(gb[k].abs().max())
+        assert d <= 2e-2 * scale, (k, d, scale)
+
+
+@pytest.mark.parametrize("s,T", [(2, 40), (3, 300), (4, 16), (4, 333)])
+def test_fused_layer_gradients_match_the_oracle_autograd(s, T):
+    """fused forward + fused backward (bf16 storage) against torch.autograd through the oracle's layer (oracle/cpu_ref.py TransformerLayer =
+    the reference's DottedAttWithMLP, models/network_utils.py:112-133) in float64 on the same bf16-rounded weights and input, dropout off:
+    the bf16 configuration's gate of SURVEY 8(d), 2e-2 of each tensor's largest magnitude"""
+    from grappa_amd import ops
+    from grappa_amd.backend import get_backend
+    from oracle import cpu_ref
+    be = get_backend()
+    y, dx, g, (x, P, wgt) = _layer_grads(be, ops, s, T, 0.0, True, True, seed=31)
+    ref = cpu_ref.TransformerLayer(F, 8, F, 0.0).double()
+    sd = {"norm1.weight": P["n1_w"], "norm1.bias": P["n1_b"], "attn.in_proj_weight": P["w_in"].to(BF), "attn.in_proj_bias": P["b_in"],
+          "attn.out_proj.weight": P["w_o"].to(BF), "attn.out_proj.bias": P["b_o"], "ff.norm1.weight": P["nf_w"], "ff.norm1.bias": P["nf_b"],
+          "ff.linear1.weight": P["w1"].to(BF), "ff.linear1.bias": P["b1"], "ff.linear2.weight": P["w2"].to(BF), "ff.linear2.bias": P["b2"]}
+    ref.load_state_dict({k: v.double().cpu() for k, v in sd.items()})
+    ref.eval()
+    xr = x.double().cpu().view(s, T, F).clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * wgt.double().cpu().view(s, T, F)).sum().backward()
+    names = {"n1_w": "norm1.weight", "n1_b": "norm1.bias", "w_in": "attn.in_proj_weight", "b_in": "attn.in_proj_bias", "w_o": "attn.out_proj.weight",
+             "b_o": "attn.out_proj.bias", "nf_w": "ff.norm1.weight", "nf_b": "ff.norm1.bias", "w1": "ff.linear1.weight", "b1": "ff.linear1.bias",
+             "w2": "ff.linear2.weight", "b2": "ff.linear2.bias"}
+    rp = dict(ref.named_parameters())
+    tol = 2e-2
+    assert float((y.cpu().double() - yr.detach().view(s * T, F)).abs().max()) <= tol * float(yr.abs().max())
+    assert float((dx.cpu().double() - xr.grad.view(s * T, F)).abs().max()) <= tol * float(xr.grad.abs().max())
+    for k in ORDER:
+        r = rp[names[k]].grad
+        d = float((g[k].cpu().double() - r).abs().max())
+        assert d <= tol * float(r.abs().max()), (k, d, float(r.abs().max()))
