@@ -26,6 +26,15 @@ typedef __bf16 wl_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wl_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float wl_f32x4 __attribute__((ext_vector_type(4)));
 
+// diagnostic build only (tools/writer_layer_lab.sh -DWL_LAB_STAMP): wavefront 0 of the first 2,048 workgroups of the forward kernel leaves the clock at
+// its phase boundaries in a device array that grappa_debug_writer_stamps() copies out.  No stamp executes in the shipped library.
+#ifdef WL_LAB_STAMP
+constexpr int WL_STAMP_WORDS = 48, WL_STAMP_WGS = 2048;
+__device__ unsigned long long g_wl_stamps[WL_STAMP_WGS * WL_STAMP_WORDS];
+#define WL_STAMP(k) do { if (tid == 0 && blockIdx.x < WL_STAMP_WGS) g_wl_stamps[blockIdx.x * WL_STAMP_WORDS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WL_STAMP(k) do { } while (0)
+#endif
 constexpr int WL_F = 512, WL_ROWS = 64, WL_THREADS = 512;
 // row strides = 32 bytes more than the data, i.e. 32 (mod 256): the 16 token rows x 4 k-chunks of a ds_read_b128 fragment read then touch
 // every bank once per lane group (MI355X LDS: groups {0-3, 12-15, 20-27}, ... : 8 rows on the even 16-byte slots, the other 8 on the odd ones)
@@ -37,7 +46,9 @@ constexpr int WL_OFF_Q = WL_ROWS * WL_LDA * 2;
 constexpr int WL_OFF_T = WL_OFF_Q + WL_ROWS * WL_LDQ * 2;
 constexpr int WL_OFF_B = WL_OFF_Q;
 constexpr int WL_OFF_RED = WL_OFF_T + WL_ROWS * WL_LDT * 2;
-constexpr int WL_SMEM = WL_OFF_RED + 2 * 8 * WL_ROWS * 4;
+constexpr int WL_OFF_PAR = WL_OFF_RED + 2 * 8 * WL_ROWS * 4;      // forward kernel: b_in (1536) | b_o | b_1 | b_2 | nf gamma | nf beta (512 each) as fp32
+constexpr int WL_PAR_BIN = 0, WL_PAR_BO = 1536, WL_PAR_B1 = 2048, WL_PAR_B2 = 2560, WL_PAR_GF = 3072, WL_PAR_BF = 3584, WL_PAR_N = 4096;
+constexpr int WL_SMEM = WL_OFF_PAR + WL_PAR_N * 4;
 static_assert(WL_OFF_B + WL_ROWS * WL_LDA * 2 <= WL_OFF_RED, "the u image must fit into the staging area");
 static_assert(WL_SMEM <= 160 * 1024, "LDS of one CU");
 
@@ -70,14 +81,23 @@ __device__ __forceinline__ float wl_round_bf16(float v) {
 
 // acc[i][mb] += W[n-block i](:, ks0 ... ks0 + KSN) act^T: pa[i] = the lane's first fragment of n-block i (consecutive k-steps are 64 uint4
 // apart), bimg = the lane's first fragment in the LDS image (row lr, k = 8 lq), rows `ldb` bytes apart.  PD k-steps of weights in flight.
-template <int NB, int KSN, int PD>
-__device__ __forceinline__ void wl_product(const uint4* const (&pa)[NB], const char* bimg, const int ldb, wl_f32x4 (&acc)[NB][4]) {
-    static_assert(KSN % PD == 0, "whole rings");
-    uint4 ring[PD][NB];
+// the first PD k-steps of a product's weight fragments -> registers.  Issued EARLY -- in front of the epilogue / barrier / attention that precedes
+// the product -- so that their L2 round trip is over when the product starts (one exposed round trip per product was ~15 % of a tile's time)
+template <int NB, int PD>
+__device__ __forceinline__ void wl_ring_fill(const uint4* const (&pa)[NB], uint4 (&ring)[PD][NB]) {
 #pragma unroll
     for (int d = 0; d < PD; ++d)
 #pragma unroll
         for (int i = 0; i < NB; ++i) ring[d][i] = pa[i][d * 64];
+}
+
+// acc[i][mb] += W[n-block i](:, KSN k-steps) act^T with the ring already filled
+template <int NB, int KSN, int PD>
+__device__ __forceinline__ void wl_product_run(const uint4* const (&pa)[NB], uint4 (&ring)[PD][NB], const char* bimg, const int ldb, wl_f32x4 (&acc)[NB][4]) {
+    static_assert(KSN % PD == 0, "whole rings");
+    // every k-step is a scheduling region of its own (sched_barrier): left alone, hipcc sinks the refill loads of the ring to just in front of their
+    // use -- one exposed L2 round trip per fragment -- instead of keeping PD k-steps of weights in flight
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int ks0 = 0; ks0 < KSN; ks0 += PD) {
 #pragma unroll
@@ -109,8 +129,61 @@ __device__ __forceinline__ void wl_product(const uint4* const (&pa)[NB], const c
                 for (int i = 0; i < NB; ++i) ring[d][i] = pa[i][(ks + PD) * 64];
 #endif
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+// acc[i][mb] += W[n-block i](:, ks0 ... ks0 + KSN) act^T: pa[i] = the lane's first fragment of n-block i (consecutive k-steps are 64 uint4
+// apart), bimg = the lane's first fragment in the LDS image (row lr, k = 8 lq), rows `ldb` bytes apart.  PD k-steps of weights in flight.
+template <int NB, int KSN, int PD>
+__device__ __forceinline__ void wl_product(const uint4* const (&pa)[NB], const char* bimg, const int ldb, wl_f32x4 (&acc)[NB][4]) {
+    uint4 ring[PD][NB];
+    wl_ring_fill<NB, PD>(pa, ring);
+    wl_product_run<NB, KSN, PD>(pa, ring, bimg, ldb, acc);
+}
+
+// The dropout decision of csrc/common.h (grappa_keep: a 32-bit finaliser of the 64-bit element index, keyed by the seed) for elements
+// row * 512 + n + e, e = 0 .. E - 1, with everything that does not depend on e hoisted -- the same bits for 3 instead of 5 quarter-rate 32-bit
+// multiplies per element (the hash was a sixth of a training tile's cycles): idx = row * 512 + c has no carry from c < 512 into its high word,
+// and (uint32) idx * K = lo(row * 512) * K + c * K (mod 2^32).
+struct WlDropRow { uint32_t a, t; };          // per token row: lo(row * 512) * K1 + lo(seed), hi(row * 512) * K2
+__device__ __forceinline__ WlDropRow wl_drop_row(uint64_t seed, long row) {
+    const uint64_t base = (uint64_t)(row < 0 ? 0 : row) * WL_F;
+    return WlDropRow{(uint32_t)base * 0x9E3779B1u + (uint32_t)seed, (uint32_t)(base >> 32) * 0x85EBCA77u};
+}
+__device__ __forceinline__ uint32_t wl_drop_threshold(float p) { return (uint32_t)ceilf(p * 16777216.0f); }      // keep iff (h >> 8) >= p * 2^24
+template <int E>
+__device__ __forceinline__ void wl_dropout(float (&v)[E], const WlDropRow& r, uint32_t col_k1, uint32_t seed_hi, uint32_t thr, float scale) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        uint32_t h = (r.a + col_k1 + (uint32_t)e * 0x9E3779B1u) ^ r.t;      // col_k1 = n * K1 of the first element's column
+        h ^= h >> 16;
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 13;
+        h *= 0xC2B2AE35u;
+        h ^= h >> 16;
+        h += seed_hi;
+        h ^= h >> 15;
+        h *= 0x2C1B3C6Du;
+        h ^= h >> 12;
+        v[e] = (h >> 8) >= thr ? v[e] * scale : 0.0f;
+    }
+}
+
+// workgroup barrier for LDS hand-offs only: waits for this wavefront's LDS operations, NOT for its global loads / stores -- __syncthreads() makes
+// hipcc drain vmcnt(0) first, i.e. every barrier would wait for the weight fragments requested ahead (wl_ring_fill) and for the by-product stores
+__device__ __forceinline__ void wl_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ELU for a result that is rounded to bf16: exp(x) - 1 from v_exp_f32 below -1/16, its cubic Taylor polynomial above (relative error < 2e-5,
+// far inside a bf16 step) -- expm1f() costs ~50 instructions per element, a tenth of the tile's time in the FF1 epilogue
+__device__ __forceinline__ float wl_elu_bf16(float x) {
+    const float t = x * (1.0f + x * (0.5f + x * 0.16666667f));
+    return x > 0.0f ? x : (x > -0.0625f ? t : __expf(x) - 1.0f);
 }
 
 template <int NB>
@@ -137,6 +210,8 @@ __device__ __forceinline__ float wl_sum64(float v) {
     v += __shfl_xor(v, 32, 64);
     return v;
 }
+// sum over the 16 lanes of a DPP row (the 16 tokens of an accumulator block); every lane gets the sum
+__device__ __forceinline__ float wl_sum16(float v) { return wl_dpp_add<0x140>(wl_sum8(v)); }
 // sum over the four lanes that hold the same token (l, l ^ 16, l ^ 32, l ^ 48)
 __device__ __forceinline__ float wl_quad_sum(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -153,6 +228,9 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
     uint16_t* imgT = reinterpret_cast<uint16_t*>(smem + WL_OFF_T);
     uint16_t* imgB = reinterpret_cast<uint16_t*>(smem + WL_OFF_B);
     float* red = reinterpret_cast<float*>(smem + WL_OFF_RED);          // [2][8 wavefronts][64 rows]
+    // the epilogues' per-feature vectors live in LDS: a global load of them behind the weight fragments requested ahead would wait for all of those
+    // (vector-memory results return in order)
+    float* par = reinterpret_cast<float*>(smem + WL_OFF_PAR);
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
     const int T = d.T;
@@ -169,51 +247,73 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
     const float drop_p = d.drop_p;
     const float drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
 
-    // ---- phase 0: x1 = LN(x) -> image A; wavefront w owns tile rows 8 w ... 8 w + 7, a lane 8 consecutive columns
+    WL_STAMP(0);
     {
-        uint4 raw[8];
-        long grow8[8];
+        const float* src[6] = {d.b_in, d.b_o, d.b1, d.b2, d.nf_gamma, d.nf_beta};
+        const int beg[7] = {WL_PAR_BIN, WL_PAR_BO, WL_PAR_B1, WL_PAR_B2, WL_PAR_GF, WL_PAR_BF, WL_PAR_N};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = w * 8 + i, p = r / TT, j = r - p * TT;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int i4 = (pass * WL_THREADS + threadIdx.x) * 4;      // 1,024 float4 = 4,096 floats
+            int a = 0;
+#pragma unroll
+            for (int q = 1; q < 6; ++q) a += i4 >= beg[q] ? 1 : 0;
+            const float* sp = a == 0 ? src[0] : (a == 1 ? src[1] : (a == 2 ? src[2] : (a == 3 ? src[3] : (a == 4 ? src[4] : src[5]))));
+            const int b0 = a == 0 ? beg[0] : (a == 1 ? beg[1] : (a == 2 ? beg[2] : (a == 3 ? beg[3] : (a == 4 ? beg[4] : beg[5]))));
+            *reinterpret_cast<float4*>(par + i4) = *reinterpret_cast<const float4*>(sp + (i4 - b0));
+        }
+    }
+    // ---- phase 0: x1 = LN(x) -> image A; wavefront w owns tile rows 8 w ... 8 w + 7, FOUR rows at a time: a row per 16 lanes (its reductions
+    // stay inside a DPP row), a lane the 16-byte chunks c, c + 16, c + 32, c + 48 of its row
+    {
+        const int rr = l >> 4, c = l & 15;
+        uint4 raw[2][4];
+        long grow2[2];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int r = w * 8 + ps * 4 + rr, p = r / TT, j = r - p * TT;
             const bool ok = p < S && j < ntup;
-            grow8[i] = ok ? (long)p * T + t0 + j : -1;
-            raw[i] = ok ? *reinterpret_cast<const uint4*>(x + (size_t)grow8[i] * WL_F + 8 * l) : make_uint4(0u, 0u, 0u, 0u);
-        }
-        float g[8], b[8];
-        {
-            const float4 g0 = reinterpret_cast<const float4*>(d.n1_gamma)[2 * l], g1 = reinterpret_cast<const float4*>(d.n1_gamma)[2 * l + 1];
-            const float4 b0 = reinterpret_cast<const float4*>(d.n1_beta)[2 * l], b1 = reinterpret_cast<const float4*>(d.n1_beta)[2 * l + 1];
-            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
-            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+            grow2[ps] = ok ? (long)p * T + t0 + j : -1;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+                raw[ps][kq] = ok ? *reinterpret_cast<const uint4*>(x + (size_t)grow2[ps] * WL_F + (c + 16 * kq) * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = w * 8 + i;
-            float v[8];
-            wl_unpack8(raw[i], v);
-            float s = 0.f;
+        for (int ps = 0; ps < 2; ++ps) {
+            const int r = w * 8 + ps * 4 + rr;
+            float v[4][8];
+            float sm = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) s += v[e] + v[e + 1];
-            const float mean = wl_sum64(s) / (float)WL_F;
+            for (int kq = 0; kq < 4; ++kq) {
+                wl_unpack8(raw[ps][kq], v[kq]);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) sm += v[kq][e] + v[kq][e + 1];
+            }
+            const float mean = wl_sum16(sm) / (float)WL_F;
             float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const float a0 = v[e] - mean, a1 = v[e + 1] - mean;
-                q += a0 * a0 + a1 * a1;
-            }
-            const float rstd = 1.0f / sqrtf(wl_sum64(q) / (float)WL_F + 1e-5f);
-            float y[8];
+            for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = grappa_ln_apply(v[e], mean, rstd, g[e], b[e]);
-            const uint4 pk = wl_pack8(y);
-            *reinterpret_cast<uint4*>(imgA + r * WL_LDA + 8 * l) = pk;
-            if (grow8[i] >= 0) {
-                if (sv_x1) *reinterpret_cast<uint4*>(sv_x1 + (size_t)grow8[i] * WL_F + 8 * l) = pk;
-                if (d.save_mean1 && l == 0) {
-                    d.save_mean1[grow8[i]] = mean;
-                    d.save_rstd1[grow8[i]] = rstd;
+                for (int e = 0; e < 8; e += 2) {
+                    const float a0 = v[kq][e] - mean, a1 = v[kq][e + 1] - mean;
+                    q += a0 * a0 + a1 * a1;
                 }
+            const float rstd = 1.0f / sqrtf(wl_sum16(q) / (float)WL_F + 1e-5f);
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const int col = (c + 16 * kq) * 8;
+                const float4 g0 = *reinterpret_cast<const float4*>(d.n1_gamma + col), g1 = *reinterpret_cast<const float4*>(d.n1_gamma + col + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(d.n1_beta + col), b1 = *reinterpret_cast<const float4*>(d.n1_beta + col + 4);
+                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = grappa_ln_apply(v[kq][e], mean, rstd, g[e], b[e]);
+                const uint4 pk = wl_pack8(y);
+                *reinterpret_cast<uint4*>(imgA + r * WL_LDA + col) = pk;
+                if (sv_x1 && grow2[ps] >= 0) *reinterpret_cast<uint4*>(sv_x1 + (size_t)grow2[ps] * WL_F + col) = pk;
+            }
+            if (d.save_mean1 && c == 0 && grow2[ps] >= 0) {
+                d.save_mean1[grow2[ps]] = mean;
+                d.save_rstd1[grow2[ps]] = rstd;
             }
         }
     }
@@ -225,6 +325,13 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
         grow[mb] = (p < S && j < ntup) ? (long)p * T + t0 + j : -1;
     }
     const uint64_t seed1 = grappa_salted(d.seed1, d.drop_salt), seed2 = grappa_salted(d.seed2, d.drop_salt);
+    const uint32_t drop_thr = wl_drop_threshold(drop_p);
+    WlDropRow drow1[4], drow2[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        drow1[mb] = wl_drop_row(seed1, grow[mb]);
+        drow2[mb] = wl_drop_row(seed2, grow[mb]);
+    }
     const uint4* __restrict__ wq_in = reinterpret_cast<const uint4*>(d.w_in_pk);
     const uint4* __restrict__ wq_o = reinterpret_cast<const uint4*>(d.w_o_pk);
     const uint4* __restrict__ wq_1 = reinterpret_cast<const uint4*>(d.w1_pk);
@@ -232,64 +339,83 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
     const char* fragA = smem + WL_OFF_A + (lr * WL_LDA + 8 * lq) * 2;
     const char* fragT = smem + WL_OFF_T + (lr * WL_LDT + 8 * lq) * 2;
     const char* fragB = smem + WL_OFF_B + (lr * WL_LDA + 8 * lq) * 2;
-    __syncthreads();
+    WL_STAMP(1);
+    uint4 ring_c[4][3];                                  // the first q | k | v weights of head pair 0 travel under the barrier
+    const uint4* pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pc[i] = wq_in + ((size_t)((((3 * w + i) >> 3) * 32 + ((3 * w + i) & 7)) * 16)) * 64 + l;
+    wl_ring_fill<3, 4>(pc, ring_c);
+    wl_barrier();
+    WL_STAMP(2);
 
-    // ---- phase 1: head pair by head pair: q, k, v of two heads -> staging; attention -> staging; x2 accumulator += a W_o^T (K = 128)
+    // ---- phase 1: head pair by head pair: q, k, v of two heads -> staging; attention -> staging; x2 accumulator += a W_o^T (K = 128).
+    // The weight fragments of every product are requested one phase early (wl_ring_fill).
     wl_f32x4 oacc[4][4];
     wl_zero<4>(oacc);
 #pragma unroll 1
     for (int hp = 0; hp < 4; ++hp) {
+        uint4 ring_p[2][4];
+        const uint4* pp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pp[i] = wq_o + ((size_t)(4 * w + i) * 16 + hp * 4) * 64 + l;
         {
             wl_f32x4 acc[3][4];
             wl_zero<3>(acc);
-            const uint4* pa[3];
             int nbw[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int cb = 3 * w + i;                        // 16-feature block of the chunk [q(128) | k(128) | v(128)]
-                nbw[i] = (cb >> 3) * 32 + hp * 8 + (cb & 7);     // its block of W_in's 1536 rows
-                pa[i] = wq_in + ((size_t)nbw[i] * 16) * 64 + l;
-            }
-            wl_product<3, 16, 4>(pa, fragA, WL_LDA * 2, acc);
+            for (int i = 0; i < 3; ++i) nbw[i] = ((3 * w + i) >> 3) * 32 + hp * 8 + ((3 * w + i) & 7);      // the chunk's 16-feature block in W_in's 1536 rows
+            wl_product_run<3, 16, 4>(pc, ring_c, fragA, WL_LDA * 2, acc);
+            WL_STAMP(3 + 6 * hp);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int n = nbw[i] * 16 + 4 * lq;
-                const float4 bi = *reinterpret_cast<const float4*>(d.b_in + n);
+                const float4 bi = *reinterpret_cast<const float4*>(par + WL_PAR_BIN + n);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     const float v[4] = {acc[i][mb][0] + bi.x, acc[i][mb][1] + bi.y, acc[i][mb][2] + bi.z, acc[i][mb][3] + bi.w};
-                    const uint2 pk = wl_pack4(v);
-                    *reinterpret_cast<uint2*>(imgQ + (mb * 16 + lr) * WL_LDQ + (3 * w + i) * 16 + 4 * lq) = pk;
-                    if (sv_qkv && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_qkv + (size_t)grow[mb] * (3 * WL_F) + n) = pk;
+                    *reinterpret_cast<uint2*>(imgQ + (mb * 16 + lr) * WL_LDQ + (3 * w + i) * 16 + 4 * lq) = wl_pack4(v);
                 }
             }
         }
-        __syncthreads();
-        {
-            // attention of (tuple j, head 2 hp + hh): 8 lanes, 8 features each (the arithmetic of csrc/tuples.hip seqattn_fwd_kernel_e)
-            const int sub = tid & 7, pair = tid >> 3, hh = pair & 1, j = pair >> 1;
+        wl_ring_fill<4, 2>(pp, ring_p);                  // the out-projection's first fragments travel while the attention runs
+        WL_STAMP(4 + 6 * hp);
+        wl_barrier();
+        WL_STAMP(5 + 6 * hp);
+        if (sv_qkv) {
+            // the pair's q | k | v rows -> global in whole 256-byte runs (by-product for the backward pass): 64 rows x 48 chunks of 16 bytes
+#pragma unroll
+            for (int pass = 0; pass < 6; ++pass) {
+                const int idx = pass * WL_THREADS + tid, r = idx / 48, c16 = idx - r * 48, seg = c16 >> 4, off = c16 & 15;
+                const int p = r / TT, j = r - p * TT;
+                if (p < S && j < ntup)
+                    *reinterpret_cast<uint4*>(sv_qkv + ((size_t)p * T + t0 + j) * (3 * WL_F) + seg * WL_F + hp * 128 + off * 8) =
+                        *reinterpret_cast<const uint4*>(imgQ + r * WL_LDQ + c16 * 8);
+            }
+        }
+        // attention of (tuple j, head 2 hp + hh): 16 lanes, 4 features each (the arithmetic of csrc/tuples.hip seqattn_fwd_kernel_e)
+#pragma unroll 1
+        for (int pass = 0; pass < (2 * TT + 31) / 32; ++pass) {
+            const int sub = tid & 15, pair = pass * 32 + (tid >> 4), hh = pair & 1, j = pair >> 1;
 #ifdef WL_LAB_NO_ATT       // lab: without the attention arithmetic
             if (false) {
 #else
             if (j < ntup) {
 #endif
-                float q[S][8], k[S][8], v[S][8];
+                float q[S][4], k[S][4], v[S][4];
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
-                    const uint16_t* row = imgQ + (i * TT + j) * WL_LDQ + hh * 64 + sub * 8;
-                    wl_unpack8(*reinterpret_cast<const uint4*>(row), q[i]);
-                    wl_unpack8(*reinterpret_cast<const uint4*>(row + 128), k[i]);
-                    wl_unpack8(*reinterpret_cast<const uint4*>(row + 256), v[i]);
+                    const uint16_t* row = imgQ + (i * TT + j) * WL_LDQ + hh * 64 + sub * 4;
+                    wl_unpack4(*reinterpret_cast<const uint2*>(row), q[i]);
+                    wl_unpack4(*reinterpret_cast<const uint2*>(row + 128), k[i]);
+                    wl_unpack4(*reinterpret_cast<const uint2*>(row + 256), v[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
                     float sc[S], mx = -INFINITY;
 #pragma unroll
                     for (int jj = 0; jj < S; ++jj) {
-                        float dt = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; e += 2) dt += q[i][e] * k[jj][e] + q[i][e + 1] * k[jj][e + 1];
-                        sc[jj] = wl_sum8(dt) * 0.125f;
+                        const float dt = (q[i][0] * k[jj][0] + q[i][1] * k[jj][1]) + (q[i][2] * k[jj][2] + q[i][3] * k[jj][3]);
+                        sc[jj] = wl_sum16(dt) * 0.125f;
                         mx = fmaxf(mx, sc[jj]);
                     }
                     float den = 0.f;
@@ -299,29 +425,34 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
                         den += sc[jj];
                     }
                     const float inv = 1.0f / den;
-                    float o[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+                    float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int jj = 0; jj < S; ++jj) {
                         const float pw = sc[jj] * inv;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] += pw * v[jj][e];
+                        for (int e = 0; e < 4; ++e) o[e] += pw * v[jj][e];
                     }
-                    const uint4 pk = wl_pack8(o);
-                    *reinterpret_cast<uint4*>(imgT + (i * TT + j) * WL_LDT + hh * 64 + sub * 8) = pk;
-                    if (sv_att) *reinterpret_cast<uint4*>(sv_att + ((size_t)i * T + t0 + j) * WL_F + (2 * hp + hh) * 64 + sub * 8) = pk;
+                    const uint2 pk = wl_pack4(o);
+                    *reinterpret_cast<uint2*>(imgT + (i * TT + j) * WL_LDT + hh * 64 + sub * 4) = pk;
+                    if (sv_att) *reinterpret_cast<uint2*>(sv_att + ((size_t)i * T + t0 + j) * WL_F + (2 * hp + hh) * 64 + sub * 4) = pk;
                 }
             }
         }
-        __syncthreads();
-        {
-            const uint4* pa[4];
+        WL_STAMP(6 + 6 * hp);
+        wl_barrier();
+        WL_STAMP(7 + 6 * hp);
+        if (hp < 3) {                                    // the next pair's q | k | v weights travel while the out-projection runs
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pa[i] = wq_o + ((size_t)(4 * w + i) * 16 + hp * 4) * 64 + l;
-            wl_product<4, 4, 4>(pa, fragT, WL_LDT * 2, oacc);
+            for (int i = 0; i < 3; ++i) pc[i] = wq_in + ((size_t)((((3 * w + i) >> 3) * 32 + (hp + 1) * 8 + ((3 * w + i) & 7)) * 16)) * 64 + l;
+            wl_ring_fill<3, 4>(pc, ring_c);
         }
+        wl_product_run<4, 4, 2>(pp, ring_p, fragT, WL_LDT * 2, oacc);
+        WL_STAMP(8 + 6 * hp);
     }
+    uint4 ring_f[4][4];                                  // FF1's first fragments travel under the LayerNorm (requested once the x2 values exist:
+    const uint4* pf[4];                                  // before that the out-projection's accumulators are still live)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[i] = wq_1 + ((size_t)(4 * w + i) * 16) * 64 + l;
 
     // ---- phase 2: x2 = drop(acc + b_o) + x1 (rounded to bf16 like the stored tensor); x3 = LN(x2) -> image A
     {
@@ -330,30 +461,30 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
-            const float4 bo = *reinterpret_cast<const float4*>(d.b_o + n);
+            const float4 bo = *reinterpret_cast<const float4*>(par + WL_PAR_BO + n);
             const float bb[4] = {bo.x, bo.y, bo.z, bo.w};
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 float x1v[4];
                 wl_unpack4(*reinterpret_cast<const uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n), x1v);
-                const uint64_t idx = (uint64_t)(grow[mb] >= 0 ? grow[mb] : 0) * WL_F + n;
+                float v4[4] = {oacc[i][mb][0] + bb[0], oacc[i][mb][1] + bb[1], oacc[i][mb][2] + bb[2], oacc[i][mb][3] + bb[3]};
+                if (drop_p > 0.f) wl_dropout<4>(v4, drow1[mb], (uint32_t)n * 0x9E3779B1u, (uint32_t)(seed1 >> 32), drop_thr, drop_scale);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = oacc[i][mb][e] + bb[e];
-                    if (drop_p > 0.f) v = grappa_keep(seed1, idx + e, drop_p) ? v * drop_scale : 0.f;
-                    v = wl_round_bf16(v + x1v[e]);
+                    const float v = wl_round_bf16(v4[e] + x1v[e]);
                     x2v[i][mb][e] = v;
                     part[mb] += v;
                 }
                 if (sv_x2 && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_x2 + (size_t)grow[mb] * WL_F + n) = wl_pack4(x2v[i][mb]);
             }
         }
+        wl_ring_fill<4, 4>(pf, ring_f);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             part[mb] = wl_quad_sum(part[mb]);
             if (lq == 0) red[w * WL_ROWS + mb * 16 + lr] = part[mb];
         }
-        __syncthreads();
+        wl_barrier();
         float mean[4], rstd[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -372,7 +503,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
             q = wl_quad_sum(q);
             if (lq == 0) red[(8 + w) * WL_ROWS + mb * 16 + lr] = q;
         }
-        __syncthreads();
+        wl_barrier();
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             float q = 0.f;
@@ -387,7 +518,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
-            const float4 g4 = *reinterpret_cast<const float4*>(d.nf_gamma + n), b4 = *reinterpret_cast<const float4*>(d.nf_beta + n);
+            const float4 g4 = *reinterpret_cast<const float4*>(par + WL_PAR_GF + n), b4 = *reinterpret_cast<const float4*>(par + WL_PAR_BF + n);
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -396,71 +527,79 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
                 for (int e = 0; e < 4; ++e) y[e] = grappa_ln_apply(x2v[i][mb][e], mean[mb], rstd[mb], gg[e], bb[e]);
                 const uint2 pk = wl_pack4(y);
                 *reinterpret_cast<uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n) = pk;
-                if (sv_x3 && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_x3 + (size_t)grow[mb] * WL_F + n) = pk;
             }
         }
     }
-    __syncthreads();
+    wl_barrier();
+    // a finished image -> global in whole rows (by-products for the backward pass): 64 rows x 64 chunks of 16 bytes, 8 per thread
+    auto save_image = [&](const uint16_t* img, uint16_t* __restrict__ dst) {
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int idx = pass * WL_THREADS + tid, r = idx >> 6, c = idx & 63;
+            const int p = r / TT, j = r - p * TT;
+            if (p < S && j < ntup) *reinterpret_cast<uint4*>(dst + ((size_t)p * T + t0 + j) * WL_F + c * 8) = *reinterpret_cast<const uint4*>(img + r * WL_LDA + c * 8);
+        }
+    };
+    WL_STAMP(27);
+    if (sv_x3) save_image(imgA, sv_x3);
 
     // ---- phase 3: u = ELU(x3 W_1^T + b_1) -> image B
+    uint4 ring_g[4][4];
+    const uint4* pg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pg[i] = wq_2 + ((size_t)(4 * w + i) * 16) * 64 + l;
     {
         wl_f32x4 acc[4][4];
         wl_zero<4>(acc);
-        const uint4* pa[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pa[i] = wq_1 + ((size_t)(4 * w + i) * 16) * 64 + l;
-        wl_product<4, 16, 4>(pa, fragA, WL_LDA * 2, acc);
+        wl_product_run<4, 16, 4>(pf, ring_f, fragA, WL_LDA * 2, acc);
+        WL_STAMP(28);
+        wl_ring_fill<4, 4>(pg, ring_g);                  // FF2's first fragments travel under the epilogue and the barrier
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
-            const float4 b4 = *reinterpret_cast<const float4*>(d.b1 + n);
+            const float4 b4 = *reinterpret_cast<const float4*>(par + WL_PAR_B1 + n);
             const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 float y[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = grappa_elu(acc[i][mb][e] + bb[e]);
+                for (int e = 0; e < 4; ++e) y[e] = wl_elu_bf16(acc[i][mb][e] + bb[e]);
                 const uint2 pk = wl_pack4(y);
                 *reinterpret_cast<uint2*>(imgB + (mb * 16 + lr) * WL_LDA + n) = pk;
-                if (sv_u && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_u + (size_t)grow[mb] * WL_F + n) = pk;
             }
         }
     }
-    __syncthreads();
+    wl_barrier();
+    WL_STAMP(29);
+    if (sv_u) save_image(imgB, sv_u);
 
     // ---- phase 4: out = drop(u W_2^T + b_2) + x3
     {
         wl_f32x4 acc[4][4];
         wl_zero<4>(acc);
-        const uint4* pa[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pa[i] = wq_2 + ((size_t)(4 * w + i) * 16) * 64 + l;
-        wl_product<4, 16, 4>(pa, fragB, WL_LDA * 2, acc);
+        wl_product_run<4, 16, 4>(pg, ring_g, fragB, WL_LDA * 2, acc);
+        WL_STAMP(30);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
-            const float4 b4 = *reinterpret_cast<const float4*>(d.b2 + n);
+            const float4 b4 = *reinterpret_cast<const float4*>(par + WL_PAR_B2 + n);
             const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 if (grow[mb] < 0) continue;
                 float x3v[4], y[4];
                 wl_unpack4(*reinterpret_cast<const uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n), x3v);
-                const uint64_t idx = (uint64_t)grow[mb] * WL_F + n;
+                float v4[4] = {acc[i][mb][0] + bb[0], acc[i][mb][1] + bb[1], acc[i][mb][2] + bb[2], acc[i][mb][3] + bb[3]};
+                if (drop_p > 0.f) wl_dropout<4>(v4, drow2[mb], (uint32_t)n * 0x9E3779B1u, (uint32_t)(seed2 >> 32), drop_thr, drop_scale);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][mb][e] + bb[e];
-                    if (drop_p > 0.f) v = grappa_keep(seed2, idx + e, drop_p) ? v * drop_scale : 0.f;
-                    y[e] = v + x3v[e];
-                }
+                for (int e = 0; e < 4; ++e) y[e] = v4[e] + x3v[e];
                 *reinterpret_cast<uint2*>(out + (size_t)grow[mb] * WL_F + n) = wl_pack4(y);
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WL_STAMP(31);
 }
-
-// sum over the 16 lanes of a DPP row (the 16 tokens of an accumulator block); every lane gets the sum
-__device__ __forceinline__ float wl_sum16(float v) { return wl_dpp_add<0x140>(wl_sum8(v)); }
 
 // ---- the backward pass of the layer: the input-gradient chain on a tile of 64 token rows; the four weight gradients are ordinary grouped products
 // over the operands this kernel writes as by-products (dz2, dz1, dzo, dqkv) and the activations the forward saved (u, x3, att, x1).
@@ -508,11 +647,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             if (ok) {
                 float v[8];
                 wl_unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)gr * WL_F + 8 * l), v);
-                if (drop_p > 0.f) {
-                    const uint64_t idx = (uint64_t)gr * WL_F + 8 * l;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = grappa_keep(seed2, idx + e, drop_p) ? v[e] * drop_scale : 0.f;
-                }
+                if (drop_p > 0.f) wl_dropout<8>(v, wl_drop_row(seed2, gr), (uint32_t)(8 * l) * 0x9E3779B1u, (uint32_t)(seed2 >> 32), wl_drop_threshold(drop_p), drop_scale);
                 pk = wl_pack8(v);
                 *reinterpret_cast<uint4*>(o_dz2 + (size_t)gr * WL_F + 8 * l) = pk;
             }
@@ -540,7 +675,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
     const char* fragQ = smem + WL_OFF_A + (lr * WL_LDQ + 8 * lq) * 2;
     float* part_f = d.lnf_part + (size_t)blockIdx.x * 2 * WL_F;
     float* part_1 = d.ln1_part + (size_t)blockIdx.x * 2 * WL_F;
-    __syncthreads();
+    wl_barrier();
 
     // ---- phase 1: dz1 = (dz2 W_2) * ELU'(u) -> image B (+ global: operand of dW_1)
     {
@@ -571,7 +706,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             }
         }
     }
-    __syncthreads();
+    wl_barrier();
 
     // ---- phase 2: dx3 = dz1 W_1 + dout; dx2 = LN'(dx3; x2); dzo = dropout mask of the forward's first dropout applied to dx2 -> image A
     uint2 dx2p[4][4];                     // dx2 as stored (bf16): the skip branch into dx1, phase 5
@@ -634,7 +769,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                 red[(8 + w) * WL_ROWS + mb * 16 + lr] = s2[mb];
             }
         }
-        __syncthreads();
+        wl_barrier();
         float m1[4], m2[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -657,13 +792,13 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                 float dyv[4], xv[4], o[4], z[4];
                 wl_unpack4(dop[i][mb], dyv);
                 wl_unpack4(x2p[i][mb], xv);
-                const uint64_t idx = (uint64_t)(grow[mb] >= 0 ? grow[mb] : 0) * WL_F + n;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xh = (xv[e] - mean_f[mb]) * rstd_f[mb];
                     o[e] = wl_round_bf16(rstd_f[mb] * (dyv[e] * gg[e] - m1[mb] - xh * m2[mb]));      // dx2 as stored
-                    z[e] = (drop_p > 0.f) ? (grappa_keep(seed1, idx + e, drop_p) ? o[e] * drop_scale : 0.f) : o[e];
+                    z[e] = o[e];
                 }
+                if (drop_p > 0.f) wl_dropout<4>(z, wl_drop_row(seed1, grow[mb]), (uint32_t)n * 0x9E3779B1u, (uint32_t)(seed1 >> 32), wl_drop_threshold(drop_p), drop_scale);
                 dx2p[i][mb] = wl_pack4(o);
                 const uint2 pk = wl_pack4(z);
                 *reinterpret_cast<uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n) = pk;
@@ -671,7 +806,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             }
         }
     }
-    __syncthreads();
+    wl_barrier();
 
     // ---- phase 3: datt = dzo W_o -> image B
     {
@@ -691,7 +826,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             }
         }
     }
-    __syncthreads();
+    wl_barrier();
 
     // ---- phase 4: head pair by head pair: dq | dk | dv of two heads -> staging (+ global: operand of dW_in); dx1 accumulator += dqkv W_in (K = 384)
     wl_f32x4 xacc[4][4];
@@ -763,7 +898,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                 }
             }
         }
-        __syncthreads();
+        wl_barrier();
         // dx1^T += W_in^T (:, the pair's q | k | v rows) dqkv^T: three runs of 4 k-steps (rows hp 128 ... of each of W_in's three blocks of 512)
 #pragma unroll
         for (int seg = 0; seg < 3; ++seg) {
@@ -772,7 +907,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             for (int i = 0; i < 4; ++i) pa[i] = wq_in + ((size_t)(4 * w + i) * 48 + seg * 16 + hp * 4) * 64 + l;
             wl_product<4, 4, 4>(pa, fragQ + seg * 256, WL_LDQ * 2, xacc);
         }
-        __syncthreads();
+        wl_barrier();
     }
 
     // ---- phase 5: dx1 = acc + dx2; dx = LN'(dx1; x)
@@ -827,7 +962,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                 red[(8 + w) * WL_ROWS + mb * 16 + lr] = s2[mb];
             }
         }
-        __syncthreads();
+        wl_barrier();
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             float a = 0.f, b = 0.f;
@@ -943,3 +1078,10 @@ extern "C" int grappa_writer_head_bwd(void* stream, const grappa_writer_layer_bw
     GRAPPA_LAUNCH(kern, grid, dim3(WL_THREADS), WL_SMEM, st, *d);
     return grappa_launch_status();
 }
+
+#ifdef WL_LAB_STAMP
+extern "C" int grappa_debug_writer_stamps(unsigned long long* host, int nwgs) {
+    if (nwgs > WL_STAMP_WGS) nwgs = WL_STAMP_WGS;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wl_stamps), (size_t)nwgs * WL_STAMP_WORDS * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
