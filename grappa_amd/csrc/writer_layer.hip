@@ -617,6 +617,11 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
     uint16_t* imgQ = reinterpret_cast<uint16_t*>(smem + WL_OFF_A);          // staging of a head pair's dq | dk | dv: inside image A (dzo is dead by then)
     uint16_t* imgB = reinterpret_cast<uint16_t*>(smem + WL_OFF_B);
     float* red = reinterpret_cast<float*>(smem + WL_OFF_RED);              // [2][8 wavefronts][64 rows]
+    float* par = reinterpret_cast<float*>(smem + WL_OFF_PAR);              // nf gamma (512) | n1 gamma (512): see the forward kernel
+    if (threadIdx.x < 256) {
+        const int i4 = threadIdx.x * 4;
+        *reinterpret_cast<float4*>(par + i4) = *reinterpret_cast<const float4*>((i4 < WL_F ? d.nf_gamma : d.n1_gamma) + (i4 & (WL_F - 1)));
+    }
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
     const int T = d.T;
@@ -636,6 +641,16 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
     const float drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const uint64_t seed1 = grappa_salted(d.seed1, d.drop_salt), seed2 = grappa_salted(d.seed2, d.drop_salt);
 
+    const uint4* __restrict__ wq_in = reinterpret_cast<const uint4*>(d.w_in_tpk);
+    const uint4* __restrict__ wq_o = reinterpret_cast<const uint4*>(d.w_o_tpk);
+    const uint4* __restrict__ wq_1 = reinterpret_cast<const uint4*>(d.w1_tpk);
+    const uint4* __restrict__ wq_2 = reinterpret_cast<const uint4*>(d.w2_tpk);
+    // (the weight fragments of every product are requested one phase early, as in the forward kernel)
+    uint4 ring_a[4][4];
+    const uint4* pa2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pa2[i] = wq_2 + ((size_t)(4 * w + i) * 16) * 64 + l;
+    wl_ring_fill<4, 4>(pa2, ring_a);
     // ---- phase 0: dz2 = dropout mask of the forward's last dropout applied to dout -> image A (+ global: operand of dW_2)
     {
 #pragma unroll
@@ -666,10 +681,6 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
         mean_1[mb] = ok ? d.mean1[grow[mb]] : 0.f;
         rstd_1[mb] = ok ? d.rstd1[grow[mb]] : 0.f;
     }
-    const uint4* __restrict__ wq_in = reinterpret_cast<const uint4*>(d.w_in_tpk);
-    const uint4* __restrict__ wq_o = reinterpret_cast<const uint4*>(d.w_o_tpk);
-    const uint4* __restrict__ wq_1 = reinterpret_cast<const uint4*>(d.w1_tpk);
-    const uint4* __restrict__ wq_2 = reinterpret_cast<const uint4*>(d.w2_tpk);
     const char* fragA = smem + WL_OFF_A + (lr * WL_LDA + 8 * lq) * 2;
     const char* fragB = smem + WL_OFF_B + (lr * WL_LDA + 8 * lq) * 2;
     const char* fragQ = smem + WL_OFF_A + (lr * WL_LDQ + 8 * lq) * 2;
@@ -687,10 +698,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                 upk[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(us + (size_t)grow[mb] * WL_F + (4 * w + i) * 16 + 4 * lq) : make_uint2(0u, 0u);
         wl_f32x4 acc[4][4];
         wl_zero<4>(acc);
-        const uint4* pa[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pa[i] = wq_2 + ((size_t)(4 * w + i) * 16) * 64 + l;
-        wl_product<4, 16, 4>(pa, fragA, WL_LDA * 2, acc);
+        wl_product_run<4, 16, 4>(pa2, ring_a, fragA, WL_LDA * 2, acc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
@@ -706,7 +714,6 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             }
         }
     }
-    wl_barrier();
 
     // ---- phase 2: dx3 = dz1 W_1 + dout; dx2 = LN'(dx3; x2); dzo = dropout mask of the forward's first dropout applied to dx2 -> image A
     uint2 dx2p[4][4];                     // dx2 as stored (bf16): the skip branch into dx1, phase 5
@@ -725,12 +732,15 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
         const uint4* pa[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) pa[i] = wq_1 + ((size_t)(4 * w + i) * 16) * 64 + l;
-        wl_product<4, 16, 4>(pa, fragB, WL_LDA * 2, acc);
+        uint4 ring_b[4][4];
+        wl_ring_fill<4, 4>(pa, ring_b);
+        wl_barrier();
+        wl_product_run<4, 16, 4>(pa, ring_b, fragB, WL_LDA * 2, acc);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
-            const float4 g4 = *reinterpret_cast<const float4*>(d.nf_gamma + n);
+            const float4 g4 = *reinterpret_cast<const float4*>(par + n);
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
             float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -785,7 +795,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
-            const float4 g4 = *reinterpret_cast<const float4*>(d.nf_gamma + n);
+            const float4 g4 = *reinterpret_cast<const float4*>(par + n);
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -806,7 +816,6 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             }
         }
     }
-    wl_barrier();
 
     // ---- phase 3: datt = dzo W_o -> image B
     {
@@ -815,7 +824,10 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
         const uint4* pa[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) pa[i] = wq_o + ((size_t)(4 * w + i) * 16) * 64 + l;
-        wl_product<4, 16, 4>(pa, fragA, WL_LDA * 2, acc);
+        uint4 ring[4][4];
+        wl_ring_fill<4, 4>(pa, ring);
+        wl_barrier();
+        wl_product_run<4, 16, 4>(pa, ring, fragA, WL_LDA * 2, acc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
@@ -898,14 +910,21 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                 }
             }
         }
-        wl_barrier();
         // dx1^T += W_in^T (:, the pair's q | k | v rows) dqkv^T: three runs of 4 k-steps (rows hp 128 ... of each of W_in's three blocks of 512)
+        {
+            const uint4* pq[3][4];
 #pragma unroll
-        for (int seg = 0; seg < 3; ++seg) {
-            const uint4* pa[4];
+            for (int seg = 0; seg < 3; ++seg)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pa[i] = wq_in + ((size_t)(4 * w + i) * 48 + seg * 16 + hp * 4) * 64 + l;
-            wl_product<4, 4, 4>(pa, fragQ + seg * 256, WL_LDQ * 2, xacc);
+                for (int i = 0; i < 4; ++i) pq[seg][i] = wq_in + ((size_t)(4 * w + i) * 48 + seg * 16 + hp * 4) * 64 + l;
+            uint4 r0[2][4], r1[2][4];
+            wl_ring_fill<4, 2>(pq[0], r0);
+            wl_barrier();
+            wl_ring_fill<4, 2>(pq[1], r1);
+            wl_product_run<4, 4, 2>(pq[0], r0, fragQ, WL_LDQ * 2, xacc);
+            wl_ring_fill<4, 2>(pq[2], r0);
+            wl_product_run<4, 4, 2>(pq[1], r1, fragQ + 256, WL_LDQ * 2, xacc);
+            wl_product_run<4, 4, 2>(pq[2], r0, fragQ + 512, WL_LDQ * 2, xacc);
         }
         wl_barrier();
     }
@@ -922,7 +941,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
-            const float4 g4 = *reinterpret_cast<const float4*>(d.n1_gamma + n);
+            const float4 g4 = *reinterpret_cast<const float4*>(par + WL_F + n);
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
             float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -977,7 +996,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
-            const float4 g4 = *reinterpret_cast<const float4*>(d.n1_gamma + n);
+            const float4 g4 = *reinterpret_cast<const float4*>(par + WL_F + n);
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {

@@ -39,6 +39,18 @@ def main():
             ms = e0.elapsed_time(e1) / 5
             fl = 2.0 * M * F * 6 * F
             rows.append(f"s={s} T={T:6d} save={'yes' if save else 'no '} drop={p}: {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  {ms * 1e3 / ((T + 64 // s - 1) // (64 // s) / 256):7.1f} us per round of 256 tiles")
+        # the backward chain (grappa_writer_head_bwd) over what the last forward saved
+        dout = (rn(M, F) * 0.1).to(BF)
+        for _ in range(2):
+            be.writer_layer_bwd(dout, x, s, T, 8, 0.1, 11, 12, sv, P[0], P[1], P[2], P[4], P[6], P[7], P[8], P[10])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            be.writer_layer_bwd(dout, x, s, T, 8, 0.1, 11, 12, sv, P[0], P[1], P[2], P[4], P[6], P[7], P[8], P[10])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        rows.append(f"s={s} T={T:6d} BACKWARD drop=0.1      : {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  {ms * 1e3 / ((T + 64 // s - 1) // (64 // s) / 256):7.1f} us per round of 256 tiles  (incl. the two small LayerNorm-partial reductions)")
     print("\n".join(rows))
     tag = sys.argv[1] if len(sys.argv) > 1 else "run"
     os.makedirs("gpurun_out", exist_ok=True)
