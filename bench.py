@@ -299,6 +299,15 @@ def cpu_baseline(workload: str, n_mols: int, steps: int, warmup: int, limit_s: f
             "single_process": single, "multi_process": mp}
 
 
+def distinct_devices(ranks, world: int, enforce: bool) -> int:
+    """-> how many distinct devices the ranks of this job sit on (index + uuid as each rank reports them).  enforce (RCCL on GPUs): fewer than
+    `world` means several ranks share a GPU -- a "scaling" figure from such a run would be meaningless, so the job REFUSES to print a line"""
+    distinct = len({(r["device_index"], r["device_uuid"]) for r in ranks})
+    if enforce and distinct != world:
+        raise SystemExit(f"{world} ranks over RCCL but only {distinct} distinct devices: no scaling line is reported ({ranks})")
+    return distinct
+
+
 def log(*a):
     print(f"[bench {time.strftime('%H:%M:%S')}]", *a, file=sys.stderr, flush=True)
 
@@ -931,9 +940,7 @@ def main():
               "device_uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")) if on_gpu else None}
         everyone = [None] * world
         dist.all_gather_object(everyone, me)
-        distinct = len({(r["device_index"], r["device_uuid"]) for r in everyone})
-        if on_gpu and args.dist_backend == "nccl" and distinct != world:
-            raise SystemExit(f"{world} ranks over RCCL but only {distinct} distinct devices: {everyone}")
+        distinct = distinct_devices(everyone, world, enforce=on_gpu and args.dist_backend == "nccl")
         # overlapped vs post-backward reduction of the SAME gradients, bit for bit: the same batch and dropout seeds through both
         # orders, no optimiser step in between; the two orders cut the buffer alike (dist.BucketedGradReducer.finish)
         n_check = min(args.steps, 10)

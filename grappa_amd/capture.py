@@ -124,17 +124,32 @@ class CapturedTrainStep(_StaticInputs):
 
     `opt` (optim.FusedAdam) is switched to device-side scalars (`opt.enable_dynamic()`); `opt.lr = x` between replays takes effect."""
 
-    def __init__(self, model, energy, loss_fn, opt, g, warmup: int = 3, preserve_state: bool = False, static_inputs: bool = False):
+    def __init__(self, model, energy, loss_fn, opt, g, warmup: int = 3, preserve_state: bool = False, static_inputs: bool = False, reducer=None,
+                 record: bool = True):
         """preserve_state: parameters, Adam moments and step count are put back after the warm-up steps and the recording, so that making the
         graph does not train (a trainer that records in the middle of an epoch); the first replay is then that batch's one real step.
         static_inputs: every input of the step (index plan, position tables, features and references of all levels) is moved into ONE device
         buffer the recorded kernels read from, and `load(g2)` copies another batch of the same shape signature in (`DeviceDataset.collate(
-        pad_to=...)` makes batches of one signature): the graph then serves every such batch."""
-        if not torch.cuda.is_available():
-            raise RuntimeError("CapturedTrainStep needs a GPU")
+        pad_to=...)` makes batches of one signature): the graph then serves every such batch.
+        reducer (data parallelism, SURVEY 8(e): anything with `finish()`, e.g. dist.BucketedGradReducer): the step is recorded as TWO graphs --
+        zero_grad .. backward, and clip + Adam -- and one call = replay the first, `reducer.finish()` EAGERLY (the RCCL all-reduce of the flat
+        gradient buffer is not recorded), replay the second.  Every rank issues exactly ONE collective per call whatever it replays or
+        records: with preserve_state the warm-up steps and the recording run WITHOUT the reducer (their effect is undone anyway), so a rank
+        that records a new shape in the middle of an epoch stays in step with ranks that replay.
+        record=False: no hipGraph at all -- the same object runs its phases eagerly (the fallback for a shape whose recording failed, and the
+        CPU / gloo tests of the split sequence)."""
         self.model, self.energy, self.loss_fn, self.opt, self.g = model, energy, loss_fn, opt, g
+        self.reducer = reducer
+        self.record = bool(record)
         self.be = get_backend()
         self.static_inputs = bool(static_inputs)
+        if not self.record:
+            self.graph = self.graph_b = None
+            self.replays = 0
+            self.loss = None
+            return
+        if not torch.cuda.is_available():
+            raise RuntimeError("CapturedTrainStep needs a GPU (record=False runs the same sequence eagerly)")
         if self.static_inputs:
             self.plan = g.plan()
             for lvl in ("n2", "n3", "n4", "n4_improper"):     # built eagerly: their construction sorts (host-synchronising torch ops)
@@ -159,16 +174,30 @@ class CapturedTrainStep(_StaticInputs):
         try:
             self.stream = torch.cuda.Stream(device=g.device)
             self.stream.wait_stream(torch.cuda.current_stream(g.device))
+            collective = self.reducer is not None and not preserve_state       # (see the docstring: one collective per CALL on every rank)
             with torch.cuda.stream(self.stream):
                 for _ in range(max(int(warmup), 1)):           # on the capturing stream: workspaces and side streams are keyed by it
                     self.be.bump_dropout_salt()
-                    self._eager()
+                    self._eager_a()
+                    if collective:
+                        self.reducer.finish()
+                    self._eager_b()
             self.stream.synchronize()
             # (the last warm-up step's optimiser left every per-weight cache stale: the recorded step starts by refreshing them, in the graph)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.be.bump_dropout_salt()
-                self.loss = self._eager()
+            self.graph_b = None
+            if self.reducer is None:
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self.be.bump_dropout_salt()
+                    self.loss = self._eager()
+            else:
+                pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(self.graph, stream=self.stream, pool=pool):
+                    self.be.bump_dropout_salt()
+                    self.loss = self._eager_a()
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, stream=self.stream, pool=pool):
+                    self._eager_b()
             self.opt.step_count -= 1                            # (recorded, not executed: the device-side count did not move)
             self._pinned = _pinned_by_graph(self.be)
         finally:
@@ -189,16 +218,36 @@ class CapturedTrainStep(_StaticInputs):
         torch.cuda.current_stream(g.device).wait_stream(self.stream)
         self.replays = 0
 
-    def _eager(self):
+    def _eager_a(self):
+        """zero_grad .. backward (every queued weight-gradient product is launched by the end of the pass)"""
         self.opt.zero_grad()
         _drop_outputs(self.g)
         loss = self.loss_fn(self.energy(self.model(self.g)))
         loss.backward()
-        self.opt.step()
+        if hasattr(self.be, "flush_wgrads"):
+            self.be.flush_wgrads()
         return loss.detach()
 
+    def _eager_b(self):
+        self.opt.step()
+
+    def _eager(self):
+        loss = self._eager_a()
+        self._eager_b()
+        return loss
+
     def __call__(self) -> torch.Tensor:
+        if not self.record:                                 # the same sequence without graphs
+            self.loss = self._eager_a()
+            if self.reducer is not None:
+                self.reducer.finish()
+            self._eager_b()
+            self.replays += 1
+            return self.loss
         self.graph.replay()
+        if self.graph_b is not None:
+            self.reducer.finish()                           # eager: RCCL's all-reduce of the flat gradient buffer, ordered behind the first graph
+            self.graph_b.replay()
         self.replays += 1
         self.opt.step_count += 1                            # host mirror of the device-side counter
         self.be.invalidate_weights()                        # the weights moved under the host-side caches' feet

@@ -106,6 +106,7 @@ class Trainer:
         self._eval_steps: Dict[tuple, object] = {}
         self.pipelined, self._prep_pool = bool(pipelined), None
         self.recorded_stats = {"replayed": 0, "eager": 0, "graphs_recorded": 0, "padding_rows": 0, "real_rows": 0}
+        self._graphs_off = False           # set when the recorded mode turned out not to be usable for this run (train_epoch)
         self.batch_size, self.conf_strategy = batch_size, conf_strategy
         self.val_batch_size, self.val_conf_strategy = val_batch_size, val_conf_strategy
         self.weights, self.balance_factor = dict(weights), balance_factor
@@ -147,9 +148,19 @@ class Trainer:
     def _step_stamp(self) -> tuple:
         """what a recorded step has baked in besides the batch's shape: the loss weights the schedule moves, the optimiser's constants"""
         lf, o = self.loss_fn, self.opt
+        from . import ops
+        from .backend import get_backend
+        be = get_backend()
+        pw = getattr(self.model, "parameter_writer", None)
+        # (ADVICE r5) ... and the backend settings baked into the recorded launches: arithmetic, operand formats, plan options, head streams,
+        # activation storage, fused layer switches -- a setting changed in the middle of a run means new graphs, not stale ones
+        backend_cfg = tuple(getattr(be, k, None) for k in ("gemm_precision_name", "gemm_precision_bwd_name", "inference_pairs", "training_pairs", "backward_pairs",
+                                                            "_tails", "plan_override", "splitk_reduce", "weight_pairs_min_rows", "pairs_min_rows",
+                                                            "fused_writer_layer", "fused_writer_layer_bwd", "group_launches", "wgrads_aside"))
         return (float(lf.gradient_weight), float(lf.energy_weight), float(lf.param_weight), float(lf.tuplewise_weight), float(lf.proper_regularisation),
                 float(lf.improper_regularisation), tuple(sorted(lf.weights.items())), tuple(sorted(lf.param_weights_by_dataset.items())),
-                tuple(o.betas), float(o.eps), float(o.weight_decay), o.max_grad_norm, bool(self.model.training))
+                tuple(o.betas), float(o.eps), float(o.weight_decay), o.max_grad_norm, bool(self.model.training), backend_cfg,
+                str(ops.act_dtype()), getattr(pw, "head_streams", None), getattr(pw, "merged_heads", None))
 
     def calibrate_buckets(self, batches: Sequence[np.ndarray]) -> ShapeBuckets:
         self._buckets = ShapeBuckets(self.train_set, batches, n_buckets=self.shape_buckets)
@@ -182,9 +193,10 @@ class Trainer:
     def _prepare(self, ids: np.ndarray):
         """what a recorded step needs of the batch `ids`: None if no bucket takes it (it runs eagerly), else (graph, names, event, totals, caps).
         Called on the trainer's thread, or -- pipelined epochs -- on its worker thread while the trainer's thread launches the previous graph"""
+        ids = self._my_share(np.asarray(ids))              # data parallelism: this rank's molecules of the batch (the buckets were cut on shards)
         tot = self.train_set.totals(ids)
         caps = self._buckets.choose(tot) if self._buckets is not None else None
-        if caps is None or self.world > 1 or any(caps[k] - tot[k] > self.train_set.pad_caps[k] for k in tot):
+        if caps is None or any(caps[k] - tot[k] > self.train_set.pad_caps[k] for k in tot):
             return None
         if self.train_set.device.type == "cuda" and self.train_set.device.index is not None:
             torch.cuda.set_device(self.train_set.device)       # (a worker thread starts on device 0)
@@ -211,14 +223,18 @@ class Trainer:
         g, names, ready, tot, caps = prepared
         main = torch.cuda.current_stream(self.train_set.device)
         main.wait_event(ready)
-        self.loss_fn.global_batch_size = None
-        key = (train_signature(g), self._step_stamp())
+        # data parallelism: the loss's 1 / B_global is a constant of the recorded step, so it is part of the key; the step is
+        # two graphs with the eager all-reduce between them (capture.CapturedTrainStep reducer=)
+        self.loss_fn.global_batch_size = len(ids) if self.world > 1 else None
+        reducer = self.reducer if self.world > 1 else None
+        key = (train_signature(g), self._step_stamp(), self.loss_fn.global_batch_size)
         step = self._steps.pop(key, None) if key not in self._unrecordable else None
         if step is None and key not in self._unrecordable:
             if len(self._steps) >= self.max_recorded_steps:
-                self._steps.pop(next(iter(self._steps)))                 # least recently used out
+                old = self._steps.pop(next(iter(self._steps)))           # least recently used out
+                self._release(old)
             try:
-                step = CapturedTrainStep(self.model, self.energy, self.loss_fn, self.opt, g, preserve_state=True, static_inputs=True)
+                step = CapturedTrainStep(self.model, self.energy, self.loss_fn, self.opt, g, preserve_state=True, static_inputs=True, reducer=reducer)
                 self.recorded_stats["graphs_recorded"] += 1
             except Exception as e:  # noqa: BLE001  (a recording that fails -- memory, a call a capture cannot hold -- must not end the run)
                 import warnings
@@ -226,7 +242,13 @@ class Trainer:
                 warnings.warn(f"Trainer(recorded=True): recording a train step failed ({e!r}); batches of this shape run eagerly")
                 step = None
         elif step is not None:
-            step.load(g)
+            try:
+                step.load(g)
+            except Exception as e:  # noqa: BLE001  (an input-table or shape mismatch of THIS batch must not end the run: it runs eagerly)
+                import warnings
+                warnings.warn(f"Trainer(recorded=True): a batch did not fit its recorded step ({e!r}); it runs eagerly")
+                self._steps[key] = step
+                step = None
         if step is None:
             # the padded batch itself, eagerly: the loss skips its padding molecule (parameters and optimiser state are as before the attempt)
             self.recorded_stats["eager"] += 1
@@ -234,6 +256,8 @@ class Trainer:
             self.opt.zero_grad()
             loss = self.loss_fn(self.energy(self.model(g)), list(names))
             loss.backward()
+            if reducer is not None:
+                reducer.finish()
             self.opt.step()
             self._load_done = torch.cuda.Event()
             self._load_done.record(main)
@@ -251,15 +275,37 @@ class Trainer:
         self.recorded_stats["padding_rows"] += sum(caps[k] - tot[k] for k in tot)
         return step()
 
+    def _release(self, step) -> None:
+        """an evicted recorded step: the backend's per-stream workspaces it pinned are dropped with it (one entry per capture stream
+        was never pruned), its memory pool goes back to the allocator with the graph object"""
+        from .backend import get_backend
+        be = get_backend()
+        st = getattr(step, "stream", None)
+        if st is not None:
+            for k in [k for k in list(be._ws) if isinstance(k, tuple) and len(k) >= 2 and k[1] == st.cuda_stream]:
+                be._ws.pop(k, None)
+            for k in [k for k in list(be._side_streams) if isinstance(k, tuple) and len(k) >= 2 and k[1] == st.cuda_stream]:
+                be._side_streams.pop(k, None)
+
     def train_epoch(self, epoch: int) -> float:
         self.model.train()
+        self._unrecordable.clear()                  # (a shape that failed to record once -- e.g. out of memory next to other graphs -- gets another try per epoch)
         self.schedule.on_train_epoch_start(epoch, self.loss_fn, self.opt)
         total, count = None, 0
         batches = epoch_batches(self.train_set.names, self.batch_size, True, self.weights, self.balance_factor, self.gen, min_last=self.world,
                                 sizes=self.train_set.count["n1"] if self.size_window >= 2 else None, size_window=self.size_window)
-        use_graphs = self.recorded and self.world == 1 and torch.cuda.is_available()
+        use_graphs = self.recorded and torch.cuda.is_available() and not self._graphs_off
         if use_graphs and self._buckets is None:
-            self.calibrate_buckets(batches)
+            # (ADVICE r5: what the docstring promises -- a dataset the padded batches cannot serve, or a calibration that finds no caps, means the
+            #  eager step for the whole run, with one warning, not an exception in the middle of fit())
+            try:
+                if not getattr(self.train_set, "bonds_are_n2", True):
+                    raise ValueError("the dataset's bonds are not its n2 tuples: batches of a fixed shape cannot be padded")
+                self.calibrate_buckets([self._my_share(np.asarray(b)) for b in batches])      # data parallel: this rank's shards are what it records
+            except Exception as e:  # noqa: BLE001
+                import warnings
+                warnings.warn(f"Trainer(recorded=True): {e!r}; every step runs eagerly")
+                self._graphs_off, use_graphs = True, False
         nxt = None
         if use_graphs and self.pipelined and len(batches) > 1:
             if self._prep_pool is None:
@@ -270,7 +316,12 @@ class Trainer:
             if nxt is not None:
                 # the batch was prepared while the previous graph was being launched; the next one is handed to the worker as soon as this one
                 # sits in its graph's inputs
-                prepared, box = nxt.result(), []
+                try:
+                    prepared, box = nxt.result(), []
+                except Exception as e:  # noqa: BLE001  (the worker's preparation failed: this batch runs eagerly, the run goes on)
+                    import warnings
+                    warnings.warn(f"Trainer(recorded=True): preparing a padded batch failed ({e!r}); it runs eagerly")
+                    prepared, box = None, []
                 follow = (lambda j=bi + 1: box.append(self._prep_pool.submit(self._prepare, np.asarray(batches[j])))) if bi + 1 < len(batches) else None
                 loss = self.train_step_recorded(ids, prepared, follow)
                 nxt = box[0] if box else None

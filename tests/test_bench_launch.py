@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SITE = '''
@@ -61,6 +63,17 @@ def test_bench_eight_gloo_ranks_check_themselves(tmp_path):
     assert rec["config"]["world_size"] == 8 and rec["config"]["dist_backend"] == "gloo" and rec["config"]["molecules_rank0"] == 2
     d = rec["dist"]
     assert d["world_size"] == 8 and d["backend"] == "gloo" and sorted(r["rank"] for r in d["ranks"]) == list(range(8))
-    assert len({r["pid"] for r in d["ranks"]}) == 8
+    assert len({r["pid"] for r in d["ranks"]}) == 8 and "distinct_devices" in d
     assert d["allreduce_bit_check"]["mismatching_steps_summed_over_ranks"] == 0
     assert rec["strong_scaling_reference"]["config"]["molecules_rank0"] == 16 and rec["scaling_factor"] > 0
+
+
+def test_bench_refuses_a_scaling_line_when_ranks_share_a_device():
+    """N ranks over RCCL on fewer than N distinct devices must not produce a `scaling` line"""
+    sys.path.insert(0, ROOT)
+    import bench
+    two_on_one = [dict(rank=0, device_index=0, device_uuid="a"), dict(rank=1, device_index=0, device_uuid="a")]
+    assert bench.distinct_devices(two_on_one, 2, enforce=False) == 1          # (gloo rehearsals on the CPU: reported, not enforced)
+    with pytest.raises(SystemExit):
+        bench.distinct_devices(two_on_one, 2, enforce=True)
+    assert bench.distinct_devices([dict(rank=0, device_index=0, device_uuid="a"), dict(rank=1, device_index=1, device_uuid="b")], 2, enforce=True) == 2

@@ -237,3 +237,42 @@ def test_predict_cache_follows_backend_settings_and_replaced_parameters():
         if len(cache.seen) > cache.max_seen:
             cache.seen.pop(next(iter(cache.seen)))
     assert len(cache.seen) <= 4
+
+
+class _CountingReducer:
+    """stands in for dist.BucketedGradReducer on one GPU: finish() is where the RCCL all-reduce of the flat gradient buffer would run"""
+
+    def __init__(self):
+        self.calls = 0
+
+    def finish(self):
+        from grappa_amd.backend import get_backend
+        get_backend().flush_wgrads()
+        self.calls += 1
+
+
+@pytest.mark.parametrize("preserve", [False, True])
+def test_split_recorded_step_equals_the_single_graph_step(preserve):
+    """data parallelism: the recorded step as TWO graphs -- zero_grad .. backward, and clip + Adam -- with the reducer called
+    eagerly between their replays; same kernels in the same order as the one-graph step, so the same bits.  preserve_state: the warm-up and
+    the recording run without the reducer (a rank recording a new shape issues no collective of its own), every call issues exactly one."""
+    from grappa_amd import ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.capture import CapturedTrainStep
+    be = get_backend()
+    res = []
+    for split in (False, True):
+        ops.manual_seed(11)
+        be.enable_dropout_salt()
+        be._salt.zero_()
+        model, flat, opt, g, energy, loss_fn = _setup()
+        red = _CountingReducer() if split else None
+        step = CapturedTrainStep(model, energy, loss_fn, opt, g, warmup=3, preserve_state=preserve, reducer=red)
+        losses = [float(step()) for _ in range(4)]
+        torch.cuda.synchronize()
+        if split:
+            assert step.graph_b is not None and red.calls == 4 + (0 if preserve else 3)
+        res.append((losses, flat.data.clone(), opt.step_count))
+        be._salt.zero_()
+    (la, pa, ca), (lb, pb, cb) = res
+    assert la == lb and ca == cb and torch.equal(pa, pb)

@@ -180,3 +180,81 @@ def test_data_parallel_two_ranks_gloo(ref_backend):
         p.join(timeout=300)
         assert p.exitcode == 0
     assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
+
+
+def _split_step_worker(rank, world, port, ids, sd, out_q):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from grappa_amd import Energy, GrappaModel, MolwiseLoss, backend, ops
+    from grappa_amd.capture import CapturedTrainStep
+    from grappa_amd.datasets import build_batch_from_pool, pool_atom_counts
+    from grappa_amd.dist import BucketedGradReducer, init_process_group_from_env, shard_indices
+    from grappa_amd.optim import FlatParams, FusedAdam
+    from oracle.ops_ref import RefBackend
+    backend.set_backend(RefBackend())
+    init_process_group_from_env("gloo")
+    model = GrappaModel(**TINY).eval()
+    model.load_state_dict(sd)
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=1e-3, eps=1e-4, max_grad_norm=1.0)
+    sizes = [int(pool_atom_counts()[i]) for i in ids]
+    mine = [ids[j] for j in shard_indices(sizes, world, rank)]
+    lf = MolwiseLoss(**LK)
+    lf.global_batch_size = len(ids)
+    calls = {"n": 0}
+    reducer = BucketedGradReducer(model, flat)
+    inner = reducer.finish
+
+    def counted():
+        calls["n"] += 1
+        inner()
+    reducer.finish = counted
+    # the recorded step's SPLIT sequence (zero_grad .. backward | all-reduce | clip + Adam) without graphs (record=False): what a rank runs per
+    # call when Trainer(recorded=True) meets world > 1
+    ops.manual_seed(5)
+    step = CapturedTrainStep(model, Energy(), lf, opt, build_batch_from_pool(mine, n_confs=3, seed=1), reducer=reducer, record=False)
+    for _ in range(2):
+        step()
+    assert calls["n"] == 2 and step.replays == 2          # ONE collective per call
+    if rank == 0:
+        out_q.put(flat.data.clone().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_recorded_step_two_ranks_gloo_equals_the_single_process_step(ref_backend):
+    """the train step as `Trainer(recorded=True)` runs it under data parallelism -- two recorded halves with the eager
+    all-reduce of the flat gradient buffer between them (capture.CapturedTrainStep reducer=) -- here in its graph-less form (record=False,
+    the test backend) on two gloo ranks: two steps on the sharded batch == two single-process steps on the whole batch."""
+    from grappa_amd import Energy, GrappaModel, MolwiseLoss, ops
+    from grappa_amd.datasets import build_batch_from_pool
+    from grappa_amd.optim import FlatParams, FusedAdam
+    torch.manual_seed(0)
+    model = GrappaModel(**TINY).eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ids = [30, 31, 32, 33, 34]
+    flat = FlatParams(model)
+    opt = FusedAdam(flat, lr=1e-3, eps=1e-4, max_grad_norm=1.0)
+    lf = MolwiseLoss(**LK)
+    g = build_batch_from_pool(ids, n_confs=3, seed=1)
+    ops.manual_seed(5)
+    for _ in range(2):
+        opt.zero_grad()
+        for lvl in ("n2", "n3", "n4", "n4_improper"):
+            for k in ("k", "eq"):
+                g.nodes[lvl].data.pop(k, None)
+        lf(Energy()(model(g))).backward()
+        opt.step()
+    want = flat.data.clone().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_step_worker, args=(r, 2, port, ids, sd, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-6)

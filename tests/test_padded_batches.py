@@ -175,6 +175,66 @@ def test_shape_buckets_cover_their_epoch():
     assert all(sb.max_pad[k] >= max(c[k] for c in sb.caps) - min(ds.totals(b)[k] for b in batches) for k in sb.max_pad)
 
 
+def _with_param_refs(g, seed):
+    """reference parameters on every level (k_ref / eq_ref; some NaN: the loss masks them), as a dataset with classical parameters carries them"""
+    rng = np.random.default_rng(seed)
+    for lvl, name, lo, hi, cols in (("n2", "k", 200., 900., None), ("n2", "eq", 0.9, 1.6, None), ("n3", "k", 50., 200., None), ("n3", "eq", 1.6, 2.2, None),
+                                    ("n4", "k", -2., 2., 6), ("n4_improper", "k", -2., 2., 3)):
+        n = g.num_nodes(lvl)
+        v = rng.uniform(lo, hi, size=(n,) if cols is None else (n, cols)).astype(np.float32)
+        if n > 3 and name == "k":
+            v[rng.integers(0, n)] = np.nan
+        g.nodes[lvl].data[name + "_ref"] = torch.from_numpy(v)
+    return g
+
+
+@pytest.mark.gpu
+def test_recorded_epochs_match_the_eager_trainer_in_the_production_like_setting():
+    """the recorded trainer against the eager one where the default Grappa schedule actually trains -- a parameter loss with
+    per-dataset weights (the graph's `plan.param_weight_rows` input, copied by `load`), reference parameters with NaNs, and start_qm_epochs = 1
+    (epoch 0: parameter loss only; the schedule then moves the loss weights, i.e. the recorded steps' stamp, so new graphs are recorded);
+    dropout off so that the two trainers are comparable step by step"""
+    from grappa_amd import GrappaModel, ops
+    from grappa_amd.trainer import Trainer
+    cfg = dict(TINY, gnn_dropout_attention=0.0, gnn_dropout_initial=0.0, gnn_dropout_conv=0.0, gnn_dropout_final=0.0, parameter_dropout=0.0)
+    items = [(_with_param_refs(graph_from_pool(300 + i, n_confs=4, seed=2), i), f"ds{i % 2}") for i in range(40)]
+    hist, stats = [], None
+    for recorded in (False, True):
+        torch.manual_seed(0)
+        ops.manual_seed(5)
+        model = GrappaModel(**cfg).to("cuda")
+        train = DeviceDataset(items, device="cuda")
+        tr = Trainer(model, train, None, batch_size=8, conf_strategy=4, lr=2e-3, proper_regularisation=1e-3, start_qm_epochs=1, warmup_steps=2,
+                     energy_weight=1.0, gradient_weight=0.8, param_weight=1e-3, param_weights_by_dataset={"ds1": 5e-3}, recorded=recorded, shape_buckets=2)
+        h = tr.fit(3)
+        hist.append([e["train_loss"] for e in h])
+        if recorded:
+            stats = dict(tr.recorded_stats)
+    eager, rec = hist
+    assert stats["eager"] == 0 and stats["replayed"] == 15, stats
+    assert all(np.isfinite(eager)) and eager[0] != eager[1]
+    for a, b in zip(eager, rec):
+        assert abs(a - b) <= 5e-5 * abs(a), (eager, rec)
+
+
+@pytest.mark.gpu
+def test_recorded_epochs_with_dropout_draw_new_masks_every_replay():
+    """dropout on: finite losses, and the same batch replayed twice through one graph gives different losses (the device-side salt moves)"""
+    from grappa_amd import GrappaModel, ops
+    from grappa_amd.trainer import Trainer
+    items = [(graph_from_pool(300 + i, n_confs=4, seed=2), "ds") for i in range(16)]
+    torch.manual_seed(0)
+    ops.manual_seed(5)
+    model = GrappaModel(**dict(TINY, parameter_dropout=0.3)).to("cuda")
+    tr = Trainer(model, DeviceDataset(items, device="cuda"), None, batch_size=8, conf_strategy=4, lr=0.0, start_qm_epochs=0, warmup_steps=2,
+                 energy_weight=1.0, gradient_weight=0.8, param_weight=0.0, recorded=True, shape_buckets=1)
+    tr.model.train()
+    ids = np.arange(8)
+    tr.calibrate_buckets([ids])
+    a, b = float(tr.train_step_recorded(ids)), float(tr.train_step_recorded(ids))      # lr = 0: the weights stay, only the masks differ
+    assert np.isfinite(a) and np.isfinite(b) and a != b and tr.recorded_stats["replayed"] >= 1
+
+
 @pytest.mark.gpu
 def test_recorded_epochs_match_the_eager_trainer():
     """two epochs, batches of 8 from 44 molecules (a short last batch included), dropout off (a recorded step salts its dropout seeds: with
