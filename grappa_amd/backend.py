@@ -1536,11 +1536,14 @@ class HipBackend:
                 if t.numel() != M:
                     raise ValueError(f"writer_layer_fwd: save[{name!r}] length")
                 setattr(d, "save_" + name, t.data_ptr())
+            tiles = self.lib.grappa_writer_head_tiles(s, T)
+            d.x2_tiled = int(bool(save.get("x2_tiled", False)))
             for name in ("x1", "qkv", "att", "x2", "x3", "u"):
                 t = save[name]
                 _flat(t, name, dev, torch.bfloat16)
-                if tuple(t.shape) != (M, 3 * Fd if name == "qkv" else Fd):
-                    raise ValueError(f"writer_layer_fwd: save[{name!r}] shape")
+                want = (tiles * 64, Fd) if (name == "x2" and d.x2_tiled) else (M, 3 * Fd if name == "qkv" else Fd)
+                if tuple(t.shape) != want:
+                    raise ValueError(f"writer_layer_fwd: save[{name!r}] shape {tuple(t.shape)}, expected {want}")
                 setattr(d, "save_" + name, t.data_ptr())
             keep = save
         flops = 2.0 * M * Fd * (6 * Fd) + 4.0 * M * s * Fd
@@ -1560,7 +1563,10 @@ class HipBackend:
             raise ValueError("writer_layer_bwd: shapes")
         d = _lib.WriterLayerBwdDesc()
         d.s, d.T, d.F, d.nheads, d.dtype = s, T, Fd, nheads, _lib.WRITER_BF16
-        for name, t, shape in (("dout", dout, (M, Fd)), ("x", x, (M, Fd)), ("qkv", saved["qkv"], (M, 3 * Fd)), ("x2", saved["x2"], (M, Fd)), ("u", saved["u"], (M, Fd))):
+        ntiles = self.lib.grappa_writer_head_tiles(s, T)
+        d.x2_tiled = int(bool(saved.get("x2_tiled", False)))
+        for name, t, shape in (("dout", dout, (M, Fd)), ("x", x, (M, Fd)), ("qkv", saved["qkv"], (M, 3 * Fd)),
+                               ("x2", saved["x2"], (ntiles * 64, Fd) if d.x2_tiled else (M, Fd)), ("u", saved["u"], (M, Fd))):
             _flat(t, name, dev, bf)
             if tuple(t.shape) != shape:
                 raise ValueError(f"writer_layer_bwd: {name} shape")
@@ -1575,7 +1581,6 @@ class HipBackend:
         d.drop_p, d.seed1, d.seed2, d.drop_salt = float(drop_p), int(seed1) & (2 ** 64 - 1), int(seed2) & (2 ** 64 - 1), self._salt_ptr
         new = lambda *sh: torch.empty(sh, dtype=bf, device=dev)      # noqa: E731
         dx, dz2, dz1, dzo, dqkv = new(M, Fd), new(M, Fd), new(M, Fd), new(M, Fd), new(M, 3 * Fd)
-        ntiles = self.lib.grappa_writer_head_tiles(s, T)
         parts = torch.empty((2, ntiles, 2, Fd), dtype=torch.float32, device=dev)
         d.dx, d.dz2, d.dz1, d.dzo, d.dqkv = dx.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), dzo.data_ptr(), dqkv.data_ptr()
         d.ln1_part, d.lnf_part = parts[0].data_ptr(), parts[1].data_ptr()

@@ -475,10 +475,22 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
                     x2v[i][mb][e] = v;
                     part[mb] += v;
                 }
-                if (sv_x2 && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_x2 + (size_t)grow[mb] * WL_F + n) = wl_pack4(x2v[i][mb]);
+                if (sv_x2 && !d.x2_tiled && grow[mb] >= 0) *reinterpret_cast<uint2*>(sv_x2 + (size_t)grow[mb] * WL_F + n) = wl_pack4(x2v[i][mb]);
             }
         }
         wl_ring_fill<4, 4>(pf, ring_f);
+        if (sv_x2 && d.x2_tiled) {
+            // x2 for the fused backward kernel only (its LayerNorm backward reads it per accumulator element): the 16 quads of a lane behind one
+            // another, 128 contiguous bytes per lane and tile -- whole lines for both kernels instead of 16 x 32-byte pieces per instruction
+            uint4* xt = reinterpret_cast<uint4*>(sv_x2 + ((size_t)blockIdx.x * WL_THREADS + tid) * 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint2 a = grow[2 * h] >= 0 ? wl_pack4(x2v[i][2 * h]) : make_uint2(0u, 0u), c2 = grow[2 * h + 1] >= 0 ? wl_pack4(x2v[i][2 * h + 1]) : make_uint2(0u, 0u);
+                    xt[i * 2 + h] = make_uint4(a.x, a.y, c2.x, c2.y);
+                }
+        }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             part[mb] = wl_quad_sum(part[mb]);
@@ -651,22 +663,33 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
 #pragma unroll
     for (int i = 0; i < 4; ++i) pa2[i] = wq_2 + ((size_t)(4 * w + i) * 16) * 64 + l;
     wl_ring_fill<4, 4>(pa2, ring_a);
+    WL_STAMP(0);
     // ---- phase 0: dz2 = dropout mask of the forward's last dropout applied to dout -> image A (+ global: operand of dW_2)
+    // (every tensor this kernel reads or writes per ELEMENT of an accumulator -- u, dout, x, dz1, dzo -- passes through an LDS image in whole rows:
+    //  fragment-shaped global accesses, 16 rows x 32 bytes per instruction, cost a third of the tile's time in the first version)
     {
+        uint4 rawd[8], rawu[8];
+        long gr8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = w * 8 + i, p = r / TT, j = r - p * TT;
-            const bool ok = p < S && j < ntup;
-            const long gr = ok ? (long)p * T + t0 + j : -1;
+            gr8[i] = (p < S && j < ntup) ? (long)p * T + t0 + j : -1;
+            rawd[i] = gr8[i] >= 0 ? *reinterpret_cast<const uint4*>(dout + (size_t)gr8[i] * WL_F + 8 * l) : make_uint4(0u, 0u, 0u, 0u);
+            rawu[i] = gr8[i] >= 0 ? *reinterpret_cast<const uint4*>(us + (size_t)gr8[i] * WL_F + 8 * l) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = w * 8 + i;
             uint4 pk = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) {
+            if (gr8[i] >= 0) {
                 float v[8];
-                wl_unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)gr * WL_F + 8 * l), v);
-                if (drop_p > 0.f) wl_dropout<8>(v, wl_drop_row(seed2, gr), (uint32_t)(8 * l) * 0x9E3779B1u, (uint32_t)(seed2 >> 32), wl_drop_threshold(drop_p), drop_scale);
+                wl_unpack8(rawd[i], v);
+                if (drop_p > 0.f) wl_dropout<8>(v, wl_drop_row(seed2, gr8[i]), (uint32_t)(8 * l) * 0x9E3779B1u, (uint32_t)(seed2 >> 32), wl_drop_threshold(drop_p), drop_scale);
                 pk = wl_pack8(v);
-                *reinterpret_cast<uint4*>(o_dz2 + (size_t)gr * WL_F + 8 * l) = pk;
+                *reinterpret_cast<uint4*>(o_dz2 + (size_t)gr8[i] * WL_F + 8 * l) = pk;
             }
             *reinterpret_cast<uint4*>(imgA + r * WL_LDA + 8 * l) = pk;
+            *reinterpret_cast<uint4*>(imgB + r * WL_LDA + 8 * l) = rawu[i];          // u: read back per element by phase 1's epilogue, which overwrites it with dz1
         }
     }
     long grow[4];
@@ -684,49 +707,79 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
     const char* fragA = smem + WL_OFF_A + (lr * WL_LDA + 8 * lq) * 2;
     const char* fragB = smem + WL_OFF_B + (lr * WL_LDA + 8 * lq) * 2;
     const char* fragQ = smem + WL_OFF_A + (lr * WL_LDQ + 8 * lq) * 2;
+    auto save_image = [&](const uint16_t* img, uint16_t* __restrict__ dst) {           // a finished image -> global in whole rows
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int idx = pass * WL_THREADS + tid, r = idx >> 6, c = idx & 63;
+            const int p = r / TT, j = r - p * TT;
+            if (p < S && j < ntup) *reinterpret_cast<uint4*>(dst + ((size_t)p * T + t0 + j) * WL_F + c * 8) = *reinterpret_cast<const uint4*>(img + r * WL_LDA + c * 8);
+        }
+    };
+    // whole rows of a global tensor -> an image (zeros beyond the tile's tuples), in two halves (request, LDS writes)
+    auto fetch_rows = [&](const uint16_t* __restrict__ src, uint4 (&t)[8]) {
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int idx = pass * WL_THREADS + tid, r = idx >> 6, c = idx & 63;
+            const int p = r / TT, j = r - p * TT;
+            t[pass] = (p < S && j < ntup) ? *reinterpret_cast<const uint4*>(src + ((size_t)p * T + t0 + j) * WL_F + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto place_rows = [&](const uint4 (&t)[8], uint16_t* img) {
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int idx = pass * WL_THREADS + tid, r = idx >> 6, c = idx & 63;
+            *reinterpret_cast<uint4*>(img + r * WL_LDA + c * 8) = t[pass];
+        }
+    };
     float* part_f = d.lnf_part + (size_t)blockIdx.x * 2 * WL_F;
     float* part_1 = d.ln1_part + (size_t)blockIdx.x * 2 * WL_F;
     wl_barrier();
 
+    WL_STAMP(1);
     // ---- phase 1: dz1 = (dz2 W_2) * ELU'(u) -> image B (+ global: operand of dW_1)
     {
-        uint2 upk[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                upk[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(us + (size_t)grow[mb] * WL_F + (4 * w + i) * 16 + 4 * lq) : make_uint2(0u, 0u);
         wl_f32x4 acc[4][4];
         wl_zero<4>(acc);
         wl_product_run<4, 16, 4>(pa2, ring_a, fragA, WL_LDA * 2, acc);
+        WL_STAMP(2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 float uv[4], y[4];
-                wl_unpack4(upk[i][mb], uv);
+                wl_unpack4(*reinterpret_cast<const uint2*>(imgB + (mb * 16 + lr) * WL_LDA + n), uv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = acc[i][mb][e] * grappa_elu_grad_from_out(uv[e]);
                 const uint2 pk = wl_pack4(y);
                 *reinterpret_cast<uint2*>(imgB + (mb * 16 + lr) * WL_LDA + n) = pk;
-                if (grow[mb] >= 0) *reinterpret_cast<uint2*>(o_dz1 + (size_t)grow[mb] * WL_F + n) = pk;
             }
         }
     }
 
+    WL_STAMP(3);
     // ---- phase 2: dx3 = dz1 W_1 + dout; dx2 = LN'(dx3; x2); dzo = dropout mask of the forward's first dropout applied to dx2 -> image A
     uint2 dx2p[4][4];                     // dx2 as stored (bf16): the skip branch into dx1, phase 5
     {
         uint2 dop[4][4], x2p[4][4];
+        if (d.x2_tiled) {
+            // x2 as the forward kernel left it for THIS kernel: per tile, the 16 accumulator quads of a lane behind one another (128 bytes per lane)
+            const uint4* xt = reinterpret_cast<const uint4*>(x2s + ((size_t)blockIdx.x * WL_THREADS + tid) * 64);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const size_t o = (size_t)(grow[mb] >= 0 ? grow[mb] : 0) * WL_F + (4 * w + i) * 16 + 4 * lq;
-                dop[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(dout + o) : make_uint2(0u, 0u);
-                x2p[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(x2s + o) : make_uint2(0u, 0u);
-            }
+                for (int h = 0; h < 2; ++h) {
+                    const uint4 t4 = xt[i * 2 + h];
+                    x2p[i][2 * h] = make_uint2(t4.x, t4.y);
+                    x2p[i][2 * h + 1] = make_uint2(t4.z, t4.w);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    x2p[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(x2s + (size_t)grow[mb] * WL_F + (4 * w + i) * 16 + 4 * lq) : make_uint2(0u, 0u);
+        }
         wl_f32x4 acc[4][4];
         wl_zero<4>(acc);
         const uint4* pa[4];
@@ -734,8 +787,26 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
         for (int i = 0; i < 4; ++i) pa[i] = wq_1 + ((size_t)(4 * w + i) * 16) * 64 + l;
         uint4 ring_b[4][4];
         wl_ring_fill<4, 4>(pa, ring_b);
-        wl_barrier();
+        wl_barrier();                                    // dz1 is complete in image B; image A (dz2) is dead
+        WL_STAMP(4);
+        save_image(imgB, o_dz1);                         // operand of dW_1
+        {
+            uint4 drows[8];                              // the skip branch's dout, per element below
+            fetch_rows(dout, drows);
+            place_rows(drows, imgA);
+        }
         wl_product_run<4, 16, 4>(pa, ring_b, fragB, WL_LDA * 2, acc);
+        wl_barrier();
+        WL_STAMP(5);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) dop[i][mb] = *reinterpret_cast<const uint2*>(imgA + (mb * 16 + lr) * WL_LDA + (4 * w + i) * 16 + 4 * lq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                if (grow[mb] < 0) x2p[i][mb] = make_uint2(0u, 0u);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -812,11 +883,11 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                 dx2p[i][mb] = wl_pack4(o);
                 const uint2 pk = wl_pack4(z);
                 *reinterpret_cast<uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n) = pk;
-                if (grow[mb] >= 0) *reinterpret_cast<uint2*>(o_dzo + (size_t)grow[mb] * WL_F + n) = pk;
             }
         }
     }
 
+    WL_STAMP(6);
     // ---- phase 3: datt = dzo W_o -> image B
     {
         wl_f32x4 acc[4][4];
@@ -827,7 +898,10 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
         uint4 ring[4][4];
         wl_ring_fill<4, 4>(pa, ring);
         wl_barrier();
+        WL_STAMP(7);
+        save_image(imgA, o_dzo);                         // operand of dW_o
         wl_product_run<4, 16, 4>(pa, ring, fragA, WL_LDA * 2, acc);
+        WL_STAMP(8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = (4 * w + i) * 16 + 4 * lq;
@@ -840,6 +914,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
     }
     wl_barrier();
 
+    WL_STAMP(9);
     // ---- phase 4: head pair by head pair: dq | dk | dv of two heads -> staging (+ global: operand of dW_in); dx1 accumulator += dqkv W_in (K = 384)
     wl_f32x4 xacc[4][4];
     wl_zero<4>(xacc);
@@ -918,25 +993,34 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pq[seg][i] = wq_in + ((size_t)(4 * w + i) * 48 + seg * 16 + hp * 4) * 64 + l;
             uint4 r0[2][4], r1[2][4];
+            WL_STAMP(10 + 3 * hp);
             wl_ring_fill<4, 2>(pq[0], r0);
             wl_barrier();
+            WL_STAMP(11 + 3 * hp);
             wl_ring_fill<4, 2>(pq[1], r1);
             wl_product_run<4, 4, 2>(pq[0], r0, fragQ, WL_LDQ * 2, xacc);
             wl_ring_fill<4, 2>(pq[2], r0);
             wl_product_run<4, 4, 2>(pq[1], r1, fragQ + 256, WL_LDQ * 2, xacc);
             wl_product_run<4, 4, 2>(pq[2], r0, fragQ + 512, WL_LDQ * 2, xacc);
+            WL_STAMP(12 + 3 * hp);
         }
         wl_barrier();
     }
 
+    WL_STAMP(22);
     // ---- phase 5: dx1 = acc + dx2; dx = LN'(dx1; x)
     {
         uint2 xp[4][4], d1p[4][4];
+        {
+            uint4 xrows[8];                              // (datt is dead: the last attention pass lies behind the loop's last barrier)
+            fetch_rows(xin, xrows);
+            place_rows(xrows, imgB);
+        }
+        wl_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                xp[i][mb] = grow[mb] >= 0 ? *reinterpret_cast<const uint2*>(xin + (size_t)grow[mb] * WL_F + (4 * w + i) * 16 + 4 * lq) : make_uint2(0u, 0u);
+            for (int mb = 0; mb < 4; ++mb) xp[i][mb] = *reinterpret_cast<const uint2*>(imgB + (mb * 16 + lr) * WL_LDA + (4 * w + i) * 16 + 4 * lq);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1000,7 +1084,6 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                if (grow[mb] < 0) continue;
                 float dyv[4], xv[4], o[4];
                 wl_unpack4(d1p[i][mb], dyv);
                 wl_unpack4(xp[i][mb], xv);
@@ -1009,10 +1092,14 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                     const float xh = (xv[e] - mean_1[mb]) * rstd_1[mb];
                     o[e] = rstd_1[mb] * (dyv[e] * gg[e] - s1[mb] - xh * s2[mb]);
                 }
-                *reinterpret_cast<uint2*>(dx + (size_t)grow[mb] * WL_F + n) = wl_pack4(o);
+                *reinterpret_cast<uint2*>(imgA + (mb * 16 + lr) * WL_LDA + n) = wl_pack4(o);      // (the staging of dq | dk | dv is dead)
             }
         }
+        wl_barrier();
+        save_image(imgA, dx);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WL_STAMP(23);
 }
 
 // W (N x K fp32, rows ldw apart; transpose: the operand is W^T, K x N) -> bf16 in fragment order: block (nb, ks) = 16 rows x 32 k is one

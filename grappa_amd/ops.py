@@ -554,12 +554,15 @@ class TransformerLayerFn(Function):
             out = _new((M, Fd), x)
             sv = None
             if infer != 1:
+                # x2 is read by the LayerNorm backward only: with the fused backward kernel it is kept in that kernel's tile order
+                tiled = bool(getattr(be, "fused_writer_layer_bwd", False))
+                rows2 = be.lib.grappa_writer_head_tiles(s, T) * 64 if tiled else M
                 sv = dict(mean1=_new((M,), x, F32), rstd1=_new((M,), x, F32), meanf=_new((M,), x, F32), rstdf=_new((M,), x, F32),
-                          x1=_new((M, Fd), x), qkv=_new((M, 3 * Fd), x), att=_new((M, Fd), x), x2=_new((M, Fd), x), x3=_new((M, Fd), x),
-                          u=_new((M, Fd), x))
+                          x1=_new((M, Fd), x), qkv=_new((M, 3 * Fd), x), att=_new((M, Fd), x), x2=_new((rows2, Fd), x), x3=_new((M, Fd), x),
+                          u=_new((M, Fd), x), x2_tiled=tiled)
             be.writer_layer_fwd(x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, out, save=sv)
             ctx.cfg, ctx.scales = (s, T, nheads, drop_p, seed1, seed2), (None, None)
-            ctx.fused_saved = sv if (sv is not None and getattr(be, "fused_writer_layer_bwd", False)) else None
+            ctx.fused_saved = sv if (sv is not None and sv.get("x2_tiled")) else None        # (tiled x2 <=> the fused backward kernel runs this layer's backward)
             if sv is not None:
                 ctx.ff_saved = (sv["x2"], sv["meanf"], sv["rstdf"], sv["x3"], sv["u"], None, None, None)
                 ctx.save_for_backward(x, sv["mean1"], sv["rstd1"], sv["x1"], sv["qkv"], sv["att"], n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2)

@@ -598,6 +598,8 @@ typedef struct grappa_writer_layer_desc {
     const uint64_t* drop_salt;                            /* device word mixed into both seeds, or NULL (grappa_gemm_desc.drop_salt) */
     float *save_mean1, *save_rstd1, *save_meanf, *save_rstdf;      /* (s*T) each, or NULL */
     void *save_x1, *save_qkv, *save_att, *save_x2, *save_x3, *save_u;      /* (s*T, F), qkv (s*T, 3F), or NULL */
+    int x2_tiled;      /* != 0: save_x2 holds grappa_writer_head_tiles(s, T) * 64 rows in the TILE order of grappa_writer_head_bwd (x2_tiled there too):
+                          per tile and lane the 16 accumulator quads behind one another; 0: plain rows (what grappa_layernorm_bwd_bf16 reads) */
 } grappa_writer_layer_desc;
 int grappa_writer_head_fwd(void* stream, const grappa_writer_layer_desc* d);
 /* The backward pass of the same layer: the whole input-gradient chain in one kernel per tile of 64 token rows
@@ -621,6 +623,7 @@ typedef struct grappa_writer_layer_bwd_desc {
     void* dx;                                             /* (s*T, F): gradient of the layer's input */
     void *dz2, *dz1, *dzo, *dqkv;
     float *ln1_part, *lnf_part;                           /* (tiles, 2, F) each */
+    int x2_tiled;                                         /* the layout of x2: see grappa_writer_layer_desc */
 } grappa_writer_layer_bwd_desc;
 int grappa_writer_head_bwd(void* stream, const grappa_writer_layer_bwd_desc* d);
 int grappa_writer_head_tiles(int s, int T);

@@ -25,7 +25,7 @@ def main():
         x = (rn(M, F) * 1.5).to(BF)
         out = torch.empty_like(x)
         sv = dict(mean1=torch.empty(M, device="cuda"), rstd1=torch.empty(M, device="cuda"), meanf=torch.empty(M, device="cuda"), rstdf=torch.empty(M, device="cuda"),
-                  x1=torch.empty_like(x), qkv=torch.empty((M, 3 * F), dtype=BF, device="cuda"), att=torch.empty_like(x), x2=torch.empty_like(x),
+                  x1=torch.empty_like(x), qkv=torch.empty((M, 3 * F), dtype=BF, device="cuda"), att=torch.empty_like(x), x2=torch.empty((be.lib.grappa_writer_head_tiles(s, T) * 64, F), dtype=BF, device="cuda"), x2_tiled=True,
                   x3=torch.empty_like(x), u=torch.empty_like(x))
         for save, p in ((None, 0.0), (sv, 0.0), (sv, 0.1)):
             for _ in range(2):
