@@ -637,6 +637,17 @@ def main():
             roof.update({"maxima_pass_ms_per_step": ms_amax / steps, "maxima_pass_launches_per_step": n_amax / steps,
                          "products_only_ms_per_step": ms_products / steps,
                          "products_only_tflops": (fl_launched / (ms_products * 1e-3)) / 1e12 if ms_products > 0 else 0.0})
+        # round 6: the fused writer-head layer (grappa_writer_head_fwd / _bwd, bf16 storage) is a kernel family of its own: its products are NOT in
+        # `achieved` above (which stays the dense products' launches), so it carries its own line -- 12 * 512^2 FLOP per token row and launch
+        nw, msw, flw, byw = prof.get("writer_layer", (0, 0.0, 0.0, 0.0))
+        if nw:
+            aw = (flw / (msw * 1e-3)) / 1e12 if msw > 0 else 0.0
+            roof["writer_layer"] = {"bound": "mfma", "kernel": "writer_layer_fwd/bwd_bf16_kernel (v_mfma_f32_16x16x32_bf16, one launch per transformer layer and pass)",
+                                    "achieved": aw, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": aw / PEAK_BF16_MFMA_TFLOPS,
+                                    "launches_per_step": nw / steps, "kernel_ms_per_step": msw / steps, "tflop_per_step": flw / steps / 1e12,
+                                    "algorithmic_bytes_per_launch": byw / max(nw, 1),
+                                    "all_products_achieved": ((fl_launched + flw) / ((ms + msw) * 1e-3)) / 1e12 if (ms + msw) > 0 else 0.0}
+            roof["writer_layer"]["all_products_frac"] = roof["writer_layer"]["all_products_achieved"] / peak
         gat = {}
         for fam in ("gat_fwd", "gat_bwd"):
             n_, ms_, fl_, by_ = prof.get(fam, (0, 0.0, 0.0, 0.0))

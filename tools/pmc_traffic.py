@@ -25,7 +25,9 @@ FAMILIES = {"dense_products": r"gemm_|amax_|group_upload|group_index|split_pairs
             "adam": r"adam_kernel",
             "gemm_f32": r"gemm_f32_kernel|gemm_bf16x_kernel", "gemm_bf16x": r"gemm_bf16x_kernel", "gemm_pairs_il": r"gemm_pairs_il", "gemm_wpairs_il": r"gemm_wpairs_il",
             "gemm_wgrad_grouped": r"gemm_bf16x_grouped_kernel", "gemm_splitk_reduce": r"gemm_splitk_reduce_kernel", "gat_fwd": r"gat_fwd_kernel",
-            "gat_bwd": r"gat_bwd_kernel|gat_delta_kernel", "layernorm": r"layernorm_", "seqattn": r"seqattn_"}
+            "gat_bwd": r"gat_bwd_kernel|gat_delta_kernel", "layernorm": r"layernorm_", "seqattn": r"seqattn_",
+            # round 6: the fused writer-head layer (csrc/writer_layer.hip) and, for whole-step comparisons, every kernel of the step
+            "writer_layer_fwd": r"writer_layer_fwd", "writer_layer_bwd": r"writer_layer_bwd", "writer_layer": r"writer_layer_|writer_pack", "whole_step": r"."}
 
 
 def collect(d, counter):
