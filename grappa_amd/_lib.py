@@ -97,7 +97,7 @@ class WriterLayerDesc(C.Structure):
                 ("drop_p", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64), ("drop_salt", C.c_void_p),
                 ("save_mean1", C.c_void_p), ("save_rstd1", C.c_void_p), ("save_meanf", C.c_void_p), ("save_rstdf", C.c_void_p),
                 ("save_x1", C.c_void_p), ("save_qkv", C.c_void_p), ("save_att", C.c_void_p), ("save_x2", C.c_void_p), ("save_x3", C.c_void_p),
-                ("save_u", C.c_void_p), ("x2_tiled", C.c_int)]
+                ("save_u", C.c_void_p), ("gather_idx", C.c_void_p), ("x1_tab", C.c_void_p), ("qkv_tab", C.c_void_p), ("x2_tiled", C.c_int)]
 
 
 class WriterLayerBwdDesc(C.Structure):
@@ -109,7 +109,7 @@ class WriterLayerBwdDesc(C.Structure):
                 ("w_in_tpk", C.c_void_p), ("w_o_tpk", C.c_void_p), ("w1_tpk", C.c_void_p), ("w2_tpk", C.c_void_p),
                 ("drop_p", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64), ("drop_salt", C.c_void_p),
                 ("dx", C.c_void_p), ("dz2", C.c_void_p), ("dz1", C.c_void_p), ("dzo", C.c_void_p), ("dqkv", C.c_void_p),
-                ("ln1_part", C.c_void_p), ("lnf_part", C.c_void_p), ("x2_tiled", C.c_int)]
+                ("ln1_part", C.c_void_p), ("lnf_part", C.c_void_p), ("x2_tiled", C.c_int), ("gather_idx", C.c_void_p)]
 
 
 WRITER_BF16 = 1

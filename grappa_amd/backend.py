@@ -204,6 +204,9 @@ class HipBackend:
         # ... and its backward pass: the input-gradient chain as one kernel (grappa_writer_head_bwd); 0: the unfused backward over the tensors
         # the fused forward saved
         self.fused_writer_layer_bwd = os.environ.get("GRAPPA_FUSED_WRITER_LAYER_BWD", "1") not in ("0", "")
+        # ... and the first layer of the angle / proper heads (ops.ProjFirstLayerFn: LayerNorm + q | k | v on (atom, position) rows) through the same
+        # kernels in their gather mode; 0: the unfused sequence behind the table-level products
+        self.fused_first_layer = os.environ.get("GRAPPA_FUSED_FIRST_LAYER", "1") not in ("0", "")
         self._wplanes = {}     # (data_ptr, rows, cols, transposed) -> (version key, planes tensor)
         self._wpairs = {}      # (data_ptr, rows, cols, "pairs" | "pairsT") -> [version key, pairs, weakref of the weight, epoch of last use, transposed, maxima record]
         self._wptable = None   # (device table of grappa_split_pairs_item, count, tiles, records kept alive)
@@ -1504,24 +1507,41 @@ class HipBackend:
             return False
         return all(p is not None and p.dtype == torch.float32 and p.is_contiguous() for p in params)
 
-    def writer_layer_fwd(self, x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, out, save=None):
+    def writer_layer_fwd(self, x, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, out, save=None, gather=None):
         """out = the transformer layer of a writer head applied to the token table x (s*T, 512) in ONE launch (include/grappa_hip.h
         grappa_writer_head_fwd; reference models/network_utils.py:112-133, :44-54).  save: None (inference) or the tensors the unfused
         backward reads, written as by-products: dict(mean1, rstd1, x1, qkv, att, x2, meanf, rstdf, x3, u)."""
-        dev = x.device
-        M, Fd = x.shape
-        if M != s * T or tuple(out.shape) != (M, Fd) or out.dtype != x.dtype:
-            raise ValueError("writer_layer_fwd: shapes")
+        dev = out.device
+        M, Fd = out.shape
         d = _lib.WriterLayerDesc()
         d.s, d.T, d.F, d.nheads, d.dtype = s, T, Fd, nheads, _lib.WRITER_BF16
-        _flat(x, "x", dev, torch.bfloat16), _flat(out, "out", dev, torch.bfloat16)
-        d.x, d.out = x.data_ptr(), out.data_ptr()
+        _flat(out, "out", dev, torch.bfloat16)
+        d.out = out.data_ptr()
+        if gather is not None:
+            # gather = (idx_tab (T, s) int32: table row of every token, x1_tab (rows, F): normalised table rows, qkv_tab (rows, 3F)): the first layer of a
+            # head on (atom, position) rows -- x, the first LayerNorm and the q | k | v product are not part of the launch
+            idx_tab, x1_tab, qkv_tab = gather
+            if M != s * T or idx_tab.dtype != torch.int32 or tuple(idx_tab.shape) != (T, s) or not idx_tab.is_contiguous() or idx_tab.device != dev:
+                raise ValueError("writer_layer_fwd: gather index")
+            _flat(x1_tab, "x1_tab", dev, torch.bfloat16), _flat(qkv_tab, "qkv_tab", dev, torch.bfloat16)
+            if x1_tab.shape[1] != Fd or tuple(qkv_tab.shape) != (x1_tab.shape[0], 3 * Fd):
+                raise ValueError("writer_layer_fwd: gather tables")
+            d.gather_idx, d.x1_tab, d.qkv_tab = idx_tab.data_ptr(), x1_tab.data_ptr(), qkv_tab.data_ptr()
+        else:
+            if tuple(x.shape) != (M, Fd) or M != s * T or out.dtype != x.dtype:
+                raise ValueError("writer_layer_fwd: shapes")
+            _flat(x, "x", dev, torch.bfloat16)
+            d.x = x.data_ptr()
         for name, wt, shape in (("w_in_pk", w_in, (3 * Fd, Fd)), ("w_o_pk", w_o, (Fd, Fd)), ("w1_pk", w1, (Fd, Fd)), ("w2_pk", w2, (Fd, Fd))):
+            if gather is not None and name == "w_in_pk":
+                continue
             if tuple(wt.shape) != shape:
                 raise ValueError(f"writer_layer_fwd: {name[:-3]} has shape {tuple(wt.shape)}, expected {shape}")
             setattr(d, name, self._packed_weight(wt).data_ptr())
         for name, v, n in (("b_in", b_in, 3 * Fd), ("b_o", b_o, Fd), ("b1", b1, Fd), ("b2", b2, Fd), ("n1_gamma", n1_w, Fd), ("n1_beta", n1_b, Fd),
                            ("nf_gamma", nf_w, Fd), ("nf_beta", nf_b, Fd)):
+            if gather is not None and name.startswith("n1_"):
+                continue
             _flat(v, name, dev)
             if v.numel() != n:
                 raise ValueError(f"writer_layer_fwd: {name} length")
@@ -1530,7 +1550,7 @@ class HipBackend:
         d.drop_salt = self._salt_ptr
         keep = None
         if save is not None:
-            for name in ("mean1", "rstd1", "meanf", "rstdf"):
+            for name in ("meanf", "rstdf") if gather is not None else ("mean1", "rstd1", "meanf", "rstdf"):
                 t = save[name]
                 _flat(t, name, dev)
                 if t.numel() != M:
@@ -1538,7 +1558,7 @@ class HipBackend:
                 setattr(d, "save_" + name, t.data_ptr())
             tiles = self.lib.grappa_writer_head_tiles(s, T)
             d.x2_tiled = int(bool(save.get("x2_tiled", False)))
-            for name in ("x1", "qkv", "att", "x2", "x3", "u"):
+            for name in ("att", "x2", "x3", "u") if gather is not None else ("x1", "qkv", "att", "x2", "x3", "u"):
                 t = save[name]
                 _flat(t, name, dev, torch.bfloat16)
                 want = (tiles * 64, Fd) if (name == "x2" and d.x2_tiled) else (M, 3 * Fd if name == "qkv" else Fd)
@@ -1546,37 +1566,53 @@ class HipBackend:
                     raise ValueError(f"writer_layer_fwd: save[{name!r}] shape {tuple(t.shape)}, expected {want}")
                 setattr(d, "save_" + name, t.data_ptr())
             keep = save
-        flops = 2.0 * M * Fd * (6 * Fd) + 4.0 * M * s * Fd
-        nbytes = 2.0 * M * Fd * (2 + (9 if save is not None else 0)) + 2.0 * 6 * Fd * Fd
+        nprod = 3 if gather is not None else 6
+        flops = 2.0 * M * Fd * (nprod * Fd) + 4.0 * M * s * Fd
+        nbytes = 2.0 * M * Fd * ((5 if gather is not None else 2) + ((5 if gather is not None else 9) if save is not None else 0)) + 2.0 * nprod * Fd * Fd
         self._timed("writer_layer", flops, nbytes, lambda: _chk(self.lib.grappa_writer_head_fwd(self._stream(), C.byref(d)), "grappa_writer_head_fwd"),
-                    lambda: [{"M": M, "s": s, "save": keep is not None}])
+                    lambda: [{"M": M, "s": s, "save": keep is not None, "gather": gather is not None}])
 
-    def writer_layer_bwd(self, dout, x, s, T, nheads, drop_p, seed1, seed2, saved, n1_w, n1_b, w_in, w_o, nf_w, nf_b, w1, w2):
+    def writer_layer_bwd(self, dout, x, s, T, nheads, drop_p, seed1, seed2, saved, n1_w, n1_b, w_in, w_o, nf_w, nf_b, w1, w2, gather=None):
         """the input-gradient chain of the fused layer in ONE launch (grappa_writer_head_bwd) -> (dx, dz2, dz1, dzo, dqkv): dx = the gradient of
         the layer's input, the other four = the operands of the weight-gradient products (against saved u, x3, att, x1).  The LayerNorm
         parameter gradients (per-tile partials) are queued for the end-of-pass reduction like layernorm_bwd's, or reduced at once.
         saved: the dict `writer_layer_fwd` filled."""
         dev = dout.device
-        M, Fd = x.shape
+        M, Fd = dout.shape
         bf = torch.bfloat16
-        if M != s * T or tuple(dout.shape) != (M, Fd):
+        if M != s * T:
             raise ValueError("writer_layer_bwd: shapes")
         d = _lib.WriterLayerBwdDesc()
         d.s, d.T, d.F, d.nheads, d.dtype = s, T, Fd, nheads, _lib.WRITER_BF16
         ntiles = self.lib.grappa_writer_head_tiles(s, T)
         d.x2_tiled = int(bool(saved.get("x2_tiled", False)))
-        for name, t, shape in (("dout", dout, (M, Fd)), ("x", x, (M, Fd)), ("qkv", saved["qkv"], (M, 3 * Fd)),
-                               ("x2", saved["x2"], (ntiles * 64, Fd) if d.x2_tiled else (M, Fd)), ("u", saved["u"], (M, Fd))):
+        if gather is not None:
+            # gather = (idx_tab (T, s) int32, qkv_tab (rows, 3F)): q | k | v from the table; returns dx2 (the skip branch's gradient) in place of dx
+            idx_tab, qkv_tab = gather
+            if idx_tab.dtype != torch.int32 or tuple(idx_tab.shape) != (T, s) or not idx_tab.is_contiguous() or qkv_tab.shape[1] != 3 * Fd:
+                raise ValueError("writer_layer_bwd: gather arguments")
+            d.gather_idx = idx_tab.data_ptr()
+            tensors = (("dout", dout, (M, Fd)), ("qkv", qkv_tab, tuple(qkv_tab.shape)), ("x2", saved["x2"], (ntiles * 64, Fd) if d.x2_tiled else (M, Fd)),
+                       ("u", saved["u"], (M, Fd)))
+        else:
+            tensors = (("dout", dout, (M, Fd)), ("x", x, (M, Fd)), ("qkv", saved["qkv"], (M, 3 * Fd)),
+                       ("x2", saved["x2"], (ntiles * 64, Fd) if d.x2_tiled else (M, Fd)), ("u", saved["u"], (M, Fd)))
+        for name, t, shape in tensors:
             _flat(t, name, dev, bf)
             if tuple(t.shape) != shape:
                 raise ValueError(f"writer_layer_bwd: {name} shape")
             setattr(d, name, t.data_ptr())
-        for name in ("mean1", "rstd1", "meanf", "rstdf"):
+        for name in ("meanf", "rstdf") if gather is not None else ("mean1", "rstd1", "meanf", "rstdf"):
             _flat(saved[name], name, dev)
             setattr(d, name, saved[name].data_ptr())
-        _flat(n1_w, "n1_gamma", dev), _flat(nf_w, "nf_gamma", dev)
-        d.n1_gamma, d.nf_gamma = n1_w.data_ptr(), nf_w.data_ptr()
+        _flat(nf_w, "nf_gamma", dev)
+        d.nf_gamma = nf_w.data_ptr()
+        if gather is None:
+            _flat(n1_w, "n1_gamma", dev)
+            d.n1_gamma = n1_w.data_ptr()
         for name, wt in (("w_in_tpk", w_in), ("w_o_tpk", w_o), ("w1_tpk", w1), ("w2_tpk", w2)):
+            if gather is not None and name == "w_in_tpk":
+                continue
             setattr(d, name, self._packed_weight(wt, transposed=True).data_ptr())
         d.drop_p, d.seed1, d.seed2, d.drop_salt = float(drop_p), int(seed1) & (2 ** 64 - 1), int(seed2) & (2 ** 64 - 1), self._salt_ptr
         new = lambda *sh: torch.empty(sh, dtype=bf, device=dev)      # noqa: E731
@@ -1584,10 +1620,12 @@ class HipBackend:
         parts = torch.empty((2, ntiles, 2, Fd), dtype=torch.float32, device=dev)
         d.dx, d.dz2, d.dz1, d.dzo, d.dqkv = dx.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), dzo.data_ptr(), dqkv.data_ptr()
         d.ln1_part, d.lnf_part = parts[0].data_ptr(), parts[1].data_ptr()
-        flops = 2.0 * M * Fd * (6 * Fd) + 8.0 * M * s * Fd
-        self._timed("writer_layer", flops, 2.0 * M * Fd * 15 + 2.0 * 6 * Fd * Fd,
-                    lambda: _chk(self.lib.grappa_writer_head_bwd(self._stream(), C.byref(d)), "grappa_writer_head_bwd"), lambda: [{"M": M, "s": s, "bwd": True}])
-        for part, g, b in ((parts[0], n1_w, n1_b), (parts[1], nf_w, nf_b)):
+        nprod = 3 if gather is not None else 6
+        flops = 2.0 * M * Fd * (nprod * Fd) + 8.0 * M * s * Fd
+        self._timed("writer_layer", flops, 2.0 * M * Fd * 15 + 2.0 * nprod * Fd * Fd,
+                    lambda: _chk(self.lib.grappa_writer_head_bwd(self._stream(), C.byref(d)), "grappa_writer_head_bwd"),
+                    lambda: [{"M": M, "s": s, "bwd": True, "gather": gather is not None}])
+        for part, g, b in ((parts[1], nf_w, nf_b),) if gather is not None else ((parts[0], n1_w, n1_b), (parts[1], nf_w, nf_b)):
             self._reduce_ln_partials(part, ntiles, Fd, g, b)
         return dx, dz2, dz1, dzo, dqkv
 

@@ -48,7 +48,8 @@ constexpr int WL_OFF_B = WL_OFF_Q;
 constexpr int WL_OFF_RED = WL_OFF_T + WL_ROWS * WL_LDT * 2;
 constexpr int WL_OFF_PAR = WL_OFF_RED + 2 * 8 * WL_ROWS * 4;      // forward kernel: b_in (1536) | b_o | b_1 | b_2 | nf gamma | nf beta (512 each) as fp32
 constexpr int WL_PAR_BIN = 0, WL_PAR_BO = 1536, WL_PAR_B1 = 2048, WL_PAR_B2 = 2560, WL_PAR_GF = 3072, WL_PAR_BF = 3584, WL_PAR_N = 4096;
-constexpr int WL_SMEM = WL_OFF_PAR + WL_PAR_N * 4;
+constexpr int WL_OFF_IDX = WL_OFF_PAR + WL_PAR_N * 4;             // gather mode: the table row of each of the tile's 64 token rows (or -1)
+constexpr int WL_SMEM = WL_OFF_IDX + WL_ROWS * 4;
 static_assert(WL_OFF_B + WL_ROWS * WL_LDA * 2 <= WL_OFF_RED, "the u image must fit into the staging area");
 static_assert(WL_SMEM <= 160 * 1024, "LDS of one CU");
 
@@ -219,7 +220,10 @@ __device__ __forceinline__ float wl_quad_sum(float v) {
     return v;
 }
 
-template <int S>
+// GATHER (the first layer of a head whose LayerNorm and q | k | v were computed once per (atom, position) TABLE row, ops.ProjFirstLayerFn): the
+// normalised rows x1 and q | k | v are not computed but gathered from those tables through gather_idx[t * s + pos] (the row of
+// grappa_tuple_gather_fwd); everything behind them is the same kernel.
+template <int S, bool GATHER>
 __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const grappa_writer_layer_desc d) {
     constexpr int TT = WL_ROWS / S;                 // tuples per tile: 32, 21, 16
     extern __shared__ char smem[];
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
     // the epilogues' per-feature vectors live in LDS: a global load of them behind the weight fragments requested ahead would wait for all of those
     // (vector-memory results return in order)
     float* par = reinterpret_cast<float*>(smem + WL_OFF_PAR);
+    int* trow = reinterpret_cast<int*>(smem + WL_OFF_IDX);
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
     const int T = d.T;
@@ -262,6 +267,26 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
             *reinterpret_cast<float4*>(par + i4) = *reinterpret_cast<const float4*>(sp + (i4 - b0));
         }
     }
+    if constexpr (GATHER) {
+        // ---- phase 0 (gather): the table rows of the tile -> LDS; x1 = their normalised rows, as they stand -> image A
+        const int* __restrict__ gidx = d.gather_idx;
+        const uint16_t* __restrict__ x1t = reinterpret_cast<const uint16_t*>(d.x1_tab);
+        if (tid < WL_ROWS) {
+            const int p = tid / TT, j = tid - p * TT;
+            trow[tid] = (p < S && j < ntup) ? gidx[(size_t)(t0 + j) * S + p] : -1;
+        }
+        const int rr = l >> 4, c = l & 15;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int r = w * 8 + ps * 4 + rr, p = r / TT, j = r - p * TT;
+            const int tr = (p < S && j < ntup) ? gidx[(size_t)(t0 + j) * S + p] : -1;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const int col = (c + 16 * kq) * 8;
+                *reinterpret_cast<uint4*>(imgA + r * WL_LDA + col) = tr >= 0 ? *reinterpret_cast<const uint4*>(x1t + (size_t)tr * WL_F + col) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    } else
     // ---- phase 0: x1 = LN(x) -> image A; wavefront w owns tile rows 8 w ... 8 w + 7, FOUR rows at a time: a row per 16 lanes (its reductions
     // stay inside a DPP row), a lane the 16-byte chunks c, c + 16, c + 32, c + 48 of its row
     {
@@ -344,7 +369,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
     const uint4* pc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) pc[i] = wq_in + ((size_t)((((3 * w + i) >> 3) * 32 + ((3 * w + i) & 7)) * 16)) * 64 + l;
-    wl_ring_fill<3, 4>(pc, ring_c);
+    if constexpr (!GATHER) wl_ring_fill<3, 4>(pc, ring_c);
     wl_barrier();
     WL_STAMP(2);
 
@@ -358,7 +383,17 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
         const uint4* pp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) pp[i] = wq_o + ((size_t)(4 * w + i) * 16 + hp * 4) * 64 + l;
-        {
+        if constexpr (GATHER) {
+            // the pair's q | k | v of every token row from its TABLE row: 64 rows x 3 segments of 256 bytes
+            const uint16_t* __restrict__ qt = reinterpret_cast<const uint16_t*>(d.qkv_tab);
+#pragma unroll
+            for (int pass = 0; pass < 6; ++pass) {
+                const int idx = pass * WL_THREADS + tid, r = idx / 48, c16 = idx - r * 48, seg = c16 >> 4, off = c16 & 15;
+                const int tr = trow[r];
+                *reinterpret_cast<uint4*>(imgQ + r * WL_LDQ + c16 * 8) =
+                    tr >= 0 ? *reinterpret_cast<const uint4*>(qt + (size_t)tr * (3 * WL_F) + seg * WL_F + hp * 128 + off * 8) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else {
             wl_f32x4 acc[3][4];
             wl_zero<3>(acc);
             int nbw[3];
@@ -381,7 +416,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
         WL_STAMP(4 + 6 * hp);
         wl_barrier();
         WL_STAMP(5 + 6 * hp);
-        if (sv_qkv) {
+        if (!GATHER && sv_qkv) {
             // the pair's q | k | v rows -> global in whole 256-byte runs (by-product for the backward pass): 64 rows x 48 chunks of 16 bytes
 #pragma unroll
             for (int pass = 0; pass < 6; ++pass) {
@@ -441,7 +476,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
         WL_STAMP(6 + 6 * hp);
         wl_barrier();
         WL_STAMP(7 + 6 * hp);
-        if (hp < 3) {                                    // the next pair's q | k | v weights travel while the out-projection runs
+        if (!GATHER && hp < 3) {                         // the next pair's q | k | v weights travel while the out-projection runs
 #pragma unroll
             for (int i = 0; i < 3; ++i) pc[i] = wq_in + ((size_t)((((3 * w + i) >> 3) * 32 + (hp + 1) * 8 + ((3 * w + i) & 7)) * 16)) * 64 + l;
             wl_ring_fill<3, 4>(pc, ring_c);
@@ -621,7 +656,10 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_fwd_bf16_kernel(const
 // every tensor the unfused kernels store is rounded to bf16 at the same place.  Products as in the forward kernel, with the TRANSPOSED weights
 // packed (grappa_writer_pack_weight transpose = 1): out^T = W^T act^T.  LDS: image A (dz2, then dzo, then the staging of one head pair's dq | dk | dv),
 // image B (dz1, then datt).  LayerNorm parameter gradients: per-tile partial sums [tile][dgamma | dbeta][512], reduced by the caller.
-template <int S>
+// GATHER (see the forward kernel): q | k | v come from the table rows, the chain ends behind the attention -- dqkv (token rows) and the skip branch's
+// gradient dx2 (`dx`) are this kernel's outputs, the caller sums them into the table rows (grappa_tuple_gather_bwd) and runs the table-level
+// products and the first LayerNorm's backward there.
+template <int S, bool GATHER>
 __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const grappa_writer_layer_bwd_desc d) {
     constexpr int TT = WL_ROWS / S;
     extern __shared__ char smem[];
@@ -630,9 +668,16 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
     uint16_t* imgB = reinterpret_cast<uint16_t*>(smem + WL_OFF_B);
     float* red = reinterpret_cast<float*>(smem + WL_OFF_RED);              // [2][8 wavefronts][64 rows]
     float* par = reinterpret_cast<float*>(smem + WL_OFF_PAR);              // nf gamma (512) | n1 gamma (512): see the forward kernel
-    if (threadIdx.x < 256) {
+    int* trow = reinterpret_cast<int*>(smem + WL_OFF_IDX);
+    if (threadIdx.x < (GATHER ? 128 : 256)) {
         const int i4 = threadIdx.x * 4;
         *reinterpret_cast<float4*>(par + i4) = *reinterpret_cast<const float4*>((i4 < WL_F ? d.nf_gamma : d.n1_gamma) + (i4 & (WL_F - 1)));
+    }
+    if constexpr (GATHER) {
+        if (threadIdx.x < WL_ROWS) {
+            const int r = threadIdx.x, p = r / (WL_ROWS / S), j = r - p * (WL_ROWS / S);
+            trow[r] = (p < S && j < min(WL_ROWS / S, d.T - (int)blockIdx.x * (WL_ROWS / S))) ? d.gather_idx[(size_t)(blockIdx.x * (WL_ROWS / S) + j) * S + p] : -1;
+        }
     }
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
@@ -701,8 +746,8 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
         const bool ok = grow[mb] >= 0;
         mean_f[mb] = ok ? d.meanf[grow[mb]] : 0.f;
         rstd_f[mb] = ok ? d.rstdf[grow[mb]] : 0.f;
-        mean_1[mb] = ok ? d.mean1[grow[mb]] : 0.f;
-        rstd_1[mb] = ok ? d.rstd1[grow[mb]] : 0.f;
+        mean_1[mb] = (!GATHER && ok) ? d.mean1[grow[mb]] : 0.f;
+        rstd_1[mb] = (!GATHER && ok) ? d.rstd1[grow[mb]] : 0.f;
     }
     const char* fragA = smem + WL_OFF_A + (lr * WL_LDA + 8 * lq) * 2;
     const char* fragB = smem + WL_OFF_B + (lr * WL_LDA + 8 * lq) * 2;
@@ -928,7 +973,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
                 float q[S][4], k[S][4], v[S][4], go[S][4], dq[S][4], dk[S][4], dv[S][4];
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
-                    const uint16_t* row = qkv + ((size_t)i * T + t0 + j) * (3 * WL_F) + (2 * hp + hh) * 64 + sub * 4;
+                    const uint16_t* row = qkv + (GATHER ? (size_t)trow[i * TT + j] : (size_t)i * T + t0 + j) * (3 * WL_F) + (2 * hp + hh) * 64 + sub * 4;
                     wl_unpack4(*reinterpret_cast<const uint2*>(row), q[i]);
                     wl_unpack4(*reinterpret_cast<const uint2*>(row + WL_F), k[i]);
                     wl_unpack4(*reinterpret_cast<const uint2*>(row + 2 * WL_F), v[i]);
@@ -974,10 +1019,12 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
                     const uint2 pq = wl_pack4(dq[i]), pk = wl_pack4(dk[i]), pv = wl_pack4(dv[i]);
-                    uint16_t* st = imgQ + (i * TT + j) * WL_LDQ + hh * 64 + sub * 4;
-                    *reinterpret_cast<uint2*>(st) = pq;
-                    *reinterpret_cast<uint2*>(st + 128) = pk;
-                    *reinterpret_cast<uint2*>(st + 256) = pv;
+                    if constexpr (!GATHER) {
+                        uint16_t* st = imgQ + (i * TT + j) * WL_LDQ + hh * 64 + sub * 4;
+                        *reinterpret_cast<uint2*>(st) = pq;
+                        *reinterpret_cast<uint2*>(st + 128) = pk;
+                        *reinterpret_cast<uint2*>(st + 256) = pv;
+                    }
                     uint16_t* gp = o_dqkv + ((size_t)i * T + t0 + j) * (3 * WL_F) + (2 * hp + hh) * 64 + sub * 4;
                     *reinterpret_cast<uint2*>(gp) = pq;
                     *reinterpret_cast<uint2*>(gp + WL_F) = pk;
@@ -986,7 +1033,7 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             }
         }
         // dx1^T += W_in^T (:, the pair's q | k | v rows) dqkv^T: three runs of 4 k-steps (rows hp 128 ... of each of W_in's three blocks of 512)
-        {
+        if constexpr (!GATHER) {
             const uint4* pq[3][4];
 #pragma unroll
             for (int seg = 0; seg < 3; ++seg)
@@ -1003,11 +1050,20 @@ __global__ __launch_bounds__(WL_THREADS) void writer_layer_bwd_bf16_kernel(const
             wl_product_run<4, 4, 2>(pq[1], r1, fragQ + 256, WL_LDQ * 2, xacc);
             wl_product_run<4, 4, 2>(pq[2], r0, fragQ + 512, WL_LDQ * 2, xacc);
             WL_STAMP(12 + 3 * hp);
+            wl_barrier();
         }
-        wl_barrier();
     }
 
     WL_STAMP(22);
+    if constexpr (GATHER) {
+        // the skip branch's gradient dx2 is the layer's second output (image A -- dzo -- is dead since phase 3's barrier)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<uint2*>(imgA + (mb * 16 + lr) * WL_LDA + (4 * w + i) * 16 + 4 * lq) = dx2p[i][mb];
+        wl_barrier();
+        save_image(imgA, dx);
+    } else
     // ---- phase 5: dx1 = acc + dx2; dx = LN'(dx1; x)
     {
         uint2 xp[4][4], d1p[4][4];
@@ -1137,8 +1193,12 @@ extern "C" int grappa_writer_pack_weight(void* stream, int N, int K, const float
 extern "C" int grappa_writer_head_fwd(void* stream, const grappa_writer_layer_desc* d) {
     if (!d || d->dtype != GRAPPA_WRITER_BF16 || d->F != WL_F || d->nheads != 8 || d->s < 2 || d->s > 4 || d->T < 0) return GRAPPA_ERR_ARG;
     if (d->T == 0) return GRAPPA_OK;
-    if (!d->x || !d->out || !d->w_in_pk || !d->w_o_pk || !d->w1_pk || !d->w2_pk || !d->b_in || !d->b_o || !d->b1 || !d->b2 || !d->n1_gamma ||
-        !d->n1_beta || !d->nf_gamma || !d->nf_beta)
+    if (d->gather_idx) {          // gather mode: x1_tab / qkv_tab instead of x, the first LayerNorm and the q | k | v product (their parameters are not read)
+        if (!d->x1_tab || !d->qkv_tab || d->save_x1 || d->save_qkv || d->save_mean1) return GRAPPA_ERR_ARG;
+        if (((uintptr_t)d->x1_tab | (uintptr_t)d->qkv_tab) & 15) return GRAPPA_ERR_ARG;
+        if (!d->out || !d->w_o_pk || !d->w1_pk || !d->w2_pk || !d->b_in || !d->b_o || !d->b1 || !d->b2 || !d->nf_gamma || !d->nf_beta) return GRAPPA_ERR_ARG;
+    } else if (!d->x || !d->out || !d->w_in_pk || !d->w_o_pk || !d->w1_pk || !d->w2_pk || !d->b_in || !d->b_o || !d->b1 || !d->b2 || !d->n1_gamma ||
+               !d->n1_beta || !d->nf_gamma || !d->nf_beta)
         return GRAPPA_ERR_ARG;
     if (!(d->drop_p >= 0.f && d->drop_p < 1.f)) return GRAPPA_ERR_ARG;
     if ((d->save_mean1 == nullptr) != (d->save_rstd1 == nullptr) || (d->save_meanf == nullptr) != (d->save_rstdf == nullptr)) return GRAPPA_ERR_ARG;
@@ -1150,9 +1210,16 @@ extern "C" int grappa_writer_head_fwd(void* stream, const grappa_writer_layer_de
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int tt = WL_ROWS / d->s;
     const dim3 grid((unsigned)((d->T + tt - 1) / tt));
+    const bool gather = d->gather_idx != nullptr;
     void (*kern)(const grappa_writer_layer_desc) =
-        d->s == 2 ? writer_layer_fwd_bf16_kernel<2> : (d->s == 3 ? writer_layer_fwd_bf16_kernel<3> : writer_layer_fwd_bf16_kernel<4>);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WL_SMEM) != hipSuccess) return GRAPPA_ERR_LAUNCH;
+        gather ? (d->s == 2 ? writer_layer_fwd_bf16_kernel<2, true> : (d->s == 3 ? writer_layer_fwd_bf16_kernel<3, true> : writer_layer_fwd_bf16_kernel<4, true>))
+               : (d->s == 2 ? writer_layer_fwd_bf16_kernel<2, false> : (d->s == 3 ? writer_layer_fwd_bf16_kernel<3, false> : writer_layer_fwd_bf16_kernel<4, false>));
+    static bool attr_set[6] = {false, false, false, false, false, false};          // (idempotent: two threads setting it at once set the same value)
+    const int ki = (gather ? 3 : 0) + d->s - 2;
+    if (!attr_set[ki]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WL_SMEM) != hipSuccess) return GRAPPA_ERR_LAUNCH;
+        attr_set[ki] = true;
+    }
     GRAPPA_LAUNCH(kern, grid, dim3(WL_THREADS), WL_SMEM, st, *d);
     return grappa_launch_status();
 }
@@ -1166,21 +1233,35 @@ extern "C" int grappa_writer_head_tiles(int s, int T) {
 extern "C" int grappa_writer_head_bwd(void* stream, const grappa_writer_layer_bwd_desc* d) {
     if (!d || d->dtype != GRAPPA_WRITER_BF16 || d->F != WL_F || d->nheads != 8 || d->s < 2 || d->s > 4 || d->T < 0) return GRAPPA_ERR_ARG;
     if (d->T == 0) return GRAPPA_OK;
-    const void* ptrs[] = {d->dout, d->x, d->qkv, d->x2, d->u, d->mean1, d->rstd1, d->meanf, d->rstdf, d->n1_gamma, d->nf_gamma, d->w_in_tpk, d->w_o_tpk,
-                          d->w1_tpk, d->w2_tpk, d->dx, d->dz2, d->dz1, d->dzo, d->dqkv, d->ln1_part, d->lnf_part};
+    // gather mode (gather_idx != NULL): `qkv` is the TABLE, `dx` receives dx2; x, the first LayerNorm's tensors and W_in^T are not read
+    const void* always[] = {d->dout, d->qkv, d->x2, d->u, d->meanf, d->rstdf, d->nf_gamma, d->w_o_tpk, d->w1_tpk, d->w2_tpk, d->dx, d->dz2, d->dz1, d->dzo, d->dqkv,
+                            d->lnf_part};
+    const void* full[] = {d->x, d->mean1, d->rstd1, d->n1_gamma, d->w_in_tpk, d->ln1_part};
     uintptr_t al = 0;
-    for (const void* q : ptrs) {
+    for (const void* q : always) {
         if (!q) return GRAPPA_ERR_ARG;
         al |= (uintptr_t)q;
     }
+    if (!d->gather_idx)
+        for (const void* q : full) {
+            if (!q) return GRAPPA_ERR_ARG;
+            al |= (uintptr_t)q;
+        }
     if (al & 15) return GRAPPA_ERR_ARG;
     if (!(d->drop_p >= 0.f && d->drop_p < 1.f)) return GRAPPA_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int tt = WL_ROWS / d->s;
     const dim3 grid((unsigned)((d->T + tt - 1) / tt));
+    const bool gather = d->gather_idx != nullptr;
     void (*kern)(const grappa_writer_layer_bwd_desc) =
-        d->s == 2 ? writer_layer_bwd_bf16_kernel<2> : (d->s == 3 ? writer_layer_bwd_bf16_kernel<3> : writer_layer_bwd_bf16_kernel<4>);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WL_SMEM) != hipSuccess) return GRAPPA_ERR_LAUNCH;
+        gather ? (d->s == 2 ? writer_layer_bwd_bf16_kernel<2, true> : (d->s == 3 ? writer_layer_bwd_bf16_kernel<3, true> : writer_layer_bwd_bf16_kernel<4, true>))
+               : (d->s == 2 ? writer_layer_bwd_bf16_kernel<2, false> : (d->s == 3 ? writer_layer_bwd_bf16_kernel<3, false> : writer_layer_bwd_bf16_kernel<4, false>));
+    static bool attr_set[6] = {false, false, false, false, false, false};
+    const int ki = (gather ? 3 : 0) + d->s - 2;
+    if (!attr_set[ki]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WL_SMEM) != hipSuccess) return GRAPPA_ERR_LAUNCH;
+        attr_set[ki] = true;
+    }
     GRAPPA_LAUNCH(kern, grid, dim3(WL_THREADS), WL_SMEM, st, *d);
     return grappa_launch_status();
 }

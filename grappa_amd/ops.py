@@ -655,6 +655,30 @@ class ProjFirstLayerFn(Function):
         M = s * T
         if hasattr(be, "credit"):                 # profiling: the per-token count of this product (and of its two backward products below)
             be.credit("gemm_saved", 2.0 * (M - s * N) * 3 * Fd * Fd)
+        fused = getattr(be, "writer_layer_ok", None)
+        if fused is not None and fused(tab, s, nheads, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2) and getattr(be, "fused_first_layer", True):
+            # everything behind the table-level LayerNorm and q | k | v product as ONE launch: the fused writer layer in its GATHER mode takes x1 and
+            # q | k | v of a token from the table rows (C ABI 11 grappa_writer_layer_desc.gather_idx) -- no token-level copy of either exists
+            out = _new((M, Fd), tab)
+            sv = None
+            if infer != 1:
+                tiled = bool(getattr(be, "fused_writer_layer_bwd", False))
+                rows2 = be.lib.grappa_writer_head_tiles(s, T) * 64 if tiled else M
+                sv = dict(meanf=_new((M,), tab, F32), rstdf=_new((M,), tab, F32), att=_new((M, Fd), tab), x2=_new((rows2, Fd), tab), x3=_new((M, Fd), tab),
+                          u=_new((M, Fd), tab), x2_tiled=tiled)
+            be.writer_layer_fwd(None, s, T, nheads, drop_p, seed1, seed2, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, out, save=sv,
+                                gather=(idx_tab, x1_tab, qkv_tab))
+            ctx.cfg, ctx.scales = (s, T, N, Wp, pe is not None, nheads, drop_p, seed1, seed2), (sh, sx1, None)
+            ctx.fused_saved = sv if (sv is not None and sv["x2_tiled"]) else None
+            ctx.fused_gather = True
+            if sv is not None:
+                ctx.ff_saved = (sv["x2"], sv["meanf"], sv["rstdf"], sv["x3"], sv["u"], None, None, None)
+                ctx.save_for_backward(h, a, tab, mean1, rstd1, x1_tab, qkv_tab, sv["att"], invid_ptr, invid_rows, invtab_ptr, invtab_rows,
+                                      w, b, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, idx_tab)
+            if drop_p > 0:
+                out._grappa_drop = (drop_p, seed2)
+            return out
+        ctx.fused_gather = False
         x1, qkv = _new((M, Fd), tab), _new((M, 3 * Fd), tab)
         be.tuple_gather_fwd(x1_tab, idx_tab, s, None, x1)          # x1[pos*T + t] = x1_tab[pos*N + idx[t, pos]]
         be.tuple_gather_fwd(qkv_tab, idx_tab, s, None, qkv)
@@ -675,20 +699,40 @@ class ProjFirstLayerFn(Function):
     @staticmethod
     def backward(ctx, dout):
         be = get_backend()
-        (h, a, tab, mean1, rstd1, x1_tab, qkv, att, invid_ptr, invid_rows, invtab_ptr, invtab_rows,
-         w, b, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2) = ctx.saved_tensors
+        idx_tab = None
+        if getattr(ctx, "fused_gather", False):
+            (h, a, tab, mean1, rstd1, x1_tab, qkv, att, invid_ptr, invid_rows, invtab_ptr, invtab_rows,
+             w, b, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2, idx_tab) = ctx.saved_tensors      # (qkv: the TABLE here)
+        else:
+            (h, a, tab, mean1, rstd1, x1_tab, qkv, att, invid_ptr, invid_rows, invtab_ptr, invtab_rows,
+             w, b, n1_w, n1_b, w_in, b_in, w_o, b_o, nf_w, nf_b, w1, b1, w2, b2) = ctx.saved_tensors
         s, T, N, Wp, has_pe, nheads, drop_p, seed1, seed2 = ctx.cfg
         sh, sx1, satt = ctx.scales
-        M, Fd = qkv.shape[0], qkv.shape[1] // 3
+        M, Fd = s * T, qkv.shape[1] // 3
         R = h.shape[1]
-        dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True, then_drop=(drop_p, seed1))
-        ctx.ff_saved = None
-        dzo, sz = _drop_bwd(be, dx2, drop_p, seed1, w_o)
-        sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)
-        datt = _new((M, Fd), qkv)
-        be.gemm(dzo, w_o, datt, M=M, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)
-        dqkv = _new(qkv.shape, qkv)
-        be.seqattn_bwd(qkv, datt, s, T, nheads, dqkv)                      # (its rows are summed into the table before any product reads them)
+        sv = getattr(ctx, "fused_saved", None)
+        if idx_tab is not None and sv is not None:
+            # the input-gradient chain down to the attention as ONE launch (grappa_writer_head_bwd in its gather mode): the token-level gradients of
+            # q | k | v and of the skip branch come back, the table-level part below is unchanged
+            ctx.fused_saved = ctx.ff_saved = None
+            dx2, dz2, dz1, dzo, dqkv = be.writer_layer_bwd(_c(dout), None, s, T, nheads, drop_p, seed1, seed2, sv, n1_w, n1_b, w_in, w_o, nf_w, nf_b, w1, w2,
+                                                           gather=(idx_tab, qkv))
+            _linear_bwd_params(be, dz2, sv["u"], w2, b2, None, None)
+            _linear_bwd_params(be, dz1, sv["x3"], w1, b1, None, None)
+            _linear_bwd_params(be, dzo, att, w_o, b_o, None, None)
+        else:
+            if idx_tab is not None:                 # fused forward, unfused backward (A/B switch): the token-level q | k | v the unfused attention backward reads
+                qkv_tok = _new((M, 3 * Fd), tab)
+                be.tuple_gather_fwd(qkv, idx_tab, s, None, qkv_tok)
+                qkv = qkv_tok
+            dx2, sz = _ff_bwd(be, ctx.ff_saved, dout, nf_w, nf_b, w1, b1, w2, b2, False, drop_p, seed2, True, then_drop=(drop_p, seed1))
+            ctx.ff_saved = None
+            dzo, sz = _drop_bwd(be, dx2, drop_p, seed1, w_o)
+            sz = _linear_bwd_params(be, dzo, att, w_o, b_o, satt, sz)
+            datt = _new((M, Fd), qkv)
+            be.gemm(dzo, w_o, datt, M=M, N=Fd, K=Fd, b_kcontig=False, a_scales=sz)
+            dqkv = _new(qkv.shape, qkv)
+            be.seqattn_bwd(qkv, datt, s, T, nheads, dqkv)                      # (its rows are summed into the table before any product reads them)
         # token gradients -> table rows (pos*N + n): the q, k, v gradients and the skip branch of x1
         dqkv_tab, dres_tab = _new((s * N, 3 * Fd), qkv), _new((s * N, Fd), qkv)
         be.tuple_gather_bwd(invtab_ptr, invtab_rows, dqkv, dqkv_tab, False, False)

@@ -598,6 +598,12 @@ typedef struct grappa_writer_layer_desc {
     const uint64_t* drop_salt;                            /* device word mixed into both seeds, or NULL (grappa_gemm_desc.drop_salt) */
     float *save_mean1, *save_rstd1, *save_meanf, *save_rstdf;      /* (s*T) each, or NULL */
     void *save_x1, *save_qkv, *save_att, *save_x2, *save_x3, *save_u;      /* (s*T, F), qkv (s*T, 3F), or NULL */
+    /* GATHER mode (gather_idx != NULL; the first layer of a head whose LayerNorm and q | k | v were computed once per (atom, position) TABLE row,
+       reference models/interaction_parameters.py:155-180 + network_utils.py:112-133 on tokens that depend on their tuple only through (atom, position)):
+       x1 and q | k | v are GATHERED -- token (pos, t) takes row gather_idx[t * s + pos] of x1_tab (rows x F, already normalised) and of qkv_tab
+       (rows x 3F, bias included) -- instead of computed; x, n1_*, w_in_pk, save_x1 / save_qkv / save_mean1 / save_rstd1 are not used */
+    const int* gather_idx;
+    const void *x1_tab, *qkv_tab;
     int x2_tiled;      /* != 0: save_x2 holds grappa_writer_head_tiles(s, T) * 64 rows in the TILE order of grappa_writer_head_bwd (x2_tiled there too):
                           per tile and lane the 16 accumulator quads behind one another; 0: plain rows (what grappa_layernorm_bwd_bf16 reads) */
 } grappa_writer_layer_desc;
@@ -624,6 +630,9 @@ typedef struct grappa_writer_layer_bwd_desc {
     void *dz2, *dz1, *dzo, *dqkv;
     float *ln1_part, *lnf_part;                           /* (tiles, 2, F) each */
     int x2_tiled;                                         /* the layout of x2: see grappa_writer_layer_desc */
+    const int* gather_idx;                                /* GATHER mode: `qkv` is the (rows x 3F) TABLE read through gather_idx; the chain ends behind the attention:
+                                                             `dqkv` (token rows) and `dx` = the skip branch's gradient dx2 (token rows) are the outputs, x / mean1 / rstd1 /
+                                                             n1_gamma / w_in_tpk / ln1_part are not used */
 } grappa_writer_layer_bwd_desc;
 int grappa_writer_head_bwd(void* stream, const grappa_writer_layer_bwd_desc* d);
 int grappa_writer_head_tiles(int s, int T);

@@ -223,3 +223,48 @@ def test_fused_layer_gradients_match_the_oracle_autograd(s, T):
         r = rp[names[k]].grad
         d = float((g[k].cpu().double() - r).abs().max())
         assert d <= tol * float(r.abs().max()), (k, d, float(r.abs().max()))
+
+
+@pytest.mark.parametrize("s,p", [(3, 0.0), (4, 0.2)])
+def test_first_layer_on_table_rows_through_the_gather_mode_equals_the_unfused_sequence(s, p):
+    """ops.ProjFirstLayerFn (rep projector -> LayerNorm + q | k | v once per (atom, position) row -> first transformer layer) with everything
+    behind the table-level products as ONE launch forward and ONE backward (the fused layer's GATHER mode: x1 and q | k | v of a token come from
+    the table rows) against the unfused sequence: output within 3 bf16 steps, dh and every parameter gradient within 2e-2 of its largest magnitude"""
+    from grappa_amd import ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    be = get_backend()
+    g = build_batch_from_pool(list(range(40, 72)), n_confs=1, seed=0).to("cuda")
+    plan = g.plan()
+    lvl = {3: "n3", 4: "n4"}[s]
+    T, N = plan.T[lvl], plan.N
+    assert T > 64 and 4 * N <= 3 * T * 2
+    res = []
+    for fused in (True, False):
+        gen = torch.Generator(device="cuda").manual_seed(77)
+        P = {k: v.clone().requires_grad_(True) for k, v in _params(gen).items()}
+        w = (torch.randn(F - 1, 256, generator=gen, device="cuda") / 16).requires_grad_(True)
+        b = (0.1 * torch.randn(F - 1, generator=gen, device="cuda")).requires_grad_(True)
+        h = torch.randn(N, 256, generator=gen, device="cuda").requires_grad_(True)
+        pe = torch.tensor([0., 1., 0.] if s == 3 else [0., 1., 1., 0.], device="cuda")
+        keep = (be.fused_first_layer, be.fused_writer_layer_bwd)
+        be.fused_first_layer = fused
+        ops.set_activation_dtype("bf16")
+        try:
+            ops._INFERENCE["on"] = False
+            y = ops.ProjFirstLayerFn.apply(h, w, b, plan.position_tables(lvl), s, T, pe, ops.act_dtype(), 8, p, 5, 6, *[P[k] for k in ORDER])
+            wgt = torch.randn(y.shape, generator=torch.Generator(device="cuda").manual_seed(3), device="cuda").to(BF)
+            (y.float() * wgt.float()).sum().backward()
+            be.flush_wgrads()
+        finally:
+            ops.set_activation_dtype("f32")
+            be.fused_first_layer, be.fused_writer_layer_bwd = keep
+        torch.cuda.synchronize()
+        res.append((y.detach().float(), h.grad.clone(), w.grad.clone(), b.grad.clone(), {k: v.grad.clone() for k, v in P.items()}))
+    (ya, ha, wa, ba, ga), (yb, hb, wb, bb, gb) = res
+    _close_bf16(ya.to(BF), yb, "out", frac=0.90, steps=3.0)
+    for name, a_, b_ in (("dh", ha, hb), ("dW", wa, wb), ("db", ba, bb)):
+        assert float((a_ - b_).abs().max()) <= 2e-2 * float(b_.abs().max()), name
+    for k in ORDER:
+        d, scale = float((ga[k] - gb[k]).abs().max()), float(gb[k].abs().max())
+        assert d <= 2e-2 * scale, (k, d, scale)
