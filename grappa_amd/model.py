@@ -143,7 +143,8 @@ class GrappaGNN(nn.Module):
         cols = [d[f].float() if d[f].dim() >= 2 else d[f].unsqueeze(-1).float() for f in self.in_feat_name]
         n_plain = sum(c.shape[1] for c in cols)
         N = cols[0].shape[0]
-        x = torch.zeros((N, self.in_feats), dtype=torch.float32, device=cols[0].device)
+        # rows of a multiple of four floats (the weight-gradient product of pre_dense reads them in 16-byte pieces: ops._padded_cols)
+        x = torch.zeros((N, (self.in_feats + 3) // 4 * 4), dtype=torch.float32, device=cols[0].device)[:, :self.in_feats]
         if n_plain + (CHARGE_ENCODING_DIM if self.charge_encoding else 0) != self.in_feats:
             raise AssertionError(f"the input features must have {self.in_feats} columns in total, got {n_plain}")
         torch.cat(cols, dim=-1, out=x[:, :n_plain])

@@ -120,6 +120,18 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """a (rows, cols) table the kernels can address as it stands (unit inner stride, rows that do not overlap), else a contiguous copy"""
+    return t if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
+
+
+def _padded_cols(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
+    """zeroed (rows, cols) view of a table whose rows are a multiple of four floats long: a weight-gradient product reads its operands
+    across their rows in 16-byte pieces only from such tables (gemm_f32.hip grouped products; an odd leading dimension -- the 511
+    columns of a writer's projection -- sends it to the scalar-load kernel, 95 instead of 19 us at C2)"""
+    return _zeros((rows, (cols + 3) // 4 * 4), like)[:, :cols]
+
+
 # ------------------------------------------------------------------------------------------------
 # shared sub-sequences (plain functions on the backend; used inside the Functions)
 def _linear_bwd_params(be, dz, x, w, b, xs=None, zs=None):
@@ -297,7 +309,7 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, drop_p, seed, out_dtype=None):
         be = get_backend()
-        x = _c(x)
+        x = _rows(x)
         M, K = x.shape
         N = w.shape[0]
         y = _new((M, N), x, out_dtype)
@@ -529,7 +541,7 @@ class ProjGatherFn(Function):
         dx = _c(dx)
         da = _new(a.shape, a)
         be.tuple_gather_bwd(inv_ptr, inv_rows, dx, da, has_pe, False)
-        dz = _new((N, Wp), a)
+        dz = _padded_cols(N, Wp, a)
         sz = be.act_dropout_bwd(da[:, :Wp], a[:, :Wp], 0.0, 0, dz)
         sz = _linear_bwd_params(be, dz, h, w, b, ctx.sh, sz)
         dh = _new(h.shape, h)
@@ -746,7 +758,7 @@ class ProjFirstLayerFn(Function):
         dtab, _ = _ln_bwd(be, dx1_tab, tab, mean1, rstd1, n1_w, n1_b)
         da = _new(a.shape, a)
         be.tuple_gather_bwd(invid_ptr, invid_rows, dtab, da, has_pe, False)      # sum over the positions of an atom
-        dz = _new((N, Wp), a)
+        dz = _padded_cols(N, Wp, a)
         sz = be.act_dropout_bwd(da[:, :Wp], a[:, :Wp], 0.0, 0, dz)
         sz = _linear_bwd_params(be, dz, h, w, b, sh, sz)
         dh = _new(h.shape, h)
