@@ -24,6 +24,7 @@ buffer after backward(); `--weak` switches to weak scaling of C2 (256 molecules 
 import argparse
 import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -308,6 +309,16 @@ def distinct_devices(ranks, world: int, enforce: bool) -> int:
     return distinct
 
 
+def finite_loss(what: str, loss) -> float:
+    """the loss of the last timed step of `what`; a step that ends in a NaN / inf loss is not a measurement (NaN operands even run FASTER on
+    this chip -- the matrix pipes draw less power and the clock rises: a racy refresh of the operand scales once read as an 11 % gain at
+    C2): the run dies instead of printing a line"""
+    v = float(loss)
+    if not math.isfinite(v):
+        raise SystemExit(f"bench.py: the {what} step ended with a non-finite loss ({v}); no number is reported from such a run")
+    return v
+
+
 def log(*a):
     print(f"[bench {time.strftime('%H:%M:%S')}]", *a, file=sys.stderr, flush=True)
 
@@ -482,7 +493,7 @@ def main():
                 t = torch.tensor([dt], device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t)
-            return dt, float(loss.detach())
+            return dt, finite_loss(self.name, loss.detach())
 
         def describe(self):
             mdl = "TINY TEST MODEL (not a measurement)" if args.tiny_model else "production GrappaModel 40.8M params"
@@ -526,7 +537,7 @@ def main():
             d_ = time.perf_counter() - t0_
             return {"value": j.global_batch * steps / d_, "unit": "molecules/s", "ms_per_step": 1e3 * d_ / steps, "steps": steps, "warmup": 2,
                     "mode": "hipGraph replay of the whole train step on the resident batch (CapturedTrainStep), dropout masks fresh per replay",
-                    "final_loss": float(cap.loss), "gemm_precision": be.gemm_precision_name,
+                    "final_loss": finite_loss(f"recorded {j.name}", cap.loss), "gemm_precision": be.gemm_precision_name,
                     "activation_storage": "bf16" if ops.act_dtype() is not None else "f32"}
         finally:
             del cap
@@ -818,7 +829,7 @@ def main():
                                    "mode": "hipGraph replay (grappa_amd/capture.py CapturedTrainStep): one graph launch per train step",
                                    "eager": {"value": 32 * 20 / d32, "ms_per_step": 1e3 * d32 / 20, "steps": 20, "warmup": 5,
                                              "library_kernel_launches_per_step": n32},
-                                   "final_loss": float(cap.loss), "config": j32.describe(),
+                                   "final_loss": finite_loss("recorded b32_train", cap.loss), "config": j32.describe(),
                                    "note": "32 molecules x 32 conformations of the C2 molecule range, production model, train mode (dropout on: the "
                                            "recorded step draws fresh masks per replay through the device-side salt), Adam + clip 10; the SAME resident "
                                            "batch every step (shapes are part of a recorded graph: a loader must deliver batches of one shape to use it)"}

@@ -420,7 +420,11 @@ class HipBackend:
     def _amax_of_weight(self, w: torch.Tensor) -> "Amax":
         """row and column maxima of a weight matrix, refreshed when the weight changed (as _planes_of_weight).  Entries keep their
         weight alive, so its address cannot be handed to another tensor while the entry exists.  After an optimiser step the first
-        stale weight refreshes EVERY registered weight in one launch (grappa_amax_f32_batched: one workgroup per weight)."""
+        stale weight refreshes EVERY registered weight in one launch (grappa_amax_f32_batched: one workgroup per weight).
+        That refresh rewrites all maxima arrays (zero, then atomic max) on the CALLING stream: it is safe because parameters change between
+        steps, so the first stale use is the GNN's on the main stream, before the writer heads fork.  Never hand this function a tensor
+        that is rewritten inside a step on a head's stream (an experiment that did -- a per-head zero-extended copy of the projection
+        weight -- raced with the other heads' products and trained on NaN: DESIGN.md section 6, "rejected this round")."""
         R, Cc = w.shape
         key = (w.data_ptr(), R, Cc, w.stride(0))
         ver = (w._version, self._wepoch)

@@ -77,3 +77,13 @@ def test_bench_refuses_a_scaling_line_when_ranks_share_a_device():
     with pytest.raises(SystemExit):
         bench.distinct_devices(two_on_one, 2, enforce=True)
     assert bench.distinct_devices([dict(rank=0, device_index=0, device_uuid="a"), dict(rank=1, device_index=1, device_uuid="b")], 2, enforce=True) == 2
+
+
+def test_bench_refuses_a_step_that_ends_in_a_non_finite_loss():
+    """a NaN step is not a measurement (and runs faster than a real one on this chip): bench.py dies instead of printing a line"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.finite_loss("C2", 90.75) == 90.75
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        with pytest.raises(SystemExit):
+            bench.finite_loss("C2", bad)
