@@ -478,6 +478,53 @@ def test_writer_heads_on_streams_match_single_stream():
     assert torch.equal(loss4, loss1) and torch.equal(k44, k41) and torch.equal(eq4, eq1) and torch.equal(grad4, grad1)
 
 
+def test_train_steps_on_four_streams_match_single_stream():
+    """SEVERAL optimiser steps with the heads on four streams against one stream: same losses, same parameters.  One forward / backward
+    (the test above) cannot see a race that needs a parameter update between two uses -- a refresh of per-weight data (operand scales,
+    pairs, planes, packed weights) issued from one head's stream while another head reads it.  (History: DESIGN.md section 6, the NaN
+    'gain' of a per-head weight copy.)"""
+    from grappa_amd import Energy, MolwiseLoss, get_default_model_config, model_from_config, ops
+    from grappa_amd.backend import get_backend
+    from grappa_amd.datasets import build_batch_from_pool
+    from grappa_amd.optim import FlatParams, FusedAdam
+    be = get_backend()
+    g_cpu = build_batch_from_pool(list(range(100, 164)), n_confs=8, seed=5)
+    loss_fn = MolwiseLoss(gradient_weight=0.8, energy_weight=1.0, param_weight=0.0, proper_regularisation=1e-3)
+    defer, be.defer_wgrads = be.defer_wgrads, False        # (as above: one summation order for both runs)
+    be.pin_tail_launches(False)
+    out = {}
+    try:
+        for streams in (1, 4):
+            model = model_from_config(get_default_model_config())
+            model.load_state_dict(gu.keyed_state_dict(model))
+            model = model.to("cuda").train()
+            model.parameter_writer.head_streams = streams
+            flat = FlatParams(model)
+            opt = FusedAdam(flat, lr=1e-4)
+            ops.manual_seed(123)
+            g = g_cpu.to("cuda")
+            losses = []
+            for _ in range(4):
+                opt.zero_grad()
+                for lvl in ("n2", "n3", "n4", "n4_improper"):
+                    for k in ("k", "eq"):
+                        g.nodes[lvl].data.pop(k, None)
+                loss = loss_fn(Energy()(model(g)))
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach().clone())
+            torch.cuda.synchronize()
+            out[streams] = (torch.stack(losses), flat.data.clone())
+    finally:
+        be.defer_wgrads = defer
+        be.pin_tail_launches(None)
+    l1, p1 = out[1]
+    l4, p4 = out[4]
+    assert torch.isfinite(l1).all() and torch.isfinite(l4).all() and torch.isfinite(p4).all()
+    assert float(l1[-1]) != float(l1[0])                          # the steps did move the parameters
+    assert torch.equal(l4, l1) and torch.equal(p4, p1)
+
+
 def test_predict_drop_in():
     from grappa_amd import Grappa, Molecule, get_default_model_config, model_from_config
     from grappa_amd.datasets import molecule_from_pool
