@@ -1,14 +1,15 @@
 """How far are the GPU and the fp32 oracle from a float64 run of the oracle, on the batch of
 tests/test_gpu_e2e.py::test_production_config_against_oracle_on_a_larger_batch?  Prints, per quantity, the test's error metric for
 GPU vs fp32 oracle (what the test asserts), GPU vs float64 oracle and fp32 oracle vs float64 oracle.
-    [GRAPPA_HIP_LIB=...] python tools/noise_floor_check.py"""
+    [GRAPPA_HIP_LIB=...] python tests/tools/noise_floor_check.py
+(lives under tests/: it runs the oracle as the checker, which only tests, smoke() and bench.py's cpu_baseline may do)"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import golden_utils as gu  # noqa: E402

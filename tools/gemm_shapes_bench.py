@@ -56,14 +56,6 @@ WORKLOAD = "C2-pubchem-b256"
 def main():
     global DEV, WORKLOAD
     from grappa_amd.backend import get_backend
-    if "--cpu-dry-run" in sys.argv:        # host-logic check with the test-only backend (no timing)
-        from grappa_amd import backend
-        from oracle.ops_ref import RefBackend
-        backend.set_backend(RefBackend())
-        DEV, WORKLOAD = "cpu", "C1-dipeptide-b8"
-        for k, v in sorted(record_shapes().items()):
-            print(k, v)
-        return
     shapes = record_shapes()
     be = get_backend()
     # --precisions f32,f32_bf16x6,...: A/B the arithmetic modes in ONE process (same clocks, same buffers)
